@@ -1,0 +1,86 @@
+"""ctypes binding of libcslgan_hip.so (declared in include/cslgan.h).
+
+The product path has no CPU fallback for CUDA/HIP tensors: if the shared library is missing
+or fails to load, :func:`lib` raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcslgan_hip.so")
+MAX_SEGS = 16
+
+EXPORTS = [
+    "cslgan_version", "cslgan_last_error", "cslgan_device_count",
+    "cslgan_sample_sqnorm_f32", "cslgan_clip_factors_f32", "cslgan_clip_accum_noise_f32",
+    "cslgan_l2_clip_rows_f32", "cslgan_row_l2norm_f32", "cslgan_row_l2norm_bwd_f32",
+    "cslgan_conv2d_fwd_f32", "cslgan_conv2d_dgrad_f32", "cslgan_conv2d_wgrad_grouped_f32",
+    "cslgan_bias_grad_grouped_f32", "cslgan_act_bwd_f32", "cslgan_groupnorm_act_f32", "cslgan_adam_step_f32",
+]
+
+
+class SegsT(C.Structure):
+    _fields_ = [
+        ("n_seg", C.c_int32), ("_pad", C.c_int32),
+        ("inp", C.c_void_p * MAX_SEGS), ("out", C.c_void_p * MAX_SEGS), ("noise", C.c_void_p * MAX_SEGS),
+        ("len", C.c_int64 * MAX_SEGS), ("row_stride", C.c_int64 * MAX_SEGS),
+    ]
+
+
+class ConvT(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "upsample", "P", "Q")]
+
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raises HipLibraryMissing if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            "libcslgan_hip.so not found at %s — build it with `python -m csl_gan_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for device tensors." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.cslgan_last_error.restype = C.c_char_p
+    vp, i32, i64, f32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+    sig = {
+        "cslgan_version": [],
+        "cslgan_device_count": [],
+        "cslgan_sample_sqnorm_f32": [C.POINTER(SegsT), i64, vp, vp],
+        "cslgan_clip_factors_f32": [vp, i32, i64, vp, i32, f32, i64, vp, vp, vp],
+        "cslgan_clip_accum_noise_f32": [C.POINTER(SegsT), i64, vp, i32, vp, u64, u64, f32, f32, vp],
+        "cslgan_l2_clip_rows_f32": [vp, vp, i64, i64, f32, vp, vp],
+        "cslgan_row_l2norm_f32": [vp, i64, i64, vp, vp],
+        "cslgan_row_l2norm_bwd_f32": [vp, vp, vp, i64, i64, vp, vp],
+        "cslgan_conv2d_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, vp, i32, i32, vp, vp],
+        "cslgan_conv2d_dgrad_f32": [C.POINTER(ConvT), vp, vp, vp, vp, vp, vp],
+        "cslgan_conv2d_wgrad_grouped_f32": [C.POINTER(ConvT), vp, vp, i32, f32, vp, vp, vp],
+        "cslgan_bias_grad_grouped_f32": [vp, i32, i32, i32, i32, f32, vp, vp, vp],
+        "cslgan_act_bwd_f32": [vp, vp, i64, f32, vp, vp],
+        "cslgan_groupnorm_act_f32": [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp],
+        "cslgan_adam_step_f32": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    if L.cslgan_version() != 1:
+        raise HipLibraryMissing("libcslgan_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().cslgan_last_error().decode(errors="replace")
+        raise RuntimeError("cslgan %s failed (%d): %s" % (what, rc, msg))

@@ -1,0 +1,370 @@
+// Per-sample gradient-norm / clip / accumulate / Gaussian-noise kernels for gfx950.
+//
+// HBM-bound streaming work: 16-byte coalesced loads, wavefront (DPP shuffle) + LDS partial-norm
+// reductions, one atomic per 32 KB chunk.  Roofline: bytes = 2 * P * 4 per clipped sample
+// (one read for the norms, one for the weighted sum) — DESIGN.md "clip kernels".
+//
+// Reference semantics being replaced (file:line under /root/reference):
+//   train.py:311-314  calc_sample_norms           -> sample_sqnorm_kernel
+//   train.py:324      calc_clipping_factors       -> clip_factors_kernel
+//   train.py:399-402  clip(); accum_grads_across_passes()  -> clip_accum_noise_kernel
+//   train.py:484      engine-wrapped optimizer.step() noise + 1/B -> clip_accum_noise_kernel
+//   backprop_clip.py:18-22 l2_clip                -> l2_clip_rows
+//   gradient_penalty.py:52-53 gradients.norm(2, dim=1) -> row_l2norm (+ backward)
+#include "common.h"
+
+namespace cslgan {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+constexpr int SQ_THREADS = 256;
+constexpr int SQ_CHUNK = SQ_THREADS * 4 * 8;  // floats per block: 32 KB
+
+struct SqArgs {
+    int n_seg;
+    const float* in[CSLGAN_MAX_SEGS];
+    long long len[CSLGAN_MAX_SEGS];
+    long long row_stride[CSLGAN_MAX_SEGS];
+    int chunk_prefix[CSLGAN_MAX_SEGS + 1];  // blocks (chunks) per row before segment s
+    int vec_ok[CSLGAN_MAX_SEGS];            // 16-byte loads allowed for this segment
+};
+
+__global__ __launch_bounds__(SQ_THREADS) void sample_sqnorm_kernel(SqArgs a, long long n_rows, float* __restrict__ out_sq) {
+    __shared__ float red[4];
+    const int bx = blockIdx.x;
+    const long long row = blockIdx.y;
+    int s = 0;
+#pragma unroll 1
+    while (s + 1 < a.n_seg && bx >= a.chunk_prefix[s + 1]) ++s;
+    const long long off = (long long)(bx - a.chunk_prefix[s]) * SQ_CHUNK;
+    const long long len = a.len[s];
+    long long n = len - off;
+    if (n > SQ_CHUNK) n = SQ_CHUNK;
+    const float* __restrict__ p = a.in[s] + row * a.row_stride[s] + off;
+    float acc = 0.f;
+    if (a.vec_ok[s]) {
+        const long long n4 = n >> 2;
+        const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll 8
+        for (long long i = threadIdx.x; i < n4; i += SQ_THREADS) {
+            const float4 v = p4[i];
+            acc = fmaf(v.x, v.x, acc);
+            acc = fmaf(v.y, v.y, acc);
+            acc = fmaf(v.z, v.z, acc);
+            acc = fmaf(v.w, v.w, acc);
+        }
+        for (long long i = (n4 << 2) + threadIdx.x; i < n; i += SQ_THREADS) acc = fmaf(p[i], p[i], acc);
+    } else {
+#pragma unroll 4
+        for (long long i = threadIdx.x; i < n; i += SQ_THREADS) acc = fmaf(p[i], p[i], acc);
+    }
+    const float tot = block_sum_256(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out_sq + (long long)s * n_rows + row, tot);
+}
+
+__global__ void clip_factors_kernel(const float* __restrict__ sq, int n_seg, long long n_rows,
+                                    const float* __restrict__ max_norm, int flat, float eps,
+                                    long long first_private_row, float* __restrict__ out_f,
+                                    float* __restrict__ out_norm) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    if (flat) {
+        float tot = 0.f;
+        for (int s = 0; s < n_seg; ++s) tot += sq[(long long)s * n_rows + r];
+        const float nrm = sqrtf(tot);
+        float f = max_norm[0] / (nrm + eps);
+        f = f > 1.f ? 1.f : f;
+        out_f[r] = r < first_private_row ? 1.f : f;
+        if (out_norm) out_norm[r] = nrm;
+    } else {
+        for (int s = 0; s < n_seg; ++s) {
+            const float nrm = sqrtf(sq[(long long)s * n_rows + r]);
+            float f = max_norm[s] / (nrm + eps);
+            f = f > 1.f ? 1.f : f;
+            out_f[(long long)s * n_rows + r] = r < first_private_row ? 1.f : f;
+            if (out_norm) out_norm[(long long)s * n_rows + r] = nrm;
+        }
+    }
+}
+
+// ---- Philox4x32-10 ------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+    // u1 in (0,1], u2 in [0,1)
+    const float u1 = (float)(a >> 8) * (1.0f / 16777216.0f) + (0.5f / 16777216.0f);
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * __logf(u1));
+    float sn, cs;
+    __sincosf(6.283185307179586f * u2, &sn, &cs);
+    z0 = r * cs;
+    z1 = r * sn;
+}
+
+constexpr int CA_THREADS = 256;
+constexpr int CA_COLS = CA_THREADS * 4;  // columns per block
+
+struct CaArgs {
+    int n_seg;
+    const float* in[CSLGAN_MAX_SEGS];
+    float* out[CSLGAN_MAX_SEGS];
+    const float* noise[CSLGAN_MAX_SEGS];
+    long long len[CSLGAN_MAX_SEGS];
+    long long row_stride[CSLGAN_MAX_SEGS];
+    int tile_prefix[CSLGAN_MAX_SEGS + 1];
+    int vec_ok[CSLGAN_MAX_SEGS];
+};
+
+__global__ __launch_bounds__(CA_THREADS) void clip_accum_noise_kernel(CaArgs a, long long n_rows,
+                                                                      const float* __restrict__ factors,
+                                                                      int factors_per_seg,
+                                                                      const float* __restrict__ noise_std,
+                                                                      unsigned long long seed,
+                                                                      unsigned long long offset, float scale,
+                                                                      float beta) {
+    const int bx = blockIdx.x;
+    int s = 0;
+#pragma unroll 1
+    while (s + 1 < a.n_seg && bx >= a.tile_prefix[s + 1]) ++s;
+    const long long j0 = (long long)(bx - a.tile_prefix[s]) * CA_COLS + (long long)threadIdx.x * 4;
+    const long long len = a.len[s];
+    if (j0 >= len) return;
+    const long long stride = a.row_stride[s];
+    const float* __restrict__ base = a.in[s] + j0;
+    const float* __restrict__ f = factors ? factors + (factors_per_seg ? (long long)s * n_rows : 0) : nullptr;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool full = (j0 + 4 <= len);
+    if (full && a.vec_ok[s]) {
+#pragma unroll 8
+        for (long long r = 0; r < n_rows; ++r) {
+            const float4 v = *reinterpret_cast<const float4*>(base + r * stride);
+            const float fr = f ? f[r] : 1.f;
+            acc.x = fmaf(fr, v.x, acc.x);
+            acc.y = fmaf(fr, v.y, acc.y);
+            acc.z = fmaf(fr, v.z, acc.z);
+            acc.w = fmaf(fr, v.w, acc.w);
+        }
+    } else {
+        const int nv = full ? 4 : (int)(len - j0);
+#pragma unroll 4
+        for (long long r = 0; r < n_rows; ++r) {
+            const float* q = base + r * stride;
+            const float fr = f ? f[r] : 1.f;
+            acc.x = fmaf(fr, q[0], acc.x);
+            if (nv > 1) acc.y = fmaf(fr, q[1], acc.y);
+            if (nv > 2) acc.z = fmaf(fr, q[2], acc.z);
+            if (nv > 3) acc.w = fmaf(fr, q[3], acc.w);
+        }
+    }
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    float sd = 0.f;
+    if (noise_std) {
+        sd = noise_std[s];
+        if (a.noise[s]) {
+            for (int i = 0; i < 4; ++i)
+                if (j0 + i < len) z[i] = a.noise[s][j0 + i];
+        } else {
+            uint32_t rnd[4];
+            const unsigned long long ctr = (unsigned long long)(j0 >> 2);
+            philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)s + (uint32_t)(offset << 8),
+                          (uint32_t)(offset >> 24), (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+            box_muller(rnd[0], rnd[1], z[0], z[1]);
+            box_muller(rnd[2], rnd[3], z[2], z[3]);
+        }
+    }
+    float* __restrict__ o = a.out[s] + j0;
+    const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+    for (int i = 0; i < 4; ++i) {
+        if (j0 + i < len) {
+            const float val = scale * fmaf(sd, z[i], v[i]);
+            o[i] = (beta != 0.f) ? fmaf(beta, o[i], val) : val;
+        }
+    }
+}
+
+// ---- row helpers ----------------------------------------------------------------------------
+__global__ void sqrt_kernel(float* __restrict__ v, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = sqrtf(v[i]);
+}
+
+// out[r][j] = in[r][j] * (sq[r] > C^2 ? C / sqrt(sq[r]) : 1)
+__global__ void l2_clip_scale_kernel(const float* __restrict__ in, float* __restrict__ out, long long n_rows,
+                                     long long len, float C, const float* __restrict__ sq) {
+    const long long row = blockIdx.y;
+    const float nrm = sqrtf(sq[row]);
+    const float f = nrm > C ? C / nrm : 1.f;
+    const float* p = in + row * len;
+    float* o = out + row * len;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < len; j += (long long)gridDim.x * blockDim.x)
+        o[j] = nrm > C ? p[j] * f : p[j];
+}
+
+// gin[r][j] = gnorm[r] * in[r][j] / norm[r]
+__global__ void row_l2norm_bwd_kernel(const float* __restrict__ in, const float* __restrict__ norm,
+                                      const float* __restrict__ gnorm, long long len, float* __restrict__ gin) {
+    const long long row = blockIdx.y;
+    const float f = gnorm[row] / norm[row];
+    const float* p = in + row * len;
+    float* o = gin + row * len;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < len; j += (long long)gridDim.x * blockDim.x)
+        o[j] = p[j] * f;
+}
+
+static int launch_sqnorm(const float* const* in, const long long* len, const long long* stride, int n_seg,
+                         long long n_rows, float* out_sq, hipStream_t st) {
+    SqArgs a;
+    a.n_seg = n_seg;
+    int tot = 0;
+    for (int s = 0; s < n_seg; ++s) {
+        a.in[s] = in[s];
+        a.len[s] = len[s];
+        a.row_stride[s] = stride[s];
+        a.chunk_prefix[s] = tot;
+        a.vec_ok[s] = aligned16(in[s]) && (stride[s] % 4 == 0);
+        tot += (int)((len[s] + SQ_CHUNK - 1) / SQ_CHUNK);
+    }
+    a.chunk_prefix[n_seg] = tot;
+    for (int s = n_seg; s < CSLGAN_MAX_SEGS; ++s) { a.in[s] = nullptr; a.len[s] = 0; a.row_stride[s] = 0; a.vec_ok[s] = 0; a.chunk_prefix[s + 1] = tot; }
+    if (hipMemsetAsync(out_sq, 0, sizeof(float) * n_seg * n_rows, st) != hipSuccess) {
+        set_error("sample_sqnorm: hipMemsetAsync failed");
+        return CSLGAN_ERR_LAUNCH;
+    }
+    if (tot == 0 || n_rows == 0) return CSLGAN_OK;
+    hipLaunchKernelGGL(sample_sqnorm_kernel, dim3(tot, (unsigned)n_rows), dim3(SQ_THREADS), 0, st, a, n_rows, out_sq);
+    return check_launch("sample_sqnorm_kernel");
+}
+
+}  // namespace cslgan
+
+using namespace cslgan;
+
+extern "C" {
+
+int cslgan_version(void) { return CSLGAN_ABI_VERSION; }
+const char* cslgan_last_error(void) { return cslgan::g_err; }
+
+int cslgan_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int cslgan_sample_sqnorm_f32(const cslgan_segs_t* segs, int64_t n_rows, float* out_sq, void* stream) {
+    CSLGAN_REQUIRE(segs && out_sq, "sample_sqnorm: null argument");
+    CSLGAN_REQUIRE(segs->n_seg >= 1 && segs->n_seg <= CSLGAN_MAX_SEGS, "sample_sqnorm: n_seg=%d out of range", segs->n_seg);
+    CSLGAN_REQUIRE(n_rows >= 0 && n_rows <= 65535, "sample_sqnorm: n_rows=%lld out of range", (long long)n_rows);
+    const float* in[CSLGAN_MAX_SEGS];
+    long long len[CSLGAN_MAX_SEGS], stride[CSLGAN_MAX_SEGS];
+    for (int s = 0; s < segs->n_seg; ++s) {
+        CSLGAN_REQUIRE(segs->in[s] || segs->len[s] == 0, "sample_sqnorm: segment %d is null", s);
+        CSLGAN_REQUIRE(segs->len[s] >= 0 && segs->row_stride[s] >= segs->len[s], "sample_sqnorm: bad len/stride in segment %d", s);
+        in[s] = segs->in[s]; len[s] = segs->len[s]; stride[s] = segs->row_stride[s];
+    }
+    return launch_sqnorm(in, len, stride, segs->n_seg, n_rows, out_sq, (hipStream_t)stream);
+}
+
+int cslgan_clip_factors_f32(const float* sq, int n_seg, int64_t n_rows, const float* max_norm, int flat, float eps,
+                            int64_t first_private_row, float* out_f, float* out_norm, void* stream) {
+    CSLGAN_REQUIRE(sq && max_norm && out_f, "clip_factors: null argument");
+    CSLGAN_REQUIRE(n_seg >= 1 && n_rows >= 0, "clip_factors: bad sizes");
+    if (n_rows == 0) return CSLGAN_OK;
+    const int th = 128;
+    hipLaunchKernelGGL(clip_factors_kernel, dim3((unsigned)((n_rows + th - 1) / th)), dim3(th), 0, (hipStream_t)stream, sq,
+                       n_seg, (long long)n_rows, max_norm, flat, eps, (long long)first_private_row, out_f, out_norm);
+    return check_launch("clip_factors_kernel");
+}
+
+int cslgan_clip_accum_noise_f32(const cslgan_segs_t* segs, int64_t n_rows, const float* factors, int factors_per_seg,
+                                const float* noise_std, uint64_t seed, uint64_t offset, float scale, float beta,
+                                void* stream) {
+    CSLGAN_REQUIRE(segs, "clip_accum_noise: null segs");
+    CSLGAN_REQUIRE(segs->n_seg >= 1 && segs->n_seg <= CSLGAN_MAX_SEGS, "clip_accum_noise: n_seg=%d out of range", segs->n_seg);
+    CSLGAN_REQUIRE(n_rows >= 0, "clip_accum_noise: n_rows < 0");
+    CaArgs a;
+    a.n_seg = segs->n_seg;
+    int tot = 0;
+    for (int s = 0; s < CSLGAN_MAX_SEGS; ++s) {
+        if (s < segs->n_seg) {
+            CSLGAN_REQUIRE(segs->out[s] || segs->len[s] == 0, "clip_accum_noise: out[%d] is null", s);
+            CSLGAN_REQUIRE((segs->in[s] || n_rows == 0 || segs->len[s] == 0), "clip_accum_noise: in[%d] is null", s);
+            CSLGAN_REQUIRE(segs->len[s] >= 0 && (n_rows == 0 || segs->row_stride[s] >= segs->len[s]), "clip_accum_noise: bad len/stride in segment %d", s);
+            a.in[s] = segs->in[s]; a.out[s] = segs->out[s]; a.noise[s] = segs->noise[s];
+            a.len[s] = segs->len[s]; a.row_stride[s] = segs->row_stride[s];
+            a.vec_ok[s] = aligned16(segs->in[s]) && (segs->row_stride[s] % 4 == 0);
+            a.tile_prefix[s] = tot;
+            tot += (int)((segs->len[s] + CA_COLS - 1) / CA_COLS);
+        } else {
+            a.in[s] = nullptr; a.out[s] = nullptr; a.noise[s] = nullptr; a.len[s] = 0; a.row_stride[s] = 0; a.vec_ok[s] = 0;
+            a.tile_prefix[s] = tot;
+        }
+    }
+    a.tile_prefix[CSLGAN_MAX_SEGS] = tot;
+    for (int s = segs->n_seg; s <= CSLGAN_MAX_SEGS; ++s) a.tile_prefix[s] = tot;
+    if (tot == 0) return CSLGAN_OK;
+    hipLaunchKernelGGL(clip_accum_noise_kernel, dim3(tot), dim3(CA_THREADS), 0, (hipStream_t)stream, a, (long long)n_rows,
+                       factors, factors_per_seg, noise_std, (unsigned long long)seed, (unsigned long long)offset, scale, beta);
+    return check_launch("clip_accum_noise_kernel");
+}
+
+int cslgan_l2_clip_rows_f32(const float* in, float* out, int64_t n_rows, int64_t len, float C, float* norms_ws, void* stream) {
+    CSLGAN_REQUIRE(in && out && norms_ws, "l2_clip_rows: null argument");
+    CSLGAN_REQUIRE(n_rows >= 0 && n_rows <= 65535 && len >= 0, "l2_clip_rows: bad sizes");
+    if (n_rows == 0 || len == 0) return CSLGAN_OK;
+    const float* ins[1] = {in};
+    long long lens[1] = {len}, strides[1] = {len};
+    int rc = launch_sqnorm(ins, lens, strides, 1, n_rows, norms_ws, (hipStream_t)stream);
+    if (rc) return rc;
+    unsigned gx = (unsigned)((len + 1023) / 1024);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(l2_clip_scale_kernel, dim3(gx, (unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, in, out,
+                       (long long)n_rows, (long long)len, C, norms_ws);
+    return check_launch("l2_clip_scale_kernel");
+}
+
+int cslgan_row_l2norm_f32(const float* in, int64_t n_rows, int64_t len, float* out_norm, void* stream) {
+    CSLGAN_REQUIRE(in && out_norm, "row_l2norm: null argument");
+    CSLGAN_REQUIRE(n_rows >= 0 && n_rows <= 65535 && len >= 0, "row_l2norm: bad sizes");
+    if (n_rows == 0) return CSLGAN_OK;
+    const float* ins[1] = {in};
+    long long lens[1] = {len}, strides[1] = {len};
+    int rc = launch_sqnorm(ins, lens, strides, 1, n_rows, out_norm, (hipStream_t)stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sqrt_kernel, dim3((unsigned)((n_rows + 127) / 128)), dim3(128), 0, (hipStream_t)stream, out_norm, (long long)n_rows);
+    return check_launch("sqrt_kernel");
+}
+
+int cslgan_row_l2norm_bwd_f32(const float* in, const float* norm, const float* gnorm, int64_t n_rows, int64_t len,
+                              float* gin, void* stream) {
+    CSLGAN_REQUIRE(in && norm && gnorm && gin, "row_l2norm_bwd: null argument");
+    CSLGAN_REQUIRE(n_rows >= 0 && n_rows <= 65535 && len >= 0, "row_l2norm_bwd: bad sizes");
+    if (n_rows == 0 || len == 0) return CSLGAN_OK;
+    unsigned gx = (unsigned)((len + 1023) / 1024);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(row_l2norm_bwd_kernel, dim3(gx, (unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, in, norm, gnorm,
+                       (long long)len, gin);
+    return check_launch("row_l2norm_bwd_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,51 @@
+// Shared host/device helpers for libcslgan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/cslgan.h"
+
+namespace cslgan {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return CSLGAN_ERR_LAUNCH;
+    }
+    return CSLGAN_OK;
+}
+
+#define CSLGAN_REQUIRE(cond, ...)                 \
+    do {                                          \
+        if (!(cond)) {                            \
+            cslgan::set_error(__VA_ARGS__);       \
+            return CSLGAN_ERR_INVALID_ARG;        \
+        }                                         \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum for 256-thread blocks; result valid in thread 0.  red: 4 floats of LDS.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) r = red[0] + red[1] + red[2] + red[3];
+    return r;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace cslgan

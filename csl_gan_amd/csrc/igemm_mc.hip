@@ -1,0 +1,261 @@
+// fp32 MFMA grouped weight-gradient kernel ("M-contiguous" implicit GEMM).  gfx950 only.
+//
+//   gw[g][m][n] = alpha * sum_{k in group g} GY[k][m] * X(k, n)     k -> (img, oy, ox),  n -> (tap, c)
+//
+// group == 1 gives the per-sample gradients (p.grad_sample) that the reference obtains from the
+// Opacus-fork backward hooks (train.py:387; SURVEY.md §8 a7: unfold + einsum('noq,npq->nop')); the
+// per-group sum of squares is reduced in the epilogue (wavefront shuffle -> LDS -> one atomic), so
+// the separate norm pass over HBM disappears.  With gw == NULL only the norms are produced.
+//
+// The reduction index (pixels) is the strided one for both operands; a 16-byte global load is 4
+// consecutive m (output channels of GY) or 4 consecutive n (input channels of X) of one pixel, and
+// goes to a [k][m] LDS image; MFMA operands are ds_read_b32 (32 consecutive floats per half-wave:
+// conflict-free).  v_mfma_f32_32x32x2_f32, exact fp32.
+#include "common.h"
+#include "igemm.h"
+
+namespace cslgan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MC_BK = 16;
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC_A, bool VEC_B>
+__global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
+    constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
+    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "bad tile");
+    constexpr int A_PASS = (MC_BK * BM / 4) / 256, B_PASS = (MC_BK * BN / 4) / 256;
+    constexpr int A_ROWS = 256 / (BM / 4), B_ROWS = 256 / (BN / 4);  // k rows covered per pass
+    static_assert(A_PASS >= 1 && B_PASS >= 1, "tile too small");
+    __shared__ __attribute__((aligned(16))) float As[2][MC_BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][MC_BK * BN];
+    __shared__ float s_red[4];
+
+    const int tid = threadIdx.x;
+    const int per_g = p.tiles_m * p.tiles_n;
+    const int g = blockIdx.x / per_g;
+    const int tl = blockIdx.x - g * per_g;
+    const int tile_m = tl / p.tiles_n, tile_n = tl - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int PQ = p.P * p.Q;
+    const int Ktot = p.group * PQ;
+    const long long pix_base = (long long)g * p.group * PQ;
+
+    // A loader: thread -> (k row a_kr + A_ROWS*i, 4 channels at a_mc)
+    const int a_kr = tid / (BM / 4), a_mc = (tid % (BM / 4)) * 4;
+    const int b_kr = tid / (BN / 4), b_nc = (tid % (BN / 4)) * 4;
+    // B columns are fixed per thread: decode (tap, c) once
+    int b_ty[4], b_tx[4], b_c[4];
+    bool b_nok[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int n = n0 + b_nc + e;
+        b_nok[e] = n < p.Ndim;
+        const int t = b_nok[e] ? n / p.C : 0;
+        b_c[e] = n - t * p.C;
+        b_ty[e] = p.ty[t];
+        b_tx[e] = p.tx[t];
+    }
+
+    float4 ra[A_PASS], rb[B_PASS];
+
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_PASS; ++i) {
+            const int kk = kt * MC_BK + a_kr + A_ROWS * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kk < Ktot) {
+                const float* src = p.gy + (pix_base + kk) * p.Kc + m0 + a_mc;
+                if (VEC_A) {
+                    if (m0 + a_mc < p.Kc) v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (m0 + a_mc + 0 < p.Kc) v.x = src[0];
+                    if (m0 + a_mc + 1 < p.Kc) v.y = src[1];
+                    if (m0 + a_mc + 2 < p.Kc) v.z = src[2];
+                    if (m0 + a_mc + 3 < p.Kc) v.w = src[3];
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) {
+            const int kk = kt * MC_BK + b_kr + B_ROWS * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kk < Ktot) {
+                const int il = kk / PQ;
+                const int pix = kk - il * PQ;
+                const int oy = pix / p.Q, ox = pix - oy * p.Q;
+                const long long img = (long long)g * p.group + il;
+                const int by = oy * p.stride, bx = ox * p.stride;
+                if (VEC_B) {
+                    const int iy = by + b_ty[0], ix = bx + b_tx[0];
+                    if (b_nok[0] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                        v = *reinterpret_cast<const float4*>(p.x + ((img * p.H + iy) * p.W + ix) * p.C + b_c[0]);
+                } else {
+                    float t4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int iy = by + b_ty[e], ix = bx + b_tx[e];
+                        t4[e] = (b_nok[e] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                                    ? p.x[((img * p.H + iy) * p.W + ix) * p.C + b_c[e]] : 0.f;
+                    }
+                    v = make_float4(t4[0], t4[1], t4[2], t4[3]);
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_PASS; ++i) *reinterpret_cast<float4*>(&As[buf][(a_kr + A_ROWS * i) * BM + a_mc]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) *reinterpret_cast<float4*>(&Bs[buf][(b_kr + B_ROWS * i) * BN + b_nc]) = rb[i];
+    };
+
+    const int lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wid / WAVES_N, wn = wid - wm * WAVES_N;
+    const int arow0 = wm * TM * 32 + r, brow0 = wn * TN * 32 + r;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    const int nk = (Ktot + MC_BK - 1) / MC_BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        int krem = Ktot - kt * MC_BK;
+        if (krem > MC_BK) krem = MC_BK;
+        const int nsteps = (krem + 1) >> 1;
+#pragma unroll
+        for (int s = 0; s < MC_BK / 2; ++s) {
+            if (s < nsteps) {
+                const int kr = 2 * s + h;
+                float af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = As[buf][kr * BM + arow0 + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][kr * BN + brow0 + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: scale, store, per-group sum of squares ----------------------------------
+    float ss = 0.f;
+    float* __restrict__ outg = p.gw ? p.gw + (long long)g * p.Kc * p.Ndim : nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + r;
+        if (n >= p.Ndim) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = m0 + wm * TM * 32 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (m >= p.Kc) continue;
+                const float val = p.alpha * acc[i][j][v];
+                ss = fmaf(val, val, ss);
+                if (outg) outg[(long long)m * p.Ndim + n] = val;
+            }
+        }
+    }
+    if (p.sq) {
+        const float tot = block_sum_256(ss, s_red);
+        if (tid == 0) atomicAdd(p.sq + g, tot);
+    }
+}
+
+// gb[g][k] = alpha * sum over the group's pixels of gy[.,k]; one block per (group, 64-channel tile)
+__global__ __launch_bounds__(256) void bias_grad_grouped_kernel(const float* __restrict__ gy, int PQ, int K, int group,
+                                                                float alpha, float* __restrict__ gb, float* __restrict__ sq) {
+    __shared__ float part[4][64];
+    __shared__ float red[4];
+    const int g = blockIdx.y;
+    const int k = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sl = threadIdx.x >> 6;  // 4 pixel slices
+    const long long npix = (long long)group * PQ;
+    const float* base = gy + (long long)g * npix * K;
+    float acc = 0.f;
+    if (k < K)
+        for (long long px = sl; px < npix; px += 4) acc += base[px * K + k];
+    part[sl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    float ss = 0.f;
+    if (threadIdx.x < 64 && k < K) {
+        const float v = alpha * (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+        if (gb) gb[(long long)g * K + k] = v;
+        ss = v * v;
+    }
+    if (sq) {
+        const float tot = block_sum_256(ss, red);
+        if (threadIdx.x == 0) atomicAdd(sq + g, tot);
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_mc_tile(McParams& p, bool vecA, bool vecB, hipStream_t st) {
+    p.tiles_m = (p.Kc + BM - 1) / BM;
+    p.tiles_n = (p.Ndim + BN - 1) / BN;
+    const long long nb = (long long)p.n_groups * p.tiles_m * p.tiles_n;
+    if (nb > 0x7fffffffll) { set_error("wgrad: grid too large"); return CSLGAN_ERR_INVALID_ARG; }
+    const dim3 grid((unsigned)nb), block(256);
+    if (vecA && vecB) hipLaunchKernelGGL((igemm_mc_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, p);
+    else if (vecA) hipLaunchKernelGGL((igemm_mc_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, p);
+    else if (vecB) hipLaunchKernelGGL((igemm_mc_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_mc_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, p);
+    return check_launch("igemm_mc_kernel");
+}
+
+}  // namespace cslgan
+
+using namespace cslgan;
+
+extern "C" {
+
+int cslgan_conv2d_wgrad_grouped_f32(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha,
+                                    float* gw, float* sq, void* stream) {
+    CSLGAN_REQUIRE(c && gy && x, "conv2d_wgrad: null argument");
+    CSLGAN_REQUIRE(gw || sq, "conv2d_wgrad: neither gw nor sq requested");
+    CSLGAN_REQUIRE(!c->upsample, "conv2d_wgrad: upsample-on-read convs have no weight-gradient path yet");
+    CSLGAN_REQUIRE(group >= 1 && c->N % group == 0, "conv2d_wgrad: N=%d not divisible by group=%d", c->N, group);
+    CSLGAN_REQUIRE(c->R * c->S <= IG_MAX_TAPS, "conv2d_wgrad: too many taps");
+    const int P = (c->H + 2 * c->pad - c->R) / c->stride + 1, Q = (c->W + 2 * c->pad - c->S) / c->stride + 1;
+    CSLGAN_REQUIRE(P == c->P && Q == c->Q, "conv2d_wgrad: output %dx%d does not match P,Q=%d,%d", P, Q, c->P, c->Q);
+    McParams p{};
+    p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->P; p.Q = c->Q; p.Kc = c->K;
+    p.T = c->R * c->S; p.Ndim = p.T * c->C; p.stride = c->stride; p.group = group; p.n_groups = c->N / group;
+    p.alpha = alpha; p.gw = gw; p.sq = sq;
+    for (int t = 0; t < IG_MAX_TAPS; ++t) { p.ty[t] = 0; p.tx[t] = 0; }
+    for (int kh = 0; kh < c->R; ++kh)
+        for (int kw = 0; kw < c->S; ++kw) { p.ty[kh * c->S + kw] = (signed char)(kh - c->pad); p.tx[kh * c->S + kw] = (signed char)(kw - c->pad); }
+    const bool vecA = (c->K % 4 == 0) && aligned16(gy);
+    const bool vecB = (c->C % 4 == 0) && aligned16(x);
+    if (c->K > 64) return launch_mc_tile<128, 128, 2, 2>(p, vecA, vecB, (hipStream_t)stream);
+    return launch_mc_tile<64, 128, 1, 4>(p, vecA, vecB, (hipStream_t)stream);
+}
+
+int cslgan_bias_grad_grouped_f32(const float* gy, int N, int PQ, int K, int group, float alpha, float* gb, float* sq,
+                                 void* stream) {
+    CSLGAN_REQUIRE(gy && (gb || sq), "bias_grad: null argument");
+    CSLGAN_REQUIRE(N > 0 && PQ > 0 && K > 0 && group >= 1 && N % group == 0, "bias_grad: bad sizes");
+    CSLGAN_REQUIRE(N / group <= 65535, "bias_grad: too many groups");
+    hipLaunchKernelGGL(bias_grad_grouped_kernel, dim3((unsigned)((K + 63) / 64), (unsigned)(N / group)), dim3(256), 0,
+                       (hipStream_t)stream, gy, PQ, K, group, alpha, gb, sq);
+    return check_launch("bias_grad_grouped_kernel");
+}
+
+}  // extern "C"

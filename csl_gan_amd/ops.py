@@ -1,0 +1,242 @@
+"""Tensor-level wrappers over the C-ABI (include/cslgan.h).  torch is plumbing here: it owns the
+device memory and the stream; every kernel launched is hand-written HIP from csl_gan_amd/csrc.
+
+Layout convention: activations are NHWC-contiguous fp32 tensors of shape [N,H,W,C]; conv filters
+are [K,R,S,C].  Device tensors only — there is no CPU path in this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import ConvT, SegsT, check
+
+ACT_NONE, ACT_LRELU02, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a device tensor (csl_gan_amd.ops has no CPU path)" % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s must be float32, got %s" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    return t
+
+
+def conv_out_size(H, R, stride, pad, upsample=False):
+    VH = 2 * H if upsample else H
+    return (VH + 2 * pad - R) // stride + 1
+
+
+def _conv_desc(N, H, W, Cc, K, R, S, stride, pad, upsample):
+    P, Q = conv_out_size(H, R, stride, pad, upsample), conv_out_size(W, S, stride, pad, upsample)
+    return ConvT(N, H, W, Cc, K, R, S, stride, pad, 1 if upsample else 0, P, Q), P, Q
+
+
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, upsample=False, residual=None, res_shift=0, act=ACT_NONE, out=None):
+    """y[N,P,Q,K] = act(conv(x[N,H,W,C], w[K,R,S,C]) + bias [+ residual])."""
+    _chk(x, "x"); _chk(w, "w")
+    N, H, W, Cc = x.shape
+    K, R, S, C2 = w.shape
+    if C2 != Cc:
+        raise RuntimeError("conv2d_fwd: channel mismatch x C=%d, w C=%d" % (Cc, C2))
+    d, P, Q = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, upsample)
+    y = out if out is not None else torch.empty((N, P, Q, K), device=x.device, dtype=torch.float32)
+    if bias is not None:
+        _chk(bias, "bias")
+    if residual is not None:
+        _chk(residual, "residual")
+        exp = (N, P >> res_shift, Q >> res_shift, K)
+        if tuple(residual.shape) != exp:
+            raise RuntimeError("conv2d_fwd: residual shape %s, expected %s" % (tuple(residual.shape), exp))
+    check(_lib.lib().cslgan_conv2d_fwd_f32(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), res_shift, act, _p(y), _stream()),
+          "conv2d_fwd")
+    return y
+
+
+def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None):
+    """gx[N,H,W,C] = conv_transpose(gy[N,P,Q,K], w[K,R,S,C]) (* lrelu'(mask))."""
+    _chk(gy, "gy"); _chk(w, "w")
+    N, P, Q, K = gy.shape
+    K2, R, S, Cc = w.shape
+    H, W = in_hw
+    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, False)
+    if K2 != K or (P2, Q2) != (P, Q):
+        raise RuntimeError("conv2d_dgrad: gy shape %s inconsistent with input %dx%d" % (tuple(gy.shape), H, W))
+    gx = torch.empty((N, H, W, Cc), device=gy.device, dtype=torch.float32)
+    ws = torch.empty(w.numel(), device=gy.device, dtype=torch.float32)
+    if mask is not None:
+        _chk(mask, "mask")
+        if tuple(mask.shape) != tuple(gx.shape):
+            raise RuntimeError("conv2d_dgrad: mask shape mismatch")
+    check(_lib.lib().cslgan_conv2d_dgrad_f32(C.byref(d), _p(gy), _p(w), _p(ws), _p(mask), _p(gx), _stream()), "conv2d_dgrad")
+    return gx
+
+
+def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_gw=True, sq=None, out=None):
+    """gw[N/group,K,R,S,C] (per-group weight gradients) and/or sq[N/group] += ||alpha*gw_g||^2."""
+    _chk(gy, "gy"); _chk(x, "x")
+    N, H, W, Cc = x.shape
+    N2, P, Q, K = gy.shape
+    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, False)
+    if N2 != N or (P2, Q2) != (P, Q):
+        raise RuntimeError("conv2d_wgrad: gy %s inconsistent with x %s" % (tuple(gy.shape), tuple(x.shape)))
+    if N % group:
+        raise RuntimeError("conv2d_wgrad: N=%d not divisible by group=%d" % (N, group))
+    G = N // group
+    gw = None
+    if want_gw:
+        gw = out if out is not None else torch.empty((G, K, R, S, Cc), device=x.device, dtype=torch.float32)
+        _chk(gw, "gw")
+    if sq is not None:
+        _chk(sq, "sq")
+    check(_lib.lib().cslgan_conv2d_wgrad_grouped_f32(C.byref(d), _p(gy), _p(x), group, float(alpha), _p(gw), _p(sq), _stream()),
+          "conv2d_wgrad_grouped")
+    return gw
+
+
+def bias_grad_grouped(gy, group=1, alpha=1.0, want_gb=True, sq=None, out=None):
+    _chk(gy, "gy")
+    N, K = gy.shape[0], gy.shape[-1]
+    PQ = gy.numel() // (N * K)
+    gb = None
+    if want_gb:
+        gb = out if out is not None else torch.empty((N // group, K), device=gy.device, dtype=torch.float32)
+    check(_lib.lib().cslgan_bias_grad_grouped_f32(_p(gy), N, PQ, K, group, float(alpha), _p(gb), _p(sq), _stream()), "bias_grad")
+    return gb
+
+
+def _segs(ins: Sequence[torch.Tensor], outs=None, noises=None):
+    s = SegsT()
+    if len(ins) > _lib.MAX_SEGS:
+        raise RuntimeError("at most %d segments per launch" % _lib.MAX_SEGS)
+    s.n_seg = len(ins)
+    n_rows = ins[0].shape[0] if len(ins) else 0
+    for i, t in enumerate(ins):
+        _chk(t, "segment %d" % i)
+        if t.dim() != 2 or t.shape[0] != n_rows:
+            raise RuntimeError("segments must be 2-D [n_rows, len] with equal n_rows")
+        s.inp[i] = t.data_ptr()
+        s.len[i] = t.shape[1]
+        s.row_stride[i] = t.shape[1]
+        if outs is not None:
+            _chk(outs[i], "out %d" % i)
+            if outs[i].numel() != t.shape[1]:
+                raise RuntimeError("out %d has %d elements, expected %d" % (i, outs[i].numel(), t.shape[1]))
+            s.out[i] = outs[i].data_ptr()
+        if noises is not None and noises[i] is not None:
+            _chk(noises[i], "noise %d" % i)
+            if noises[i].numel() != t.shape[1]:
+                raise RuntimeError("noise %d size mismatch" % i)
+            s.noise[i] = noises[i].data_ptr()
+    return s, n_rows
+
+
+def sample_sqnorm(mats: Sequence[torch.Tensor]) -> torch.Tensor:
+    """mats: list of [n_rows, len_i] -> [n_seg, n_rows] squared row norms (all segments in one launch)."""
+    outs = []
+    for i in range(0, len(mats), _lib.MAX_SEGS):
+        chunk = list(mats[i:i + _lib.MAX_SEGS])
+        s, n_rows = _segs(chunk)
+        o = torch.empty((len(chunk), n_rows), device=chunk[0].device, dtype=torch.float32)
+        check(_lib.lib().cslgan_sample_sqnorm_f32(C.byref(s), n_rows, _p(o), _stream()), "sample_sqnorm")
+        outs.append(o)
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+
+def clip_factors(sq, max_norm, flat, eps=1e-6, first_private_row=0, want_norms=False):
+    """sq [n_seg,n_rows], max_norm device tensor [1] (flat) or [n_seg] -> factors ([n_rows] | [n_seg,n_rows])."""
+    _chk(sq, "sq"); _chk(max_norm, "max_norm")
+    n_seg, n_rows = sq.shape
+    if max_norm.numel() != (1 if flat else n_seg):
+        raise RuntimeError("clip_factors: max_norm has %d entries" % max_norm.numel())
+    shape = (n_rows,) if flat else (n_seg, n_rows)
+    f = torch.empty(shape, device=sq.device, dtype=torch.float32)
+    nrm = torch.empty(shape, device=sq.device, dtype=torch.float32) if want_norms else None
+    check(_lib.lib().cslgan_clip_factors_f32(_p(sq), n_seg, n_rows, _p(max_norm), 1 if flat else 0, float(eps),
+                                             int(first_private_row), _p(f), _p(nrm), _stream()), "clip_factors")
+    return (f, nrm) if want_norms else f
+
+
+def clip_accum_noise(mats, outs, factors=None, noise_std=None, noises=None, seed=0, offset=0, scale=1.0, beta=0.0):
+    """outs[i] = beta*outs[i] + scale*(sum_r f_r * mats[i][r] + noise_std[i]*z_i)."""
+    for i in range(0, len(mats), _lib.MAX_SEGS):
+        sl = slice(i, i + _lib.MAX_SEGS)
+        s, n_rows = _segs(list(mats[sl]), list(outs[sl]), None if noises is None else list(noises[sl]))
+        per_seg = 0
+        f = None
+        if factors is not None:
+            _chk(factors, "factors")
+            if factors.dim() == 2:
+                per_seg = 1
+                f = factors[sl].contiguous() if i or len(mats) > _lib.MAX_SEGS else factors
+            else:
+                f = factors
+        ns = None
+        if noise_std is not None:
+            _chk(noise_std, "noise_std")
+            ns = noise_std[sl].contiguous() if i or len(mats) > _lib.MAX_SEGS else noise_std
+        check(_lib.lib().cslgan_clip_accum_noise_f32(C.byref(s), n_rows, _p(f), per_seg, _p(ns), int(seed), int(offset) + i,
+                                                     float(scale), float(beta), _stream()), "clip_accum_noise")
+
+
+def l2_clip_rows(t, Cval):
+    _chk(t, "t")
+    n = t.shape[0]
+    flat = t.reshape(n, -1)
+    out = torch.empty_like(flat)
+    ws = torch.empty(n, device=t.device, dtype=torch.float32)
+    check(_lib.lib().cslgan_l2_clip_rows_f32(_p(flat), _p(out), n, flat.shape[1], float(Cval), _p(ws), _stream()), "l2_clip_rows")
+    return out.reshape(t.shape)
+
+
+def row_l2norm(t2d):
+    _chk(t2d, "t")
+    n, L = t2d.shape
+    out = torch.empty(n, device=t2d.device, dtype=torch.float32)
+    check(_lib.lib().cslgan_row_l2norm_f32(_p(t2d), n, L, _p(out), _stream()), "row_l2norm")
+    return out
+
+
+def row_l2norm_bwd(t2d, norm, gnorm):
+    _chk(t2d, "t"); _chk(norm, "norm"); _chk(gnorm, "gnorm")
+    n, L = t2d.shape
+    out = torch.empty_like(t2d)
+    check(_lib.lib().cslgan_row_l2norm_bwd_f32(_p(t2d), _p(norm), _p(gnorm), n, L, _p(out), _stream()), "row_l2norm_bwd")
+    return out
+
+
+def act_bwd(g, y, slope):
+    _chk(g, "g"); _chk(y, "y")
+    out = torch.empty_like(g)
+    check(_lib.lib().cslgan_act_bwd_f32(_p(g), _p(y), g.numel(), float(slope), _p(out), _stream()), "act_bwd")
+    return out
+
+
+def groupnorm_act(x, gamma, beta, groups, eps=1e-5, relu=True):
+    _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    N, H, W, Cc = x.shape
+    y = torch.empty_like(x)
+    ws = torch.empty(2 * N * groups, device=x.device, dtype=torch.float32)
+    check(_lib.lib().cslgan_groupnorm_act_f32(_p(x), _p(gamma), _p(beta), N, H * W, Cc, groups, float(eps), 1 if relu else 0,
+                                              _p(ws), _p(y), _stream()), "groupnorm_act")
+    return y
+
+
+def adam_step(p, g, m, v, lr, b1, b2, eps, weight_decay, step):
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, n)
+    check(_lib.lib().cslgan_adam_step_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(b1), float(b2), float(eps),
+                                          float(weight_decay), int(step), _stream()), "adam_step")

@@ -1,0 +1,151 @@
+/*
+ * cslgan.h — C-ABI of libcslgan_hip.so: the MI355X (gfx950) kernels behind the csl-gan
+ * DP discriminator step.
+ *
+ * The reference (twosixlabs/csl-gan) is pure Python and has no FFI layer: the boundary a
+ * maintainer binds is the set of PyTorch / Opacus-fork calls its D-step makes.  Every entry
+ * point below names the reference call (file:line under /root/reference) whose device work
+ * it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain C types only: device pointers are void* / float*, sizes are int / int64_t,
+ *     the stream is the raw hipStream_t handle passed as void* (0 = default stream);
+ *   - every function returns 0 on success or a negative cslgan_status; the message of the
+ *     last failure on the calling thread is returned by cslgan_last_error();
+ *   - all work is enqueued asynchronously on the given stream; the library never allocates,
+ *     frees or synchronises (graph-capturable).  Workspaces are caller-owned;
+ *   - activations are NHWC fp32 ("channels last"): x[n][h][w][c]; conv weights are
+ *     KRSC: w[cout][kh][kw][cin] (the memory of a torch channels_last [cout,cin,kh,kw] tensor).
+ */
+#ifndef CSLGAN_H
+#define CSLGAN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSLGAN_ABI_VERSION 1
+
+typedef enum {
+    CSLGAN_OK = 0,
+    CSLGAN_ERR_INVALID_ARG = -1,   /* bad shape / null pointer / unsupported configuration */
+    CSLGAN_ERR_LAUNCH = -2,        /* hipLaunchKernel / hipMemsetAsync reported an error */
+    CSLGAN_ERR_NO_DEVICE = -3      /* no gfx950 device visible */
+} cslgan_status;
+
+/* activation / epilogue codes for cslgan_conv2d_* */
+enum { CSLGAN_ACT_NONE = 0, CSLGAN_ACT_LRELU02 = 1, CSLGAN_ACT_RELU = 2, CSLGAN_ACT_TANH = 3 };
+
+#define CSLGAN_MAX_SEGS 16
+
+/* A batch of row-major [n_rows, len[i]] matrices (one per parameter tensor): the materialised
+ * per-sample gradients p.grad_sample viewed as [passes*B, numel(p)]  (train.py:233,311-315). */
+typedef struct {
+    int32_t n_seg;
+    int32_t _pad;
+    const float* in[CSLGAN_MAX_SEGS];      /* device, [n_rows, len] with row stride row_stride */
+    float* out[CSLGAN_MAX_SEGS];           /* device, [len]            (clip_accum only)       */
+    const float* noise[CSLGAN_MAX_SEGS];   /* device, [len] pre-drawn N(0,1) or NULL -> Philox  */
+    int64_t len[CSLGAN_MAX_SEGS];
+    int64_t row_stride[CSLGAN_MAX_SEGS];   /* in elements */
+} cslgan_segs_t;
+
+int cslgan_version(void);
+const char* cslgan_last_error(void);
+/* number of visible HIP devices (>=0) or a negative status */
+int cslgan_device_count(void);
+
+/* ---- per-sample norm / clip / noise  (the fused DP kernel family) ------------------------ */
+
+/* out_sq[s * n_rows + r] = sum_j in[s][r][j]^2.  Replaces
+ * opacus.utils.tensor_utils.calc_sample_norms (train.py:311-314) and the norm half of
+ * privacy_engine.clip() (train.py:399).  out_sq is overwritten (zeroed on-stream first). */
+int cslgan_sample_sqnorm_f32(const cslgan_segs_t* segs, int64_t n_rows, float* out_sq, void* stream);
+
+/* Clip factors from squared norms:  f = min(1, C / (sqrt(sq) + eps)).
+ *   flat != 0 : one factor per row from the all-segment norm; max_norm[0] is C; out_f is [n_rows]
+ *   flat == 0 : per segment; max_norm[s] is C_s; out_f is [n_seg, n_rows]
+ * rows < first_private_row get factor 1 (split mode: the generated-data pass is not clipped,
+ * train.py:112-113).  out_norm (nullable) receives the norms ([1 or n_seg, n_rows]).
+ * Replaces norm_clipper.calc_clipping_factors (train.py:324). max_norm is a DEVICE pointer. */
+int cslgan_clip_factors_f32(const float* sq, int n_seg, int64_t n_rows, const float* max_norm, int flat,
+                            float eps, int64_t first_private_row, float* out_f, float* out_norm, void* stream);
+
+/* out[s][j] = beta*out[s][j] + scale * ( sum_r f(s,r) * in[s][r][j] + noise_std[s] * z[s][j] )
+ *   factors: device [n_rows] (factors_per_seg==0) or [n_seg,n_rows] (factors_per_seg!=0), NULL -> 1
+ *   noise_std: DEVICE [n_seg] or NULL (no noise); z from segs->noise[s] when given, else
+ *   Philox4x32-10 + Box-Muller keyed by (seed, offset, s, j).
+ * Replaces privacy_engine.clip() + accum_grads_across_passes() (train.py:399-402) and, with
+ * noise/scale, the engine-wrapped d_optimizer.step() noise + 1/B (train.py:484). */
+int cslgan_clip_accum_noise_f32(const cslgan_segs_t* segs, int64_t n_rows, const float* factors,
+                                int factors_per_seg, const float* noise_std, uint64_t seed, uint64_t offset,
+                                float scale, float beta, void* stream);
+
+/* backprop_clip.py:18-22 l2_clip: rows with ||t_r|| > C are scaled to norm C (no epsilon).
+ * in/out may alias.  norms_ws: caller workspace [n_rows] floats. */
+int cslgan_l2_clip_rows_f32(const float* in, float* out, int64_t n_rows, int64_t len, float C,
+                            float* norms_ws, void* stream);
+
+/* Row L2 norms of a [n_rows, len] matrix (gradient_penalty.py:52-53) and the backward of
+ * norm: gin[r][j] = gnorm[r] * in[r][j] / norm[r]. */
+int cslgan_row_l2norm_f32(const float* in, int64_t n_rows, int64_t len, float* out_norm, void* stream);
+int cslgan_row_l2norm_bwd_f32(const float* in, const float* norm, const float* gnorm, int64_t n_rows,
+                              int64_t len, float* gin, void* stream);
+
+/* ---- convolution family: fp32 MFMA implicit GEMM ------------------------------------------ */
+
+typedef struct {
+    int32_t N, H, W, C;          /* input  x[N][H][W][C]  (for upsample: the LOW-res input) */
+    int32_t K, R, S;             /* filter w[K][R][S][C]                                     */
+    int32_t stride, pad;
+    int32_t upsample;            /* 1: nearest-2x upsample of x is applied on read (DCResNet_models.py:13-16) */
+    int32_t P, Q;                /* output y[N][P][Q][K]                                     */
+} cslgan_conv_t;
+
+/* y = act(conv(x, w) + bias) [+ residual].  Replaces torch.nn.Conv2d / nn.Linear forward at
+ * DCResNet_models.py:131-132,145 (D), :13-17,:60-70,:95-104 (G), MNIST_models.py:41-46.
+ *   bias      : [K] or NULL
+ *   residual  : NULL or r[N][P>>res_shift][Q>>res_shift][K], added before act (res_shift 0/1)
+ * A Linear layer is the 1x1 case H=W=P=Q=R=S=1. */
+int cslgan_conv2d_fwd_f32(const cslgan_conv_t* p, const float* x, const float* w, const float* bias,
+                          const float* residual, int res_shift, int act, float* y, void* stream);
+
+/* gx = conv_transpose(gy, w) [* lrelu'(mask)]: the data gradient (autograd of the conv above;
+ * "conv_transpose2d" in the north star).  wt_ws: caller workspace of K*R*S*C floats receiving
+ * the repacked filters.  mask (nullable) has gx's shape: gx *= (mask > 0 ? 1 : 0.2). */
+int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* p, const float* gy, const float* w, float* wt_ws,
+                            const float* mask, float* gx, void* stream);
+
+/* Grouped weight gradient:  gw[g][k][r][s][c] = alpha * sum_{n in group g} sum_{p,q} gy[n,p,q,k] x[n,..,c]
+ * with groups of `group` consecutive samples (N % group == 0).
+ *   group == 1 -> per-sample gradients p.grad_sample (Opacus hook, train.py:387)
+ *   gw == NULL -> norms only ("ghost" mode)
+ *   sq (nullable): [N/group] += sum of squares of alpha*gw[g]  (caller zeroes)
+ * The dense gradient is group == N, or any group followed by cslgan_clip_accum_noise_f32. */
+int cslgan_conv2d_wgrad_grouped_f32(const cslgan_conv_t* p, const float* gy, const float* x, int group,
+                                    float alpha, float* gw, float* sq, void* stream);
+
+/* Per-group bias gradient gb[g][k] = alpha * sum_{n in g, p, q} gy[n,p,q,k]; sq as above. */
+int cslgan_bias_grad_grouped_f32(const float* gy, int N, int PQ, int K, int group, float alpha,
+                                 float* gb, float* sq, void* stream);
+
+/* ---- pointwise / normalisation ------------------------------------------------------------- */
+
+/* out = g * (y > 0 ? 1 : slope)   (LeakyReLU / ReLU backward from the OUTPUT y) */
+int cslgan_act_bwd_f32(const float* g, const float* y, int64_t n, float slope, float* out, void* stream);
+
+/* GroupNorm(groups) + optional ReLU on NHWC x[N][HW][C] (DCResNet_models.py:55-57,63-67,101-102).
+ * stats_ws: caller workspace [2*N*groups] floats (mean, rstd). */
+int cslgan_groupnorm_act_f32(const float* x, const float* gamma, const float* beta, int N, int HW, int C,
+                             int groups, float eps, int relu, float* stats_ws, float* y, void* stream);
+
+/* Adam (torch.optim.Adam semantics, train.py:76): in-place on p, m, v.  step is 1-based. */
+int cslgan_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                         float b2, float eps, float weight_decay, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSLGAN_H */

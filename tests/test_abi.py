@@ -1,0 +1,60 @@
+"""CPU-side checks of the C-ABI library: it builds for gfx950, loads, and exports every symbol that
+include/cslgan.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from csl_gan_amd import build
+    return build.build()
+
+
+def test_header_symbols_are_exported(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "cslgan.h")).read()
+    declared = set(re.findall(r"\b(cslgan_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 16
+    L = ctypes.CDLL(built_lib)
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    from csl_gan_amd import _lib
+    assert set(_lib.EXPORTS) == declared
+
+
+def test_library_loads_and_reports_version(built_lib):
+    from csl_gan_amd import _lib
+    L = _lib.lib()
+    assert L.cslgan_version() == 1
+    assert L.cslgan_device_count() >= 0
+    assert isinstance(L.cslgan_last_error(), bytes)
+
+
+def test_invalid_arguments_fail_loudly_without_gpu(built_lib):
+    """Argument validation happens on the host before any launch: safe to call without a device."""
+    from csl_gan_amd import _lib
+    L = _lib.lib()
+    rc = L.cslgan_sample_sqnorm_f32(None, 4, None, None)
+    assert rc == -1 and b"null" in L.cslgan_last_error()
+    d = _lib.ConvT(1, 8, 8, 4, 4, 5, 5, 2, 2, 0, 99, 99)
+    rc = L.cslgan_conv2d_fwd_f32(ctypes.byref(d), 1, 1, None, None, 0, 0, 1, None)
+    assert rc == -1 and b"does not match" in L.cslgan_last_error()
+
+
+def test_ops_refuse_cpu_tensors(built_lib):
+    import torch
+    from csl_gan_amd import ops
+    with pytest.raises(RuntimeError, match="device tensor"):
+        ops.conv2d_fwd(torch.zeros(1, 4, 4, 4), torch.zeros(4, 3, 3, 4))
+
+
+def test_missing_library_raises(monkeypatch, tmp_path):
+    from csl_gan_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.HipLibraryMissing):
+        _lib.lib()

@@ -1,0 +1,142 @@
+"""Deep-conv ResNet GAN stacks (reference DCResNet_models.py) on the HIP kernels.
+
+Same class names, constructor arguments, sub-module names (state_dict keys) and construction
+order (weights_seed parity) as the reference; device tensors run NHWC through
+csl_gan_amd.nn.HipConv2d / HipLinear / HipGroupNormAct.
+
+MI355X-first differences, all exact re-associations of the reference arithmetic:
+  * UpsampleConv never materialises the cat+pixel_shuffle tensor (DCResNet_models.py:14-15): the
+    conv kernel reads x[h>>1][w>>1] directly.
+  * the 1x1 shortcut conv runs at the LOW resolution (a 1x1 conv commutes with nearest upsampling)
+    and is added in the epilogue of the block's last conv;
+  * bias, LeakyReLU(0.2) / tanh are conv-kernel epilogues; GroupNorm+ReLU is one op.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import functional as HF
+from . import ops
+from .models import Discriminator, Generator
+from .nn import HipConv2d, HipGroupNormAct, HipLinear
+
+
+class UpsampleConv(nn.Module):
+    """Nearest 2x upsample followed by a 'same' conv (DCResNet_models.py:8-17)."""
+
+    def __init__(self, in_ch, out_ch, filter_size, bias=True):
+        super().__init__()
+        self.conv = HipConv2d(in_ch, out_ch, filter_size, padding="same", bias=bias, upsample=True)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class _BatchNormAct(nn.BatchNorm2d):
+    """BatchNorm2d + ReLU for the bn=True generator (non-per-sample modes).  CPU only for now."""
+
+    def forward_nhwc(self, x):
+        raise NotImplementedError("BatchNorm generator (dp_mode is / none) has no HIP kernel yet; "
+                                  "per-sample-gradient modes use GroupNorm (init_util.py:46)")
+
+    def forward(self, x):
+        if x.is_cuda:
+            return HF.nchw_view(self.forward_nhwc(HF.nhwc(x)))
+        return F.relu(super().forward(x))
+
+
+def _norm_act(bn, ch):
+    return _BatchNormAct(ch) if bn else HipGroupNormAct(32, ch, relu=True)
+
+
+class ResBlockUp(nn.Module):
+    """DCResNet_models.py:19-38.  Sub-module creation order is part of the weights_seed contract."""
+
+    def __init__(self, in_ch, out_ch, filter_size, bn=True):
+        super().__init__()
+        self.shortcut = UpsampleConv(in_ch, out_ch, 1)
+        self.bn1 = _norm_act(bn, in_ch)
+        self.convUp = UpsampleConv(in_ch, out_ch, filter_size, bias=False)
+        self.bn2 = _norm_act(bn, out_ch)
+        self.conv = HipConv2d(out_ch, out_ch, filter_size, padding="same")
+
+    def forward_nhwc(self, x):
+        sc = self.shortcut.conv
+        # 1x1 conv at low resolution; upsampled on the fly by the last conv's residual read
+        s_low = HF.Conv.apply(x, sc.weight.permute(0, 2, 3, 1).contiguous(), sc.bias, 1, 0, ops.ACT_NONE, False, None, 0)
+        o = self.convUp.conv.forward_nhwc(self.bn1.forward_nhwc(x))
+        return self.conv.forward_nhwc(self.bn2.forward_nhwc(o), residual=s_low, res_shift=1)
+
+    def forward(self, x):
+        if x.is_cuda:
+            return HF.nchw_view(self.forward_nhwc(HF.nhwc(x)))
+        return self.conv(self.bn2(self.convUp(self.bn1(x)))) + self.shortcut(x)
+
+
+class DCResNetGenerator(Generator):
+    def __init__(self, channels, first_filter_size, **kwargs):
+        super().__init__(**kwargs)
+        self.first_filter_size = first_filter_size
+        extra = self.n_classes if self.emb_mode == "concat" else 0
+        self.linIn = HipLinear(self.z_dim + extra, first_filter_size ** 2 * channels[0])
+        self.blocks = nn.ModuleList([ResBlockUp(a, b, 5, bn=self.bn) for a, b in zip(channels[:-1], channels[1:])])
+        self.bn = _norm_act(self.bn, channels[-1])
+        self.convOut = HipConv2d(channels[-1], self.out_ch, 3, padding="same", act=ops.ACT_TANH)
+
+    def forward(self, z, y=None):
+        f = self.first_filter_size
+        x = self.linIn(self._condition(z, y)).reshape(z.size(0), -1, f, f)
+        if not x.is_cuda:
+            for blk in self.blocks:
+                x = blk(x)
+            return self.convOut(self.bn(x))
+        x = HF.nhwc(x)
+        for blk in self.blocks:
+            x = blk.forward_nhwc(x)
+        return HF.nchw_view(self.convOut.forward_nhwc(self.bn.forward_nhwc(x)))
+
+    def loss(self, d_output, device):
+        return -torch.mean(d_output)
+
+
+class DCResNetDiscriminator(Discriminator):
+    def __init__(self, channels, last_filter_size, **kwargs):
+        super().__init__(**kwargs)
+        channels = list(channels)       # the reference mutates its default list (DCResNet_models.py:115); we copy
+        if self.emb_mode == "concat" and self.n_classes > 1:
+            channels[0] += self.n_classes
+        self.blocks = nn.ModuleList([HipConv2d(a, b, 5, stride=2, padding=2, act=ops.ACT_LRELU02)
+                                     for a, b in zip(channels[:-1], channels[1:])])
+        size = channels[-1] * last_filter_size ** 2
+        if self.n_classes < 2 or self.conditional_arch != "WCGAN":
+            self.linOut = HipLinear(size, 1, bias=False)
+        if self.n_classes > 1 and self.conditional_arch in ("ACGAN", "WCGAN"):
+            self.linOutAux = HipLinear(size, self.n_classes, bias=True)
+
+    def forward(self, x, y=None, aux=True):
+        B = x.size(0)
+        o = x
+        if self.emb_mode == "concat" and self.n_classes > 1:
+            planes = F.one_hot(y, self.n_classes).to(x.dtype).view(B, -1, 1, 1).expand(-1, -1, x.size(2), x.size(3))
+            o = torch.cat((x, planes), dim=1)
+        if o.is_cuda:
+            o = HF.nhwc(o)
+            for blk in self.blocks:
+                o = blk.forward_nhwc(o)             # conv + bias + LeakyReLU(0.2) in one kernel
+            o = HF.nchw_view(o)
+        else:
+            for blk in self.blocks:
+                o = blk(o)
+        o = o.reshape(B, -1)                        # (c,h,w) feature order, as the reference's linOut expects
+        out_aux = self.linOutAux(o) if aux and hasattr(self, "linOutAux") else None
+        if out_aux is not None and self.conditional_arch == "WCGAN":
+            out = (out_aux * F.one_hot(y, self.n_classes)).sum(dim=1)
+        else:
+            out = self.linOut(o)
+        return out, out_aux
+
+    def real_loss(self, output, device):
+        return -torch.mean(output)
+
+    def fake_loss(self, output, device):
+        return torch.mean(output)

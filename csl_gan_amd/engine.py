@@ -1,0 +1,412 @@
+"""DP engine with the surface the reference's train.py uses from the twosixlabs Opacus fork.
+
+The fork is absent and unpinned (requirements.txt:9); what is implemented is the specification
+SURVEY.md §8 (a7)-(a10),(b) derives from the reference's call sites (cited per method).  All
+arithmetic on device tensors runs on the HIP kernels of libcslgan_hip.so.
+
+Data layout in HBM (288 GB per GPU — per-sample gradients are materialised, not recomputed):
+  grad_sample buffer of a parameter : [n_passes, B, numel(p)] fp32 in the parameter's own memory
+      order (conv filters KRSC), exposed as ``p.grad_sample`` with logical shape [n_passes, B, *p.shape];
+  squared norms                     : [n_layers, n_passes * B] — accumulated by the wgrad kernel's
+      epilogue while it writes grad_sample (no separate norm pass over HBM);
+  p.summed_grad                     : same shape/strides as p.
+"""
+from __future__ import annotations
+
+import types
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import accountant, ops
+from .nn import HipConv2d, HipLinear
+
+CLIP_EPS = 1e-6
+
+
+class HipAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (train.py:76) on the cslgan_adam_step_f32 kernel for device
+    parameters; CPU parameters (configs[0] plumbing) use the same update written with torch ops."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for grp in self.param_groups:
+            b1, b2 = grp["betas"]
+            for p in grp["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad
+                if p.is_cuda:
+                    if g.stride() != p.stride() or not _dense(p):
+                        g = _like_layout(g, p)
+                    ops.adam_step(_flat(p), _flat(g), _flat(st["exp_avg"]), _flat(st["exp_avg_sq"]), grp["lr"], b1, b2,
+                                  grp["eps"], grp["weight_decay"], st["step"])
+                else:
+                    if grp["weight_decay"]:
+                        g = g.add(p, alpha=grp["weight_decay"])
+                    m, v, t = st["exp_avg"], st["exp_avg_sq"], st["step"]
+                    m.mul_(b1).add_(g, alpha=1 - b1)
+                    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+                    denom = (v.sqrt() / (1 - b2 ** t) ** 0.5).add_(grp["eps"])
+                    p.addcdiv_(m, denom, value=-grp["lr"] / (1 - b1 ** t))
+
+
+def _dense(t):
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
+def _flat(t: torch.Tensor) -> torch.Tensor:
+    """1-D alias of a dense tensor's memory (contiguous or channels-last), no copy."""
+    if t.is_contiguous():
+        return t.view(-1)
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return t.permute(0, 2, 3, 1).reshape(-1)
+    raise RuntimeError("tensor is not dense in memory")
+
+
+def _like_layout(g, p):
+    out = torch.empty_like(p, memory_format=torch.preserve_format)
+    out.copy_(g)
+    return out
+
+
+def calc_sample_norms(named_params, flat=True):
+    """opacus.utils.tensor_utils.calc_sample_norms (train.py:311-314): list of [n_passes, B] norms,
+    one per parameter or a single all-parameter norm when flat."""
+    gs = [g for _, g in named_params]
+    if not gs:
+        return []
+    if not gs[0].is_cuda:
+        per = [g.reshape(g.size(0), g.size(1), -1).norm(2, dim=2) for g in gs]
+    else:
+        shp = gs[0].shape[:2]
+        sq = ops.sample_sqnorm([_rows(g) for g in gs])
+        per = [s.reshape(shp) for s in sq.sqrt()]
+    if flat:
+        return [torch.stack(per, 0).norm(2, dim=0)]
+    return per
+
+
+def _rows(g: torch.Tensor) -> torch.Tensor:
+    """[n_passes, B, ...] grad_sample (possibly a permuted view of a dense buffer) -> dense [n_passes*B, numel]."""
+    base = getattr(g, "_cslgan_rows", None)
+    if base is not None:
+        return base
+    n = g.size(0) * g.size(1)
+    if g.dim() == 6 and not g.is_contiguous():
+        g = g.permute(0, 1, 2, 4, 5, 3)     # logical [P,B,K,C,R,S] view of KRSC memory -> memory order
+    return g.contiguous().reshape(n, -1)
+
+
+class _NormClipper:
+    def __init__(self, engine):
+        self._e = engine
+
+    @property
+    def is_per_layer(self):
+        return self._e._per_layer
+
+    def calc_clipping_factors(self, norms):
+        """train.py:324-328: one [n_passes, B] factor tensor per entry of `norms`."""
+        C = self._e.max_grad_norm
+        if self.is_per_layer:
+            return [(float(c) / (n + CLIP_EPS)).clamp(max=1.0) for n, c in zip(norms, C)]
+        return [(float(C) / (n + CLIP_EPS)).clamp(max=1.0) for n in norms]
+
+
+class _Clipper:
+    def __init__(self, engine):
+        self._e = engine
+        self.norm_clipper = _NormClipper(engine)
+
+    def _named_grad_samples(self):
+        return [(n, p.grad_sample) for n, p in self._e.module.named_parameters() if hasattr(p, "grad_sample")]
+
+
+class _LayerCollector:
+    """Receives (gz, x) from a layer's backward and launches the per-sample wgrad kernels."""
+
+    def __init__(self, engine, layer):
+        self.e, self.layer = engine, layer
+
+    def collect(self, pass_idx, gz, x, R, S, stride, pad, has_bias):
+        e, layer = self.e, self.layer
+        B = x.shape[0]
+        n_pass = e._fwd_count[layer]
+        scale = float(B) if e.loss_reduction == "mean" else 1.0
+        w = layer.weight
+        K, Cc = gz.shape[-1], x.shape[-1]
+        buf, sq = e._buffers(w, n_pass, B, K * R * S * Cc)
+        ops.conv2d_wgrad_grouped(gz, x, R, S, stride=stride, pad=pad, group=1, alpha=scale,
+                                 out=buf[pass_idx].view(B, K, R, S, Cc), sq=sq[pass_idx])
+        if isinstance(layer, nn.Conv2d):
+            view = buf.view(n_pass, B, K, R, S, Cc).permute(0, 1, 2, 5, 3, 4)
+        else:
+            view = buf.view(n_pass, B, K, Cc)
+        view._cslgan_rows = buf.view(n_pass * B, -1)
+        w.grad_sample = view
+        if has_bias:
+            b = layer.bias
+            bbuf, bsq = e._buffers(b, n_pass, B, K)
+            ops.bias_grad_grouped(gz, group=1, alpha=scale, out=bbuf[pass_idx], sq=bsq[pass_idx])
+            bview = bbuf.view(n_pass, B, K)
+            bview._cslgan_rows = bbuf.view(n_pass * B, K)
+            b.grad_sample = bview
+
+
+class PrivacyEngine:
+    """Gradient-clipping DP engine (train.py:110-116 constructor call)."""
+
+    def __init__(self, module, batch_size, sample_size, alphas, noise_multiplier, max_grad_norm,
+                 accum_passes=True, num_private_passes=None, auto_clip_and_accum_on_step=True,
+                 loss_reduction="mean", world_size=1, **_unused):
+        self.module = module
+        self.batch_size, self.sample_size = batch_size, sample_size
+        self.alphas = list(alphas)
+        self.noise_multiplier = noise_multiplier
+        self.accum_passes, self.num_private_passes = accum_passes, num_private_passes
+        self.auto_clip_and_accum_on_step = auto_clip_and_accum_on_step
+        self.loss_reduction = loss_reduction
+        self.world_size = world_size            # ranks sharing the step
+        self.sample_rate = batch_size * world_size / sample_size
+        self.steps = 0
+        self.enabled = True                     # PerSampleSink.enabled
+        self.params = list(module.parameters())
+        if any(not p.is_cuda for p in self.params):
+            raise RuntimeError("PrivacyEngine needs the discriminator on a HIP device: per-sample gradients, clip and "
+                               "noise run on libcslgan_hip.so and there is no CPU path")
+        self.layers = [m for m in module.modules() if isinstance(m, (HipConv2d, HipLinear))]
+        covered = {id(p) for l in self.layers for p in l.parameters(recurse=False)}
+        missing = [n for n, p in module.named_parameters() if id(p) not in covered]
+        if missing:
+            raise RuntimeError("PrivacyEngine: parameters outside HipConv2d/HipLinear layers: %s" % missing)
+        for l in self.layers:
+            l._sink = self
+        self._collectors = {l: _LayerCollector(self, l) for l in self.layers}
+        self._fwd_count = {l: 0 for l in self.layers}
+        self._bufs = {}
+        self.clipper = _Clipper(self)
+        self.set_max_grad_norm(max_grad_norm)
+        self.seed, self._noise_calls = 0, 0
+        self.host_noise_generator: Optional[torch.Generator] = None   # parity mode: noise drawn on the host
+        self.host_noise = None                  # parity tests: explicit unit normals, one flat tensor per parameter
+        self.optimizer = None
+        self._accumulated = False
+        self.grad_reducer = None                # set by csl_gan_amd.distributed for N>1
+
+    # -- PerSampleSink ----------------------------------------------------------------------
+    def next_pass(self, layer):
+        i = self._fwd_count[layer]
+        self._fwd_count[layer] = i + 1
+        return i
+
+    def collector(self, layer):
+        return self._collectors[layer]
+
+    def _buffers(self, p, n_pass, B, numel):
+        key = id(p)
+        cur = self._bufs.get(key)
+        if cur is None or cur[0].shape != (n_pass, B, numel):
+            cur = (torch.empty((n_pass, B, numel), device=p.device, dtype=torch.float32),
+                   torch.zeros((n_pass, B), device=p.device, dtype=torch.float32))
+            self._bufs[key] = cur
+        return cur
+
+    # -- train.py:117,373,389 -----------------------------------------------------------------
+    def enable_hooks(self):
+        self.enabled = True
+
+    def disable_hooks(self):
+        self.enabled = False
+
+    def zero_grad(self):
+        """Drop per-sample state (the fork patches optimizer.zero_grad to do this; train.py:245)."""
+        self._reset_samples()
+        for p in self.params:
+            if hasattr(p, "summed_grad"):
+                del p.summed_grad
+            p.grad = None
+
+    # -- train.py:241-243, 321 -------------------------------------------------------------------
+    def set_max_grad_norm(self, v):
+        """float -> one flat clip norm; list / 1-D tensor -> one per parameter tensor."""
+        if isinstance(v, torch.Tensor):
+            v = v.detach().reshape(-1).tolist() if v.numel() > 1 else float(v)
+        if isinstance(v, (list, tuple, np.ndarray)):
+            v = [float(x) for x in v]
+            if len(v) != len(self.params):
+                raise ValueError("per-layer max_grad_norm needs %d entries, got %d" % (len(self.params), len(v)))
+            self._per_layer = True
+        else:
+            v = float(v)
+            self._per_layer = False
+        self._C_host, self._C_dev = v, None
+
+    def set_max_grad_norm_device(self, t: torch.Tensor):
+        """Same, from a device tensor ([1] flat or [n_params] per layer) without a host sync: adaptive
+        clipping (train.py:233-243) stays on the GPU; the floats are fetched only if someone reads
+        ``max_grad_norm``."""
+        t = t.detach().reshape(-1).to(torch.float32).contiguous()
+        if t.numel() not in (1, len(self.params)):
+            raise ValueError("max_grad_norm tensor must have 1 or %d entries" % len(self.params))
+        self._per_layer = t.numel() > 1 or (len(self.params) == 1 and self._per_layer)
+        self._C_dev, self._C_host = t, None
+
+    @property
+    def max_grad_norm(self):
+        if self._C_host is None:
+            vals = self._C_dev.cpu().tolist()
+            self._C_host = vals if self._per_layer else vals[0]
+        return self._C_host
+
+    def max_grad_norm_device(self) -> torch.Tensor:
+        return self._C_device(self.params[0].device)
+
+    def _C_device(self, device):
+        if self._C_dev is None or self._C_dev.device != device:
+            c = self._C_host if isinstance(self._C_host, list) else [self._C_host]
+            self._C_dev = torch.tensor(c, dtype=torch.float32, device=device)
+        return self._C_dev
+
+    # -- norms ------------------------------------------------------------------------------------
+    def sample_sqnorms(self, recompute=False) -> torch.Tensor:
+        """[n_params, n_passes*B] squared per-sample norms.  Default: the values the wgrad epilogue
+        accumulated; recompute=True re-reads the materialised grad_sample (cslgan_sample_sqnorm_f32),
+        which is what must be used after a caller edited p.grad_sample in place (train.py:447)."""
+        if recompute:
+            return ops.sample_sqnorm([_rows(p.grad_sample) for p in self.params])
+        return torch.stack([self._bufs[id(p)][1].reshape(-1) for p in self.params])
+
+    # -- train.py:399-402, 417 -----------------------------------------------------------------
+    def clip(self, recompute_norms=False):
+        """Per-sample clip factors + clipped sum into p.summed_grad (a SUM over samples)."""
+        ps = self.params
+        mats = [_rows(p.grad_sample) for p in ps]
+        n_pass = ps[0].grad_sample.shape[0]
+        B = ps[0].grad_sample.shape[1]
+        if self.accum_passes and n_pass > 1:
+            # passes are added per sample before clipping: column-sum over the pass axis
+            summed_ps = [torch.empty((B, m.shape[1]), device=m.device, dtype=torch.float32) for m in mats]
+            ops.clip_accum_noise([m.view(n_pass, -1) for m in mats], [s.view(-1) for s in summed_ps])
+            mats, n_pass = summed_ps, 1
+            sq = ops.sample_sqnorm(mats)
+        else:
+            sq = self.sample_sqnorms(recompute=recompute_norms)
+        n_private = n_pass if (self.accum_passes or self.num_private_passes is None) else self.num_private_passes
+        per_layer = self._per_layer
+        f = ops.clip_factors(sq, self._C_device(sq.device), flat=not per_layer, eps=CLIP_EPS,
+                             first_private_row=(n_pass - n_private) * B)
+        self.last_factors, self.last_sq = f, sq
+        outs = []
+        for p in ps:
+            p.summed_grad = torch.empty_like(p, memory_format=torch.preserve_format)
+            outs.append(_flat(p.summed_grad))
+        ops.clip_accum_noise(mats, outs, factors=f)
+        self._accumulated = False
+
+    def accum_grads_across_passes(self):
+        """The cross-pass sum (train.py:402) already happened inside clip(): rows = passes x samples."""
+        return None
+
+    def accumulate_batch(self):
+        """train.py:417: the clipped batch becomes the pending update."""
+        self._accumulated = True
+
+    # -- train.py:135-136, 484 ------------------------------------------------------------------
+    def _set_seed(self, seed):
+        self.seed = int(seed)
+        self._noise_calls = 0
+
+    def attach(self, optimizer):
+        self.optimizer = optimizer
+        engine = self
+        orig_step, orig_zero = optimizer.step, optimizer.zero_grad
+
+        def dp_step(self_opt, closure=None):
+            engine._before_step()
+            return orig_step(closure) if closure is not None else orig_step()
+
+        def dp_zero_grad(self_opt, *a, **k):
+            engine.zero_grad()
+            return orig_zero(*a, **k)
+
+        optimizer.privacy_engine = self
+        optimizer._orig_step, optimizer._orig_zero_grad = orig_step, orig_zero
+        optimizer.step = types.MethodType(dp_step, optimizer)
+        optimizer.zero_grad = types.MethodType(dp_zero_grad, optimizer)
+
+    def detach(self):
+        if self.optimizer is not None:
+            self.optimizer.step, self.optimizer.zero_grad = self.optimizer._orig_step, self.optimizer._orig_zero_grad
+            self.optimizer = None
+        for l in self.layers:
+            l._sink = None
+
+    def noise_stds(self) -> List[float]:
+        s = self.noise_multiplier
+        if isinstance(self.max_grad_norm, list):
+            return [s * c for c in self.max_grad_norm]
+        return [s * self.max_grad_norm] * len(self.params)
+
+    def _before_step(self):
+        """grad = (summed_grad + N(0,(sigma*C)^2)) / B  for every parameter, one launch."""
+        ps = self.params
+        if not all(hasattr(p, "summed_grad") for p in ps):
+            if self.auto_clip_and_accum_on_step and all(hasattr(p, "grad_sample") for p in ps):
+                self.clip()
+            else:
+                return          # non-DP step (warm-up iterations call the wrapped optimizer too)
+        R = self.world_size
+        denom = float(self.batch_size * R)
+        # R ranks each add noise of variance (sigma*C)^2 / R, so the all-reduced sum has (sigma*C)^2
+        dev = ps[0].device
+        ins = [_flat(p.summed_grad).view(1, -1) for p in ps]
+        grads = []
+        for p in ps:
+            p.grad = torch.empty_like(p, memory_format=torch.preserve_format)
+            grads.append(_flat(p.grad))
+        noises = None
+        if self.host_noise is not None:
+            noises = [z.to(dev) for z in self.host_noise]
+        elif self.host_noise_generator is not None:
+            noises = [torch.randn(p.numel(), generator=self.host_noise_generator).to(dev) for p in ps]
+        std_dev = None
+        if self.noise_multiplier > 0:
+            std_dev = (self._C_device(dev) * (self.noise_multiplier / (R ** 0.5))).expand(len(ps)).contiguous()
+        pre = 1.0 if self.grad_reducer is not None else 1.0 / denom
+        ops.clip_accum_noise(ins, grads, noise_std=std_dev, noises=noises, seed=self.seed,
+                             offset=self._noise_calls, scale=pre)
+        if self.grad_reducer is not None:
+            self.grad_reducer(grads, 1.0 / denom)
+        self._noise_calls += 1
+        self.steps += 1
+        for p in ps:
+            del p.summed_grad
+        self._reset_samples()
+
+    def _reset_samples(self):
+        """Per-sample state lives for one step: drop it once the noised gradient exists."""
+        for l in self.layers:
+            self._fwd_count[l] = 0
+        self._bufs.clear()
+        for p in self.params:
+            if hasattr(p, "grad_sample"):
+                del p.grad_sample
+        self._accumulated = False
+
+    # -- train.py:294-295, 588 ------------------------------------------------------------------
+    def get_privacy_spent(self, target_delta=None):
+        delta = 1e-6 if target_delta is None else target_delta
+        rdp = accountant.compute_rdp(self.sample_rate, self.noise_multiplier, self.steps, self.alphas)
+        return accountant.get_privacy_spent(self.alphas, rdp, delta)

@@ -1,0 +1,206 @@
+"""Autograd glue over the HIP kernels.  All tensors here are NHWC-contiguous device tensors.
+
+The three conv Functions form a closed set under differentiation, so the WGAN-GP double backward
+(gradient_penalty.py:48-54 then train.py:427) runs entirely on the hand-written kernels:
+
+    Conv   (x, w, b) -> y          d/dx = Dgrad(gz, w)       d/dw = Wgrad(gz, x)      d/db = sum(gz)
+    Dgrad  (gy, w)   -> gx         d/dgy = Conv(ggx, w)      d/dw = Wgrad(gy, ggx)
+    Wgrad  (gy, x)   -> gw         d/dgy = Conv(x, ggw)      d/dx = Dgrad(gy, ggw)
+
+LeakyReLU / ReLU are fused into the forward kernel's epilogue; their backward multiplies by a mask
+recovered from the OUTPUT (slope > 0 keeps the sign), so no pre-activation tensor is stored.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+_SLOPE = {ops.ACT_LRELU02: 0.2, ops.ACT_RELU: 0.0}
+
+
+def nhwc(x: torch.Tensor) -> torch.Tensor:
+    """logical NCHW -> NHWC-contiguous view (copy only if x is not already channels-last)."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw_view(y: torch.Tensor) -> torch.Tensor:
+    """NHWC-contiguous -> logical NCHW view (channels-last strides, no copy)."""
+    return y.permute(0, 3, 1, 2)
+
+
+class ActBwd(Function):
+    """out = g * (y > 0 ? 1 : slope).  Linear in g; the mask has zero derivative."""
+
+    @staticmethod
+    def forward(ctx, g, y, slope):
+        ctx.save_for_backward(y)
+        ctx.slope = slope
+        return ops.act_bwd(g.contiguous(), y, slope)
+
+    @staticmethod
+    def backward(ctx, gg):
+        (y,) = ctx.saved_tensors
+        return ActBwd.apply(gg, y, ctx.slope), None, None
+
+
+class BiasGrad(Function):
+    """gb[k] = sum over all pixels/samples of gy[...,k]."""
+
+    @staticmethod
+    def forward(ctx, gy):
+        ctx.shape = gy.shape
+        N = gy.shape[0]
+        group = _dense_group(N)
+        part = ops.bias_grad_grouped(gy.contiguous(), group=group)
+        if part.shape[0] == 1:
+            return part[0]
+        out = torch.empty(part.shape[1], device=gy.device, dtype=torch.float32)
+        ops.clip_accum_noise([part], [out])
+        return out
+
+    @staticmethod
+    def backward(ctx, ggb):
+        return ggb.reshape((1,) * (len(ctx.shape) - 1) + (-1,)).expand(ctx.shape)
+
+
+def _dense_group(N: int, tiles: int = 1) -> int:
+    """Samples per slab for dense (summed) gradients: the largest group that still leaves >= 512
+    workgroups (256 CUs x 2), so small layers keep per-sample slabs and big layers write few."""
+    for g in (16, 8, 4, 2):
+        if N % g == 0 and (N // g) * tiles >= 512:
+            return g
+    return 1
+
+
+class Conv(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, act, upsample, residual, res_shift):
+        y = ops.conv2d_fwd(x, w, b, stride=stride, pad=pad, upsample=upsample, residual=residual,
+                           res_shift=res_shift, act=act)
+        ctx.cfg = (stride, pad, act, upsample, res_shift)
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, w, y if act != ops.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, act, upsample, res_shift = ctx.cfg
+        if upsample or (ctx.has_res and ctx.needs_input_grad[7]):
+            raise NotImplementedError("backward through upsample-on-read / residual convs (generator) is not built yet")
+        gz = gy
+        if act in _SLOPE:
+            gz = ActBwd.apply(gy, y, _SLOPE[act])
+        elif act == ops.ACT_TANH:
+            gz = gy * (1 - y * y)
+        gz = gz.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = Dgrad.apply(gz, w, x.shape[1], x.shape[2], stride, pad)
+        if ctx.needs_input_grad[1]:
+            gw = Wgrad.apply(gz, x, w.shape[1], w.shape[2], stride, pad)
+        if ctx.needs_input_grad[2]:
+            gb = BiasGrad.apply(gz)
+        return gx, gw, gb, None, None, None, None, None, None
+
+
+class Dgrad(Function):
+    @staticmethod
+    def forward(ctx, gy, w, H, W, stride, pad):
+        ctx.cfg = (H, W, stride, pad)
+        ctx.save_for_backward(gy, w)
+        return ops.conv2d_dgrad(gy, w, (H, W), stride=stride, pad=pad)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w = ctx.saved_tensors
+        H, W, stride, pad = ctx.cfg
+        ggx = ggx.contiguous()
+        g_gy = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_gy = Conv.apply(ggx, w, None, stride, pad, ops.ACT_NONE, False, None, 0)
+        if ctx.needs_input_grad[1]:
+            g_w = Wgrad.apply(gy, ggx, w.shape[1], w.shape[2], stride, pad)
+        return g_gy, g_w, None, None, None, None
+
+
+class Wgrad(Function):
+    """Dense weight gradient: grouped slabs on the MFMA kernel, then a column sum."""
+
+    @staticmethod
+    def forward(ctx, gy, x, R, S, stride, pad):
+        ctx.cfg = (R, S, stride, pad)
+        ctx.save_for_backward(gy, x)
+        N = x.shape[0]
+        tiles = ((gy.shape[-1] + 127) // 128) * ((R * S * x.shape[-1] + 127) // 128)
+        group = _dense_group(N, tiles)
+        slabs = ops.conv2d_wgrad_grouped(gy, x, R, S, stride=stride, pad=pad, group=group)
+        if slabs.shape[0] == 1:
+            return slabs[0]
+        out = torch.empty(slabs.shape[1:], device=x.device, dtype=torch.float32)
+        ops.clip_accum_noise([slabs.reshape(slabs.shape[0], -1)], [out])
+        return out
+
+    @staticmethod
+    def backward(ctx, ggw):
+        gy, x = ctx.saved_tensors
+        R, S, stride, pad = ctx.cfg
+        ggw = ggw.contiguous()
+        g_gy = g_x = None
+        if ctx.needs_input_grad[0]:
+            g_gy = Conv.apply(x, ggw, None, stride, pad, ops.ACT_NONE, False, None, 0)
+        if ctx.needs_input_grad[1]:
+            g_x = Dgrad.apply(gy, ggw, x.shape[1], x.shape[2], stride, pad)
+        return g_gy, g_x, None, None, None, None
+
+
+class ConvPerSample(Function):
+    """Forward identical to Conv; backward writes per-sample weight/bias gradients into the engine's
+    store (the Opacus-hook replacement, train.py:373,387) and returns only the data gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, act, sink, pass_idx):
+        y = ops.conv2d_fwd(x, w, b, stride=stride, pad=pad, act=act)
+        ctx.cfg = (stride, pad, act)
+        ctx.sink, ctx.pass_idx = sink, pass_idx
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y if act != ops.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, act = ctx.cfg
+        with torch.no_grad():
+            gz = gy.contiguous()
+            if act in _SLOPE:
+                gz = ops.act_bwd(gz, y, _SLOPE[act])
+            elif act == ops.ACT_TANH:
+                gz = gz * (1 - y * y)
+            ctx.sink.collect(ctx.pass_idx, gz, x, w.shape[1], w.shape[2], stride, pad, ctx.has_bias)
+            gx = None
+            if ctx.needs_input_grad[0]:
+                gx = ops.conv2d_dgrad(gz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad)
+        return gx, None, None, None, None, None, None, None
+
+
+class RowL2Norm(Function):
+    """norms[b] = ||t[b,:]||_2 (gradient_penalty.py:52-53) with a differentiable backward."""
+
+    @staticmethod
+    def forward(ctx, t):
+        t = t.contiguous()
+        n = ops.row_l2norm(t)
+        ctx.save_for_backward(t, n)
+        return n
+
+    @staticmethod
+    def backward(ctx, gn):
+        t, n = ctx.saved_tensors
+        if torch.is_grad_enabled() and (gn.requires_grad or t.requires_grad):
+            # differentiable form for higher-order use (never hit by the D-step: the norm's backward is
+            # the last first-order node before the parameter gradients)
+            return gn.unsqueeze(1) * t / n.unsqueeze(1)
+        return ops.row_l2norm_bwd(t, n, gn.contiguous())

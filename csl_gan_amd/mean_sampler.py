@@ -1,0 +1,66 @@
+"""DP "mean samples" used as a public-data surrogate (reference mean_sampler.py:12-92).
+
+Each mean sample is the mean of `mean_size` training images plus N(0, noise_std^2); sample() draws
+a batch with per-image and per-pixel jitter.  The tensor of mean samples may live on the HIP device
+so that the D-step needs no host->device copy (the reference samples on the host every step,
+train.py:200-202, 214-216); the arithmetic is a gather plus two small Gaussian draws.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import accountant, util
+
+ALPHAS = accountant.DEFAULT_ALPHAS
+
+
+class MeanSampler:
+    def __init__(self, dataloader=None, path=None, transforms=None, noise_std=0.1, num_samples=32, mean_size=100,
+                 dataset_size=180000, res=64, ch=3, save_path=None, default_batch_size=None, n_classes=1,
+                 smallest_class_size=None, device="cpu", generator=None):
+        self.dataloader, self.noise_std, self.num_samples, self.mean_size = dataloader, noise_std, num_samples, mean_size
+        self.dataset_size, self.res, self.ch, self.default_batch_size = dataset_size, res, ch, default_batch_size
+        denom = dataset_size if smallest_class_size is None else smallest_class_size
+        self.sample_rate = mean_size / denom
+        self.smallest_class_size, self.n_classes = smallest_class_size, n_classes
+        self.device, self.generator = torch.device(device), generator
+        self.mean_samples = None
+        if path is not None:
+            raise NotImplementedError("loading mean samples from image files needs PIL/torchvision transforms (out of scope)")
+        if dataloader is not None:
+            self.make_mean_samples(dataloader, save_path=save_path)
+
+    def make_mean_samples(self, dataloader, save_path=None):
+        per_class = [[] for _ in range(self.n_classes)]
+        for _ in range(self.num_samples):
+            samples, labels = next(iter(dataloader))
+            for c in range(self.n_classes):
+                pick = samples if self.n_classes == 1 else samples[labels == c][: self.mean_size]
+                mean = pick.sum(dim=0) / self.mean_size          # divides by mean_size even if fewer were found
+                per_class[c].append(mean + torch.empty(mean.shape).normal_(0, self.noise_std))
+        self.mean_samples = torch.stack([torch.stack(v) for v in per_class]).to(self.device)
+        if save_path is not None:
+            save_path = util.add_slash(save_path)
+            os.makedirs(save_path, exist_ok=True)
+            np.save(save_path + "mean_samples.npy", self.mean_samples.cpu().numpy())
+
+    def sample(self, size, noise_std=0.01, noise_mean_std=0.01, requested_labels=None):
+        dev, gen = self.mean_samples.device, self.generator
+        reps = (size - 1) // self.num_samples + 1
+        perms = torch.cat([torch.randperm(self.num_samples, device=dev, generator=gen) for _ in range(reps)])[:size]
+        if requested_labels is None:
+            requested_labels = torch.randint(0, self.n_classes, (size,), device=dev, generator=gen)
+        requested_labels = requested_labels.to(dev)
+        r = self.mean_samples[requested_labels, perms]
+        if noise_mean_std is not None and noise_mean_std > 0:
+            r = r + torch.empty(size, device=dev).normal_(0, noise_mean_std, generator=gen).view(-1, 1, 1, 1)
+        if noise_std is not None and noise_std > 0:
+            r = r + torch.empty(r.shape, device=dev).normal_(0, noise_std, generator=gen)
+        return r, (requested_labels if self.n_classes > 1 else None)
+
+    def get_privacy_cost(self, target_delta=1e-6, alphas=ALPHAS):
+        pixel_sensitivity = 1 / self.mean_size / 2
+        l2_sensitivity = np.sqrt(self.ch * self.res ** 2 * pixel_sensitivity ** 2)
+        rdp = accountant.compute_rdp(self.sample_rate, self.noise_std / l2_sensitivity, self.num_samples * self.n_classes, alphas)
+        return accountant.get_privacy_spent(alphas, rdp, target_delta)

@@ -1,0 +1,130 @@
+"""Layer modules that keep torch.nn's parameter names / shapes / default initialisation (so
+state_dict keys and weights_seed-initialised values match the reference's nn.Conv2d / nn.Linear /
+nn.GroupNorm layers) but run their device math on the HIP kernels.
+
+Device dispatch is explicit, never a fallback: a module whose parameters live on a HIP device always
+calls the C-ABI library (and raises if it is missing); a module on the CPU runs the stock torch op —
+that mode exists only for BASELINE.json configs[0] ("-gd cpu -dd cpu", plumbing without a GPU).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import functional as HF
+from . import ops
+
+
+class PerSampleSink:
+    """Interface the DP engine implements to receive per-sample gradients from a layer's backward."""
+
+    enabled = False
+
+    def next_pass(self, layer) -> int:
+        raise NotImplementedError
+
+    def collector(self, layer):
+        raise NotImplementedError
+
+
+class _PerSampleMixin:
+    _sink = None  # set by the engine (csl_gan_amd.engine.PrivacyEngine)
+
+    def _per_sample_active(self):
+        s = self._sink
+        return s is not None and s.enabled and torch.is_grad_enabled()
+
+
+class HipConv2d(nn.Conv2d, _PerSampleMixin):
+    """nn.Conv2d (DCResNet_models.py:118, :11, :26, :85) with a fused activation epilogue.
+
+    act: ops.ACT_* applied in the conv kernel's epilogue (D: LeakyReLU 0.2, DCResNet_models.py:132).
+    upsample: nearest-2x applied on read (UpsampleConv, DCResNet_models.py:13-16).
+    """
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True, act=ops.ACT_NONE, upsample=False):
+        if padding == "same":
+            padding = k // 2
+        super().__init__(cin, cout, k, stride=stride, padding=padding, bias=bias)
+        self.act, self.upsample = act, upsample
+
+    def forward_nhwc(self, x, residual=None, res_shift=0):
+        """x: NHWC-contiguous device tensor -> NHWC output."""
+        w = self.weight.permute(0, 2, 3, 1).contiguous()
+        if self._per_sample_active() and residual is None and not self.upsample:
+            sink = self._sink
+            return HF.ConvPerSample.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act,
+                                          sink.collector(self), sink.next_pass(self))
+        return HF.Conv.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act, self.upsample,
+                             residual, res_shift)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            xin = x.repeat_interleave(2, 2).repeat_interleave(2, 3) if self.upsample else x
+            y = super().forward(xin)
+            return _act_cpu(y, self.act)
+        return HF.nchw_view(self.forward_nhwc(HF.nhwc(x)))
+
+
+class HipLinear(nn.Linear, _PerSampleMixin):
+    """nn.Linear (DCResNet_models.py:77,124,126; MNIST_models.py:14-15,36-39) as a 1x1 conv on the
+    MFMA kernel: x[B,in] is the NHWC tensor [B,1,1,in]."""
+
+    def __init__(self, fin, fout, bias=True, act=ops.ACT_NONE):
+        super().__init__(fin, fout, bias=bias)
+        self.act = act
+
+    def forward(self, x):
+        if not x.is_cuda:
+            return _act_cpu(super().forward(x), self.act)
+        B = x.shape[0]
+        x4 = x.contiguous().reshape(B, 1, 1, self.in_features)
+        w4 = self.weight.reshape(self.out_features, 1, 1, self.in_features)
+        if self._per_sample_active():
+            sink = self._sink
+            y = HF.ConvPerSample.apply(x4, w4, self.bias, 1, 0, self.act, sink.collector(self), sink.next_pass(self))
+        else:
+            y = HF.Conv.apply(x4, w4, self.bias, 1, 0, self.act, False, None, 0)
+        return y.reshape(B, self.out_features)
+
+
+class HipGroupNormAct(nn.GroupNorm):
+    """nn.GroupNorm(32, C) followed by ReLU (DCResNet_models.py:55-57, 63-67, 84, 101-102) as one
+    HIP op on NHWC data.  Forward only for now (the generator is frozen inside the D-step,
+    train.py:362); its backward belongs to the train_G row."""
+
+    def __init__(self, groups, channels, relu=True):
+        super().__init__(groups, channels)
+        self.relu = relu
+
+    def forward_nhwc(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            raise NotImplementedError("HipGroupNormAct backward (generator training) is not built yet; "
+                                      "call under torch.no_grad() or with the generator frozen")
+        return ops.groupnorm_act(x, self.weight.detach(), self.bias.detach(), self.num_groups, eps=self.eps, relu=self.relu)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            y = super().forward(x)
+            return F.relu(y) if self.relu else y
+        return HF.nchw_view(self.forward_nhwc(HF.nhwc(x)))
+
+
+def _act_cpu(y, act):
+    if act == ops.ACT_LRELU02:
+        return F.leaky_relu(y, 0.2)
+    if act == ops.ACT_RELU:
+        return F.relu(y)
+    if act == ops.ACT_TANH:
+        return torch.tanh(y)
+    return y
+
+
+def to_device_layout(module: nn.Module) -> nn.Module:
+    """After .to(device): keep 4-D conv filters channels-last in HBM (KRSC), so the kernels read them
+    in place and per-sample gradients / Adam state share that layout."""
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d) and m.weight.is_cuda:
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    return module

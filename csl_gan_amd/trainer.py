@@ -1,0 +1,382 @@
+"""The training step functions of the reference's train.py as methods of one object.
+
+The reference keeps these as closures over script globals (train.py:95-546); here `Trainer` owns
+opt / G / D / optimizers / privacy_engine / logger / mean_sampler and exposes the same function
+names with the same argument meaning: setup_privacy_engine, gen_z, gen_y, eval_G_D,
+get_penalty_data, update_adaptive_clipping_params, update_grad_logging, calc_d_fake_loss,
+calc_d_real_loss, train_D, train_G, train.
+
+MI355X-first host changes (results identical):
+  * per-step statistics stay on the device and are folded into the Logger only when a line is
+    printed — the reference forces >= 8 device->host syncs per D-step (train.py:233-238, 315, 328,
+    488-493); this path forces none outside log/gating iterations;
+  * grad-norm logging reuses the norms/factors the clip kernels already produced instead of
+    recomputing them (train.py:397 duplicates train.py:399's norm pass);
+  * the generator forward for fakes runs under no_grad when G is frozen (train.py:362).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import autograd
+
+from . import engine as E
+from . import util
+from .gradient_penalty import calc_penalty
+from .logger import Logger
+
+
+class Trainer:
+    def __init__(self, opt, G, D, dataset=None, public_dataloader=None, public_dataset=None, mean_sampler=None,
+                 log_to=None, world_size=1, rank=0, grad_reducer=None):
+        self.opt, self.G, self.D = opt, G, D
+        self.dataset, self.public_dataloader, self.public_dataset = dataset, public_dataloader, public_dataset
+        self.mean_sampler = mean_sampler
+        self.world_size, self.rank, self.grad_reducer = world_size, rank, grad_reducer
+        self.privacy_engine = None
+        self.g_optimizer, self.d_optimizer = self.init_optimizers()
+        self.logger = self._make_logger(log_to)
+        self.dev_stats = {}
+        self.batches_per_epoch = opt.train_set_size / opt.batch_size
+        self.last = {}                     # observables of the most recent D-step (device tensors), for tests
+        self.explicit = {}                 # optional explicit random inputs (alpha / noise / mean-sample batches) for parity tests
+
+    # ---- train.py:75-77 -----------------------------------------------------------------------
+    def init_optimizers(self):
+        o = self.opt
+        return (E.HipAdam(self.G.parameters(), lr=o.g_lr, betas=(o.adam_b1, o.adam_b2)),
+                E.HipAdam(self.D.parameters(), lr=o.d_lr, betas=(o.adam_b1, o.adam_b2), weight_decay=o.weight_decay))
+
+    # ---- train.py:95-138 ----------------------------------------------------------------------
+    def setup_privacy_engine(self):
+        o = self.opt
+        params = dict(batch_size=o.batch_size, sample_size=o.train_set_size,
+                      alphas=[1 + x / 10.0 for x in range(1, 100)] + list(range(12, 400)), noise_multiplier=o.sigma,
+                      world_size=self.world_size)
+        if o.dp_mode == "gc":
+            if o.clipping_param_per_layer is None:
+                o.clipping_param_per_layer = [1 for _ in self.D.parameters()]
+            per_layer = o.grad_clip_mode.endswith("-pl")
+            pe = E.PrivacyEngine(self.D, **params, accum_passes=not o.grad_clip_split,
+                                 num_private_passes=1 if o.grad_clip_split else None, auto_clip_and_accum_on_step=False,
+                                 max_grad_norm=list(o.clipping_param_per_layer) if per_layer else o.clipping_param)
+            pe.disable_hooks()
+        elif o.dp_mode == "is":
+            from .is_engine import ISPrivacyEngine
+            pe = ISPrivacyEngine(self.D, **params, per_param=o.imm_sens_per_param,
+                                 scaling_vec=None if o.imm_sens_scaling_mode == "standard" else o.imm_sens_scaling_vec)
+        else:
+            raise NotImplementedError("dp_mode=%s: the trimmed-mean / smooth-vote engines are experimental in the reference "
+                                      "(README.md:11) and out of scope" % o.dp_mode)
+        pe.grad_reducer = self.grad_reducer
+        pe.attach(self.d_optimizer)
+        pe._set_seed(o.manual_seed + 7919 * self.rank)
+        self.privacy_engine = pe
+        return pe
+
+    # ---- train.py:150-161 ---------------------------------------------------------------------
+    def gen_z(self, size):
+        return torch.empty((size, self.opt.g_latent_dim), device=self.opt.g_device).normal_(0.0, 1.0)
+
+    def gen_y(self, size):
+        o = self.opt
+        if not o.conditional:
+            return None
+        if o.n_classes < 3:
+            p1 = 0.5
+            if o.dataset == "CelebA" and self.dataset is not None and hasattr(self.dataset, "label_true_count"):
+                p1 = self.dataset.label_true_count / o.train_set_size
+            return (torch.empty(size).random_(0, 2) < p1).long()
+        return torch.empty(size).random_(0, o.n_classes).long()
+
+    # ---- train.py:163-184 ---------------------------------------------------------------------
+    def eval_G_D(self, z, y=None, g_kwarg={}, d_kwarg={}):
+        """G then D.  (The reference's micro-batch G/D software pipeline for split devices,
+        train.py:168-184, is dead at its defaults and calls torch.cat on a generator; not carried.)"""
+        o = self.opt
+        yg = None if y is None else y.to(o.g_device)
+        frozen = not any(p.requires_grad for p in self.G.parameters())
+        if frozen:
+            with torch.no_grad():
+                img = self.G(z, yg, **g_kwarg)
+        else:
+            img = self.G(z, yg, **g_kwarg)
+        img = img.to(o.d_device)
+        d_out, d_aux = self.D(img, None if y is None else y.to(o.d_device), **d_kwarg)
+        return d_out, d_aux, img
+
+    # ---- train.py:186-202 ---------------------------------------------------------------------
+    def get_penalty_data(self, data_in, labels_in):
+        o = self.opt
+        data, labels = data_in, labels_in
+        n = data_in.size(0)
+        if "pen_real" in self.explicit:
+            return self.explicit["pen_real"].to(o.d_device), labels_in
+        if o.penalty_use_public_data:
+            if o.public_set_size > 0:
+                if labels_in is None:
+                    reps = (n - 1) // o.batch_size + 1
+                    data = torch.cat([next(iter(self.public_dataloader))[0] for _ in range(reps)], dim=0)[:n]
+                else:
+                    pairs = [self.public_dataset.get_item_with_label(l) for l in labels_in]
+                    data = torch.stack([p[0] for p in pairs])
+                    labels = torch.tensor([p[1] for p in pairs])
+            elif o.num_mean_samples > 0:
+                data, labels = self.mean_sampler.sample(n, requested_labels=labels_in)
+        return data.to(o.d_device), None if labels is None else labels.to(o.d_device)
+
+    # ---- train.py:204-245 ---------------------------------------------------------------------
+    def update_adaptive_clipping_params(self):
+        o, D, pe = self.opt, self.D, self.privacy_engine
+        util.zero_grad(D)
+        if "ms_adapt" in self.explicit:
+            img, labels = self.explicit["ms_adapt"], self.explicit.get("ms_adapt_labels")
+        elif o.public_set_size > 0:
+            img, labels = next(iter(self.public_dataloader))
+            img, labels = img.clone(), (labels.clone() if o.conditional else None)
+        else:
+            img, labels = self.mean_sampler.sample(o.batch_size)
+        img = img.to(o.d_device)
+        labels = None if labels is None else labels.to(o.d_device)
+        if o.grad_clip_split:
+            d_fake_loss = d_fake_aux_loss = 0
+        else:
+            z = self.explicit["z_adapt"] if "z_adapt" in self.explicit else self.gen_z(o.batch_size)
+            _, _, d_fake_loss, d_fake_aux_loss, _ = self.calc_d_fake_loss(img, labels, z, labels)
+        _, _, d_real_loss, d_real_aux_loss = self.calc_d_real_loss(img, labels)
+        (d_real_loss + d_fake_loss + d_real_aux_loss + d_fake_aux_loss).backward()
+        with torch.no_grad():
+            B = img.size(0)
+            # per-layer per-sample norms of pass 0: produced by the wgrad epilogue, never re-read from HBM
+            norms = pe.sample_sqnorms()[:, :B].sqrt()                      # [n_params, B]
+            r = norms.mean(dim=1) if o.adaptive_stat == "mean" else norms.max(dim=1).values
+            self.last["adaptive_stats"] = r
+            if o.use_grad_clip_per_layer:
+                pe.set_max_grad_norm_device(r * o.adaptive_scalar)
+            else:
+                pe.set_max_grad_norm_device((r.norm(2) * o.adaptive_scalar).reshape(1))
+        self.d_optimizer.zero_grad()
+
+    # ---- train.py:310-329 ---------------------------------------------------------------------
+    def update_grad_logging(self):
+        """Uses the norms / factors of the clip that just ran (same numbers the reference recomputes)."""
+        o, pe = self.opt, self.privacy_engine
+        B = o.batch_size
+        per_layer = pe.clipper.norm_clipper.is_per_layer
+        if o.grad_clip_split:
+            sq, f = pe.last_sq, pe.last_factors
+            col = 1 if sq.shape[1] >= 2 * B else 0
+        else:
+            # the reference logs column 0 = the first (generated-data) pass when passes are accumulated
+            # (train.py:315); those norms come from the wgrad epilogue, the factors from the same formula
+            sq, col = pe.sample_sqnorms()[:, :B], 0
+            nrm = sq.sqrt() if per_layer else sq.sum(dim=0, keepdim=True).sqrt()
+            f = (pe.max_grad_norm_device().reshape(-1, 1) / (nrm + E.CLIP_EPS)).clamp(max=1.0)
+        norms = sq.sqrt() if per_layer else sq.sum(dim=0, keepdim=True).sqrt()
+        nm = norms[:, col * B:(col + 1) * B]
+        fac = (f if per_layer else f.reshape(1, -1))[:, col * B:(col + 1) * B]
+        self._acc("D Layer Grad Norm Means", nm.mean(dim=1))
+        self._acc("D Layer Grad Norm Stds", nm.std(dim=1, unbiased=False))
+        self._acc("D Layer Grad Norm Maxes", nm.max(dim=1).values)
+        self._acc("Clipping Params", pe.max_grad_norm_device().clone())
+        self._acc("Grads Clipped", (fac < 0.999).float().mean(dim=1))
+        self.last.update(norms=norms, clip_factors=f, clip_params=pe.max_grad_norm_device().clone())
+
+    def update_is_logging(self):
+        s = self.privacy_engine.batch_sensitivity
+        lg = self.logger
+        lg.stats["IS Mean"] += s
+        scaled = s * lg.interval
+        if self.opt.imm_sens_per_param:
+            lg.stats["IS Min"] = scaled if isinstance(lg.stats["IS Min"], float) else np.minimum(lg.stats["IS Min"], scaled)
+            lg.stats["IS Max"] = np.maximum(lg.stats["IS Max"], scaled)
+        else:
+            lg.stats["IS Min"] = min(99999 if lg.stats["IS Min"] < 1e-8 else lg.stats["IS Min"], scaled)
+            lg.stats["IS Max"] = max(lg.stats["IS Max"], scaled)
+
+    # ---- train.py:345-358 ---------------------------------------------------------------------
+    def calc_d_fake_loss(self, img, labels, z, y):
+        o, D = self.opt, self.D
+        d_fake, d_fake_aux, fake_img = self.eval_G_D(z, y, d_kwarg={"aux": o.d_fake_aux_loss})
+        fake_img = fake_img.detach()
+        d_fake_loss = D.fake_loss(d_fake, o.d_device)
+        aux = D.aux_loss(d_fake_aux, y.to(o.d_device), o.d_device, fake=True) if (o.use_aux_loss and o.d_fake_aux_loss) else 0
+        return d_fake, d_fake_aux, d_fake_loss, aux, fake_img
+
+    def calc_d_real_loss(self, img, labels):
+        o, D = self.opt, self.D
+        d_real, d_real_aux = D(img, labels)
+        d_real_loss = D.real_loss(d_real, o.d_device)
+        aux = D.aux_loss(d_real_aux, labels, o.d_device, fake=False) if o.use_aux_loss else 0
+        return d_real, d_real_aux, d_real_loss, aux
+
+    # ---- train.py:360-500 ---------------------------------------------------------------------
+    def train_D(self, img, labels, z, y, use_dp=False):
+        o, D, G, pe = self.opt, self.D, self.G, self.privacy_engine
+        util.zero_grad(D)
+        util.freeze(G)
+        use_grad_clip = o.dp_mode == "gc" and use_dp
+        use_imm_sens = o.dp_mode == "is" and use_dp
+        if o.backprop_clip and use_dp:
+            raise NotImplementedError("--backprop_clip: experimental/unfinished in the reference (options.py:243-244); only l2_clip is built")
+        if o.per_sample_grad and use_dp:
+            pe.enable_hooks()
+        if use_imm_sens:
+            img.requires_grad = True
+        if use_grad_clip and o.grad_clip_mode.startswith("adaptive"):
+            self.update_adaptive_clipping_params()
+
+        d_fake, d_fake_aux, d_fake_loss, d_fake_aux_loss, fake_img = self.calc_d_fake_loss(img, labels, z, y)
+        d_real, d_real_aux, d_real_loss, d_real_aux_loss = self.calc_d_real_loss(img, labels)
+        d_loss = d_real_loss + d_fake_loss + d_real_aux_loss + d_fake_aux_loss
+
+        if o.per_sample_grad and use_dp:
+            d_loss.backward()
+            pe.disable_hooks()
+        if use_grad_clip:
+            pe.clip()
+            if o.grad_clip_split:
+                pe.accum_grads_across_passes()
+            with torch.no_grad():
+                self.update_grad_logging()     # after clip(): reuses its norms (the reference logs first, train.py:397)
+                self.last["summed_clipped"] = [p.summed_grad.clone() for p in D.parameters()] if self.explicit.get("keep") else None
+
+        penalty = torch.zeros((), device=o.d_device)
+        if len(o.penalty) > 0:
+            pen_real, pen_labels = self.get_penalty_data(img, labels)
+            alpha = self.explicit.get("alpha")
+            kw = dict(device=o.d_device, aux_penalty=o.aux_penalty, alpha=alpha)
+            if use_dp and o.per_sample_grad:
+                if not o.penalty_use_public_data:
+                    raise NotImplementedError("per-sample gradient penalty on private data (train.py:434-450) leaks memory in the "
+                                              "reference and is not built; use mean samples / public data")
+                if use_grad_clip:
+                    pe.accumulate_batch()
+                penalty = calc_penalty(D, o.penalty, pen_real, pen_labels, fake_img, y, **kw)
+                d_loss = d_loss + penalty
+                penalty_grad = autograd.grad(penalty, list(D.parameters()), create_graph=False, retain_graph=False, allow_unused=True)
+                with torch.no_grad():
+                    for p, g in zip(D.parameters(), penalty_grad):
+                        if g is not None:
+                            p.summed_grad.add_(g, alpha=o.batch_size)     # summed_grad is a sum, not a mean (train.py:431)
+                    if self.explicit.get("keep"):
+                        self.last["penalty_grads"] = [None if g is None else g.clone() for g in penalty_grad]
+            else:
+                penalty = calc_penalty(D, o.penalty, pen_real, pen_labels, fake_img, y, **kw)
+                d_loss = d_loss + penalty
+                if use_imm_sens:
+                    pe.backward(d_loss, img)
+                    self.update_is_logging()
+                else:
+                    d_loss.backward()
+        else:
+            if use_grad_clip:
+                pe.accumulate_batch()
+            elif use_imm_sens:
+                pe.backward(d_loss, img)
+                self.update_is_logging()
+            else:
+                d_loss.backward()
+
+        if self.explicit.get("keep") and use_grad_clip:
+            self.last["summed_grad"] = [p.summed_grad.clone() for p in D.parameters()]
+        self.d_optimizer.step()
+        util.unfreeze(G)
+
+        with torch.no_grad():
+            adv = d_real_loss.detach() + d_fake_loss.detach()
+            self._acc("_d_adv_gate", adv)
+            self._acc("D Adv Loss", adv)
+            self._acc("D Real Loss", d_real_loss.detach())
+            self._acc("D Fake Loss", d_fake_loss.detach())
+            self._acc("D Real Acc", 100 * (d_real.detach() > 0).float().mean())
+            self._acc("D Fake Acc", 100 * (d_fake.detach() < 0).float().mean())
+            if len(o.penalty) > 0:
+                self._acc("D Penalty", penalty.detach().reshape(()))
+            if o.use_aux_loss:
+                self._acc("D Real Aux Loss", d_real_aux_loss.detach().reshape(()))
+                self._acc("D Real Aux Acc", 100 * (d_real_aux.detach().argmax(dim=1) == labels).float().mean())
+            self.last.update(d_real_loss=d_real_loss.detach(), d_fake_loss=d_fake_loss.detach(), penalty=penalty.detach(),
+                             d_real=d_real.detach(), d_fake=d_fake.detach(), fake_img=fake_img)
+
+    # ---- train.py:502-517 ---------------------------------------------------------------------
+    def train_G(self, z, y):
+        o, G, D = self.opt, self.G, self.D
+        util.zero_grad(G)
+        d_fake, d_fake_aux, _ = self.eval_G_D(z, y)
+        g_adv_loss = G.loss(d_fake, o.d_device)
+        g_aux_loss = D.aux_loss(d_fake_aux, y.to(o.d_device), o.d_device) if o.is_acgan else 0
+        (g_adv_loss + g_aux_loss).backward()
+        self.g_optimizer.step()
+        self._acc("G Adv Loss", g_adv_loss.detach())
+        if o.is_acgan:
+            self._acc("G Aux Loss", g_aux_loss.detach())
+            self._acc("G Aux Acc", 100 * (d_fake_aux.detach().argmax(dim=1) == y.to(o.d_device)).float().mean())
+
+    # ---- train.py:521-546 ---------------------------------------------------------------------
+    def train(self, epoch, batch_i, real_images_batch, real_labels_batch, use_dp=False):
+        o, lg = self.opt, self.logger
+        img = real_images_batch.to(o.d_device)
+        labels = real_labels_batch.to(o.d_device) if o.conditional else None
+        n = img.size(0)
+        self.train_D(img, labels, self.gen_z(n), labels, use_dp=use_dp)
+        if batch_i % o.n_d_steps == 0:
+            gate = self.dev_stats.pop("_d_adv_gate", None)
+            d_adv = 0.0 if gate is None else float(gate)           # the one host sync, every n_d_steps iterations
+            if d_adv / o.n_d_steps < o.train_d_until_threshold:
+                lg.log_g_iter += 1
+                self.train_G(self.gen_z(n), self.gen_y(n))
+        if ((batch_i + 1) * o.batch_size) % o.log_every == 0:
+            self.flush_stats()
+            for stat in [k for k in lg.stats if k.startswith("G ")]:
+                lg.stats[stat] *= 0 if lg.log_g_iter == 0 else lg.interval / lg.log_g_iter
+            lg.log_g_iter = 0
+            self.log(epoch, 100 * batch_i / self.batches_per_epoch, print_dp=use_dp)
+
+    def log(self, epoch, epoch_progress, print_dp=False):
+        self.flush_stats()
+        self.logger.log(epoch, epoch_progress)
+        pe = self.privacy_engine
+        if print_dp and pe is not None and pe.steps > 0:
+            eps, best_alpha = pe.get_privacy_spent(self.opt.delta)
+            print("({}, {})-DP for alpha={}".format(eps, self.opt.delta, best_alpha))
+
+    # ---- device-side statistics ----------------------------------------------------------------
+    def _acc(self, name, value):
+        cur = self.dev_stats.get(name)
+        self.dev_stats[name] = value.clone() if cur is None else cur + value
+
+    def flush_stats(self):
+        """Fold device-side sums into the Logger (this is where the host synchronises)."""
+        for k, v in list(self.dev_stats.items()):
+            if k.startswith("_"):
+                continue
+            val = v.detach().cpu()
+            val = float(val) if val.dim() == 0 else val.numpy().astype(np.float64)
+            if k in self.logger.stats:
+                self.logger.stats[k] = self.logger.stats[k] + val
+            del self.dev_stats[k]
+
+    # ---- train.py:263-278 ---------------------------------------------------------------------
+    def _make_logger(self, log_to):
+        o = self.opt
+        aux, pen, gc, im = o.use_aux_loss, len(o.penalty) > 0, o.dp_mode == "gc", o.dp_mode == "is"
+        fmt = "G " + ("Adv " if aux else "") + "Loss: {:4.4f}" + (", G Aux: {:4.4f} / {:3.1f}%\n" if aux else " | ")
+        fmt += "D Adv Loss: {:4.4f} (Real: {:4.4f} / {:3.1f}%, Fake: {:4.4f} / {:3.1f}%"
+        fmt += (", Real Aux: {:4.4f} / {:3.1f}%" if aux else "") + (", Penalty: {:4.4f}" if pen else "") + ")"
+        if gc:
+            fmt += "\n=== Grad Norms ===\nMean Per Layer: {}\nStd Per Layer: {}\nMax Per Layer: {}\nClipping Params: {}\nGrads Clipped: {}"
+        if im:
+            fmt += "\nIS - Mean: {} - Min: {} - Max: {}"
+        names = ["G Adv Loss"] + (["G Aux Loss", "G Aux Acc"] if aux else [])
+        names += ["D Adv Loss", "D Real Loss", "D Real Acc", "D Fake Loss", "D Fake Acc"]
+        names += (["D Real Aux Loss", "D Real Aux Acc"] if aux else []) + (["D Penalty"] if pen else [])
+        if gc:
+            names += ["D Layer Grad Norm Means", "D Layer Grad Norm Stds", "D Layer Grad Norm Maxes", "Clipping Params", "Grads Clipped"]
+        if im:
+            names += ["IS Mean", "IS Min", "IS Max"]
+        every = o.log_every_epochs * o.train_set_size if o.log_every_epochs > 0 else o.log_every
+        path = log_to if log_to is not None else o.output_dir + "log.csv"
+        lg = Logger(fmt, names, max(every // o.batch_size, 1), path)
+        lg.log_g_iter = 0
+        return lg

@@ -1,0 +1,158 @@
+"""End-to-end D-step parity (-m gpu): csl_gan_amd.trainer.Trainer.train_D on the HIP kernels against
+oracle/dstep.py on identical weights and identical random inputs (z, mean-sample batches, penalty
+alpha, DP noise).  Tolerance 1e-3 relative (the north-star bar), measured per tensor against its scale."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-3
+
+
+def _close(got, exp, what, rtol=RTOL):
+    got = torch.as_tensor(got).detach().cpu().double().reshape(-1)
+    exp = torch.as_tensor(exp).detach().cpu().double().reshape(-1)
+    assert got.shape == exp.shape, (what, got.shape, exp.shape)
+    scale = exp.abs().max().item() + 1e-12
+    err = (got - exp).abs().max().item()
+    assert err <= rtol * scale, "%s: max abs err %.3e, scale %.3e, rel %.3e" % (what, err, scale, err / scale)
+
+
+def _setup(tmp_path, dataset, extra, B, latent):
+    from csl_gan_amd import init_util, options
+    from csl_gan_amd.trainer import Trainer
+    from oracle.dstep import OracleDStep, StepConfig
+    from oracle.nets import build_models
+    argv = [dataset, "-dpm", "gc", "-nms", "4", "-bs", str(B), "-gd", "cuda:0", "-dd", "cuda:0", "-o", str(tmp_path),
+            "--manual_seed", "1", "--g_latent_dim", str(latent), "--sigma", "0.5"] + extra
+    opt = options.parse(argv)
+    G, D = init_util.init_models(opt)
+    tr = Trainer(opt, G, D, log_to=str(tmp_path / "log.csv"))
+    pe = tr.setup_privacy_engine()
+    Go, Do = build_models(dataset=dataset, model=opt.model, im_size=opt.im_size, weights_seed=opt.weights_seed, manual_seed=1,
+                          per_sample_grad=True, g_latent_dim=latent)
+    for (n1, p1), (n2, p2) in zip(D.named_parameters(), Do.named_parameters()):
+        assert n1 == n2 and torch.equal(p1.detach().cpu(), p2.detach())
+    n = len(list(Do.parameters()))
+    cfg = StepConfig(dp_mode="gc", grad_clip_mode=opt.grad_clip_mode, grad_clip_split=opt.grad_clip_split,
+                     clipping_param=opt.clipping_param,
+                     clipping_param_per_layer=list(opt.clipping_param_per_layer) if opt.clipping_param_per_layer else [1.0] * n,
+                     adaptive_scalar=opt.adaptive_scalar, sigma=opt.sigma, penalty=tuple(opt.penalty), lr=opt.d_lr,
+                     adam_b1=opt.adam_b1, adam_b2=opt.adam_b2, aux_penalty=opt.aux_penalty)
+    return opt, tr, pe, OracleDStep(Go, Do, cfg), Do
+
+
+CASES = [
+    ("MNIST", ["--model", "DeepConvResNet", "--penalty", "WGAN-GP", "-c", "3.0"], 6, 16),
+    ("MNIST", ["--model", "DeepConvResNet", "--penalty", "WGAN-GP", "-gcm", "adaptive-pl"], 6, 16),
+    ("MNIST", ["--model", "DeepConvResNet", "--penalty", "WGAN-GP", "-gcm", "adaptive", "-gcs", "False"], 6, 16),
+    ("MNIST", ["--model", "Vanilla", "-c", "0.5"], 16, 100),
+    ("CelebA", ["-gcm", "adaptive-pl"], 8, 128),
+    ("CelebA", ["-gcm", "constant-pl", "-cpl", "0.5", "0.05", "1", "0.1", "2", "0.2", "3", "0.5", "4"], 8, 128),
+    ("CelebA", ["-c", "2.0"], 8, 128),
+]
+
+
+@pytest.mark.parametrize("dataset,extra,B,latent", CASES)
+def test_train_D_matches_oracle(tmp_path, dataset, extra, B, latent):
+    opt, tr, pe, oracle, Do = _setup(tmp_path, dataset, extra, B, latent)
+    g = torch.Generator().manual_seed(77)
+    ch, im = (1, 28) if dataset == "MNIST" else (3, 64)
+    img = (torch.randn(B, ch, im, im, generator=g) * 0.5).clamp(-1, 1)
+    ms_a = (torch.randn(B, ch, im, im, generator=g) * 0.3).clamp(-1, 1)
+    ms_p = (torch.randn(B, ch, im, im, generator=g) * 0.3).clamp(-1, 1)
+    z, z_ad = torch.randn(B, latent, generator=g), torch.randn(B, latent, generator=g)
+    alpha = torch.rand(B, generator=g)
+    params_o = list(Do.parameters())
+    zs = [torch.randn(p.numel(), generator=torch.Generator().manual_seed(5 + i)) for i, p in enumerate(params_o)]
+
+    tr.explicit = dict(ms_adapt=ms_a, pen_real=ms_p, alpha=alpha, z_adapt=z_ad.cuda(), keep=True)
+    pe.host_noise = zs                   # unit normals applied in each parameter's MEMORY order
+    tr.train_D(img.cuda(), None, z.cuda(), None, use_dp=True)
+    torch.cuda.synchronize()
+    last = tr.last
+
+    # oracle noise in LOGICAL order, pre-scaled by std
+    C = oracle.max_grad_norm
+    def to_logical(zv, p):
+        if p.dim() == 4:
+            K, Cc, R, S = p.shape
+            return zv.view(K, R, S, Cc).permute(0, 3, 1, 2)
+        return zv.view(p.shape)
+    obs = None
+    def run_oracle():
+        nonlocal obs
+        # stds depend on C which adaptive modes set inside step(): pass unit noise scaled after the fact
+        obs = oracle.step(img, None, z, None, ms_adapt=ms_a, z_adapt=z_ad, pen_real=ms_p if opt.penalty else None,
+                          alpha=alpha, noise=None, noise_gen=None, apply_update=False)
+    oracle.cfg.sigma = 0.0
+    run_oracle()
+    Cfin = oracle.max_grad_norm
+    stds = [opt.sigma * c for c in Cfin] if isinstance(Cfin, list) else [opt.sigma * Cfin] * len(params_o)
+    grads_o = [(s + to_logical(zv, p) * sd) / B for s, zv, p, sd in zip(obs["summed_grad"], zs, params_o, stds)]
+
+    _close(last["d_real_loss"], obs["d_real_loss"], "d_real_loss")
+    _close(last["d_fake_loss"], obs["d_fake_loss"], "d_fake_loss")
+    _close(last["fake_img"], obs["fake_img"], "fake_img (generator forward)")
+    if opt.penalty:
+        _close(last["penalty"], obs["penalty"], "penalty")
+    if "adaptive_stats" in obs:
+        _close(last["adaptive_stats"], torch.tensor(obs["adaptive_stats"]), "adaptive stats")
+    _close(last["clip_params"], torch.tensor(Cfin if isinstance(Cfin, list) else [Cfin]), "clip params")
+    n_o, f_o = obs["norms"], obs["clip_factors"]          # [L or 1, passes, B]
+    if opt.grad_clip_split:
+        f_o = f_o.clone(); f_o[:, 0] = 1.0   # generated-data pass is not clipped
+        _close(last["norms"].reshape(n_o.shape[0], -1), n_o.reshape(n_o.shape[0], -1), "per-sample norms")
+        _close(last["clip_factors"].reshape(f_o.shape[0], -1), f_o.reshape(f_o.shape[0], -1), "clip factors")
+    else:                                    # accumulated passes: the logged column is pass 0
+        _close(last["norms"], n_o[:, 0], "per-sample norms (pass 0)")
+        _close(last["clip_factors"].reshape(f_o.shape[0], -1), f_o[:, 0], "clip factors (pass 0)")
+    for i, (a, b) in enumerate(zip(last["summed_clipped"], obs["summed_clipped"])):
+        _close(a, b, "summed_clipped[%d]" % i)
+    if opt.penalty:
+        for i, (a, b) in enumerate(zip(last["penalty_grads"], obs["penalty_grads"])):
+            if b is None or b.abs().max() == 0:
+                assert a is None or a.abs().max().item() < 1e-6
+            else:
+                _close(a, b, "penalty_grads[%d]" % i, rtol=2e-3)
+    for i, (a, b) in enumerate(zip(last["summed_grad"], obs["summed_grad"])):
+        _close(a, b, "summed_grad[%d]" % i)
+    for i, (p, b) in enumerate(zip(tr.D.parameters(), grads_o)):
+        _close(p.grad, b, "noised grad[%d]" % i)
+    # Adam update
+    import oracle.dp_engine as OE
+    with torch.no_grad():
+        OE.adam_step(params_o, grads_o, {}, opt.d_lr, opt.adam_b1, opt.adam_b2, weight_decay=opt.weight_decay)
+    for i, (p, q) in enumerate(zip(tr.D.parameters(), params_o)):
+        _close(p, q, "updated weight[%d]" % i, rtol=1e-5)
+    assert pe.steps == 1
+
+
+def test_second_step_runs_and_norm_recompute_agrees(tmp_path):
+    """Two consecutive steps (state reset between steps) and the contract kernel over the
+    materialised grad_sample (cslgan_sample_sqnorm_f32) against the wgrad-epilogue norms."""
+    opt, tr, pe, oracle, Do = _setup(tmp_path, "CelebA", ["-gcm", "adaptive-pl"], 8, 128)
+    from csl_gan_amd.mean_sampler import MeanSampler
+    ms = MeanSampler(num_samples=4, mean_size=10, device="cuda:0")
+    ms.mean_samples = torch.randn(1, 4, 3, 64, 64, device="cuda:0") * 0.2
+    tr.mean_sampler = ms
+    img = torch.randn(8, 3, 64, 64, device="cuda:0").clamp(-1, 1)
+    for it in range(2):
+        tr.train_D(img, None, tr.gen_z(8), None, use_dp=True)
+    assert pe.steps == 2
+    # epilogue norms vs contract kernel on a fresh backward
+    pe.zero_grad(); pe.enable_hooks()
+    out, _ = tr.D(img)
+    tr.D.real_loss(out, "cuda:0").backward()
+    pe.disable_hooks()
+    a = pe.sample_sqnorms(recompute=False)
+    b = pe.sample_sqnorms(recompute=True)
+    _close(a, b, "epilogue vs recomputed sq norms", rtol=1e-4)
+    from csl_gan_amd.engine import calc_sample_norms
+    per = calc_sample_norms(pe.clipper._named_grad_samples(), flat=False)
+    assert len(per) == 9 and per[0].shape == (1, 8)
+    _close(torch.stack(per).reshape(9, -1), a.sqrt(), "calc_sample_norms API", rtol=1e-4)
+    gs = tr.D.blocks[1].weight.grad_sample
+    assert gs.shape == (1, 8, 128, 64, 5, 5)
+    _close(gs[0].reshape(8, -1).norm(2, dim=1), a[2].sqrt(), "train.py:233-style norm of p.grad_sample", rtol=1e-4)

@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Benchmark of the DP discriminator step (BASELINE.json metric) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one `train_D` (train.py:360-500) of the headline configuration
+    CelebA DCResNet, dp_mode=gc, -gcm adaptive-pl, -nms 32, WGAN-GP on mean samples, bs=128 per GPU
+on synthetic 3x64x64 data already resident in HBM: adaptive-clipping pass on mean samples, generator
+forward for the fakes, fake + real discriminator passes, per-sample gradients, norms, clip,
+accumulate, WGAN-GP double backward, Gaussian noise, Adam.  Weak scaling: every rank processes its
+own 128 images; the clipped+noised gradients are all-reduced over RCCL.
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the roofline accounting).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# algorithmic work per image (SURVEY.md §8d / BASELINE.md §6), FLOP
+FLOP_PER_IMG_STEP = 14.3e9
+PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+B_PER_GPU = 128
+
+
+def build_trainer(rank, world, local, batch=B_PER_GPU, outdir=None):
+    from csl_gan_amd import distributed as D, init_util, options
+    from csl_gan_amd.mean_sampler import MeanSampler
+    from csl_gan_amd.trainer import Trainer
+    dev = "cuda:%d" % local
+    outdir = outdir or tempfile.mkdtemp(prefix="cslgan_bench_")
+    opt = options.parse(["CelebA", "-dpm", "gc", "-gcm", "adaptive-pl", "-nms", "32", "-bs", str(batch), "-gd", dev, "-dd", dev,
+                         "-o", outdir, "--manual_seed", "1234", "--synthetic"])
+    G, Dm = init_util.init_models(opt)
+    g = torch.Generator().manual_seed(1234)
+    # 32 mean samples: mean of 1000 synthetic images + N(0, 0.12^2)  (options.py:71-72)
+    acc = torch.zeros(32, 3, 64, 64)
+    for i in range(32):
+        acc[i] = (torch.randn(1000, 3, 64, 64, generator=g) * 0.5).clamp(-1, 1).mean(0)
+    ms = MeanSampler(noise_std=0.12, num_samples=32, mean_size=1000, dataset_size=opt.train_set_size, device=dev)
+    ms.mean_samples = (acc + torch.randn(acc.shape, generator=g) * 0.12).unsqueeze(0).to(dev)
+    reducer = D.FlatGradReducer() if world > 1 else None
+    tr = Trainer(opt, G, Dm, mean_sampler=ms, log_to=os.path.join(outdir, "log_rank%d.csv" % rank), world_size=world,
+                 rank=rank, grad_reducer=reducer)
+    tr.setup_privacy_engine()
+    gr = torch.Generator().manual_seed(1234 + rank)
+    img = (torch.randn(batch, 3, 64, 64, generator=gr) * 0.5).clamp(-1, 1).to(dev)
+    return opt, tr, img
+
+
+def cpu_baseline():
+    """The oracle's D-step (same step definition, hook-based unfold+einsum per-sample gradients —
+    the algorithm family the reference's Opacus dependency uses) on the host cores."""
+    from oracle.dstep import OracleDStep, StepConfig
+    from oracle.nets import build_models
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    G, Dm = build_models(weights_seed=42, manual_seed=1234)
+    st = OracleDStep(G, Dm, StepConfig(grad_clip_mode="adaptive-pl", clipping_param_per_layer=[1.0] * 9, sigma=0.5))
+    g = torch.Generator().manual_seed(1234)
+
+    def one(B):
+        img = (torch.randn(B, 3, 64, 64, generator=g) * 0.5).clamp(-1, 1)
+        ms = torch.randn(B, 3, 64, 64, generator=g) * 0.2
+        t0 = time.perf_counter()
+        st.step(img, None, torch.randn(B, 128, generator=g), None, ms_adapt=ms, pen_real=ms, alpha=torch.rand(B, generator=g), noise_gen=g)
+        return time.perf_counter() - t0
+    one(16)                      # warm-up (allocator, thread pool)
+    dt = one(B_PER_GPU)
+    return {"value": round(B_PER_GPU / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 oracle D-step (config 3) at bs=128 after a bs=16 warm-up, %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    from csl_gan_amd import distributed as D, ops
+    world, rank, local = D.init("nccl")
+    if world != a.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local)
+    opt, tr, img = build_trainer(rank, world, local)
+    B = img.shape[0]
+
+    def step():
+        tr.train_D(img, None, tr.gen_z(B), None, use_dp=True)
+        tr.dev_stats.clear()
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    D.barrier()
+    timer = ops.LaunchTimer()
+    ops.set_launch_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = time.perf_counter() - t0
+    ops.set_launch_timer(None)
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    if rank != 0:
+        return
+    ips = world * B * a.steps / dt
+    kernels = timer.summary()
+    dom = max(kernels.values(), key=lambda k: k["ms"]) if kernels else None
+    roof = None
+    if dom:
+        ach = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "launches_per_step": dom["n"] / a.steps,
+                "avg_launch_ms": round(dom["ms"] / dom["n"], 4), "share_of_step": round(dom["ms"] / (dt * 1e3), 3)}
+    line = {
+        "metric": "images/sec/GPU CelebA DCResNet dp_mode=gc bs=128 at 1/2/4/8 MI355X",
+        "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "CelebA DCResNet D-step: dp_mode=gc -gcm adaptive-pl -nms 32, WGAN-GP on mean samples, 3x64x64",
+                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                   "step": "train_D (adaptive pass + G fwd + 2 D passes + per-sample grads + clip + GP + noise + Adam)"},
+        "per_gpu": round(ips / world, 2),
+        "step_tflops_algorithmic": round(FLOP_PER_IMG_STEP * ips / 1e12, 2),
+        "step_frac_of_fp32_mfma_peak": round(FLOP_PER_IMG_STEP * ips / world / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+        "roofline": roof,
+        "kernels_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline()
+        line["gpu_over_cpu"] = round(ips / line["cpu_baseline"]["value"], 1)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,70 @@
+"""Multi-GPU data parallelism for the D-step: one process per GPU, torch.distributed over RCCL/xGMI.
+
+The path shards by sample (per-sample gradients and clip factors are independent per sample,
+SURVEY.md §8e): every rank runs the whole D-step on its own B_local images; the only data-path
+exchange is ONE all-reduce(SUM) of the already-clipped-and-noised gradients — 17.3 MB fp32 for D64,
+sent as a single flat bucket (xGMI is point-to-point, 7 links x ~153 GB/s: at this size the
+collective is latency-bound, so fewer/larger messages, never per-tensor calls).  Each rank adds
+Gaussian noise of variance (sigma*C)^2 / R so the reduced sum carries exactly (sigma*C)^2, and
+pre-scales by 1/(B_local*R), so nothing follows the collective.  Adaptive clip norms are averaged
+across ranks (9 floats) so every rank clips and noises with the same C.
+
+The reference has no distributed code at all; this module is the build's extension
+for BASELINE.json configs 4-5.  `backend="nccl"` is RCCL on ROCm; CPU tests use gloo.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None):
+    """Initialise the default process group from the torchrun environment (no-op for WORLD_SIZE=1)."""
+    world, rank, local = env_world()
+    if world == 1:
+        return world, rank, local
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return world, rank, local
+
+
+class FlatGradReducer:
+    """all-reduce(SUM) of one flat gradient bucket.  The engine hands over the flat fp32 buffer its
+    per-parameter .grad tensors alias, already scaled by 1/(B_local*R)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bytes_reduced = 0
+
+    def __call__(self, flat: torch.Tensor):
+        if self.world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.bytes_reduced += flat.numel() * flat.element_size()
+        return flat
+
+
+def average_across_ranks(t: torch.Tensor, use_max=False, group=None):
+    """In-place mean (or max) of a small tensor over ranks: adaptive clipping statistics."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if use_max else dist.ReduceOp.SUM, group=group)
+        if not use_max:
+            t /= dist.get_world_size(group)
+    return t
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

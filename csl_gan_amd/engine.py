@@ -372,10 +372,14 @@ class PrivacyEngine:
         # R ranks each add noise of variance (sigma*C)^2 / R, so the all-reduced sum has (sigma*C)^2
         dev = ps[0].device
         ins = [_flat(p.summed_grad).view(1, -1) for p in ps]
-        grads = []
+        # one flat fp32 bucket; every p.grad aliases its slice (same strides as p), so the all-reduce
+        # needs no gather/scatter copies
+        flat = torch.empty(sum(p.numel() for p in ps), device=dev, dtype=torch.float32)
+        grads, off = [], 0
         for p in ps:
-            p.grad = torch.empty_like(p, memory_format=torch.preserve_format)
-            grads.append(_flat(p.grad))
+            p.grad = torch.as_strided(flat, p.size(), p.stride(), storage_offset=off)
+            grads.append(flat[off:off + p.numel()])
+            off += p.numel()
         noises = None
         if self.host_noise is not None:
             noises = [z.to(dev) for z in self.host_noise]
@@ -384,11 +388,10 @@ class PrivacyEngine:
         std_dev = None
         if self.noise_multiplier > 0:
             std_dev = (self._C_device(dev) * (self.noise_multiplier / (R ** 0.5))).expand(len(ps)).contiguous()
-        pre = 1.0 if self.grad_reducer is not None else 1.0 / denom
         ops.clip_accum_noise(ins, grads, noise_std=std_dev, noises=noises, seed=self.seed,
-                             offset=self._noise_calls, scale=pre)
+                             offset=self._noise_calls, scale=1.0 / denom)
         if self.grad_reducer is not None:
-            self.grad_reducer(grads, 1.0 / denom)
+            self.grad_reducer(flat)
         self._noise_calls += 1
         self.steps += 1
         for p in ps:

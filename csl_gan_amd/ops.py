@@ -21,6 +21,52 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class LaunchTimer:
+    """HIP-event timing of individual C-ABI launches on the stream they are enqueued on (torch's
+    current stream), for bench.py's live roofline figures.  Events are resolved once, after the
+    caller has synchronised."""
+
+    def __init__(self):
+        self.records = []
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, name, flop, nbytes, start):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.records.append((name, flop, nbytes, start, e))
+
+    def summary(self):
+        out = {}
+        for name, flop, nbytes, s, e in self.records:
+            d = out.setdefault(name, {"name": name, "ms": 0.0, "flop": 0.0, "bytes": 0.0, "n": 0})
+            d["ms"] += s.elapsed_time(e)
+            d["flop"] += flop
+            d["bytes"] += nbytes
+            d["n"] += 1
+        return out
+
+
+_timer = None
+
+
+def set_launch_timer(t):
+    global _timer
+    _timer = t
+
+
+def _timed(name, flop, nbytes, fn):
+    if _timer is None:
+        return fn()
+    s = _timer.begin()
+    r = fn()
+    _timer.end(name, flop, nbytes, s)
+    return r
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -61,8 +107,12 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, upsample=False, residual=None, 
         exp = (N, P >> res_shift, Q >> res_shift, K)
         if tuple(residual.shape) != exp:
             raise RuntimeError("conv2d_fwd: residual shape %s, expected %s" % (tuple(residual.shape), exp))
-    check(_lib.lib().cslgan_conv2d_fwd_f32(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), res_shift, act, _p(y), _stream()),
-          "conv2d_fwd")
+    VH, VW = (2 * H, 2 * W) if upsample else (H, W)
+    flop = 2.0 * N * P * Q * K * R * S * Cc       # the dense conv the reference executes on the (up-sampled) input
+    nbytes = 4.0 * (N * VH * VW * Cc + K * R * S * Cc + N * P * Q * K)
+    _timed("conv2d_fwd", flop, nbytes, lambda: check(
+        _lib.lib().cslgan_conv2d_fwd_f32(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), res_shift, act, _p(y), _stream()),
+        "conv2d_fwd"))
     return y
 
 
@@ -81,7 +131,10 @@ def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None):
         _chk(mask, "mask")
         if tuple(mask.shape) != tuple(gx.shape):
             raise RuntimeError("conv2d_dgrad: mask shape mismatch")
-    check(_lib.lib().cslgan_conv2d_dgrad_f32(C.byref(d), _p(gy), _p(w), _p(ws), _p(mask), _p(gx), _stream()), "conv2d_dgrad")
+    flop = 2.0 * N * P * Q * K * R * S * Cc
+    nbytes = 4.0 * (N * H * W * Cc + K * R * S * Cc + N * P * Q * K)
+    _timed("conv2d_dgrad", flop, nbytes, lambda: check(
+        _lib.lib().cslgan_conv2d_dgrad_f32(C.byref(d), _p(gy), _p(w), _p(ws), _p(mask), _p(gx), _stream()), "conv2d_dgrad"))
     return gx
 
 
@@ -102,8 +155,11 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
         _chk(gw, "gw")
     if sq is not None:
         _chk(sq, "sq")
-    check(_lib.lib().cslgan_conv2d_wgrad_grouped_f32(C.byref(d), _p(gy), _p(x), group, float(alpha), _p(gw), _p(sq), _stream()),
-          "conv2d_wgrad_grouped")
+    flop = 2.0 * N * P * Q * K * R * S * Cc
+    nbytes = 4.0 * (N * H * W * Cc + N * P * Q * K + (G * K * R * S * Cc if want_gw else 0))
+    _timed("conv2d_wgrad_grouped" + ("" if want_gw else "_normonly"), flop, nbytes, lambda: check(
+        _lib.lib().cslgan_conv2d_wgrad_grouped_f32(C.byref(d), _p(gy), _p(x), group, float(alpha), _p(gw), _p(sq), _stream()),
+        "conv2d_wgrad_grouped"))
     return gw
 
 
@@ -151,7 +207,9 @@ def sample_sqnorm(mats: Sequence[torch.Tensor]) -> torch.Tensor:
         chunk = list(mats[i:i + _lib.MAX_SEGS])
         s, n_rows = _segs(chunk)
         o = torch.empty((len(chunk), n_rows), device=chunk[0].device, dtype=torch.float32)
-        check(_lib.lib().cslgan_sample_sqnorm_f32(C.byref(s), n_rows, _p(o), _stream()), "sample_sqnorm")
+        nbytes = 4.0 * sum(n_rows * m.shape[1] for m in chunk)
+        _timed("sample_sqnorm", 0.0, nbytes, lambda: check(
+            _lib.lib().cslgan_sample_sqnorm_f32(C.byref(s), n_rows, _p(o), _stream()), "sample_sqnorm"))
         outs.append(o)
     return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
@@ -188,8 +246,10 @@ def clip_accum_noise(mats, outs, factors=None, noise_std=None, noises=None, seed
         if noise_std is not None:
             _chk(noise_std, "noise_std")
             ns = noise_std[sl].contiguous() if i or len(mats) > _lib.MAX_SEGS else noise_std
-        check(_lib.lib().cslgan_clip_accum_noise_f32(C.byref(s), n_rows, _p(f), per_seg, _p(ns), int(seed), int(offset) + i,
-                                                     float(scale), float(beta), _stream()), "clip_accum_noise")
+        nbytes = 4.0 * sum((n_rows + 1) * m.shape[1] for m in mats[sl])
+        _timed("clip_accum_noise", 0.0, nbytes, lambda: check(
+            _lib.lib().cslgan_clip_accum_noise_f32(C.byref(s), n_rows, _p(f), per_seg, _p(ns), int(seed), int(offset) + i,
+                                                   float(scale), float(beta), _stream()), "clip_accum_noise"))
 
 
 def l2_clip_rows(t, Cval):

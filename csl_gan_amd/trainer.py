@@ -150,6 +150,9 @@ class Trainer:
             # per-layer per-sample norms of pass 0: produced by the wgrad epilogue, never re-read from HBM
             norms = pe.sample_sqnorms()[:, :B].sqrt()                      # [n_params, B]
             r = norms.mean(dim=1) if o.adaptive_stat == "mean" else norms.max(dim=1).values
+            if self.world_size > 1:        # every rank must clip and noise with the same C
+                from .distributed import average_across_ranks
+                r = average_across_ranks(r.contiguous(), use_max=o.adaptive_stat == "max")
             self.last["adaptive_stats"] = r
             if o.use_grad_clip_per_layer:
                 pe.set_max_grad_norm_device(r * o.adaptive_scalar)

@@ -131,7 +131,7 @@ class OracleDStep:
         d_fake, d_fake_aux, fl, fal, fake = self._fake(z, y)
         d_real, d_real_aux, rl, ral = self._real(img, labels)
         d_loss = rl + fl + ral + fal
-        obs.update(d_real_loss=float(rl), d_fake_loss=float(fl), d_real=d_real.detach().clone(),
+        obs.update(d_real_loss=float(rl.detach()), d_fake_loss=float(fl.detach()), d_real=d_real.detach().clone(),
                    d_fake=d_fake.detach().clone(), fake_img=fake)
         penalty = torch.tensor(0.0)
 
@@ -188,7 +188,7 @@ class OracleDStep:
             gl = torch.autograd.grad(d_loss, params, allow_unused=True)
             grads = [torch.zeros_like(p) if g is None else g for g, p in zip(gl, params)]
 
-        obs["penalty"] = float(penalty)
+        obs["penalty"] = float(penalty.detach())
         obs["grads"] = [g.clone() for g in grads]
         if apply_update:
             with torch.no_grad():
@@ -196,5 +196,5 @@ class OracleDStep:
         obs["d_real_acc"] = 100 * float((d_real.detach() > 0).float().mean())
         obs["d_fake_acc"] = 100 * float((d_fake.detach() < 0).float().mean())
         if cfg.use_aux_loss:
-            obs["d_real_aux_loss"] = float(ral)
+            obs["d_real_aux_loss"] = float(ral.detach())
         return obs

@@ -125,7 +125,7 @@ def test_train_D_matches_oracle(tmp_path, dataset, extra, B, latent):
     with torch.no_grad():
         OE.adam_step(params_o, grads_o, {}, opt.d_lr, opt.adam_b1, opt.adam_b2, weight_decay=opt.weight_decay)
     for i, (p, q) in enumerate(zip(tr.D.parameters(), params_o)):
-        _close(p, q, "updated weight[%d]" % i, rtol=1e-5)
+        _close(p, q, "updated weight[%d]" % i, rtol=1e-4)
     assert pe.steps == 1
 
 

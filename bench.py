@@ -62,7 +62,7 @@ def cpu_baseline():
     the algorithm family the reference's Opacus dependency uses) on the host cores."""
     from oracle.dstep import OracleDStep, StepConfig
     from oracle.nets import build_models
-    threads = os.cpu_count() or 1
+    threads = min(16, os.cpu_count() or 1)      # the GPU box gives one GPU a 16-core CPU share
     torch.set_num_threads(threads)
     G, Dm = build_models(weights_seed=42, manual_seed=1234)
     st = OracleDStep(G, Dm, StepConfig(grad_clip_mode="adaptive-pl", clipping_param_per_layer=[1.0] * 9, sigma=0.5))
@@ -74,10 +74,11 @@ def cpu_baseline():
         t0 = time.perf_counter()
         st.step(img, None, torch.randn(B, 128, generator=g), None, ms_adapt=ms, pen_real=ms, alpha=torch.rand(B, generator=g), noise_gen=g)
         return time.perf_counter() - t0
-    one(16)                      # warm-up (allocator, thread pool)
-    dt = one(B_PER_GPU)
-    return {"value": round(B_PER_GPU / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 oracle D-step (config 3) at bs=128 after a bs=16 warm-up, %.1f s" % dt}
+    one(8)                       # warm-up (allocator, thread pool)
+    Bs = 32
+    dt = one(Bs)
+    return {"value": round(Bs / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 oracle D-step (config 3) on a bs=%d slice of the bs=128 workload after a bs=8 warm-up, %.1f s" % (Bs, dt)}
 
 
 def main():

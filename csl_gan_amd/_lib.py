@@ -50,6 +50,9 @@ def lib():
         raise HipLibraryMissing(
             "libcslgan_hip.so not found at %s — build it with `python -m csl_gan_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for device tensors." % LIB_PATH)
+    # torch first: its bundled HIP runtime must be the one already mapped when our library's
+    # libamdhip64 dependency is resolved (two HIP runtimes in one process cannot share a device context)
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     L.cslgan_last_error.restype = C.c_char_p
     vp, i32, i64, f32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64

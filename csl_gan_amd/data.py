@@ -1,0 +1,40 @@
+"""Synthetic in-memory datasets with the reference DataLoader contract (init_util.py:13-42 returns
+(dataset, dataloader, public_dataset, public_dataloader); batches are (images, labels)).
+
+The container and the GPU box hold no MNIST / CelebA files and there is no network, so the CLI and
+the benchmark train on synthetic tensors of the right shape and range:
+CelebA-like: clamp(N(0, 0.5^2), -1, 1), 3 x im_size x im_size, binary label ~ Bernoulli(0.42);
+MNIST-like:  U[0,1], 1 x 28 x 28, label ~ randint(10).  Real-data loaders are §8f item 4 (out of scope).
+"""
+import torch
+from torch.utils.data import DataLoader, TensorDataset
+
+
+class SyntheticImages(TensorDataset):
+    def __init__(self, dataset, n, im_size, seed=1234, offset=0):
+        g = torch.Generator().manual_seed(seed + offset)
+        if dataset == "MNIST":
+            x = torch.rand(n, 1, 28, 28, generator=g)
+            y = torch.randint(0, 10, (n,), generator=g)
+        else:
+            x = (torch.randn(n, 3, im_size, im_size, generator=g) * 0.5).clamp(-1, 1)
+            y = (torch.rand(n, generator=g) < 0.42).long()
+        super().__init__(x, y)
+        self.label_true_count = int(y.sum()) if dataset != "MNIST" else None
+
+    def get_item_with_label(self, label):
+        x, y = self.tensors
+        idx = torch.nonzero(y == int(label)).flatten()
+        i = idx[torch.randint(0, len(idx), (1,))].item()
+        return x[i], int(y[i])
+
+
+def init_data(opt):
+    """Synthetic counterpart of init_util.init_data: same return tuple, shuffle=True loaders."""
+    n = min(opt.train_set_size, getattr(opt, "synthetic_cap", 4096))
+    ds = SyntheticImages(opt.dataset, n, opt.im_size, seed=opt.manual_seed)
+    pub = SyntheticImages(opt.dataset, min(opt.public_set_size, 2048), opt.im_size, seed=opt.manual_seed, offset=1) \
+        if opt.public_set_size > 0 else None
+    dl = DataLoader(ds, batch_size=opt.batch_size, shuffle=True, drop_last=True, num_workers=0)
+    pdl = DataLoader(pub, batch_size=opt.batch_size, shuffle=True, num_workers=0) if pub is not None else None
+    return ds, dl, pub, pdl

@@ -160,3 +160,48 @@ def test_second_step_runs_and_norm_recompute_agrees(tmp_path):
     gs = tr.D.blocks[1].weight.grad_sample
     assert gs.shape == (1, 8, 128, 64, 5, 5)
     _close(gs[0].reshape(8, -1).norm(2, dim=1), a[2].sqrt(), "train.py:233-style norm of p.grad_sample", rtol=1e-4)
+
+
+def test_double_backward_wiring_without_activations():
+    """WGAN-GP through a stack of the HIP conv Functions with NO activation: the penalty is still
+    non-linear (row norm, square) but nothing is discontinuous, so the parameter gradients must match
+    torch's CPU double backward to fp32 accuracy (1e-4), isolating the Conv/Dgrad/Wgrad closure."""
+    import torch.nn.functional as F
+    from csl_gan_amd import functional as HF, ops
+    g = torch.Generator().manual_seed(9)
+    B = 6
+    ws = [torch.randn(16, 3, 5, 5, generator=g) * 0.1, torch.randn(32, 16, 5, 5, generator=g) * 0.05,
+          torch.randn(1, 32 * 4 * 4, generator=g) * 0.05]
+    bs = [torch.randn(16, generator=g) * 0.1, torch.randn(32, generator=g) * 0.1]
+    x = torch.randn(B, 3, 16, 16, generator=g)
+
+    def run(dev):
+        W = [w.clone().to(dev).requires_grad_(True) for w in ws]
+        Bi = [b.clone().to(dev).requires_grad_(True) for b in bs]
+        xx = x.clone().to(dev).requires_grad_(True)
+        if dev == "cpu":
+            h = F.conv2d(xx, W[0], Bi[0], stride=2, padding=2)
+            h = F.conv2d(h, W[1], Bi[1], stride=2, padding=2)
+            out = F.linear(h.reshape(B, -1), W[2])
+            gr, = torch.autograd.grad(out, xx, torch.ones_like(out), create_graph=True)
+            n = gr.reshape(B, -1).norm(2, dim=1)
+        else:
+            h = HF.nhwc(xx)
+            for w_, b_ in zip(W[:2], Bi):
+                h = HF.Conv.apply(h, w_.permute(0, 2, 3, 1).contiguous(), b_, 2, 2, ops.ACT_NONE, False, None, 0)
+            flat = HF.nchw_view(h).reshape(B, -1)
+            out = HF.Conv.apply(flat.reshape(B, 1, 1, -1), W[2].reshape(1, 1, 1, -1), None, 1, 0, ops.ACT_NONE, False, None, 0).reshape(B, 1)
+            gr, = torch.autograd.grad(out, xx, torch.ones_like(out), create_graph=True)
+            n = HF.RowL2Norm.apply(gr.reshape(B, -1))
+        pen = 10 * ((n - 1) ** 2).mean()
+        grads = torch.autograd.grad(pen, W + Bi, allow_unused=True)
+        return pen.detach().cpu(), [None if t is None else t.detach().cpu() for t in grads]
+
+    pc, gc = run("cpu")
+    pg, gg = run("cuda")
+    _close(pg, pc, "penalty", rtol=1e-5)
+    for i, (a, b) in enumerate(zip(gg, gc)):
+        if b is None or b.abs().max() == 0:
+            assert a is None or a.abs().max() < 1e-7
+        else:
+            _close(a, b, "d penalty / d param %d" % i, rtol=1e-4)

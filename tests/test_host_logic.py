@@ -1,0 +1,145 @@
+"""CPU tests of the host-side logic: options surface, accountant known answers, logger format
+(against the reference's own output), mean sampler, model factory / state_dict keys, CLI plumbing
+for BASELINE configs[0] (MNIST vanilla GAN, cpu/cpu, no DP)."""
+import io
+import json
+import math
+import os
+import contextlib
+
+import numpy as np
+import pytest
+import torch
+
+from csl_gan_amd import accountant, options
+
+
+def test_options_defaults_and_quirks(tmp_path):
+    o = options.parse(["CelebA", "-o", str(tmp_path), "-dpm", "gc", "-nms", "32", "-gcm", "adaptive-pl"])
+    assert (o.batch_size, o.n_d_steps, o.g_latent_dim, o.sigma, o.delta) == (128, 5, 128, 0.5, 1e-6)
+    assert o.penalty == ["WGAN-GP"] and o.use_dp and o.per_sample_grad and o.use_grad_clip_per_layer
+    assert o.train_d_until_threshold == -1                      # forced for DCResNet + DP (options.py:240-242)
+    assert o.imm_sens_per_param is True                          # False-as-unset quirk (options.py:95,77)
+    assert o.clipping_param_per_layer == [1000, 200, 1000, 100, 1000, 100, 1000, 5, 2500]
+    assert os.path.isdir(o.output_dir + "saves/")
+    m = options.parse(["MNIST", "-o", str(tmp_path / "m"), "--conditional", "-dpm", "gc", "--sigma", "10", "-bs", "600"])
+    assert (m.model, m.n_classes, m.is_acgan, m.use_aux_loss, m.sigma) == ("Vanilla", 10, True, True, 10.0)
+    assert m.log_every_epochs == 1 and m.log_every == 99600      # 100000 rounded to a multiple of 600
+
+
+def test_options_incompatibilities(tmp_path):
+    with pytest.raises(Exception, match="mean sampling"):
+        options.parse(["CelebA", "-o", str(tmp_path), "-dpm", "gc"])      # penalty on public data without mean samples
+    with pytest.raises(Exception, match="select only one"):
+        options.parse(["CelebA", "-o", str(tmp_path), "-pss", "10", "-nms", "4"])
+    with pytest.raises(Exception, match="IS per parameter"):
+        options.parse(["CelebA", "-o", str(tmp_path), "-dpm", "is", "-nms", "4", "-issm", "constant-pl"])
+    with pytest.raises(SystemExit):
+        options.parse(["ImageNet"])
+
+
+def test_options_resume_roundtrip(tmp_path):
+    o = options.parse(["MNIST", "-o", str(tmp_path), "--manual_seed", "5"])
+    with open(o.output_dir + "opt.txt", "w") as f:
+        json.dump(o.__dict__, f)
+    r = options.parse(["MNIST", "-rp", str(tmp_path), "-re", "3", "-dd", "cuda:0"])
+    assert r.manual_seed == 5 and r.resume_epochs == 3 and r.d_device == "cuda:0" and r.output_dir == o.output_dir
+
+
+def test_accountant_known_answers():
+    # q = 1: plain Gaussian mechanism, RDP(alpha) = alpha / (2 sigma^2) per step
+    for sigma in (0.5, 1.1, 4.0):
+        for a in (1.5, 2, 8, 64.5):
+            assert accountant.compute_rdp(1.0, sigma, 10, a) == pytest.approx(10 * a / (2 * sigma ** 2))
+    assert accountant.compute_rdp(0.0, 1.0, 5, 4.0) == 0.0
+    # integer order: closed form  1/(a-1) log sum_i C(a,i) (1-q)^(a-i) q^i exp((i^2-i)/(2 s^2))
+    q, s, a = 0.01, 1.1, 6
+    exact = math.log(sum(math.comb(a, i) * (1 - q) ** (a - i) * q ** i * math.exp((i * i - i) / (2 * s * s)) for i in range(a + 1))) / (a - 1)
+    assert accountant.compute_rdp(q, s, 1, a) == pytest.approx(exact, rel=1e-10)
+    # fractional orders interpolate smoothly between the neighbouring integers and RDP grows with the order
+    orders = [5.0, 5.5, 6.0]
+    r = accountant.compute_rdp(q, s, 1, orders)
+    assert r[0] < r[1] < r[2] and abs(r[1] - 0.5 * (r[0] + r[2])) < 0.05 * r[2]
+    # composition is linear in steps; epsilon decreases with sigma and increases with steps
+    alphas = accountant.DEFAULT_ALPHAS
+    e = [accountant.get_privacy_spent(alphas, accountant.compute_rdp(128 / 180000, sg, 1000, alphas), 1e-6)[0] for sg in (0.5, 1.0, 2.0)]
+    assert e[0] > e[1] > e[2] > 0
+    e1 = accountant.get_privacy_spent(alphas, accountant.compute_rdp(0.01, 1.1, 100, alphas), 1e-5)[0]
+    e2 = accountant.get_privacy_spent(alphas, accountant.compute_rdp(0.01, 1.1, 1000, alphas), 1e-5)[0]
+    assert e2 > e1
+    # classic conversion is never tighter than the improved one by more than the log terms allow
+    rdp = accountant.compute_rdp(0.01, 1.1, 1000, alphas)
+    assert accountant.get_privacy_spent(alphas, rdp, 1e-5, improved=False)[0] >= accountant.get_privacy_spent(alphas, rdp, 1e-5)[0]
+
+
+def test_logger_matches_reference_output(tmp_path, golden_dir):
+    from csl_gan_amd.logger import Logger
+    path = str(tmp_path / "log.csv")
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        lg = Logger("A: {:4.4f} | B: {:3.1f}", ["A", "B"], 4, path)
+        for i in range(8):
+            lg.stats["A"] += 0.25 * i
+            lg.stats["B"] += 10.0 + i
+            if (i + 1) % 4 == 0:
+                lg.log(i // 4, 50.0 * (i // 4))
+        lg.close()
+    exp = open(os.path.join(golden_dir, "logger_expected.txt")).read()
+    csv_exp, out_exp = exp.split("#STDOUT\n")
+    assert open(path).read().replace("\r\n", "\n") == csv_exp[len("#CSV\n"):].replace("\r\n", "\n")
+    assert buf.getvalue() == out_exp
+
+
+def test_mean_sampler_sample_and_cost():
+    from csl_gan_amd.mean_sampler import MeanSampler
+    ms = MeanSampler(noise_std=0.12, num_samples=4, mean_size=1000, dataset_size=180000, n_classes=2, smallest_class_size=70000)
+    ms.mean_samples = torch.arange(2 * 4, dtype=torch.float32).view(2, 4, 1, 1, 1).expand(2, 4, 3, 8, 8).clone()
+    labels = torch.tensor([0, 1, 1, 0, 1, 0])
+    r, y = ms.sample(6, noise_std=0, noise_mean_std=0, requested_labels=labels)
+    assert torch.equal(y, labels) and r.shape == (6, 3, 8, 8)
+    base = r[:, 0, 0, 0]
+    assert all(4 * int(l) <= v < 4 * int(l) + 4 for v, l in zip(base.tolist(), labels.tolist()))   # right class row
+    assert sorted(base[:4].tolist() - 4 * labels[:4].float().numpy()) == [0, 1, 2, 3]                # a permutation per 4 draws
+    r2, _ = ms.sample(6, requested_labels=labels)
+    assert 0 < (r2 - ms.mean_samples[labels, (r2[:, 0, 0, 0] * 0).long()]).abs().mean() < 10      # jitter applied
+    eps, alpha = ms.get_privacy_cost(target_delta=1e-6)
+    assert eps > 0 and alpha > 1
+    ms1 = MeanSampler(noise_std=0.24, num_samples=4, mean_size=1000, dataset_size=180000, n_classes=2, smallest_class_size=70000)
+    assert ms1.get_privacy_cost(1e-6)[0] < eps
+
+
+def test_state_dict_keys_and_shapes_match_reference_layout():
+    from types import SimpleNamespace as NS
+    from csl_gan_amd import init_util
+    opt = NS(dataset="CelebA", model="DeepConvResNet", im_size=64, conditional=False, n_classes=2, per_sample_grad=True,
+             weights_seed=42, manual_seed=1, g_latent_dim=128, g_label_emb_mode="concat", d_label_emb_mode="concat",
+             conditional_arch="ACGAN", aux_loss_type="wasserstein", aux_loss_scalar=1, g_device="cpu", d_device="cpu")
+    G, D = init_util.init_models(opt)
+    assert list(D.state_dict().keys()) == ["blocks.%d.%s" % (i, n) for i in range(4) for n in ("weight", "bias")] + ["linOut.weight"]
+    assert [tuple(p.shape) for p in D.parameters()] == [(64, 3, 5, 5), (64,), (128, 64, 5, 5), (128,), (256, 128, 5, 5), (256,),
+                                                        (512, 256, 5, 5), (512,), (1, 8192)]
+    assert sum(p.numel() for p in D.parameters()) == 4314752 and sum(p.numel() for p in G.parameters()) == 21057859
+    gk = list(G.state_dict().keys())
+    assert gk[:2] == ["linIn.weight", "linIn.bias"] and "blocks.0.shortcut.conv.weight" in gk and "blocks.3.convUp.conv.weight" in gk
+    assert "blocks.0.convUp.conv.bias" not in gk and gk[-2:] == ["convOut.weight", "convOut.bias"]
+
+
+def test_cli_config0_mnist_vanilla_cpu_no_dp(tmp_path):
+    """BASELINE configs[0]: MNIST vanilla GAN, -gd cpu -dd cpu, bs=64, no DP — plumbing without a GPU."""
+    from csl_gan_amd import train
+    tr = train.main(["MNIST", "-bs", "64", "-gd", "cpu", "-dd", "cpu", "-o", str(tmp_path), "--max_iters", "12", "--synthetic",
+                     "--log_every", "256", "--manual_seed", "3"])
+    rows = open(str(tmp_path / "log.csv")).read().strip().splitlines()
+    assert rows[0].startswith("Epoch,Batch,G Adv Loss,D Adv Loss") and len(rows) >= 3
+    vals = [float(v) for v in rows[1].split(",")[2:]]
+    assert all(np.isfinite(vals)) and 0 < vals[1] < 5
+    assert os.path.exists(str(tmp_path / "saves" / "D-1")) and os.path.exists(str(tmp_path / "opt.txt"))
+    ck = torch.load(str(tmp_path / "saves" / "D-1"), weights_only=False)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss"}
+
+
+def test_dp_engine_refuses_cpu_modules():
+    from csl_gan_amd.engine import PrivacyEngine
+    from csl_gan_amd.MNIST_models import MNISTVanillaD
+    with pytest.raises(RuntimeError, match="HIP device"):
+        PrivacyEngine(MNISTVanillaD(), batch_size=4, sample_size=100, alphas=[2, 3], noise_multiplier=1.0, max_grad_norm=1.0)

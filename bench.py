@@ -94,7 +94,9 @@ def main():
     if world != a.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
     torch.cuda.set_device(local)
-    opt, tr, img = build_trainer(rank, world, local)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):          # option parsing prints notices; stdout carries ONE JSON line
+        opt, tr, img = build_trainer(rank, world, local)
     B = img.shape[0]
 
     def step():

@@ -16,7 +16,7 @@ EXPORTS = [
     "cslgan_version", "cslgan_last_error", "cslgan_device_count",
     "cslgan_sample_sqnorm_f32", "cslgan_clip_factors_f32", "cslgan_clip_accum_noise_f32",
     "cslgan_l2_clip_rows_f32", "cslgan_row_l2norm_f32", "cslgan_row_l2norm_bwd_f32",
-    "cslgan_conv2d_fwd_f32", "cslgan_conv2d_dgrad_f32", "cslgan_conv2d_wgrad_grouped_f32",
+    "cslgan_conv2d_fwd_f32", "cslgan_conv2d_up_fwd_f32", "cslgan_conv2d_up_ws_floats", "cslgan_conv2d_dgrad_f32", "cslgan_conv2d_wgrad_grouped_f32",
     "cslgan_bias_grad_grouped_f32", "cslgan_act_bwd_f32", "cslgan_groupnorm_act_f32", "cslgan_adam_step_f32",
 ]
 
@@ -66,6 +66,7 @@ def lib():
         "cslgan_row_l2norm_f32": [vp, i64, i64, vp, vp],
         "cslgan_row_l2norm_bwd_f32": [vp, vp, vp, i64, i64, vp, vp],
         "cslgan_conv2d_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, vp, i32, i32, vp, vp],
+        "cslgan_conv2d_up_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, vp, vp, i32, i32, vp, vp],
         "cslgan_conv2d_dgrad_f32": [C.POINTER(ConvT), vp, vp, vp, vp, vp, vp],
         "cslgan_conv2d_wgrad_grouped_f32": [C.POINTER(ConvT), vp, vp, i32, f32, vp, vp, vp],
         "cslgan_bias_grad_grouped_f32": [vp, i32, i32, i32, i32, f32, vp, vp, vp],
@@ -77,6 +78,8 @@ def lib():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    L.cslgan_conv2d_up_ws_floats.argtypes = [i32, i32, i32]
+    L.cslgan_conv2d_up_ws_floats.restype = C.c_int64
     if L.cslgan_version() != 1:
         raise HipLibraryMissing("libcslgan_hip.so ABI version mismatch")
     _lib = L

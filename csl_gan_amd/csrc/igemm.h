@@ -18,29 +18,41 @@ constexpr int IG_MAX_TAPS = 32;
 //   m -> (img, oy, ox) over a per-image grid OHc x OWc
 //   k -> (tap t, channel c), k = t*AC + c
 //   A(m,k) = a[img][(oy*sy+ty[t]) >> ups][(ox*sx+tx[t]) >> ups][c]   (zero outside the virtual VH x VW image)
-// Forward conv: sy=stride, ty[t]=kh-pad.  Data gradient of a stride-s conv: one launch per output
-// parity class with sy=1 and ty[t]=(py+pad-kh)/s over the taps kh == (py+pad) mod s.
+// One launch covers up to 4 "classes" that share a, out and the channel counts but have their own
+// row grid, tap table, filter matrix and output phase:
+//   forward conv            : 1 class, sy=stride, ty[t]=kh-pad
+//   data gradient, stride s : s*s output-parity classes, sy=1, ty[t]=(py+pad-kh)/s over kh == (py+pad) mod s
+//   nearest-2x upsample+conv: 4 output-phase classes, each a (R/2+1)^2-tap conv of the LOW-res input with
+//                             summed filter taps (sub-pixel decomposition: 25 -> 9 MACs per output for 5x5)
+constexpr int IG_MAX_CLS = 4;
+struct KcClass {
+    int M, OHc, OWc;     // rows and per-image grid of this class
+    int T, Kdim;         // taps, T*AC
+    int w_off;           // float offset of this class's [Nn][Kdim] filter matrix from KcParams::w
+    int oy0, ox0;        // output phase: out[img][oy*osy+oy0][ox*osx+ox0][n]
+    int tile0;           // first m-tile (in the launch's concatenated m-tile space)
+    signed char ty[IG_MAX_TAPS], tx[IG_MAX_TAPS];
+};
 struct KcParams {
     const float* a;
     int AH, AW, AC;      // stored dims of a
     int VH, VW;          // virtual dims used for the bounds test (2*AH,2*AW when ups==1)
     int ups;
-    int M, OHc, OWc;     // rows and per-image grid
     int sy, sx;
-    int T;
-    int Kdim;            // T*AC
-    const float* w;      // [Nn][ldw]
-    int Nn, ldw;
-    float* out;          // out[img][oy*osy+oy0][ox*osx+ox0][n], full dims OHf x OWf, ldo channels
-    int OHf, OWf, osy, oy0, osx, ox0, ldo;
-    int dense_out;       // 1: out offset == m*ldo (forward conv)
+    const float* w;
+    int Nn;
+    float* out;
+    int OHf, OWf, osy, osx, ldo;
+    int dense_out;       // 1: out offset == m*ldo (single-class forward conv)
     const float* bias;
     const float* res;    // res[img][oyf>>rs][oxf>>rs][n]
     int res_shift;
     const float* mask;   // same indexing as out
     int act;
-    int tiles_m, tiles_n;
-    signed char ty[IG_MAX_TAPS], tx[IG_MAX_TAPS];
+    int n_cls;
+    int tiles_m, tiles_n;   // total m-tiles over all classes, n-tiles
+    int ksplit;             // >1: K tiles are divided over ksplit workgroups that atomically add into zeroed out
+    KcClass cls[IG_MAX_CLS];
 };
 
 struct RowCoord {
@@ -58,19 +70,12 @@ CSL_HD RowCoord kc_decode_row(int m, int OHc, int OWc) {
 }
 
 // Element offset into `a` of A(row, k) or -1 when the tap falls outside the image / k >= Kdim.
-CSL_HD long long kc_a_offset(const KcParams& p, const RowCoord& rc, int k, int ty, int tx, int c) {
-    (void)k;
-    const int iy = rc.oy * p.sy + ty, ix = rc.ox * p.sx + tx;
-    if (iy < 0 || iy >= p.VH || ix < 0 || ix >= p.VW) return -1;
-    return (((long long)rc.img * p.AH + (iy >> p.ups)) * p.AW + (ix >> p.ups)) * p.AC + c;
+CSL_HD int kc_out_offset(const KcParams& p, const KcClass& k, const RowCoord& rc) {
+    return ((rc.img * p.OHf + rc.oy * p.osy + k.oy0) * p.OWf + rc.ox * p.osx + k.ox0) * p.ldo;
 }
 
-CSL_HD int kc_out_offset(const KcParams& p, const RowCoord& rc) {
-    return ((rc.img * p.OHf + rc.oy * p.osy + p.oy0) * p.OWf + rc.ox * p.osx + p.ox0) * p.ldo;
-}
-
-CSL_HD int kc_res_offset(const KcParams& p, const RowCoord& rc) {
-    const int oyf = rc.oy * p.osy + p.oy0, oxf = rc.ox * p.osx + p.ox0;
+CSL_HD int kc_res_offset(const KcParams& p, const KcClass& k, const RowCoord& rc) {
+    const int oyf = rc.oy * p.osy + k.oy0, oxf = rc.ox * p.osx + k.ox0;
     const int RH = p.OHf >> p.res_shift, RW = p.OWf >> p.res_shift;
     return ((rc.img * RH + (oyf >> p.res_shift)) * RW + (oxf >> p.res_shift)) * p.ldo;
 }

@@ -1,7 +1,7 @@
-// fp32 MFMA implicit-GEMM convolution, "K-contiguous" form: forward conv / linear and the data
-// gradient (transposed conv).  gfx950 only.
+// fp32 MFMA implicit-GEMM convolution, "K-contiguous" form: forward conv / linear, nearest-2x
+// upsample + conv (sub-pixel decomposed) and the data gradient (transposed conv).  gfx950 only.
 //
-//   Out[m][n] = epilogue( sum_k A(m,k) * Wm[n][k] )      (index maps: igemm.h)
+//   Out[m][n] = epilogue( sum_k A(m,k) * Wm[n][k] )      (index maps and classes: igemm.h)
 //
 // Tiling: 256 threads = 4 wavefronts; block tile BM x BN, K tile 32.  Both operands have k
 // contiguous in HBM (NHWC activations, KRSC filters), so a 16-byte global load is 4 consecutive
@@ -11,6 +11,10 @@
 // per operand per 8 k: half-wave h owns k = 8g+4h+e at step e — the same permutation for A and B,
 // so the sum is unchanged.  Global loads for tile t+1 are issued before the MFMAs of tile t and
 // written to the other LDS buffer after them (one barrier per K tile).
+//
+// One launch covers every output class of an op (the 4 parity classes of a stride-2 data gradient,
+// the 4 output phases of an upsample+conv), so small layers still put >= 256 workgroups on the chip;
+// layers with few tiles and a long K (the [B,8192]x[8192,1] critic head) split K over workgroups.
 //
 // Replaces (reference file:line): torch.nn.Conv2d / nn.Linear forward DCResNet_models.py:131-132,
 // 145, 13-17, 60-70, 95-104; MNIST_models.py:17-23, 41-46; and the autograd data-gradient of those.
@@ -35,11 +39,18 @@ __global__ __launch_bounds__(256) void igemm_kc_kernel(const KcParams p) {
 
     const int tid = threadIdx.x;
     const int nwg = p.tiles_m * p.tiles_n;
-    const int wg = xcd_remap(blockIdx.x, nwg);
-    const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.x / nwg;
+    const int wg = xcd_remap(blockIdx.x - split * nwg, nwg);
+    const int tile_mg = wg / p.tiles_n, tile_n = wg - tile_mg * p.tiles_n;
+    int ci = 0;
+#pragma unroll 1
+    while (ci + 1 < p.n_cls && tile_mg >= p.cls[ci + 1].tile0) ++ci;
+    const KcClass& kc = p.cls[ci];
+    const int M = kc.M, OHc = kc.OHc, OWc = kc.OWc, Kdim = kc.Kdim;
+    const int m0 = (tile_mg - kc.tile0) * BM, n0 = tile_n * BN;
+    const float* __restrict__ wbase = p.w + kc.w_off;
 
-    if (tid < IG_MAX_TAPS) s_tap[tid] = ((int)p.ty[tid] << 16) | ((int)p.tx[tid] & 0xffff);
+    if (tid < IG_MAX_TAPS) s_tap[tid] = ((int)kc.ty[tid] << 16) | ((int)kc.tx[tid] & 0xffff);
 
     // ---- per-thread loader coordinates -----------------------------------------------------
     const int lrow = tid >> 3;   // 0..31
@@ -49,8 +60,8 @@ __global__ __launch_bounds__(256) void igemm_kc_kernel(const KcParams p) {
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
         const int m = m0 + lrow + 32 * i;
-        a_ok[i] = m < p.M;
-        const RowCoord rc = kc_decode_row(a_ok[i] ? m : 0, p.OHc, p.OWc);
+        a_ok[i] = m < M;
+        const RowCoord rc = kc_decode_row(a_ok[i] ? m : 0, OHc, OWc);
         a_img[i] = rc.img;
         a_iy[i] = rc.oy * p.sy;
         a_ix[i] = rc.ox * p.sx;
@@ -61,7 +72,7 @@ __global__ __launch_bounds__(256) void igemm_kc_kernel(const KcParams p) {
     for (int i = 0; i < B_PASS; ++i) {
         const int n = n0 + lrow + 32 * i;
         b_ok[i] = n < p.Nn;
-        b_ptr[i] = p.w + (long long)(b_ok[i] ? n : 0) * p.ldw;
+        b_ptr[i] = wbase + (long long)(b_ok[i] ? n : 0) * Kdim;
     }
     __syncthreads();  // s_tap visible
 
@@ -70,7 +81,7 @@ __global__ __launch_bounds__(256) void igemm_kc_kernel(const KcParams p) {
     auto load_tile = [&](int kt) {
         const int kb = kt * IG_BK + q * 4;
         if (VEC_A) {
-            const bool kin = kb < p.Kdim;
+            const bool kin = kb < Kdim;
             const int t = kin ? kb / p.AC : 0;
             const int c = kb - t * p.AC;
             const int tap = s_tap[t];
@@ -91,7 +102,7 @@ __global__ __launch_bounds__(256) void igemm_kc_kernel(const KcParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int k = kb + e;
-                const bool kin = k < p.Kdim;
+                const bool kin = k < Kdim;
                 const int t = kin ? k / p.AC : 0;
                 const int c = k - t * p.AC;
                 const int tap = s_tap[t];
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(256) void igemm_kc_kernel(const KcParams p) {
             for (int i = 0; i < A_PASS; ++i) ra[i] = make_float4(tmp[i][0], tmp[i][1], tmp[i][2], tmp[i][3]);
         }
         if (VEC_B) {
-            const bool kin = kb < p.Kdim;
+            const bool kin = kb < Kdim;
 #pragma unroll
             for (int i = 0; i < B_PASS; ++i) {
                 if (kin && b_ok[i]) rb[i] = *reinterpret_cast<const float4*>(b_ptr[i] + kb);
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(256) void igemm_kc_kernel(const KcParams p) {
             for (int i = 0; i < B_PASS; ++i) {
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (b_ok[i] && (kb + e) < p.Kdim) ? b_ptr[i][kb + e] : 0.f;
+                for (int e = 0; e < 4; ++e) v[e] = (b_ok[i] && (kb + e) < Kdim) ? b_ptr[i][kb + e] : 0.f;
                 rb[i] = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
@@ -149,14 +160,21 @@ __global__ __launch_bounds__(256) void igemm_kc_kernel(const KcParams p) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-    const int nk = (p.Kdim + IG_BK - 1) / IG_BK;
-    load_tile(0);
+    const int nk_all = (Kdim + IG_BK - 1) / IG_BK;
+    int kt0 = 0, kt1 = nk_all;
+    if (p.ksplit > 1) {
+        const int per = (nk_all + p.ksplit - 1) / p.ksplit;
+        kt0 = split * per;
+        kt1 = kt0 + per < nk_all ? kt0 + per : nk_all;
+        if (kt0 >= kt1) return;   // uniform across the workgroup
+    }
+    load_tile(kt0);
     store_tile(0);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < kt1) load_tile(kt + 1);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int ch = 2 * g + h;
@@ -175,7 +193,7 @@ __global__ __launch_bounds__(256) void igemm_kc_kernel(const KcParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+        if (kt + 1 < kt1) store_tile(buf ^ 1);
         __syncthreads();
     }
 
@@ -183,13 +201,13 @@ __global__ __launch_bounds__(256) void igemm_kc_kernel(const KcParams p) {
     if (tid < BM) {
         const int m = m0 + tid;
         int off = -1, roff = 0;
-        if (m < p.M) {
+        if (m < M) {
             if (p.dense_out && !p.res) {
                 off = m * p.ldo;
             } else {
-                const RowCoord rc = kc_decode_row(m, p.OHc, p.OWc);
-                off = kc_out_offset(p, rc);
-                if (p.res) roff = kc_res_offset(p, rc);
+                const RowCoord rc = kc_decode_row(m, OHc, OWc);
+                off = kc_out_offset(p, kc, rc);
+                if (p.res) roff = kc_res_offset(p, kc, rc);
             }
         }
         s_off[tid] = off;
@@ -197,11 +215,12 @@ __global__ __launch_bounds__(256) void igemm_kc_kernel(const KcParams p) {
     }
     __syncthreads();
 
+    const bool atomic_out = p.ksplit > 1;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * TN * 32 + j * 32 + r;
         if (n >= p.Nn) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+        const float bv = (p.bias && split == 0) ? p.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -210,6 +229,10 @@ __global__ __launch_bounds__(256) void igemm_kc_kernel(const KcParams p) {
                 const int off = s_off[row];
                 if (off < 0) continue;
                 float val = acc[i][j][v] + bv;
+                if (atomic_out) {
+                    atomicAdd(p.out + off + n, val);
+                    continue;
+                }
                 if (p.res) val += p.res[s_roff[row] + n];
                 if (p.act == CSLGAN_ACT_LRELU02) val = val > 0.f ? val : 0.2f * val;
                 else if (p.act == CSLGAN_ACT_RELU) val = val > 0.f ? val : 0.f;
@@ -221,72 +244,121 @@ __global__ __launch_bounds__(256) void igemm_kc_kernel(const KcParams p) {
     }
 }
 
-// Repack KRSC filters into the per-parity-class [C][taps][K] matrices the data gradient consumes.
-//   wt[class_off + (c*Tc + t)*K + k] = w[((k*R + kh_t)*S + kw_t)*C + c]
+// Repack KRSC filters into per-class [Nout][taps][Cred] matrices.
+//   transposed == 1 (data gradient): wt[off + (c*Tc + t)*K + k]      = w[((k*R + kh_t)*S + kw_t)*C + c]
+//   transposed == 0 (upsample phases): wt[off + (k*Tc + t)*C + c]    = sum over the (kh,kw) that fold onto tap t
 struct RepackArgs {
     int K, R, S, C;
     int n_class;
-    int cls_off[4];     // float offset of each class matrix in wt
-    int cls_T[4];
-    signed char kh[4][IG_MAX_TAPS], kw[4][IG_MAX_TAPS];
+    int transposed;
+    int cls_off[IG_MAX_CLS];
+    int cls_T[IG_MAX_CLS];
+    // transposed: the single (kh,kw) of tap t.  phases: [kh_lo,kh_hi) x [kw_lo,kw_hi) folded onto tap t
+    signed char kh_lo[IG_MAX_CLS][IG_MAX_TAPS], kh_hi[IG_MAX_CLS][IG_MAX_TAPS];
+    signed char kw_lo[IG_MAX_CLS][IG_MAX_TAPS], kw_hi[IG_MAX_CLS][IG_MAX_TAPS];
 };
 
-__global__ void repack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wt, RepackArgs a) {
+__global__ void repack_filters_kernel(const float* __restrict__ w, float* __restrict__ wt, RepackArgs a) {
     const int cls = blockIdx.y;
     const int Tc = a.cls_T[cls];
     const long long total = (long long)a.C * Tc * a.K;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int k = (int)(i % a.K);
-        const long long rest = i / a.K;
-        const int t = (int)(rest % Tc);
-        const int c = (int)(rest / Tc);
-        wt[a.cls_off[cls] + i] = w[(((long long)k * a.R + a.kh[cls][t]) * a.S + a.kw[cls][t]) * a.C + c];
+        int k, t, c;
+        if (a.transposed) {
+            k = (int)(i % a.K);
+            const long long rest = i / a.K;
+            t = (int)(rest % Tc);
+            c = (int)(rest / Tc);
+        } else {
+            c = (int)(i % a.C);
+            const long long rest = i / a.C;
+            t = (int)(rest % Tc);
+            k = (int)(rest / Tc);
+        }
+        float sum = 0.f;
+        for (int kh = a.kh_lo[cls][t]; kh < a.kh_hi[cls][t]; ++kh)
+            for (int kw = a.kw_lo[cls][t]; kw < a.kw_hi[cls][t]; ++kw)
+                sum += w[(((long long)k * a.R + kh) * a.S + kw) * a.C + c];
+        wt[a.cls_off[cls] + i] = sum;
     }
 }
 
 template <int BM, int BN, int WM, int WN>
-static int launch_kc_tile(const KcParams& p, bool vecA, bool vecB, hipStream_t st) {
-    KcParams q = p;
-    q.tiles_m = (p.M + BM - 1) / BM;
-    q.tiles_n = (p.Nn + BN - 1) / BN;
-    const dim3 grid((unsigned)(q.tiles_m * q.tiles_n)), block(256);
-    if (vecA && vecB) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, q);
-    else if (vecA) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, q);
-    else if (vecB) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, q);
-    else hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, q);
+static int launch_kc_tile(KcParams& p, bool vecA, bool vecB, hipStream_t st, long long out_elems) {
+    int tm = 0;
+    for (int c = 0; c < p.n_cls; ++c) {
+        p.cls[c].tile0 = tm;
+        tm += (p.cls[c].M + BM - 1) / BM;
+    }
+    p.tiles_m = tm;
+    p.tiles_n = (p.Nn + BN - 1) / BN;
+    const int tiles = p.tiles_m * p.tiles_n;
+    // split K only for purely linear epilogues and launches that would leave most CUs idle
+    p.ksplit = 1;
+    int nk_max = 0;
+    for (int c = 0; c < p.n_cls; ++c) {
+        const int nk = (p.cls[c].Kdim + IG_BK - 1) / IG_BK;
+        nk_max = nk > nk_max ? nk : nk_max;
+    }
+    if (tiles < 96 && nk_max >= 16 && p.act == CSLGAN_ACT_NONE && !p.res && !p.mask && out_elems > 0) {
+        int want = (256 + tiles - 1) / tiles;
+        const int cap = nk_max / 4;
+        p.ksplit = want < cap ? want : cap;
+        if (p.ksplit < 1) p.ksplit = 1;
+    }
+    if (p.ksplit > 1) {
+        if (hipMemsetAsync(p.out, 0, sizeof(float) * (size_t)out_elems, st) != hipSuccess) {
+            set_error("igemm_kc: hipMemsetAsync failed");
+            return CSLGAN_ERR_LAUNCH;
+        }
+    }
+    const dim3 grid((unsigned)(tiles * p.ksplit)), block(256);
+    if (vecA && vecB) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, p);
+    else if (vecA) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, p);
+    else if (vecB) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, p);
     return check_launch("igemm_kc_kernel");
 }
 
-int launch_kc(const KcParams& p, hipStream_t st) {
-    if (p.M <= 0 || p.Nn <= 0) return CSLGAN_OK;
-    const bool vecA = (p.AC % 4 == 0) && aligned16(p.a);
-    const bool vecB = (p.ldw % 4 == 0) && (p.Kdim % 4 == 0) && aligned16(p.w);
-    if (p.Nn > 64) {
-        // small-M problems fill the chip better with 64-row tiles
-        const long long t128 = (long long)((p.M + 127) / 128) * ((p.Nn + 127) / 128);
-        if (t128 < 192) return launch_kc_tile<64, 128, 1, 4>(p, vecA, vecB, st);
-        return launch_kc_tile<128, 128, 2, 2>(p, vecA, vecB, st);
-    }
-    if (p.Nn > 32) return launch_kc_tile<128, 64, 2, 2>(p, vecA, vecB, st);
-    return launch_kc_tile<128, 32, 4, 1>(p, vecA, vecB, st);
+static long long tiles_for(const KcParams& p, int BM, int BN) {
+    long long tm = 0;
+    for (int c = 0; c < p.n_cls; ++c) tm += (p.cls[c].M + BM - 1) / BM;
+    return tm * ((p.Nn + BN - 1) / BN);
 }
 
-static int fill_conv_fwd(const cslgan_conv_t* c, KcParams& p) {
-    CSLGAN_REQUIRE(c->R * c->S <= IG_MAX_TAPS, "conv: %dx%d filter has more than %d taps", c->R, c->S, IG_MAX_TAPS);
+// out_elems: total floats of the output tensor (needed to zero it when K is split), or 0 to forbid splitting
+int launch_kc(KcParams& p, hipStream_t st, long long out_elems) {
+    long long rows = 0;
+    for (int c = 0; c < p.n_cls; ++c) rows += p.cls[c].M;
+    if (rows <= 0 || p.Nn <= 0) return CSLGAN_OK;
+    bool kd4 = true;
+    for (int c = 0; c < p.n_cls; ++c) kd4 = kd4 && (p.cls[c].Kdim % 4 == 0) && (p.cls[c].w_off % 4 == 0);
+    const bool vecA = (p.AC % 4 == 0) && aligned16(p.a);
+    const bool vecB = kd4 && aligned16(p.w);
+    if (p.Nn <= 32) return launch_kc_tile<128, 32, 4, 1>(p, vecA, vecB, st, out_elems);
+    if (p.Nn <= 64) {
+        if (tiles_for(p, 128, 64) >= 192) return launch_kc_tile<128, 64, 2, 2>(p, vecA, vecB, st, out_elems);
+        return launch_kc_tile<64, 64, 2, 2>(p, vecA, vecB, st, out_elems);
+    }
+    if (tiles_for(p, 128, 128) >= 192) return launch_kc_tile<128, 128, 2, 2>(p, vecA, vecB, st, out_elems);
+    if (tiles_for(p, 64, 128) >= 192) return launch_kc_tile<64, 128, 1, 4>(p, vecA, vecB, st, out_elems);
+    return launch_kc_tile<64, 64, 2, 2>(p, vecA, vecB, st, out_elems);
+}
+
+static int check_conv(const cslgan_conv_t* c, const char* who) {
+    CSLGAN_REQUIRE(c->N > 0 && c->H > 0 && c->W > 0 && c->C > 0 && c->K > 0 && c->R > 0 && c->S > 0 && c->stride > 0 && c->pad >= 0,
+                   "%s: non-positive dimension", who);
+    CSLGAN_REQUIRE(c->R * c->S <= IG_MAX_TAPS, "%s: %dx%d filter has more than %d taps", who, c->R, c->S, IG_MAX_TAPS);
     const int VH = c->upsample ? 2 * c->H : c->H, VW = c->upsample ? 2 * c->W : c->W;
     const int P = (VH + 2 * c->pad - c->R) / c->stride + 1, Q = (VW + 2 * c->pad - c->S) / c->stride + 1;
-    CSLGAN_REQUIRE(P == c->P && Q == c->Q, "conv: output %dx%d does not match P,Q=%d,%d", P, Q, c->P, c->Q);
-    CSLGAN_REQUIRE((long long)c->N * c->P * c->Q * c->K < (1ll << 31) && (long long)c->N * c->H * c->W * c->C < (1ll << 40),
-                   "conv: tensor too large for 32-bit output offsets");
-    p.AH = c->H; p.AW = c->W; p.AC = c->C; p.VH = VH; p.VW = VW; p.ups = c->upsample ? 1 : 0;
-    p.M = c->N * c->P * c->Q; p.OHc = c->P; p.OWc = c->Q; p.sy = p.sx = c->stride;
-    p.T = c->R * c->S; p.Kdim = p.T * c->C;
-    for (int t = 0; t < IG_MAX_TAPS; ++t) { p.ty[t] = 0; p.tx[t] = 0; }
-    for (int kh = 0; kh < c->R; ++kh)
-        for (int kw = 0; kw < c->S; ++kw) { p.ty[kh * c->S + kw] = (signed char)(kh - c->pad); p.tx[kh * c->S + kw] = (signed char)(kw - c->pad); }
-    p.Nn = c->K; p.ldw = p.Kdim;
-    p.OHf = c->P; p.OWf = c->Q; p.osy = p.osx = 1; p.oy0 = p.ox0 = 0; p.ldo = c->K; p.dense_out = 1;
+    CSLGAN_REQUIRE(P == c->P && Q == c->Q, "%s: output %dx%d does not match P,Q=%d,%d", who, P, Q, c->P, c->Q);
+    CSLGAN_REQUIRE((long long)c->N * c->P * c->Q * c->K < (1ll << 31) && (long long)c->N * VH * VW * c->C < (1ll << 31) &&
+                   (long long)c->K * c->R * c->S * c->C < (1ll << 31), "%s: tensor too large for 32-bit offsets", who);
     return CSLGAN_OK;
+}
+
+static void clear_taps(KcClass& k) {
+    for (int t = 0; t < IG_MAX_TAPS; ++t) { k.ty[t] = 0; k.tx[t] = 0; }
 }
 
 }  // namespace cslgan
@@ -298,79 +370,142 @@ extern "C" {
 int cslgan_conv2d_fwd_f32(const cslgan_conv_t* c, const float* x, const float* w, const float* bias,
                           const float* residual, int res_shift, int act, float* y, void* stream) {
     CSLGAN_REQUIRE(c && x && w && y, "conv2d_fwd: null argument");
-    CSLGAN_REQUIRE(c->N > 0 && c->H > 0 && c->W > 0 && c->C > 0 && c->K > 0 && c->R > 0 && c->S > 0 && c->stride > 0 && c->pad >= 0,
-                   "conv2d_fwd: non-positive dimension");
+    int rc = check_conv(c, "conv2d_fwd");
+    if (rc) return rc;
     CSLGAN_REQUIRE(res_shift == 0 || res_shift == 1, "conv2d_fwd: res_shift must be 0 or 1");
     CSLGAN_REQUIRE(act >= 0 && act <= 3, "conv2d_fwd: unknown activation %d", act);
-    KcParams p{};
-    int rc = fill_conv_fwd(c, p);
-    if (rc) return rc;
     CSLGAN_REQUIRE(!residual || res_shift == 0 || (c->P % 2 == 0 && c->Q % 2 == 0), "conv2d_fwd: shifted residual needs even output dims");
-    p.a = x; p.w = w; p.out = y; p.bias = bias; p.res = residual; p.res_shift = res_shift; p.mask = nullptr; p.act = act;
-    return launch_kc(p, (hipStream_t)stream);
+    KcParams p{};
+    p.a = x; p.AH = c->H; p.AW = c->W; p.AC = c->C;
+    p.VH = c->upsample ? 2 * c->H : c->H; p.VW = c->upsample ? 2 * c->W : c->W; p.ups = c->upsample ? 1 : 0;
+    p.sy = p.sx = c->stride;
+    p.w = w; p.Nn = c->K; p.out = y; p.OHf = c->P; p.OWf = c->Q; p.osy = p.osx = 1; p.ldo = c->K; p.dense_out = 1;
+    p.bias = bias; p.res = residual; p.res_shift = res_shift; p.mask = nullptr; p.act = act;
+    p.n_cls = 1;
+    KcClass& k = p.cls[0];
+    k.M = c->N * c->P * c->Q; k.OHc = c->P; k.OWc = c->Q; k.T = c->R * c->S; k.Kdim = k.T * c->C; k.w_off = 0; k.oy0 = k.ox0 = 0;
+    clear_taps(k);
+    for (int kh = 0; kh < c->R; ++kh)
+        for (int kw = 0; kw < c->S; ++kw) { k.ty[kh * c->S + kw] = (signed char)(kh - c->pad); k.tx[kh * c->S + kw] = (signed char)(kw - c->pad); }
+    return launch_kc(p, (hipStream_t)stream, (long long)c->N * c->P * c->Q * c->K);
+}
+
+int cslgan_conv2d_up_fwd_f32(const cslgan_conv_t* c, const float* x, const float* w, float* wphase_ws, const float* bias,
+                             const float* residual, int res_shift, int act, float* y, void* stream) {
+    CSLGAN_REQUIRE(c && x && w && wphase_ws && y, "conv2d_up_fwd: null argument");
+    int rc = check_conv(c, "conv2d_up_fwd");
+    if (rc) return rc;
+    CSLGAN_REQUIRE(c->upsample == 1 && c->stride == 1, "conv2d_up_fwd: needs upsample=1, stride=1");
+    CSLGAN_REQUIRE(c->R == c->S && (c->R % 2 == 1) && c->pad == c->R / 2, "conv2d_up_fwd: needs an odd square 'same' filter");
+    CSLGAN_REQUIRE(res_shift == 0 || res_shift == 1, "conv2d_up_fwd: res_shift must be 0 or 1");
+    CSLGAN_REQUIRE(act >= 0 && act <= 3, "conv2d_up_fwd: unknown activation %d", act);
+    hipStream_t st = (hipStream_t)stream;
+    // fold the R taps of each axis onto the low-res offsets d = floor((a + kh - pad) / 2)
+    const int R = c->R, pad = c->pad;
+    int d_lo[2], nd[2], first[2][8], last[2][8];   // per phase a: offsets d_lo .. d_lo+nd-1 and their kh ranges
+    for (int a = 0; a < 2; ++a) {
+        auto fl = [](int v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); };
+        d_lo[a] = fl(a - pad);
+        const int d_hi = fl(a + R - 1 - pad);
+        nd[a] = d_hi - d_lo[a] + 1;
+        CSLGAN_REQUIRE(nd[a] <= 8, "conv2d_up_fwd: filter too large");
+        for (int u = 0; u < nd[a]; ++u) { first[a][u] = R; last[a][u] = -1; }
+        for (int kh = 0; kh < R; ++kh) {
+            const int u = fl(a + kh - pad) - d_lo[a];
+            if (kh < first[a][u]) first[a][u] = kh;
+            if (kh > last[a][u]) last[a][u] = kh;
+        }
+    }
+    RepackArgs ra{};
+    ra.K = c->K; ra.R = R; ra.S = R; ra.C = c->C; ra.n_class = 4; ra.transposed = 0;
+    KcParams p{};
+    p.a = x; p.AH = c->H; p.AW = c->W; p.AC = c->C; p.VH = c->H; p.VW = c->W; p.ups = 0; p.sy = p.sx = 1;
+    p.w = wphase_ws; p.Nn = c->K; p.out = y; p.OHf = c->P; p.OWf = c->Q; p.osy = p.osx = 2; p.ldo = c->K; p.dense_out = 0;
+    p.bias = bias; p.res = residual; p.res_shift = res_shift; p.mask = nullptr; p.act = act; p.n_cls = 4;
+    int off = 0;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            const int cls = a * 2 + b;
+            const int T = nd[a] * nd[b];
+            CSLGAN_REQUIRE(T <= IG_MAX_TAPS, "conv2d_up_fwd: too many folded taps");
+            KcClass& k = p.cls[cls];
+            k.M = c->N * c->H * c->W; k.OHc = c->H; k.OWc = c->W; k.T = T; k.Kdim = T * c->C; k.w_off = off; k.oy0 = a; k.ox0 = b;
+            clear_taps(k);
+            for (int u = 0; u < nd[a]; ++u)
+                for (int v = 0; v < nd[b]; ++v) {
+                    const int t = u * nd[b] + v;
+                    k.ty[t] = (signed char)(d_lo[a] + u); k.tx[t] = (signed char)(d_lo[b] + v);
+                    ra.kh_lo[cls][t] = (signed char)first[a][u]; ra.kh_hi[cls][t] = (signed char)(last[a][u] + 1);
+                    ra.kw_lo[cls][t] = (signed char)first[b][v]; ra.kw_hi[cls][t] = (signed char)(last[b][v] + 1);
+                }
+            ra.cls_T[cls] = T; ra.cls_off[cls] = off; off += T * c->K * c->C;
+        }
+    {
+        unsigned gxn = (unsigned)(((long long)c->K * c->C * 9 + 255) / 256);
+        gxn = gxn > 1024 ? 1024 : (gxn < 1 ? 1 : gxn);
+        hipLaunchKernelGGL(repack_filters_kernel, dim3(gxn, 4), dim3(256), 0, st, w, wphase_ws, ra);
+        rc = check_launch("repack_filters_kernel");
+        if (rc) return rc;
+    }
+    return launch_kc(p, st, 0);
+}
+
+// floats of workspace cslgan_conv2d_up_fwd_f32 needs for a K x R x R x C filter
+int64_t cslgan_conv2d_up_ws_floats(int K, int R, int C) {
+    const int n = R / 2 + 1;   // folded taps per axis (upper bound over both phases)
+    return (int64_t)4 * n * n * K * C;
 }
 
 int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* c, const float* gy, const float* w, float* wt_ws, const float* mask,
                             float* gx, void* stream) {
     CSLGAN_REQUIRE(c && gy && w && wt_ws && gx, "conv2d_dgrad: null argument");
+    int rc = check_conv(c, "conv2d_dgrad");
+    if (rc) return rc;
     CSLGAN_REQUIRE(!c->upsample, "conv2d_dgrad: upsample-on-read convs have no data-gradient path yet");
     CSLGAN_REQUIRE(c->stride >= 1 && c->stride <= 2, "conv2d_dgrad: stride %d unsupported", c->stride);
-    CSLGAN_REQUIRE(c->R * c->S <= IG_MAX_TAPS, "conv2d_dgrad: too many taps");
-    CSLGAN_REQUIRE((long long)c->N * c->H * c->W * c->C < (1ll << 31), "conv2d_dgrad: tensor too large");
     const int s = c->stride;
     hipStream_t st = (hipStream_t)stream;
-    // ---- class tables + filter repack ----
     RepackArgs ra{};
-    ra.K = c->K; ra.R = c->R; ra.S = c->S; ra.C = c->C; ra.n_class = s * s;
-    int off = 0;
+    ra.K = c->K; ra.R = c->R; ra.S = c->S; ra.C = c->C; ra.n_class = s * s; ra.transposed = 1;
+    KcParams p{};
+    p.a = gy; p.AH = c->P; p.AW = c->Q; p.AC = c->K; p.VH = c->P; p.VW = c->Q; p.ups = 0; p.sy = p.sx = 1;
+    p.w = wt_ws; p.Nn = c->C; p.out = gx; p.OHf = c->H; p.OWf = c->W; p.osy = p.osx = s; p.ldo = c->C;
+    p.dense_out = (s == 1) ? 1 : 0;
+    p.bias = nullptr; p.res = nullptr; p.res_shift = 0; p.mask = mask; p.act = CSLGAN_ACT_NONE;
+    int off = 0, ncls = 0;
     for (int py = 0; py < s; ++py)
         for (int px = 0; px < s; ++px) {
-            const int cls = py * s + px;
+            const int OHc = (c->H - py + s - 1) / s, OWc = (c->W - px + s - 1) / s;
+            if (OHc <= 0 || OWc <= 0) continue;
+            const int cls = ncls++;
+            KcClass& k = p.cls[cls];
+            clear_taps(k);
             int T = 0;
             for (int kh = 0; kh < c->R; ++kh) {
                 if (((py + c->pad - kh) % s + s) % s != 0) continue;
                 for (int kw = 0; kw < c->S; ++kw) {
                     if (((px + c->pad - kw) % s + s) % s != 0) continue;
-                    ra.kh[cls][T] = (signed char)kh; ra.kw[cls][T] = (signed char)kw; ++T;
+                    ra.kh_lo[cls][T] = (signed char)kh; ra.kh_hi[cls][T] = (signed char)(kh + 1);
+                    ra.kw_lo[cls][T] = (signed char)kw; ra.kw_hi[cls][T] = (signed char)(kw + 1);
+                    k.ty[T] = (signed char)((py + c->pad - kh) / s);
+                    k.tx[T] = (signed char)((px + c->pad - kw) / s);
+                    ++T;
                 }
             }
+            CSLGAN_REQUIRE(T > 0, "conv2d_dgrad: a parity class has no taps (filter smaller than stride)");
+            k.M = c->N * OHc * OWc; k.OHc = OHc; k.OWc = OWc; k.T = T; k.Kdim = T * c->K; k.w_off = off; k.oy0 = py; k.ox0 = px;
             ra.cls_T[cls] = T; ra.cls_off[cls] = off; off += T * c->K * c->C;
         }
+    p.n_cls = ncls; ra.n_class = ncls;
     {
         unsigned gxn = (unsigned)(((long long)c->K * c->C * c->R * c->S / (s * s) + 255) / 256);
-        if (gxn > 1024) gxn = 1024;
-        if (gxn < 1) gxn = 1;
-        hipLaunchKernelGGL(repack_dgrad_kernel, dim3(gxn, (unsigned)(s * s)), dim3(256), 0, st, w, wt_ws, ra);
-        int rc = check_launch("repack_dgrad_kernel");
+        gxn = gxn > 1024 ? 1024 : (gxn < 1 ? 1 : gxn);
+        hipLaunchKernelGGL(repack_filters_kernel, dim3(gxn, (unsigned)ncls), dim3(256), 0, st, w, wt_ws, ra);
+        rc = check_launch("repack_filters_kernel");
         if (rc) return rc;
     }
-    for (int py = 0; py < s; ++py)
-        for (int px = 0; px < s; ++px) {
-            const int cls = py * s + px;
-            const int OHc = (c->H - py + s - 1) / s, OWc = (c->W - px + s - 1) / s;
-            if (OHc <= 0 || OWc <= 0) continue;
-            KcParams p{};
-            p.a = gy; p.AH = c->P; p.AW = c->Q; p.AC = c->K; p.VH = c->P; p.VW = c->Q; p.ups = 0;
-            p.M = c->N * OHc * OWc; p.OHc = OHc; p.OWc = OWc; p.sy = p.sx = 1;
-            p.T = ra.cls_T[cls]; p.Kdim = p.T * c->K;
-            for (int t = 0; t < IG_MAX_TAPS; ++t) { p.ty[t] = 0; p.tx[t] = 0; }
-            for (int t = 0; t < p.T; ++t) {
-                p.ty[t] = (signed char)((py + c->pad - ra.kh[cls][t]) / s);
-                p.tx[t] = (signed char)((px + c->pad - ra.kw[cls][t]) / s);
-            }
-            p.w = wt_ws + ra.cls_off[cls]; p.Nn = c->C; p.ldw = p.Kdim;
-            p.out = gx; p.OHf = c->H; p.OWf = c->W; p.osy = p.osx = s; p.oy0 = py; p.ox0 = px; p.ldo = c->C;
-            p.dense_out = (s == 1) ? 1 : 0;
-            p.bias = nullptr; p.res = nullptr; p.res_shift = 0; p.mask = mask; p.act = CSLGAN_ACT_NONE;
-            if (p.T == 0) {
-                // no tap reaches this class: gradient is zero there (cannot happen for R,S >= stride)
-                set_error("conv2d_dgrad: empty tap class");
-                return CSLGAN_ERR_INVALID_ARG;
-            }
-            int rc = launch_kc(p, st);
-            if (rc) return rc;
-        }
-    return CSLGAN_OK;
+    // K can be split only for the dense (stride-1, single-class) form whose output we may zero here
+    return launch_kc(p, st, (s == 1 && !mask) ? (long long)c->N * c->H * c->W * c->C : 0);
 }
 
 }  // extern "C"

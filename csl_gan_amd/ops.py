@@ -91,8 +91,12 @@ def _conv_desc(N, H, W, Cc, K, R, S, stride, pad, upsample):
     return ConvT(N, H, W, Cc, K, R, S, stride, pad, 1 if upsample else 0, P, Q), P, Q
 
 
-def conv2d_fwd(x, w, bias=None, stride=1, pad=0, upsample=False, residual=None, res_shift=0, act=ACT_NONE, out=None):
-    """y[N,P,Q,K] = act(conv(x[N,H,W,C], w[K,R,S,C]) + bias [+ residual])."""
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, upsample=False, residual=None, res_shift=0, act=ACT_NONE, out=None,
+               direct_upsample=False):
+    """y[N,P,Q,K] = act(conv(x[N,H,W,C], w[K,R,S,C]) + bias [+ residual]).
+
+    upsample=True: nearest-2x upsample of x first; computed by sub-pixel decomposition
+    (cslgan_conv2d_up_fwd_f32) unless direct_upsample=True (address shift on read, full RxS taps)."""
     _chk(x, "x"); _chk(w, "w")
     N, H, W, Cc = x.shape
     K, R, S, C2 = w.shape
@@ -110,6 +114,13 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, upsample=False, residual=None, 
     VH, VW = (2 * H, 2 * W) if upsample else (H, W)
     flop = 2.0 * N * P * Q * K * R * S * Cc       # the dense conv the reference executes on the (up-sampled) input
     nbytes = 4.0 * (N * VH * VW * Cc + K * R * S * Cc + N * P * Q * K)
+    if upsample and not direct_upsample and stride == 1 and R == S and R % 2 == 1 and pad == R // 2 and R > 1:
+        L = _lib.lib()
+        ws = torch.empty(L.cslgan_conv2d_up_ws_floats(K, R, Cc), device=x.device, dtype=torch.float32)
+        _timed("conv2d_fwd", flop, nbytes, lambda: check(
+            L.cslgan_conv2d_up_fwd_f32(C.byref(d), _p(x), _p(w), _p(ws), _p(bias), _p(residual), res_shift, act, _p(y), _stream()),
+            "conv2d_up_fwd"))
+        return y
     _timed("conv2d_fwd", flop, nbytes, lambda: check(
         _lib.lib().cslgan_conv2d_fwd_f32(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), res_shift, act, _p(y), _stream()),
         "conv2d_fwd"))

@@ -112,6 +112,17 @@ typedef struct {
 int cslgan_conv2d_fwd_f32(const cslgan_conv_t* p, const float* x, const float* w, const float* bias,
                           const float* residual, int res_shift, int act, float* y, void* stream);
 
+/* Same result as cslgan_conv2d_fwd_f32 with p->upsample == 1 (nearest-2x upsample then an odd "same"
+ * RxR stride-1 conv, DCResNet_models.py:13-17) computed by sub-pixel decomposition: each of the four
+ * output phases is an (R/2+1)^2-tap conv of the LOW-resolution input with summed filter taps — 9
+ * instead of 25 MACs per output for 5x5; the sums only re-associate the reference arithmetic.
+ * wphase_ws: caller workspace of cslgan_conv2d_up_ws_floats(K,R,C) floats (folded filters, rebuilt
+ * every call).  All four phases run in ONE launch. */
+int cslgan_conv2d_up_fwd_f32(const cslgan_conv_t* p, const float* x, const float* w, float* wphase_ws,
+                             const float* bias, const float* residual, int res_shift, int act, float* y,
+                             void* stream);
+int64_t cslgan_conv2d_up_ws_floats(int K, int R, int C);
+
 /* gx = conv_transpose(gy, w) [* lrelu'(mask)]: the data gradient (autograd of the conv above;
  * "conv_transpose2d" in the north star).  wt_ws: caller workspace of K*R*S*C floats receiving
  * the repacked filters.  mask (nullable) has gx's shape: gx *= (mask > 0 ? 1 : 0.2). */

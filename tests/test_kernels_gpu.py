@@ -42,6 +42,13 @@ FWD_CASES = [
     (2, 8, 8, 64, 128, 5, 2, 2, True, 0, False, None),
     (4, 64, 64, 8, 160, 5, 1, 2, False, 2, False, None),
     (2, 4, 4, 32, 32, 5, 1, 2, False, 0, True, None),
+    (3, 8, 8, 16, 24, 5, 1, 2, True, 2, True, 1),
+    (2, 5, 7, 12, 20, 3, 1, 1, True, 0, True, None),
+    (2, 4, 4, 512, 512, 5, 1, 2, False, 0, True, None),
+    (16, 8, 8, 256, 512, 5, 2, 2, True, 1, False, None),
+    (128, 1, 1, 8192, 1, 1, 1, 0, False, 0, False, None),
+    (128, 1, 1, 8192, 1, 1, 1, 0, True, 0, False, None),
+    (3, 1, 1, 1000, 10, 1, 1, 0, True, 0, False, None),
     (2, 8, 8, 32, 48, 5, 1, 2, True, 0, False, 1),
     (2, 8, 8, 32, 48, 1, 1, 0, True, 0, False, 0),
     (7, 1, 1, 794, 128, 1, 1, 0, True, 2, False, None),
@@ -76,6 +83,10 @@ def test_conv2d_fwd(case):
     y = ops.conv2d_fwd(_nhwc(x), _krsc(w), None if b is None else b.cuda(), stride=s, pad=p, upsample=ups,
                        residual=resid, res_shift=res or 0, act=act)
     _close(y.permute(0, 3, 1, 2), ref, what="fwd %s" % (case,))
+    if ups:   # the address-shift variant must agree with the sub-pixel decomposition
+        y2 = ops.conv2d_fwd(_nhwc(x), _krsc(w), None if b is None else b.cuda(), stride=s, pad=p, upsample=True,
+                            residual=resid, res_shift=res or 0, act=act, direct_upsample=True)
+        _close(y2.permute(0, 3, 1, 2), ref, what="fwd direct-upsample %s" % (case,))
 
 
 DGRAD_CASES = [

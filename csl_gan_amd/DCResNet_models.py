@@ -33,11 +33,20 @@ class UpsampleConv(nn.Module):
 
 
 class _BatchNormAct(nn.BatchNorm2d):
-    """BatchNorm2d + ReLU for the bn=True generator (non-per-sample modes).  CPU only for now."""
+    """BatchNorm2d + ReLU for the bn=True generator of the non-per-sample modes (init_util.py:46): batch
+    statistics and the running-stat update run on cslgan_batchnorm_act_f32.  Forward only (the generator is
+    frozen inside the D-step); eval-mode (running statistics) inference is the image-sampling path, which is
+    out of scope."""
 
     def forward_nhwc(self, x):
-        raise NotImplementedError("BatchNorm generator (dp_mode is / none) has no HIP kernel yet; "
-                                  "per-sample-gradient modes use GroupNorm (init_util.py:46)")
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            raise NotImplementedError("BatchNorm backward (generator training) is not built yet")
+        if not self.training:
+            raise NotImplementedError("eval-mode BatchNorm on HIP (image sampling) is out of scope")
+        if self.num_batches_tracked is not None:
+            self.num_batches_tracked += 1
+        return ops.batchnorm_act(x, self.weight.detach(), self.bias.detach(), self.running_mean, self.running_var,
+                                 momentum=self.momentum, eps=self.eps, relu=True)
 
     def forward(self, x):
         if x.is_cuda:

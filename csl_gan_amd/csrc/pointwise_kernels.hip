@@ -27,54 +27,141 @@ __global__ void act_bwd_kernel(const float* __restrict__ g, const float* __restr
     }
 }
 
-// one block per (n, group): two-pass mean / variance over HW x cpg elements
-__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const float* __restrict__ x, int HW, int C, int groups,
-                                                              float eps, float* __restrict__ stats) {
-    __shared__ float red[4];
-    __shared__ float s_mean;
-    const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
-    const int cpg = C / groups;
-    const long long tot = (long long)HW * cpg;
-    const float* base = x + (long long)n * HW * C + g * cpg;
-    float acc = 0.f;
-    for (long long i = threadIdx.x; i < tot; i += 256) {
-        const long long px = i / cpg;
-        const int j = (int)(i - px * cpg);
-        acc += base[px * C + j];
-    }
-    float t = block_sum_256(acc, red);
-    if (threadIdx.x == 0) s_mean = t / (float)tot;
+// ---- normalisation statistics over NHWC data ------------------------------------------------
+// x is [R][C] (R = N*H*W rows).  A statistic s covers `rows_per_stat` consecutive rows and `cpg`
+// consecutive channels:  s = (row / rows_per_stat) * n_groups + c / cpg.
+//   GroupNorm(G): rows_per_stat = H*W, cpg = C/G, n_groups = G        (per image, per group)
+//   BatchNorm   : rows_per_stat = R,   cpg = 1,   n_groups = C        (per channel over the batch)
+// PASS 0 accumulates sum(x) into stats[2s]; PASS 1 accumulates sum((x-mean_s)^2) into stats[2s+1]
+// (two-pass variance: no E[x^2]-mean^2 cancellation).  Rows are read with 16-byte loads, coalesced along
+// C; partial sums go thread -> LDS (one float per channel) -> one global atomic per channel per block.
+constexpr int NS_ROWS = 64;   // rows per block
+
+template <int PASS, bool VEC>
+__global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x, long long rows_per_stat, int C, int cpg,
+                                                         int n_groups, float* __restrict__ stats) {
+    extern __shared__ float s_acc[];   // [C]
+    const int tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) s_acc[c] = 0.f;
     __syncthreads();
-    const float mean = s_mean;
-    acc = 0.f;
-    for (long long i = threadIdx.x; i < tot; i += 256) {
-        const long long px = i / cpg;
-        const int j = (int)(i - px * cpg);
-        const float d = base[px * C + j] - mean;
-        acc = fmaf(d, d, acc);
+    const long long sr = blockIdx.y;                      // which row-group of statistics
+    const long long r0 = sr * rows_per_stat + (long long)blockIdx.x * NS_ROWS;
+    long long r1 = r0 + NS_ROWS;
+    const long long rend = (sr + 1) * rows_per_stat;
+    if (r1 > rend) r1 = rend;
+    const float inv_cnt = 1.f / ((float)rows_per_stat * (float)cpg);
+    if (VEC) {
+        const int c4n = C >> 2;
+        const int c4 = tid % c4n, rl = tid / c4n, rstep = 256 / c4n;
+        float m[4] = {0.f, 0.f, 0.f, 0.f};
+        if (PASS == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = stats[2 * (sr * n_groups + (4 * c4 + e) / cpg)] * inv_cnt;
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long long r = r0 + rl; r < r1; r += rstep) {
+            const float4 v = *reinterpret_cast<const float4*>(x + r * C + 4 * c4);
+            if (PASS == 0) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            else {
+                const float a = v.x - m[0], b = v.y - m[1], c = v.z - m[2], d = v.w - m[3];
+                acc.x = fmaf(a, a, acc.x); acc.y = fmaf(b, b, acc.y); acc.z = fmaf(c, c, acc.z); acc.w = fmaf(d, d, acc.w);
+            }
+        }
+        atomicAdd(&s_acc[4 * c4 + 0], acc.x);
+        atomicAdd(&s_acc[4 * c4 + 1], acc.y);
+        atomicAdd(&s_acc[4 * c4 + 2], acc.z);
+        atomicAdd(&s_acc[4 * c4 + 3], acc.w);
+    } else {
+        const long long n = (r1 - r0) * C;
+        for (long long i = tid; i < n; i += 256) {
+            const int c = (int)(i % C);
+            float v = x[r0 * C + i];
+            if (PASS == 1) {
+                v -= stats[2 * (sr * n_groups + c / cpg)] * inv_cnt;
+                v *= v;
+            }
+            atomicAdd(&s_acc[c], v);
+        }
     }
     __syncthreads();
-    t = block_sum_256(acc, red);
-    if (threadIdx.x == 0) {
-        stats[2 * blockIdx.x] = mean;
-        stats[2 * blockIdx.x + 1] = rsqrtf(t / (float)tot + eps);
+    for (int c = tid; c < C; c += 256) atomicAdd(&stats[2 * (sr * n_groups + c / cpg) + PASS], s_acc[c]);
+}
+
+// y = act((x - mean_s) * rstd_s * gamma[c] + beta[c])
+template <bool VEC>
+__global__ void norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                  const float* __restrict__ stats, long long total, long long rows_per_stat, int C, int cpg,
+                                  int n_groups, float eps, int relu, float* __restrict__ y) {
+    const float inv_cnt = 1.f / ((float)rows_per_stat * (float)cpg);
+    const long long per_stat_elems = rows_per_stat * C;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    if (VEC) {
+        const long long n4 = total >> 2;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            const long long e0 = i << 2;
+            const int c = (int)(e0 % C);
+            const long long sr = e0 / per_stat_elems;
+            const float4 v = reinterpret_cast<const float4*>(x)[i];
+            float in[4] = {v.x, v.y, v.z, v.w}, o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const long long s = sr * n_groups + (c + e) / cpg;
+                const float mean = stats[2 * s] * inv_cnt;
+                const float rstd = rsqrtf(stats[2 * s + 1] * inv_cnt + eps);
+                float t = (in[e] - mean) * rstd * gamma[c + e] + beta[c + e];
+                o[e] = (relu && t < 0.f) ? 0.f : t;
+            }
+            reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+            const int c = (int)(i % C);
+            const long long s = (i / per_stat_elems) * n_groups + c / cpg;
+            const float mean = stats[2 * s] * inv_cnt;
+            const float rstd = rsqrtf(stats[2 * s + 1] * inv_cnt + eps);
+            float t = (x[i] - mean) * rstd * gamma[c] + beta[c];
+            y[i] = (relu && t < 0.f) ? 0.f : t;
+        }
     }
 }
 
-__global__ void groupnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                       const float* __restrict__ beta, const float* __restrict__ stats, long long total,
-                                       int HW, int C, int groups, int relu, float* __restrict__ y) {
-    const int cpg = C / groups;
-    const long long per_img = (long long)HW * C;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const long long n = i / per_img;
-        const int g = c / cpg;
-        const float mean = stats[2 * (n * groups + g)], rstd = stats[2 * (n * groups + g) + 1];
-        float v = (x[i] - mean) * rstd * gamma[c] + beta[c];
-        if (relu) v = v > 0.f ? v : 0.f;
-        y[i] = v;
+// BatchNorm running statistics (torch semantics: running_var uses the unbiased batch variance)
+__global__ void bn_running_kernel(const float* __restrict__ stats, int C, float cnt, float momentum, float* __restrict__ rm,
+                                  float* __restrict__ rv) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = stats[2 * c] / cnt;
+    const float var_unb = cnt > 1.f ? stats[2 * c + 1] / (cnt - 1.f) : 0.f;
+    rm[c] = (1.f - momentum) * rm[c] + momentum * mean;
+    rv[c] = (1.f - momentum) * rv[c] + momentum * var_unb;
+}
+
+static int launch_norm(const float* x, const float* gamma, const float* beta, long long R, long long rows_per_stat, int C, int cpg,
+                       int n_groups, float eps, int relu, float* stats, float* y, hipStream_t st) {
+    const long long n_row_groups = R / rows_per_stat;
+    const long long n_stats = n_row_groups * n_groups;
+    if (hipMemsetAsync(stats, 0, sizeof(float) * 2 * n_stats, st) != hipSuccess) {
+        set_error("norm: hipMemsetAsync failed");
+        return CSLGAN_ERR_LAUNCH;
     }
+    const bool vec = (C % 4 == 0) && ((C / 4) <= 256) && (256 % (C / 4) == 0) && aligned16(x) && aligned16(y);
+    const dim3 grid((unsigned)((rows_per_stat + NS_ROWS - 1) / NS_ROWS), (unsigned)n_row_groups), block(256);
+    const size_t lds = sizeof(float) * C;
+    if (vec) {
+        hipLaunchKernelGGL((norm_stats_kernel<0, true>), grid, block, lds, st, x, rows_per_stat, C, cpg, n_groups, stats);
+        hipLaunchKernelGGL((norm_stats_kernel<1, true>), grid, block, lds, st, x, rows_per_stat, C, cpg, n_groups, stats);
+    } else {
+        hipLaunchKernelGGL((norm_stats_kernel<0, false>), grid, block, lds, st, x, rows_per_stat, C, cpg, n_groups, stats);
+        hipLaunchKernelGGL((norm_stats_kernel<1, false>), grid, block, lds, st, x, rows_per_stat, C, cpg, n_groups, stats);
+    }
+    int rc = check_launch("norm_stats_kernel");
+    if (rc) return rc;
+    const long long total = R * C;
+    long long nb = (total / 4 + 255) / 256;
+    nb = nb > 4096 ? 4096 : (nb < 1 ? 1 : nb);
+    if (vec) hipLaunchKernelGGL((norm_apply_kernel<true>), dim3((unsigned)nb), dim3(256), 0, st, x, gamma, beta, stats, total, rows_per_stat, C, cpg, n_groups, eps, relu, y);
+    else hipLaunchKernelGGL((norm_apply_kernel<false>), dim3((unsigned)nb), dim3(256), 0, st, x, gamma, beta, stats, total, rows_per_stat, C, cpg, n_groups, eps, relu, y);
+    return check_launch("norm_apply_kernel");
 }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
@@ -118,14 +205,23 @@ int cslgan_groupnorm_act_f32(const float* x, const float* gamma, const float* be
                              float eps, int relu, float* stats_ws, float* y, void* stream) {
     CSLGAN_REQUIRE(x && gamma && beta && stats_ws && y, "groupnorm: null argument");
     CSLGAN_REQUIRE(N > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, "groupnorm: C=%d not divisible by groups=%d", C, groups);
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3((unsigned)(N * groups)), dim3(256), 0, st, x, HW, C, groups, eps, stats_ws);
-    int rc = check_launch("groupnorm_stats_kernel");
+    CSLGAN_REQUIRE(N <= 65535 && C <= 8192, "groupnorm: N or C too large");
+    return launch_norm(x, gamma, beta, (long long)N * HW, HW, C, C / groups, groups, eps, relu, stats_ws, y, (hipStream_t)stream);
+}
+
+int cslgan_batchnorm_act_f32(const float* x, const float* gamma, const float* beta, int64_t rows, int C, float eps, int relu,
+                             float momentum, float* running_mean, float* running_var, float* stats_ws, float* y, void* stream) {
+    CSLGAN_REQUIRE(x && gamma && beta && stats_ws && y, "batchnorm: null argument");
+    CSLGAN_REQUIRE(rows > 0 && C > 0 && C <= 8192, "batchnorm: bad sizes");
+    CSLGAN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "batchnorm: running_mean/var must both be given or both null");
+    int rc = launch_norm(x, gamma, beta, rows, rows, C, 1, C, eps, relu, stats_ws, y, (hipStream_t)stream);
     if (rc) return rc;
-    const long long total = (long long)N * HW * C;
-    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, gamma, beta, stats_ws, total, HW, C,
-                       groups, relu, y);
-    return check_launch("groupnorm_apply_kernel");
+    if (running_mean) {
+        hipLaunchKernelGGL(bn_running_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, (hipStream_t)stream, stats_ws, C,
+                           (float)rows, momentum, running_mean, running_var);
+        return check_launch("bn_running_kernel");
+    }
+    return CSLGAN_OK;
 }
 
 int cslgan_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,

@@ -19,6 +19,23 @@ from . import ops
 
 _SLOPE = {ops.ACT_LRELU02: 0.2, ops.ACT_RELU: 0.0}
 
+_INPUT_GRADS_ONLY = False
+
+
+class input_grads_only:
+    """Context for forwards whose FIRST-order backward is only ever asked for input gradients — the
+    gradient-penalty forward (gradient_penalty.py:46-50): parameters enter the penalty solely through the
+    second-order Dgrad nodes, so the first-order weight / bias gradient kernels would be wasted work
+    (autograd cannot tell a custom Function which of its outputs the caller requested)."""
+
+    def __enter__(self):
+        global _INPUT_GRADS_ONLY
+        self._prev, _INPUT_GRADS_ONLY = _INPUT_GRADS_ONLY, True
+
+    def __exit__(self, *a):
+        global _INPUT_GRADS_ONLY
+        _INPUT_GRADS_ONLY = self._prev
+
 
 def nhwc(x: torch.Tensor) -> torch.Tensor:
     """logical NCHW -> NHWC-contiguous view (copy only if x is not already channels-last)."""
@@ -81,6 +98,7 @@ class Conv(Function):
                            res_shift=res_shift, act=act)
         ctx.cfg = (stride, pad, act, upsample, res_shift)
         ctx.has_res = residual is not None
+        ctx.input_only = _INPUT_GRADS_ONLY
         ctx.save_for_backward(x, w, y if act != ops.ACT_NONE else None)
         return y
 
@@ -99,9 +117,9 @@ class Conv(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = Dgrad.apply(gz, w, x.shape[1], x.shape[2], stride, pad)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not ctx.input_only:
             gw = Wgrad.apply(gz, x, w.shape[1], w.shape[2], stride, pad)
-        if ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[2] and not ctx.input_only:
             gb = BiasGrad.apply(gz)
         return gx, gw, gb, None, None, None, None, None, None
 

@@ -52,7 +52,8 @@ def calc_lipschitz_penalty_WRT(model, inputs, input_labels=None, device="cpu", p
                                aux_penalty=True):
     x = inputs.detach().requires_grad_(True)
     labels = None if input_labels is None else input_labels.detach()
-    out, aux_out = model(x, labels)
+    with HF.input_grads_only():
+        out, aux_out = model(x, labels)
 
     def term(scalar_outputs):
         g, = autograd.grad(outputs=scalar_outputs, inputs=x, grad_outputs=torch.ones_like(scalar_outputs),

@@ -306,6 +306,18 @@ def groupnorm_act(x, gamma, beta, groups, eps=1e-5, relu=True):
     return y
 
 
+def batchnorm_act(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, relu=True):
+    """Training-mode BatchNorm (+ReLU) over all leading dims of NHWC x; updates the running stats in place."""
+    _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    y = torch.empty_like(x)
+    ws = torch.empty(2 * Cc, device=x.device, dtype=torch.float32)
+    check(_lib.lib().cslgan_batchnorm_act_f32(_p(x), _p(gamma), _p(beta), rows, Cc, float(eps), 1 if relu else 0, float(momentum),
+                                              _p(running_mean), _p(running_var), _p(ws), _p(y), _stream()), "batchnorm_act")
+    return y
+
+
 def adam_step(p, g, m, v, lr, b1, b2, eps, weight_decay, step):
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t, n)

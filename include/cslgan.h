@@ -152,6 +152,14 @@ int cslgan_act_bwd_f32(const float* g, const float* y, int64_t n, float slope, f
 int cslgan_groupnorm_act_f32(const float* x, const float* gamma, const float* beta, int N, int HW, int C,
                              int groups, float eps, int relu, float* stats_ws, float* y, void* stream);
 
+/* Training-mode BatchNorm2d (+ optional ReLU) on NHWC x[rows][C], rows = N*H*W: batch statistics per channel,
+ * running_mean / running_var (nullable pair) updated with `momentum` and the unbiased variance — the bn=True
+ * generator of the non-per-sample modes (init_util.py:46, DCResNet_models.py:23,25,84).
+ * stats_ws: caller workspace [2*C] floats. */
+int cslgan_batchnorm_act_f32(const float* x, const float* gamma, const float* beta, int64_t rows, int C, float eps,
+                             int relu, float momentum, float* running_mean, float* running_var, float* stats_ws,
+                             float* y, void* stream);
+
 /* Adam (torch.optim.Adam semantics, train.py:76): in-place on p, m, v.  step is 1-based. */
 int cslgan_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
                          float b2, float eps, float weight_decay, int step, void* stream);

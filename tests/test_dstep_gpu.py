@@ -221,3 +221,60 @@ def test_double_backward_wiring_without_activations():
             assert a is None or a.abs().max() < 1e-7
         else:
             _close(a, b, "d penalty / d param %d" % i, rtol=1e-4)
+
+
+@pytest.mark.parametrize("per_param", [True, False])
+def test_train_D_immediate_sensitivity_matches_oracle(tmp_path, per_param):
+    """dp_mode=is (train.py:375, 453-460): BatchNorm generator forward on HIP, parameter gradients with
+    create_graph, one double-backward sweep per sensitivity, noise scaled by the batch sensitivity."""
+    from csl_gan_amd import init_util, options
+    from csl_gan_amd.trainer import Trainer
+    from oracle.dstep import OracleDStep, StepConfig
+    from oracle.nets import build_models
+    B, latent = 6, 16
+    argv = ["MNIST", "--model", "DeepConvResNet", "-dpm", "is", "-nms", "4", "-bs", str(B), "-gd", "cuda:0", "-dd", "cuda:0",
+            "-o", str(tmp_path), "--manual_seed", "1", "--g_latent_dim", str(latent), "--sigma", "0.5", "--penalty", "WGAN-GP",
+            "-ispp", "True" if per_param else "False"]
+    opt = options.parse(argv)
+    assert opt.imm_sens_per_param == per_param and not opt.per_sample_grad
+    G, D = init_util.init_models(opt)
+    tr = Trainer(opt, G, D, log_to=str(tmp_path / "log.csv"))
+    pe = tr.setup_privacy_engine()
+    Go, Do = build_models(dataset="MNIST", model="DeepConvResNet", im_size=28, weights_seed=42, manual_seed=1,
+                          per_sample_grad=False, g_latent_dim=latent)
+    cfg = StepConfig(dp_mode="is", sigma=0.0, penalty=("WGAN-GP",), lr=opt.d_lr, adam_b1=opt.adam_b1, adam_b2=opt.adam_b2,
+                     imm_sens_per_param=per_param, imm_sens_scaling_vec=None)
+    oracle = OracleDStep(Go, Do, cfg)
+    g = torch.Generator().manual_seed(21)
+    img = torch.rand(B, 1, 28, 28, generator=g)
+    ms_p = torch.rand(B, 1, 28, 28, generator=g)
+    z, alpha = torch.randn(B, latent, generator=g), torch.rand(B, generator=g)
+    params_o = list(Do.parameters())
+    zs = [torch.randn(p.numel(), generator=torch.Generator().manual_seed(50 + i)) for i, p in enumerate(params_o)]
+    tr.explicit = dict(pen_real=ms_p, alpha=alpha, keep=True)
+    pe.host_noise = zs
+    tr.train_D(img.cuda(), None, z.cuda(), None, use_dp=True)
+    torch.cuda.synchronize()
+    obs = oracle.step(img, None, z, None, pen_real=ms_p, alpha=alpha, apply_update=False)
+    _close(tr.last["fake_img"], obs["fake_img"], "fake_img (BatchNorm generator)")
+    _close(tr.last["d_real_loss"], obs["d_real_loss"], "d_real_loss")
+    _close(tr.last["penalty"], obs["penalty"], "penalty")
+    s_o = np.atleast_1d(np.asarray(obs["batch_sensitivity"], dtype=np.float64))
+    s_g = np.atleast_1d(np.asarray(pe.batch_sensitivity, dtype=np.float64))
+    assert s_g.shape == s_o.shape == ((len(params_o),) if per_param else (1,))
+    np.testing.assert_allclose(s_g, s_o, rtol=2e-2, atol=1e-7)
+    sens = np.broadcast_to(s_o, (len(params_o),))
+
+    def to_logical(zv, p):
+        if p.dim() == 4:
+            K, Cc, R, S = p.shape
+            return zv.view(K, R, S, Cc).permute(0, 3, 1, 2)
+        return zv.view(p.shape)
+    for i, (p, go, zv, po) in enumerate(zip(tr.D.parameters(), obs["is_param_grads"], zs, params_o)):
+        exp = go + to_logical(zv, po) * (opt.sigma * float(sens[i]) / B)
+        _close_grad(p.grad, exp, "IS noised grad[%d]" % i, l2_tol=2e-2, frac_tol=0.1)
+    assert pe.steps == 1
+    # running statistics of the BatchNorm generator were updated like torch's
+    for (n1, b1), (n2, b2) in zip(G.named_buffers(), Go.named_buffers()):
+        if "running" in n1:
+            _close(b1, b2, "G buffer " + n1)

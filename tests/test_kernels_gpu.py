@@ -260,7 +260,7 @@ def test_act_bwd_groupnorm_adam():
     g = torch.Generator().manual_seed(4)
     gg, y = torch.randn(1000003, generator=g), torch.randn(1000003, generator=g)
     _close(ops.act_bwd(_dev(gg), _dev(y), 0.2), torch.where(y > 0, gg, 0.2 * gg), what="act_bwd")
-    for (N, H, C) in ((3, 8, 64), (2, 4, 512), (2, 16, 128)):
+    for (N, H, C) in ((3, 8, 64), (2, 4, 512), (2, 16, 128), (2, 3, 96)):
         x = torch.randn(N, C, H, H, generator=g) * 2 + 0.5
         gn = torch.nn.GroupNorm(32, C)
         with torch.no_grad():
@@ -268,6 +268,20 @@ def test_act_bwd_groupnorm_adam():
             ref = F.relu(gn(x))
         out = ops.groupnorm_act(_nhwc(x), _dev(gn.weight.detach()), _dev(gn.bias.detach()), 32, eps=gn.eps, relu=True)
         _close(out.permute(0, 3, 1, 2), ref, what="groupnorm %s" % ((N, H, C),))
+    for (N, H, C) in ((4, 8, 64), (3, 5, 12), (2, 16, 512)):
+        x = torch.randn(N, C, H, H, generator=g) * 1.5 - 0.3
+        bn = torch.nn.BatchNorm2d(C)
+        with torch.no_grad():
+            bn.weight.copy_(torch.randn(C, generator=g)); bn.bias.copy_(torch.randn(C, generator=g))
+            bn.running_mean.copy_(torch.randn(C, generator=g)); bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+        rm, rv = bn.running_mean.clone().cuda(), bn.running_var.clone().cuda()
+        bn.train()
+        with torch.no_grad():
+            ref = F.relu(bn(x))
+        out = ops.batchnorm_act(_nhwc(x), _dev(bn.weight.detach()), _dev(bn.bias.detach()), rm, rv, momentum=bn.momentum, eps=bn.eps)
+        _close(out.permute(0, 3, 1, 2), ref, what="batchnorm %s" % ((N, H, C),))
+        _close(rm, bn.running_mean, what="bn running mean")
+        _close(rv, bn.running_var, what="bn running var")
     p = torch.randn(5000, generator=g)
     pr = p.clone().requires_grad_(True)
     opt = torch.optim.Adam([pr], lr=1e-3, betas=(0.0, 0.9), weight_decay=0.01)

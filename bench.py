@@ -90,7 +90,10 @@ def main():
     a = ap.parse_args()
 
     from csl_gan_amd import distributed as D, ops
-    world, rank, local = D.init("nccl")
+    # CSLGAN_DIST_BACKEND=gloo + CSLGAN_FORCE_DEVICE=0 rehearse the N>1 code path on a one-GPU box
+    world, rank, local = D.init(os.environ.get("CSLGAN_DIST_BACKEND", "nccl"))
+    if "CSLGAN_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["CSLGAN_FORCE_DEVICE"])
     if world != a.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
     torch.cuda.set_device(local)

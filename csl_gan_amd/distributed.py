@@ -35,7 +35,7 @@ def init(backend=None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(int(os.environ.get("CSLGAN_FORCE_DEVICE", local)))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return world, rank, local
 

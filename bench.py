@@ -129,10 +129,17 @@ def main():
     kernels = timer.summary()
     dom = max(kernels.values(), key=lambda k: k["ms"]) if kernels else None
     roof = None
+    traffic = None
+    try:        # HBM bytes per launch of the conv kernel family, from the committed rocprofv3 PMC passes
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            traffic = round(json.load(f)["igemm_kc_all_instantiations"]["MB_per_launch"] * 1e6)
+    except Exception:
+        traffic = None
     if dom:
         ach = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "launches_per_step": dom["n"] / a.steps,
+                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic if dom["name"].startswith("conv2d") else None,
+                "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]), "launches_per_step": dom["n"] / a.steps,
                 "avg_launch_ms": round(dom["ms"] / dom["n"], 4), "share_of_step": round(dom["ms"] / (dt * 1e3), 3)}
     line = {
         "metric": "images/sec/GPU CelebA DCResNet dp_mode=gc bs=128 at 1/2/4/8 MI355X",

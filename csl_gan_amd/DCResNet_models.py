@@ -34,17 +34,16 @@ class UpsampleConv(nn.Module):
 
 class _BatchNormAct(nn.BatchNorm2d):
     """BatchNorm2d + ReLU for the bn=True generator of the non-per-sample modes (init_util.py:46): batch
-    statistics and the running-stat update run on cslgan_batchnorm_act_f32.  Forward only (the generator is
-    frozen inside the D-step); eval-mode (running statistics) inference is the image-sampling path, which is
-    out of scope."""
+    statistics and the running-stat update run on cslgan_batchnorm_act_f32, the backward on
+    cslgan_norm_act_bwd_f32; eval-mode (running statistics) inference is the image-sampling path, out of scope."""
 
     def forward_nhwc(self, x):
-        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            raise NotImplementedError("BatchNorm backward (generator training) is not built yet")
         if not self.training:
             raise NotImplementedError("eval-mode BatchNorm on HIP (image sampling) is out of scope")
         if self.num_batches_tracked is not None:
             self.num_batches_tracked += 1
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            return HF.NormAct.apply(x, self.weight, self.bias, 0, self.eps, True, self.running_mean, self.running_var, self.momentum)
         return ops.batchnorm_act(x, self.weight.detach(), self.bias.detach(), self.running_mean, self.running_var,
                                  momentum=self.momentum, eps=self.eps, relu=True)
 

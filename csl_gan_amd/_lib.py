@@ -16,8 +16,9 @@ EXPORTS = [
     "cslgan_version", "cslgan_last_error", "cslgan_device_count",
     "cslgan_sample_sqnorm_f32", "cslgan_clip_factors_f32", "cslgan_clip_accum_noise_f32",
     "cslgan_l2_clip_rows_f32", "cslgan_row_l2norm_f32", "cslgan_row_l2norm_bwd_f32",
-    "cslgan_conv2d_fwd_f32", "cslgan_conv2d_up_fwd_f32", "cslgan_conv2d_up_ws_floats", "cslgan_conv2d_dgrad_f32", "cslgan_conv2d_wgrad_grouped_f32",
-    "cslgan_bias_grad_grouped_f32", "cslgan_act_bwd_f32", "cslgan_groupnorm_act_f32", "cslgan_batchnorm_act_f32", "cslgan_adam_step_f32",
+    "cslgan_conv2d_fwd_f32", "cslgan_conv2d_up_fwd_f32", "cslgan_conv2d_up_ws_floats", "cslgan_conv2d_up_dgrad_f32", "cslgan_conv2d_dgrad_f32", "cslgan_conv2d_wgrad_grouped_f32",
+    "cslgan_bias_grad_grouped_f32", "cslgan_act_bwd_f32", "cslgan_groupnorm_act_f32", "cslgan_batchnorm_act_f32", "cslgan_norm_act_bwd_f32", "cslgan_norm_bwd_ws_floats", "cslgan_sum2x2_f32",
+    "cslgan_adam_step_f32",
 ]
 
 
@@ -68,6 +69,9 @@ def lib():
         "cslgan_conv2d_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, vp, i32, i32, vp, vp],
         "cslgan_conv2d_up_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, vp, vp, i32, i32, vp, vp],
         "cslgan_conv2d_dgrad_f32": [C.POINTER(ConvT), vp, vp, vp, vp, vp, vp],
+        "cslgan_conv2d_up_dgrad_f32": [C.POINTER(ConvT), vp, vp, vp, vp, vp],
+        "cslgan_norm_act_bwd_f32": [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, i32, vp, vp, vp, vp, vp],
+        "cslgan_sum2x2_f32": [vp, i32, i32, i32, i32, vp, vp],
         "cslgan_conv2d_wgrad_grouped_f32": [C.POINTER(ConvT), vp, vp, i32, f32, vp, vp, vp],
         "cslgan_bias_grad_grouped_f32": [vp, i32, i32, i32, i32, f32, vp, vp, vp],
         "cslgan_act_bwd_f32": [vp, vp, i64, f32, vp, vp],
@@ -81,6 +85,8 @@ def lib():
         fn.restype = C.c_int
     L.cslgan_conv2d_up_ws_floats.argtypes = [i32, i32, i32]
     L.cslgan_conv2d_up_ws_floats.restype = C.c_int64
+    L.cslgan_norm_bwd_ws_floats.argtypes = [i64, i64, i32, i32]
+    L.cslgan_norm_bwd_ws_floats.restype = C.c_int64
     if L.cslgan_version() != 1:
         raise HipLibraryMissing("libcslgan_hip.so ABI version mismatch")
     _lib = L

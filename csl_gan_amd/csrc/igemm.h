@@ -12,7 +12,7 @@
 namespace cslgan {
 
 constexpr int IG_BK = 32;          // K depth of one LDS tile (KC kernel)
-constexpr int IG_MAX_TAPS = 32;
+constexpr int IG_MAX_TAPS = 40;
 
 // "K-contiguous" implicit GEMM:  Out[m][n] = sum_k A(m,k) * Wm[n][k]
 //   m -> (img, oy, ox) over a per-image grid OHc x OWc
@@ -98,6 +98,7 @@ struct McParams {
     int T;               // taps R*S
     int Ndim;            // T*C
     int stride;
+    int ups;             // 1: x is read through a nearest-2x upsample (H, W are the stored low-res dims)
     int group;           // samples per group
     int n_groups;
     float alpha;

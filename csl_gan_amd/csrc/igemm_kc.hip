@@ -456,6 +456,48 @@ int64_t cslgan_conv2d_up_ws_floats(int K, int R, int C) {
     return (int64_t)4 * n * n * K * C;
 }
 
+// Data gradient of (nearest-2x upsample -> RxR 'same' conv) with respect to the LOW-res input:
+//   gx[i] = sum_o w'(o) gy[2i + o],  o in [pad-R+1, pad+1] per axis, w'(o) = sum of the filter taps kh with
+//   kh in {pad-o, pad-o+1}: the 2x2 sum-pool of the dense data gradient folded into (R+1)^2 strided taps
+//   (36 instead of 4*25 MACs per low-res pixel for 5x5).
+int cslgan_conv2d_up_dgrad_f32(const cslgan_conv_t* c, const float* gy, const float* w, float* wt_ws, float* gx, void* stream) {
+    CSLGAN_REQUIRE(c && gy && w && wt_ws && gx, "conv2d_up_dgrad: null argument");
+    int rc = check_conv(c, "conv2d_up_dgrad");
+    if (rc) return rc;
+    CSLGAN_REQUIRE(c->upsample == 1 && c->stride == 1, "conv2d_up_dgrad: needs upsample=1, stride=1");
+    CSLGAN_REQUIRE(c->R == c->S && (c->R % 2 == 1) && c->pad == c->R / 2, "conv2d_up_dgrad: needs an odd square 'same' filter");
+    const int R = c->R, pad = c->pad, no = R + 1;
+    CSLGAN_REQUIRE(no * no <= IG_MAX_TAPS, "conv2d_up_dgrad: filter too large (%d folded taps)", no * no);
+    hipStream_t st = (hipStream_t)stream;
+    RepackArgs ra{};
+    ra.K = c->K; ra.R = R; ra.S = R; ra.C = c->C; ra.n_class = 1; ra.transposed = 1;
+    KcParams p{};
+    p.a = gy; p.AH = c->P; p.AW = c->Q; p.AC = c->K; p.VH = c->P; p.VW = c->Q; p.ups = 0; p.sy = p.sx = 2;
+    p.w = wt_ws; p.Nn = c->C; p.out = gx; p.OHf = c->H; p.OWf = c->W; p.osy = p.osx = 1; p.ldo = c->C; p.dense_out = 1;
+    p.bias = nullptr; p.res = nullptr; p.res_shift = 0; p.mask = nullptr; p.act = CSLGAN_ACT_NONE; p.n_cls = 1;
+    KcClass& k = p.cls[0];
+    clear_taps(k);
+    k.M = c->N * c->H * c->W; k.OHc = c->H; k.OWc = c->W; k.T = no * no; k.Kdim = k.T * c->K; k.w_off = 0; k.oy0 = k.ox0 = 0;
+    for (int u = 0; u < no; ++u)
+        for (int v = 0; v < no; ++v) {
+            const int t = u * no + v;
+            const int oy = pad - R + 1 + u, ox = pad - R + 1 + v;
+            k.ty[t] = (signed char)oy; k.tx[t] = (signed char)ox;
+            const int ylo = pad - oy, xlo = pad - ox;
+            ra.kh_lo[0][t] = (signed char)(ylo < 0 ? 0 : ylo); ra.kh_hi[0][t] = (signed char)(ylo + 2 > R ? R : ylo + 2);
+            ra.kw_lo[0][t] = (signed char)(xlo < 0 ? 0 : xlo); ra.kw_hi[0][t] = (signed char)(xlo + 2 > R ? R : xlo + 2);
+        }
+    ra.cls_T[0] = k.T; ra.cls_off[0] = 0;
+    {
+        unsigned gxn = (unsigned)(((long long)c->K * c->C * k.T + 255) / 256);
+        gxn = gxn > 1024 ? 1024 : (gxn < 1 ? 1 : gxn);
+        hipLaunchKernelGGL(repack_filters_kernel, dim3(gxn, 1), dim3(256), 0, st, w, wt_ws, ra);
+        rc = check_launch("repack_filters_kernel");
+        if (rc) return rc;
+    }
+    return launch_kc(p, st, (long long)c->N * c->H * c->W * c->C);
+}
+
 int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* c, const float* gy, const float* w, float* wt_ws, const float* mask,
                             float* gx, void* stream) {
     CSLGAN_REQUIRE(c && gy && w && wt_ws && gx, "conv2d_dgrad: null argument");

@@ -86,17 +86,18 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
                 const int oy = pix / p.Q, ox = pix - oy * p.Q;
                 const long long img = (long long)g * p.group + il;
                 const int by = oy * p.stride, bx = ox * p.stride;
+                const int VH = p.H << p.ups, VW = p.W << p.ups;
                 if (VEC_B) {
                     const int iy = by + b_ty[0], ix = bx + b_tx[0];
-                    if (b_nok[0] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                        v = *reinterpret_cast<const float4*>(p.x + ((img * p.H + iy) * p.W + ix) * p.C + b_c[0]);
+                    if (b_nok[0] && iy >= 0 && iy < VH && ix >= 0 && ix < VW)
+                        v = *reinterpret_cast<const float4*>(p.x + ((img * p.H + (iy >> p.ups)) * p.W + (ix >> p.ups)) * p.C + b_c[0]);
                 } else {
                     float t4[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int iy = by + b_ty[e], ix = bx + b_tx[e];
-                        t4[e] = (b_nok[e] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                                    ? p.x[((img * p.H + iy) * p.W + ix) * p.C + b_c[e]] : 0.f;
+                        t4[e] = (b_nok[e] && iy >= 0 && iy < VH && ix >= 0 && ix < VW)
+                                    ? p.x[((img * p.H + (iy >> p.ups)) * p.W + (ix >> p.ups)) * p.C + b_c[e]] : 0.f;
                     }
                     v = make_float4(t4[0], t4[1], t4[2], t4[3]);
                 }
@@ -230,14 +231,14 @@ int cslgan_conv2d_wgrad_grouped_f32(const cslgan_conv_t* c, const float* gy, con
                                     float* gw, float* sq, void* stream) {
     CSLGAN_REQUIRE(c && gy && x, "conv2d_wgrad: null argument");
     CSLGAN_REQUIRE(gw || sq, "conv2d_wgrad: neither gw nor sq requested");
-    CSLGAN_REQUIRE(!c->upsample, "conv2d_wgrad: upsample-on-read convs have no weight-gradient path yet");
     CSLGAN_REQUIRE(group >= 1 && c->N % group == 0, "conv2d_wgrad: N=%d not divisible by group=%d", c->N, group);
     CSLGAN_REQUIRE(c->R * c->S <= IG_MAX_TAPS, "conv2d_wgrad: too many taps");
-    const int P = (c->H + 2 * c->pad - c->R) / c->stride + 1, Q = (c->W + 2 * c->pad - c->S) / c->stride + 1;
+    const int VH = c->upsample ? 2 * c->H : c->H, VW = c->upsample ? 2 * c->W : c->W;
+    const int P = (VH + 2 * c->pad - c->R) / c->stride + 1, Q = (VW + 2 * c->pad - c->S) / c->stride + 1;
     CSLGAN_REQUIRE(P == c->P && Q == c->Q, "conv2d_wgrad: output %dx%d does not match P,Q=%d,%d", P, Q, c->P, c->Q);
     McParams p{};
     p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->P; p.Q = c->Q; p.Kc = c->K;
-    p.T = c->R * c->S; p.Ndim = p.T * c->C; p.stride = c->stride; p.group = group; p.n_groups = c->N / group;
+    p.T = c->R * c->S; p.Ndim = p.T * c->C; p.stride = c->stride; p.ups = c->upsample ? 1 : 0; p.group = group; p.n_groups = c->N / group;
     p.alpha = alpha; p.gw = gw; p.sq = sq;
     for (int t = 0; t < IG_MAX_TAPS; ++t) { p.ty[t] = 0; p.tx[t] = 0; }
     for (int kh = 0; kh < c->R; ++kh)

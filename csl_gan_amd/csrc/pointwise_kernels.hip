@@ -125,6 +125,129 @@ __global__ void norm_apply_kernel(const float* __restrict__ x, const float* __re
     }
 }
 
+// ---- normalisation backward (GroupNorm / BatchNorm + optional ReLU) -------------------------------
+// With xh = (x-mean_s)*rstd_s, dy' = dy * [y > 0] (ReLU fused; y is the forward output):
+//   per (row-group sr, channel c):  A = sum_rows dy',  Bq = sum_rows dy' * xh        -> ab[(sr*C + c)*2 + {0,1}]
+//   d gamma[c] = sum_sr Bq,  d beta[c] = sum_sr A
+//   per statistic s: s1 = sum_{c in s} gamma_c A, s2 = sum_{c in s} gamma_c Bq
+//   dx = rstd_s * (gamma_c dy' - s1/cnt - xh * s2/cnt)
+template <bool VEC>
+__global__ __launch_bounds__(256) void norm_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const float* __restrict__ y, const float* __restrict__ stats,
+                                                             long long rows_per_stat, int C, int cpg, int n_groups, float eps,
+                                                             int relu, float* __restrict__ ab) {
+    extern __shared__ float s_acc[];   // [2*C]
+    const int tid = threadIdx.x;
+    for (int c = tid; c < 2 * C; c += 256) s_acc[c] = 0.f;
+    __syncthreads();
+    const long long sr = blockIdx.y;
+    const long long r0 = sr * rows_per_stat + (long long)blockIdx.x * NS_ROWS;
+    long long r1 = r0 + NS_ROWS;
+    const long long rend = (sr + 1) * rows_per_stat;
+    if (r1 > rend) r1 = rend;
+    const float inv_cnt = 1.f / ((float)rows_per_stat * (float)cpg);
+    if (VEC) {
+        const int c4n = C >> 2;
+        const int c4 = tid % c4n, rl = tid / c4n, rstep = 256 / c4n;
+        float mean[4], rstd[4], a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long long s = sr * n_groups + (4 * c4 + e) / cpg;
+            mean[e] = stats[2 * s] * inv_cnt;
+            rstd[e] = rsqrtf(stats[2 * s + 1] * inv_cnt + eps);
+        }
+        for (long long r = r0 + rl; r < r1; r += rstep) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + r * C + 4 * c4);
+            const float4 gv = *reinterpret_cast<const float4*>(dy + r * C + 4 * c4);
+            float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (relu) yv = *reinterpret_cast<const float4*>(y + r * C + 4 * c4);
+            const float xi[4] = {xv.x, xv.y, xv.z, xv.w}, gi[4] = {gv.x, gv.y, gv.z, gv.w}, yi[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g = yi[e] > 0.f ? gi[e] : 0.f;
+                a[e] += g;
+                b[e] = fmaf(g, (xi[e] - mean[e]) * rstd[e], b[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(&s_acc[2 * (4 * c4 + e)], a[e]);
+            atomicAdd(&s_acc[2 * (4 * c4 + e) + 1], b[e]);
+        }
+    } else {
+        const long long n = (r1 - r0) * C;
+        for (long long i = tid; i < n; i += 256) {
+            const int c = (int)(i % C);
+            const long long s = sr * n_groups + c / cpg;
+            const float m = stats[2 * s] * inv_cnt, rs = rsqrtf(stats[2 * s + 1] * inv_cnt + eps);
+            const long long off = r0 * C + i;
+            const float g = (!relu || y[off] > 0.f) ? dy[off] : 0.f;
+            atomicAdd(&s_acc[2 * c], g);
+            atomicAdd(&s_acc[2 * c + 1], g * (x[off] - m) * rs);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * C; c += 256) atomicAdd(&ab[sr * 2 * C + c], s_acc[c]);
+}
+
+// gs[s] = (s1, s2);  dgamma/dbeta accumulate over row groups
+__global__ void norm_bwd_finalize_kernel(const float* __restrict__ ab, const float* __restrict__ gamma, long long n_row_groups,
+                                         int C, int cpg, int n_groups, float* __restrict__ gs, float* __restrict__ dgamma,
+                                         float* __restrict__ dbeta) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n_stats = n_row_groups * n_groups;
+    if (i < n_stats) {
+        const long long sr = i / n_groups;
+        const int g = (int)(i - sr * n_groups);
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            s1 = fmaf(gamma[c], ab[(sr * C + c) * 2], s1);
+            s2 = fmaf(gamma[c], ab[(sr * C + c) * 2 + 1], s2);
+        }
+        gs[2 * i] = s1;
+        gs[2 * i + 1] = s2;
+    }
+    if (i < C) {
+        float da = 0.f, db = 0.f;
+        for (long long sr = 0; sr < n_row_groups; ++sr) {
+            da += ab[(sr * C + i) * 2];
+            db += ab[(sr * C + i) * 2 + 1];
+        }
+        dbeta[i] = da;
+        dgamma[i] = db;
+    }
+}
+
+__global__ void norm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+                                      const float* __restrict__ gamma, const float* __restrict__ stats, const float* __restrict__ gs,
+                                      long long total, long long rows_per_stat, int C, int cpg, int n_groups, float eps, int relu,
+                                      float* __restrict__ dx) {
+    const float inv_cnt = 1.f / ((float)rows_per_stat * (float)cpg);
+    const long long per_stat_elems = rows_per_stat * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long long s = (i / per_stat_elems) * n_groups + c / cpg;
+        const float mean = stats[2 * s] * inv_cnt, rstd = rsqrtf(stats[2 * s + 1] * inv_cnt + eps);
+        const float xh = (x[i] - mean) * rstd;
+        const float g = (!relu || y[i] > 0.f) ? dy[i] : 0.f;
+        dx[i] = rstd * (gamma[c] * g - gs[2 * s] * inv_cnt - xh * gs[2 * s + 1] * inv_cnt);
+    }
+}
+
+// out[n][i][j][c] = sum of the 2x2 block in[n][2i+a][2j+b][c]  (gradient of a nearest-2x upsampled read)
+__global__ void sum2x2_kernel(const float* __restrict__ in, int N, int H, int W, int C, float* __restrict__ out) {
+    const long long total = (long long)N * H * W * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int j = (int)(r % W); r /= W;
+        const int ii = (int)(r % H);
+        const long long n = r / H;
+        const float* b = in + (((n * 2 * H + 2 * ii) * 2 * W) + 2 * j) * C + c;
+        out[i] = b[0] + b[C] + b[(long long)2 * W * C] + b[(long long)2 * W * C + C];
+    }
+}
+
 // BatchNorm running statistics (torch semantics: running_var uses the unbiased batch variance)
 __global__ void bn_running_kernel(const float* __restrict__ stats, int C, float cnt, float momentum, float* __restrict__ rm,
                                   float* __restrict__ rv) {
@@ -222,6 +345,48 @@ int cslgan_batchnorm_act_f32(const float* x, const float* gamma, const float* be
         return check_launch("bn_running_kernel");
     }
     return CSLGAN_OK;
+}
+
+int cslgan_norm_act_bwd_f32(const float* x, const float* dy, const float* y, const float* gamma, const float* stats,
+                            int64_t rows, int64_t rows_per_stat, int C, int groups, float eps, int relu, float* ws, float* dx,
+                            float* dgamma, float* dbeta, void* stream) {
+    CSLGAN_REQUIRE(x && dy && gamma && stats && ws && dx && dgamma && dbeta, "norm_bwd: null argument");
+    CSLGAN_REQUIRE(!relu || y, "norm_bwd: relu backward needs the forward output");
+    CSLGAN_REQUIRE(rows > 0 && rows_per_stat > 0 && rows % rows_per_stat == 0 && C > 0 && groups > 0 && C % groups == 0 && C <= 4096,
+                   "norm_bwd: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const long long nrg = rows / rows_per_stat;
+    CSLGAN_REQUIRE(nrg <= 65535, "norm_bwd: too many row groups");
+    const int cpg = C / groups;
+    float* ab = ws;                         // [nrg][C][2]
+    float* gs = ws + nrg * C * 2;           // [nrg*groups][2]
+    if (hipMemsetAsync(ab, 0, sizeof(float) * nrg * C * 2, st) != hipSuccess) { set_error("norm_bwd: memset failed"); return CSLGAN_ERR_LAUNCH; }
+    const bool vec = (C % 4 == 0) && ((C / 4) <= 256) && (256 % (C / 4) == 0) && aligned16(x) && aligned16(dy) && (!relu || aligned16(y));
+    const dim3 grid((unsigned)((rows_per_stat + NS_ROWS - 1) / NS_ROWS), (unsigned)nrg), block(256);
+    if (vec) hipLaunchKernelGGL((norm_bwd_stats_kernel<true>), grid, block, sizeof(float) * 2 * C, st, x, dy, y, stats, (long long)rows_per_stat, C, cpg, groups, eps, relu, ab);
+    else hipLaunchKernelGGL((norm_bwd_stats_kernel<false>), grid, block, sizeof(float) * 2 * C, st, x, dy, y, stats, (long long)rows_per_stat, C, cpg, groups, eps, relu, ab);
+    int rc = check_launch("norm_bwd_stats_kernel");
+    if (rc) return rc;
+    const long long nfin = nrg * groups > C ? nrg * groups : C;
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)((nfin + 127) / 128)), dim3(128), 0, st, ab, gamma, nrg, C, cpg, groups, gs, dgamma, dbeta);
+    rc = check_launch("norm_bwd_finalize_kernel");
+    if (rc) return rc;
+    const long long total = rows * C;
+    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, dy, y, gamma, stats, gs, total,
+                       (long long)rows_per_stat, C, cpg, groups, eps, relu, dx);
+    return check_launch("norm_bwd_apply_kernel");
+}
+
+int64_t cslgan_norm_bwd_ws_floats(int64_t rows, int64_t rows_per_stat, int C, int groups) {
+    const int64_t nrg = rows_per_stat > 0 ? rows / rows_per_stat : 0;
+    return nrg * C * 2 + nrg * groups * 2;
+}
+
+int cslgan_sum2x2_f32(const float* in, int N, int H, int W, int C, float* out, void* stream) {
+    CSLGAN_REQUIRE(in && out, "sum2x2: null argument");
+    CSLGAN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "sum2x2: bad sizes");
+    hipLaunchKernelGGL(sum2x2_kernel, dim3(grid_for((long long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, in, N, H, W, C, out);
+    return check_launch("sum2x2_kernel");
 }
 
 int cslgan_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,

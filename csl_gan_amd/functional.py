@@ -106,8 +106,8 @@ class Conv(Function):
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         stride, pad, act, upsample, res_shift = ctx.cfg
-        if upsample or (ctx.has_res and ctx.needs_input_grad[7]):
-            raise NotImplementedError("backward through upsample-on-read / residual convs (generator) is not built yet")
+        if upsample or ctx.has_res:
+            return Conv._backward_generator(ctx, gy, x, w, y)
         gz = gy
         if act in _SLOPE:
             gz = ActBwd.apply(gy, y, _SLOPE[act])
@@ -122,6 +122,66 @@ class Conv(Function):
         if ctx.needs_input_grad[2] and not ctx.input_only:
             gb = BiasGrad.apply(gz)
         return gx, gw, gb, None, None, None, None, None, None
+
+
+def _conv_backward_generator(ctx, gy, x, w, y):
+    """First-order backward of the generator-only conv forms (upsample-on-read, residual epilogue): train_G
+    (train.py:502-511).  Not differentiable again — nothing in the reference differentiates G twice."""
+    stride, pad, act, upsample, res_shift = ctx.cfg
+    with torch.no_grad():
+        gz = gy.contiguous()
+        if act in _SLOPE:
+            gz = ops.act_bwd(gz, y, _SLOPE[act])
+        elif act == ops.ACT_TANH:
+            gz = gz * (1 - y * y)
+        gx = gw = gb = gres = None
+        R, S = w.shape[1], w.shape[2]
+        if ctx.needs_input_grad[0]:
+            gx = ops.conv2d_up_dgrad(gz, w, pad) if upsample else ops.conv2d_dgrad(gz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad)
+        if ctx.needs_input_grad[1]:
+            N = x.shape[0]
+            tiles = ((gz.shape[-1] + 127) // 128) * ((R * S * x.shape[-1] + 127) // 128)
+            slabs = ops.conv2d_wgrad_grouped(gz, x, R, S, stride=stride, pad=pad, group=_dense_group(N, tiles), upsample=upsample)
+            if slabs.shape[0] == 1:
+                gw = slabs[0]
+            else:
+                gw = torch.empty(slabs.shape[1:], device=x.device, dtype=torch.float32)
+                ops.clip_accum_noise([slabs.reshape(slabs.shape[0], -1)], [gw])
+        if ctx.needs_input_grad[2]:
+            part = ops.bias_grad_grouped(gz, group=1)
+            gb = torch.empty(part.shape[1], device=x.device, dtype=torch.float32)
+            ops.clip_accum_noise([part], [gb])
+        if ctx.has_res and ctx.needs_input_grad[7]:
+            gres = ops.sum2x2(gz) if res_shift else gz
+    return gx, gw, gb, None, None, None, None, gres, None
+
+
+Conv._backward_generator = staticmethod(_conv_backward_generator)
+
+
+class NormAct(Function):
+    """GroupNorm / BatchNorm (+ReLU) on NHWC data with the HIP forward and backward kernels.
+    groups == 0 selects BatchNorm (batch statistics per channel, running stats updated in place)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, relu, running_mean, running_var, momentum):
+        if groups > 0:
+            y, stats = ops.groupnorm_act(x, gamma, beta, groups, eps=eps, relu=relu, return_stats=True)
+            ctx.rows_per_stat, ctx.groups = x.shape[1] * x.shape[2], groups
+        else:
+            y, stats = ops.batchnorm_act(x, gamma, beta, running_mean, running_var, momentum=momentum, eps=eps, relu=relu,
+                                         return_stats=True)
+            ctx.rows_per_stat, ctx.groups = x.numel() // x.shape[-1], x.shape[-1]
+        ctx.eps, ctx.relu = eps, relu
+        ctx.save_for_backward(x, y, gamma, stats)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, y, gamma, stats = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.norm_act_bwd(x, gy.contiguous(), y, gamma, stats, ctx.rows_per_stat, ctx.groups, ctx.eps, ctx.relu)
+        return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
 class Dgrad(Function):

@@ -90,9 +90,8 @@ class HipLinear(nn.Linear, _PerSampleMixin):
 
 
 class HipGroupNormAct(nn.GroupNorm):
-    """nn.GroupNorm(32, C) followed by ReLU (DCResNet_models.py:55-57, 63-67, 84, 101-102) as one
-    HIP op on NHWC data.  Forward only for now (the generator is frozen inside the D-step,
-    train.py:362); its backward belongs to the train_G row."""
+    """nn.GroupNorm(32, C) followed by ReLU (DCResNet_models.py:55-57, 63-67, 84, 101-102) as one HIP op on
+    NHWC data, forward and backward (cslgan_groupnorm_act_f32 / cslgan_norm_act_bwd_f32)."""
 
     def __init__(self, groups, channels, relu=True):
         super().__init__(groups, channels)
@@ -100,8 +99,7 @@ class HipGroupNormAct(nn.GroupNorm):
 
     def forward_nhwc(self, x):
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            raise NotImplementedError("HipGroupNormAct backward (generator training) is not built yet; "
-                                      "call under torch.no_grad() or with the generator frozen")
+            return HF.NormAct.apply(x, self.weight, self.bias, self.num_groups, self.eps, self.relu, None, None, 0.0)
         return ops.groupnorm_act(x, self.weight.detach(), self.bias.detach(), self.num_groups, eps=self.eps, relu=self.relu)
 
     def forward(self, x):

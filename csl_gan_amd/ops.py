@@ -149,12 +149,13 @@ def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None):
     return gx
 
 
-def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_gw=True, sq=None, out=None):
-    """gw[N/group,K,R,S,C] (per-group weight gradients) and/or sq[N/group] += ||alpha*gw_g||^2."""
+def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_gw=True, sq=None, out=None, upsample=False):
+    """gw[N/group,K,R,S,C] (per-group weight gradients) and/or sq[N/group] += ||alpha*gw_g||^2.
+    upsample=True: x is the LOW-res input of an upsample+conv (read through the nearest-2x map)."""
     _chk(gy, "gy"); _chk(x, "x")
     N, H, W, Cc = x.shape
     N2, P, Q, K = gy.shape
-    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, False)
+    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, upsample)
     if N2 != N or (P2, Q2) != (P, Q):
         raise RuntimeError("conv2d_wgrad: gy %s inconsistent with x %s" % (tuple(gy.shape), tuple(x.shape)))
     if N % group:
@@ -172,6 +173,48 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
         _lib.lib().cslgan_conv2d_wgrad_grouped_f32(C.byref(d), _p(gy), _p(x), group, float(alpha), _p(gw), _p(sq), _stream()),
         "conv2d_wgrad_grouped"))
     return gw
+
+
+def conv2d_up_dgrad(gy, w, pad):
+    """gx[N,H,W,C] for y = conv(nearest_up2(x), w[K,R,R,C]) ('same', stride 1) from gy[N,2H,2W,K]."""
+    _chk(gy, "gy"); _chk(w, "w")
+    N, P, Q, K = gy.shape
+    K2, R, S, Cc = w.shape
+    H, W = P // 2, Q // 2
+    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, 1, pad, True)
+    if K2 != K or (P2, Q2) != (P, Q):
+        raise RuntimeError("conv2d_up_dgrad: gy shape %s inconsistent" % (tuple(gy.shape),))
+    gx = torch.empty((N, H, W, Cc), device=gy.device, dtype=torch.float32)
+    ws = torch.empty((R + 1) * (R + 1) * K * Cc, device=gy.device, dtype=torch.float32)
+    flop = 2.0 * N * P * Q * K * R * S * Cc
+    _timed("conv2d_dgrad", flop, 4.0 * (gy.numel() + gx.numel() + w.numel()), lambda: check(
+        _lib.lib().cslgan_conv2d_up_dgrad_f32(C.byref(d), _p(gy), _p(w), _p(ws), _p(gx), _stream()), "conv2d_up_dgrad"))
+    return gx
+
+
+def sum2x2(t):
+    """[N,2H,2W,C] -> [N,H,W,C] summing each 2x2 block."""
+    _chk(t, "t")
+    N, H2, W2, Cc = t.shape
+    out = torch.empty((N, H2 // 2, W2 // 2, Cc), device=t.device, dtype=torch.float32)
+    check(_lib.lib().cslgan_sum2x2_f32(_p(t), N, H2 // 2, W2 // 2, Cc, _p(out), _stream()), "sum2x2")
+    return out
+
+
+def norm_act_bwd(x, dy, y, gamma, stats, rows_per_stat, groups, eps, relu):
+    """Backward of groupnorm_act / batchnorm_act: returns (dx, dgamma, dbeta)."""
+    for t, n in ((x, "x"), (dy, "dy"), (gamma, "gamma"), (stats, "stats")):
+        _chk(t, n)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    L = _lib.lib()
+    ws = torch.empty(L.cslgan_norm_bwd_ws_floats(rows, rows_per_stat, Cc, groups), device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(Cc, device=x.device, dtype=torch.float32)
+    dbeta = torch.empty(Cc, device=x.device, dtype=torch.float32)
+    check(L.cslgan_norm_act_bwd_f32(_p(x), _p(dy), _p(y), _p(gamma), _p(stats), rows, rows_per_stat, Cc, groups, float(eps),
+                                    1 if relu else 0, _p(ws), _p(dx), _p(dgamma), _p(dbeta), _stream()), "norm_act_bwd")
+    return dx, dgamma, dbeta
 
 
 def bias_grad_grouped(gy, group=1, alpha=1.0, want_gb=True, sq=None, out=None):
@@ -296,17 +339,17 @@ def act_bwd(g, y, slope):
     return out
 
 
-def groupnorm_act(x, gamma, beta, groups, eps=1e-5, relu=True):
+def groupnorm_act(x, gamma, beta, groups, eps=1e-5, relu=True, return_stats=False):
     _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
     N, H, W, Cc = x.shape
     y = torch.empty_like(x)
     ws = torch.empty(2 * N * groups, device=x.device, dtype=torch.float32)
     check(_lib.lib().cslgan_groupnorm_act_f32(_p(x), _p(gamma), _p(beta), N, H * W, Cc, groups, float(eps), 1 if relu else 0,
                                               _p(ws), _p(y), _stream()), "groupnorm_act")
-    return y
+    return (y, ws) if return_stats else y
 
 
-def batchnorm_act(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, relu=True):
+def batchnorm_act(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, relu=True, return_stats=False):
     """Training-mode BatchNorm (+ReLU) over all leading dims of NHWC x; updates the running stats in place."""
     _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
     Cc = x.shape[-1]
@@ -315,7 +358,7 @@ def batchnorm_act(x, gamma, beta, running_mean=None, running_var=None, momentum=
     ws = torch.empty(2 * Cc, device=x.device, dtype=torch.float32)
     check(_lib.lib().cslgan_batchnorm_act_f32(_p(x), _p(gamma), _p(beta), rows, Cc, float(eps), 1 if relu else 0, float(momentum),
                                               _p(running_mean), _p(running_var), _p(ws), _p(y), _stream()), "batchnorm_act")
-    return y
+    return (y, ws) if return_stats else y
 
 
 def adam_step(p, g, m, v, lr, b1, b2, eps, weight_decay, step):

@@ -306,10 +306,17 @@ class Trainer:
     def train_G(self, z, y):
         o, G, D = self.opt, self.G, self.D
         util.zero_grad(G)
-        d_fake, d_fake_aux, _ = self.eval_G_D(z, y)
-        g_adv_loss = G.loss(d_fake, o.d_device)
-        g_aux_loss = D.aux_loss(d_fake_aux, y.to(o.d_device), o.d_device) if o.is_acgan else 0
-        (g_adv_loss + g_aux_loss).backward()
+        # The reference lets D's parameters collect (stale, later discarded) gradients here (train.py:505-510,
+        # cleared at train.py:361).  Freezing D for the G step skips those weight-gradient kernels; G's
+        # gradients are unchanged.
+        util.freeze(D)
+        try:
+            d_fake, d_fake_aux, _ = self.eval_G_D(z, y)
+            g_adv_loss = G.loss(d_fake, o.d_device)
+            g_aux_loss = D.aux_loss(d_fake_aux, y.to(o.d_device), o.d_device) if o.is_acgan else 0
+            (g_adv_loss + g_aux_loss).backward()
+        finally:
+            util.unfreeze(D)
         self.g_optimizer.step()
         self._acc("G Adv Loss", g_adv_loss.detach())
         if o.is_acgan:

@@ -123,6 +123,12 @@ int cslgan_conv2d_up_fwd_f32(const cslgan_conv_t* p, const float* x, const float
                              void* stream);
 int64_t cslgan_conv2d_up_ws_floats(int K, int R, int C);
 
+/* Data gradient of the upsample+conv above with respect to its LOW-res input x[N][H][W][C], from
+ * gy[N][2H][2W][K]: the 2x2 sum-pool of the dense data gradient folded into (R+1)^2 stride-2 taps.
+ * wt_ws: caller workspace of (R+1)*(R+1)*K*C floats.  (Generator backward, train.py:502-511.) */
+int cslgan_conv2d_up_dgrad_f32(const cslgan_conv_t* p, const float* gy, const float* w, float* wt_ws, float* gx,
+                               void* stream);
+
 /* gx = conv_transpose(gy, w) [* lrelu'(mask)]: the data gradient (autograd of the conv above;
  * "conv_transpose2d" in the north star).  wt_ws: caller workspace of K*R*S*C floats receiving
  * the repacked filters.  mask (nullable) has gx's shape: gx *= (mask > 0 ? 1 : 0.2). */
@@ -159,6 +165,17 @@ int cslgan_groupnorm_act_f32(const float* x, const float* gamma, const float* be
 int cslgan_batchnorm_act_f32(const float* x, const float* gamma, const float* beta, int64_t rows, int C, float eps,
                              int relu, float momentum, float* running_mean, float* running_var, float* stats_ws,
                              float* y, void* stream);
+
+/* Backward of GroupNorm / BatchNorm (+ReLU): dx, dgamma, dbeta from the forward's x, y (ReLU mask) and the
+ * stats workspace the forward filled.  rows_per_stat = H*W (GroupNorm) or rows (BatchNorm, groups = C).
+ * ws: caller workspace of cslgan_norm_bwd_ws_floats(...) floats. */
+int cslgan_norm_act_bwd_f32(const float* x, const float* dy, const float* y, const float* gamma, const float* stats,
+                            int64_t rows, int64_t rows_per_stat, int C, int groups, float eps, int relu, float* ws,
+                            float* dx, float* dgamma, float* dbeta, void* stream);
+int64_t cslgan_norm_bwd_ws_floats(int64_t rows, int64_t rows_per_stat, int C, int groups);
+
+/* out[n][i][j][c] = sum of in[n][2i..2i+1][2j..2j+1][c]: gradient of a nearest-2x upsampled (shifted) read. */
+int cslgan_sum2x2_f32(const float* in, int N, int H, int W, int C, float* out, void* stream);
 
 /* Adam (torch.optim.Adam semantics, train.py:76): in-place on p, m, v.  step is 1-based. */
 int cslgan_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,

@@ -292,3 +292,47 @@ def test_act_bwd_groupnorm_adam():
         opt.step()
         ops.adam_step(dp, _dev(gr), m, v, 1e-3, 0.0, 0.9, 1e-8, 0.01, step)
     _close(dp, pr, rtol=1e-5, what="adam")
+
+
+@pytest.mark.parametrize("case", [(2, 4, 4, 32, 48, 5), (3, 5, 7, 12, 20, 3), (2, 8, 8, 64, 64, 5), (1, 3, 3, 8, 8, 1)])
+def test_upsample_conv_backward(case):
+    """Data and weight gradients of nearest-2x upsample + 'same' conv (generator backward)."""
+    ops = _ops()
+    N, H, W, C, K, R = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, C, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x.repeat_interleave(2, 2).repeat_interleave(2, 3), w, None, padding=R // 2)
+    gy = torch.randn(y.shape, generator=g)
+    gx_ref, gw_ref = torch.autograd.grad(y, (x, w), gy)
+    if R > 1:
+        gx = ops.conv2d_up_dgrad(_nhwc(gy), _krsc(w.detach()), R // 2)
+        _close(gx.permute(0, 3, 1, 2), gx_ref, what="up dgrad %s" % (case,))
+    gw = ops.conv2d_wgrad_grouped(_nhwc(gy), _nhwc(x.detach()), R, R, stride=1, pad=R // 2, group=N, upsample=True)
+    _close(gw[0].permute(0, 3, 1, 2), gw_ref, what="up wgrad %s" % (case,))
+    s = ops.sum2x2(_nhwc(gy))
+    _close(s.permute(0, 3, 1, 2), F.avg_pool2d(gy, 2) * 4, what="sum2x2")
+
+
+@pytest.mark.parametrize("kind,N,H,C", [("gn", 3, 8, 64), ("gn", 2, 4, 512), ("gn", 2, 3, 96), ("bn", 4, 8, 64), ("bn", 3, 5, 12)])
+def test_norm_act_backward(kind, N, H, C):
+    ops = _ops()
+    g = torch.Generator().manual_seed(N * 100 + C)
+    x = (torch.randn(N, C, H, H, generator=g) * 1.5 + 0.2).requires_grad_(True)
+    m = torch.nn.GroupNorm(32, C) if kind == "gn" else torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        m.weight.copy_(torch.randn(C, generator=g)); m.bias.copy_(torch.randn(C, generator=g) * 0.5)
+    y = F.relu(m(x))
+    gy = torch.randn(y.shape, generator=g)
+    gx_ref, gg_ref, gb_ref = torch.autograd.grad(y, (x, m.weight, m.bias), gy)
+    xn = _nhwc(x.detach())
+    if kind == "gn":
+        yd, stats = ops.groupnorm_act(xn, _dev(m.weight.detach()), _dev(m.bias.detach()), 32, eps=m.eps, relu=True, return_stats=True)
+        rows_per_stat, groups = H * H, 32
+    else:
+        yd, stats = ops.batchnorm_act(xn, _dev(m.weight.detach()), _dev(m.bias.detach()), None, None, eps=m.eps, relu=True, return_stats=True)
+        rows_per_stat, groups = N * H * H, C
+    dx, dgam, dbet = ops.norm_act_bwd(xn, _nhwc(gy), yd, _dev(m.weight.detach()), stats, rows_per_stat, groups, m.eps, True)
+    _close(dx.permute(0, 3, 1, 2), gx_ref, rtol=2e-4, what="norm bwd dx")
+    _close(dgam, gg_ref, rtol=2e-4, what="norm bwd dgamma")
+    _close(dbet, gb_ref, rtol=2e-4, what="norm bwd dbeta")

@@ -19,7 +19,7 @@ def _close(got, exp, what, rtol=RTOL):
     assert err <= rtol * scale, "%s: max abs err %.3e, scale %.3e, rel %.3e" % (what, err, scale, err / scale)
 
 
-def _close_grad(got, exp, what, l2_tol=5e-3, frac_tol=0.03):
+def _close_grad(got, exp, what, l2_tol=5e-3, frac_tol=0.03, abs_floor=0.0):
     """Gradient TENSORS of a LeakyReLU network are discontinuous in the activations: a unit whose
     pre-activation is within fp32 rounding of zero takes a different slope on CPU and GPU and shifts the
     gradient entries it feeds by a whole term (entries are sums of hundreds of cancelling terms, so that is
@@ -28,6 +28,8 @@ def _close_grad(got, exp, what, l2_tol=5e-3, frac_tol=0.03):
     got = torch.as_tensor(got).detach().cpu().double().reshape(-1)
     exp = torch.as_tensor(exp).detach().cpu().double().reshape(-1)
     assert got.shape == exp.shape, (what, got.shape, exp.shape)
+    if exp.abs().max().item() <= abs_floor and got.abs().max().item() <= abs_floor:
+        return          # both are rounding noise (e.g. a bias feeding a BatchNorm has an exactly-zero gradient)
     l2 = ((got - exp).norm() / (exp.norm() + 1e-30)).item()
     assert l2 <= l2_tol, "%s: relative L2 error %.3e" % (what, l2)
     scale = exp.abs().max().item() + 1e-30
@@ -305,11 +307,61 @@ def test_train_G_gradients_match_oracle(tmp_path, dataset, B, latent, mode):
     loss.backward()
     util.unfreeze(D)
     _close(loss, lo, "G loss")
+    gscale = max(g.abs().max().item() for g in go)
     for (n, p), g in zip(G.named_parameters(), go):
         assert p.grad is not None, n
-        _close_grad(p.grad, g, "dL/d " + n, l2_tol=1e-2, frac_tol=0.05)
+        # every ReLU of G and LeakyReLU of D sits between the loss and these gradients, so a handful of flipped
+        # units perturbs EVERY upstream entry at the 1e-3 level: only the L2 bound is meaningful here; the
+        # activation-free variant below checks the same wiring to 1e-4
+        _close_grad(p.grad, g, "dL/d " + n, l2_tol=1e-2, frac_tol=1.0, abs_floor=1e-6 * gscale)
     # and the full train_G call updates the generator
     before = [p.detach().clone() for p in G.parameters()]
     tr.train_G(z.cuda(), None)
     assert any((a != b).any().item() for a, b in zip(before, G.parameters()))
     assert all(p.grad is None for p in D.parameters())
+
+
+def test_train_G_gradients_exact_without_activations(tmp_path):
+    """Same generator/critic wiring with every ReLU / LeakyReLU turned off on both sides: the network is
+    smooth (GroupNorm, tanh, residual adds, sub-pixel convs remain), so HIP and CPU gradients must agree
+    to fp32 accuracy."""
+    import torch.nn.functional as F
+    from csl_gan_amd import init_util, options, ops, util
+    from csl_gan_amd.nn import HipConv2d, HipGroupNormAct
+    from csl_gan_amd.trainer import Trainer
+    from oracle.nets import build_models
+    B, latent = 4, 16
+    opt = options.parse(["MNIST", "--model", "DeepConvResNet", "-dpm", "gc", "-nms", "4", "-bs", str(B), "-gd", "cuda:0", "-dd", "cuda:0",
+                         "-o", str(tmp_path), "--manual_seed", "1", "--g_latent_dim", str(latent), "--penalty", "WGAN-GP"])
+    G, D = init_util.init_models(opt)
+    for m in G.modules():
+        if isinstance(m, HipGroupNormAct):
+            m.relu = False
+    for m in D.modules():
+        if isinstance(m, HipConv2d):
+            m.act = ops.ACT_NONE
+    tr = Trainer(opt, G, D, log_to=str(tmp_path / "log.csv"))
+    Go, Do = build_models(dataset="MNIST", model="DeepConvResNet", im_size=28, weights_seed=opt.weights_seed, manual_seed=1,
+                          per_sample_grad=True, g_latent_dim=latent)
+    z = torch.randn(B, latent, generator=torch.Generator().manual_seed(32)) * 0.3
+    relu, lrelu = F.relu, F.leaky_relu
+    try:
+        F.relu = lambda t, *a, **k: t
+        F.leaky_relu = lambda t, *a, **k: t
+        lo = Go.loss(Do(Go(z))[0])
+        go = torch.autograd.grad(lo, list(Go.parameters()))
+    finally:
+        F.relu, F.leaky_relu = relu, lrelu
+    util.zero_grad(G)
+    util.freeze(D)
+    d_fake, _, _ = tr.eval_G_D(z.cuda(), None)
+    loss = G.loss(d_fake, "cuda:0")
+    loss.backward()
+    util.unfreeze(D)
+    _close(loss, lo, "G loss", rtol=1e-4)
+    gscale = max(g.abs().max().item() for g in go)
+    for (n, p), g in zip(G.named_parameters(), go):
+        if g.abs().max().item() < 1e-5 * gscale:
+            assert p.grad.abs().max().item() < 1e-4 * gscale, n
+        else:
+            _close(p.grad, g, "dL/d " + n, rtol=5e-4)

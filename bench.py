@@ -148,6 +148,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "CelebA DCResNet D-step: dp_mode=gc -gcm adaptive-pl -nms 32, WGAN-GP on mean samples, 3x64x64",
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                   "materialize": getattr(opt, "materialize", "all"),
                    "step": "train_D (adaptive pass + G fwd + 2 D passes + per-sample grads + clip + GP + noise + Adam)"},
         "per_gpu": round(ips / world, 2),
         "step_tflops_algorithmic": round(FLOP_PER_IMG_STEP * ips / 1e12, 2),

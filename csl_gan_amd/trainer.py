@@ -59,7 +59,8 @@ class Trainer:
             per_layer = o.grad_clip_mode.endswith("-pl")
             pe = E.PrivacyEngine(self.D, **params, accum_passes=not o.grad_clip_split,
                                  num_private_passes=1 if o.grad_clip_split else None, auto_clip_and_accum_on_step=False,
-                                 max_grad_norm=list(o.clipping_param_per_layer) if per_layer else o.clipping_param)
+                                 max_grad_norm=list(o.clipping_param_per_layer) if per_layer else o.clipping_param,
+                                 materialize=getattr(o, "materialize", "private"))
             pe.disable_hooks()
         elif o.dp_mode == "is":
             from .is_engine import ISPrivacyEngine
@@ -144,7 +145,11 @@ class Trainer:
             z = self.explicit["z_adapt"] if "z_adapt" in self.explicit else self.gen_z(o.batch_size)
             _, _, d_fake_loss, d_fake_aux_loss, _ = self.calc_d_fake_loss(img, labels, z, labels)
         _, _, d_real_loss, d_real_aux_loss = self.calc_d_real_loss(img, labels)
-        (d_real_loss + d_fake_loss + d_real_aux_loss + d_fake_aux_loss).backward()
+        pe.norms_only = pe.materialize == "private"      # this pass only feeds the per-sample norms below
+        try:
+            (d_real_loss + d_fake_loss + d_real_aux_loss + d_fake_aux_loss).backward()
+        finally:
+            pe.norms_only = False
         with torch.no_grad():
             B = img.size(0)
             # per-layer per-sample norms of pass 0: produced by the wgrad epilogue, never re-read from HBM

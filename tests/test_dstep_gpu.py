@@ -44,6 +44,8 @@ def _setup(tmp_path, dataset, extra, B, latent):
     from oracle.nets import build_models
     argv = [dataset, "-dpm", "gc", "-nms", "4", "-bs", str(B), "-gd", "cuda:0", "-dd", "cuda:0", "-o", str(tmp_path),
             "--manual_seed", "1", "--g_latent_dim", str(latent), "--sigma", "0.5"] + extra
+    if "--materialize" not in extra:
+        argv += ["--materialize", "all"]          # the fork's p.grad_sample layout is the contract under test
     opt = options.parse(argv)
     G, D = init_util.init_models(opt)
     tr = Trainer(opt, G, D, log_to=str(tmp_path / "log.csv"))
@@ -69,6 +71,10 @@ CASES = [
     ("CelebA", ["-gcm", "adaptive-pl"], 8, 128),
     ("CelebA", ["-gcm", "constant-pl", "-cpl", "0.5", "0.05", "1", "0.1", "2", "0.2", "3", "0.5", "4"], 8, 128),
     ("CelebA", ["-c", "2.0"], 8, 128),
+    # lean materialisation: generated-data pass summed densely, adaptive pass norms-only
+    ("CelebA", ["-gcm", "adaptive-pl", "--materialize", "private"], 8, 128),
+    ("MNIST", ["--model", "DeepConvResNet", "--penalty", "WGAN-GP", "-c", "3.0", "--materialize", "private"], 6, 16),
+    ("MNIST", ["--model", "DeepConvResNet", "--penalty", "WGAN-GP", "-gcm", "adaptive", "-gcs", "False", "--materialize", "private"], 6, 16),
 ]
 
 
@@ -119,7 +125,11 @@ def test_train_D_matches_oracle(tmp_path, dataset, extra, B, latent):
         _close(last["adaptive_stats"], torch.tensor(obs["adaptive_stats"]), "adaptive stats")
     _close(last["clip_params"], torch.tensor(Cfin if isinstance(Cfin, list) else [Cfin]), "clip params")
     n_o, f_o = obs["norms"], obs["clip_factors"]          # [L or 1, passes, B]
-    if opt.grad_clip_split:
+    if opt.grad_clip_split and opt.materialize == "private":   # only the clipped (real) pass has per-sample state
+        _close(last["norms"], n_o[:, 1], "per-sample norms (private pass)")
+        _close(last["clip_factors"].reshape(f_o.shape[0], -1), f_o[:, 1], "clip factors (private pass)")
+        assert tr.D.blocks[0].weight.grad is not None
+    elif opt.grad_clip_split:
         f_o = f_o.clone(); f_o[:, 0] = 1.0   # generated-data pass is not clipped
         _close(last["norms"].reshape(n_o.shape[0], -1), n_o.reshape(n_o.shape[0], -1), "per-sample norms")
         _close(last["clip_factors"].reshape(f_o.shape[0], -1), f_o.reshape(f_o.shape[0], -1), "clip factors")

@@ -35,6 +35,8 @@ struct KcClass {
 };
 struct KcParams {
     const float* a;
+    unsigned a_bytes, w_bytes;   // byte sizes of a and w (buffer-descriptor range checks)
+    unsigned ac_recip;           // ceil(2^32 / AC)
     int AH, AW, AC;      // stored dims of a
     int VH, VW;          // virtual dims used for the bounds test (2*AH,2*AW when ups==1)
     int ups;

@@ -18,21 +18,41 @@
 //
 // Replaces (reference file:line): torch.nn.Conv2d / nn.Linear forward DCResNet_models.py:131-132,
 // 145, 13-17, 60-70, 95-104; MNIST_models.py:17-23, 41-46; and the autograd data-gradient of those.
+#include <stdlib.h>
+#ifndef CSLGAN_KC_INTERLEAVE
+#define CSLGAN_KC_INTERLEAVE 0
+#endif
 #include "common.h"
 #include "igemm.h"
 
 namespace cslgan {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC_A, bool VEC_B>
-__global__ __launch_bounds__(256) void igemm_kc_kernel(const KcParams p) {
+// Range-checked buffer loads: an offset at or beyond the descriptor's byte count returns 0, so padding taps,
+// ragged rows and the K tail need neither a branch nor a select — the loader is straight-line code that the
+// scheduler can interleave with MFMAs.  32-bit byte offsets (tensors are < 4 GB; checked on the host).
+constexpr unsigned OOB = 0xFFFFFFF0u;
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+
+// NBUF = 2: LDS double buffer, one barrier per K tile (2 workgroups/CU for the 128x128 tile).
+// NBUF = 1: single LDS buffer, two barriers per K tile, half the LDS -> twice the resident wavefronts,
+//           which hide the loader's address arithmetic and LDS latency behind other waves' MFMAs.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC_A, bool VEC_B, int NBUF>
+__global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void igemm_kc_kernel(const KcParams p) {
     constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
     static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "bad tile");
     constexpr int A_CH = BM * 4 + 4, B_CH = BN * 4 + 4;  // floats per k-chunk (padded)
     constexpr int A_PASS = BM / 32, B_PASS = BN / 32;
-    __shared__ __attribute__((aligned(16))) float As[2][8 * A_CH];
-    __shared__ __attribute__((aligned(16))) float Bs[2][8 * B_CH];
+    __shared__ __attribute__((aligned(16))) float As[NBUF][8 * A_CH];
+    __shared__ __attribute__((aligned(16))) float Bs[NBUF][8 * B_CH];
     __shared__ int s_tap[IG_MAX_TAPS];
     __shared__ int s_off[BM];
     __shared__ int s_roff[BM];
@@ -55,83 +75,73 @@ __global__ __launch_bounds__(256) void igemm_kc_kernel(const KcParams p) {
     // ---- per-thread loader coordinates -----------------------------------------------------
     const int lrow = tid >> 3;   // 0..31
     const int q = tid & 7;       // k-chunk within the tile
-    int a_img[A_PASS], a_iy[A_PASS], a_ix[A_PASS];
-    bool a_ok[A_PASS];
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wbase), 0, p.w_bytes - 4u * (unsigned)kc.w_off, 0x00020000);
+    int a_img[A_PASS], a_iy[A_PASS], a_ix[A_PASS];   // a_img: image base in elements; a_iy = -2^20 marks a row past M
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
         const int m = m0 + lrow + 32 * i;
-        a_ok[i] = m < M;
-        const RowCoord rc = kc_decode_row(a_ok[i] ? m : 0, OHc, OWc);
-        a_img[i] = rc.img;
-        a_iy[i] = rc.oy * p.sy;
+        const bool ok = m < M;
+        const RowCoord rc = kc_decode_row(ok ? m : 0, OHc, OWc);
+        a_img[i] = rc.img * p.AH * p.AW * p.AC;
+        a_iy[i] = ok ? rc.oy * p.sy : -(1 << 20);
         a_ix[i] = rc.ox * p.sx;
     }
-    const float* b_ptr[B_PASS];
-    bool b_ok[B_PASS];
+    unsigned b_off[B_PASS];      // byte offset of row n in this class's filter matrix, OOB when n >= Nn
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
         const int n = n0 + lrow + 32 * i;
-        b_ok[i] = n < p.Nn;
-        b_ptr[i] = wbase + (long long)(b_ok[i] ? n : 0) * Kdim;
+        b_off[i] = n < p.Nn ? 4u * (unsigned)n * (unsigned)Kdim : OOB;
     }
     __syncthreads();  // s_tap visible
 
     float4 ra[A_PASS], rb[B_PASS];
 
+    auto a_offset = [&](int i, int ty, int tx, int c, bool kin) -> unsigned {
+        const int iy = a_iy[i] + ty, ix = a_ix[i] + tx;
+        const bool ok = kin && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
+        const unsigned e = (unsigned)(a_img[i] + ((iy >> p.ups) * p.AW + (ix >> p.ups)) * p.AC + c);
+        return ok ? 4u * e : OOB;
+    };
+
+    int k_end = Kdim;            // exclusive K bound of this workgroup's slice (split-K), set below
     auto load_tile = [&](int kt) {
         const int kb = kt * IG_BK + q * 4;
+        const int Kdim = k_end;  // shadows the class's Kdim inside the loader: beyond the slice everything is OOB
         if (VEC_A) {
             const bool kin = kb < Kdim;
-            const int t = kin ? kb / p.AC : 0;
+            const int t = kin ? (p.AC == 1 ? kb : (int)__umulhi((unsigned)kb, p.ac_recip)) : 0;   // kb / AC by reciprocal (range checked on the host)
             const int c = kb - t * p.AC;
             const int tap = s_tap[t];
             const int ty = tap >> 16, tx = (int)(short)(tap & 0xffff);
 #pragma unroll
-            for (int i = 0; i < A_PASS; ++i) {
-                const int iy = a_iy[i] + ty, ix = a_ix[i] + tx;
-                const bool ok = kin && a_ok[i] && iy >= 0 && iy < p.VH && ix >= 0 && ix < p.VW;
-                if (ok) {
-                    const long long off = (((long long)a_img[i] * p.AH + (iy >> p.ups)) * p.AW + (ix >> p.ups)) * p.AC + c;
-                    ra[i] = *reinterpret_cast<const float4*>(p.a + off);
-                } else {
-                    ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
+            for (int i = 0; i < A_PASS; ++i) ra[i] = buf_load4(a_rsrc, a_offset(i, ty, tx, c, kin));
         } else {
             float tmp[A_PASS][4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int k = kb + e;
                 const bool kin = k < Kdim;
-                const int t = kin ? k / p.AC : 0;
+                const int t = kin ? (p.AC == 1 ? k : (int)__umulhi((unsigned)k, p.ac_recip)) : 0;
                 const int c = k - t * p.AC;
                 const int tap = s_tap[t];
                 const int ty = tap >> 16, tx = (int)(short)(tap & 0xffff);
 #pragma unroll
-                for (int i = 0; i < A_PASS; ++i) {
-                    const int iy = a_iy[i] + ty, ix = a_ix[i] + tx;
-                    const bool ok = kin && a_ok[i] && iy >= 0 && iy < p.VH && ix >= 0 && ix < p.VW;
-                    float v = 0.f;
-                    if (ok) v = p.a[(((long long)a_img[i] * p.AH + (iy >> p.ups)) * p.AW + (ix >> p.ups)) * p.AC + c];
-                    tmp[i][e] = v;
-                }
+                for (int i = 0; i < A_PASS; ++i) tmp[i][e] = buf_load1(a_rsrc, a_offset(i, ty, tx, c, kin));
             }
 #pragma unroll
             for (int i = 0; i < A_PASS; ++i) ra[i] = make_float4(tmp[i][0], tmp[i][1], tmp[i][2], tmp[i][3]);
         }
         if (VEC_B) {
-            const bool kin = kb < Kdim;
+            const unsigned kofs = kb < Kdim ? 4u * (unsigned)kb : OOB;
 #pragma unroll
-            for (int i = 0; i < B_PASS; ++i) {
-                if (kin && b_ok[i]) rb[i] = *reinterpret_cast<const float4*>(b_ptr[i] + kb);
-                else rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int i = 0; i < B_PASS; ++i) rb[i] = buf_load4(w_rsrc, (b_off[i] == OOB || kofs == OOB) ? OOB : b_off[i] + kofs);
         } else {
 #pragma unroll
             for (int i = 0; i < B_PASS; ++i) {
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (b_ok[i] && (kb + e) < Kdim) ? b_ptr[i][kb + e] : 0.f;
+                for (int e = 0; e < 4; ++e) v[e] = buf_load1(w_rsrc, (b_off[i] != OOB && (kb + e) < Kdim) ? b_off[i] + 4u * (unsigned)(kb + e) : OOB);
                 rb[i] = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
@@ -167,34 +177,63 @@ __global__ __launch_bounds__(256) void igemm_kc_kernel(const KcParams p) {
         kt0 = split * per;
         kt1 = kt0 + per < nk_all ? kt0 + per : nk_all;
         if (kt0 >= kt1) return;   // uniform across the workgroup
+        k_end = kt1 * IG_BK < Kdim ? kt1 * IG_BK : Kdim;
     }
     load_tile(kt0);
     store_tile(0);
     __syncthreads();
 
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (kt - kt0) & 1;
-        if (kt + 1 < kt1) load_tile(kt + 1);
+        const int buf = NBUF == 2 ? ((kt - kt0) & 1) : 0;
+        // LDS fragments are software-pipelined one k-group ahead of the MFMAs that consume them, and the
+        // next tile's global loads (address arithmetic + 8 x dwordx4) are issued between the first and the
+        // second k-group so that they execute in the shadow of MFMAs instead of in front of them.
+        float4 af[2][TM], bf[2][TN];
+        auto load_frags = [&](int g, int slot) {
+            const int ch = 2 * g + h;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[slot][i] = *reinterpret_cast<const float4*>(&As[buf][ch * A_CH + (arow0 + i * 32) * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[slot][j] = *reinterpret_cast<const float4*>(&Bs[buf][ch * B_CH + (brow0 + j * 32) * 4]);
+        };
+        load_frags(0, 0);
+        load_tile(kt + 1);   // past the last tile every offset is out of range: loads return 0, no branch
+#if CSLGAN_KC_INTERLEAVE
+        // one MFMA, a slice of the loader's address arithmetic, one buffer load — repeated over the first k-group
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);    // VALU
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read
+        }
+#else
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int ch = 2 * g + h;
-            float4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(&As[buf][ch * A_CH + (arow0 + i * 32) * 4]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[buf][ch * B_CH + (brow0 + j * 32) * 4]);
+            const int cur = g & 1;
+            if (g < 3) load_frags(g + 1, cur ^ 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].x, bf[cur][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].y, bf[cur][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].z, bf[cur][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].w, bf[cur][j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (kt + 1 < kt1) store_tile(buf ^ 1);
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if (NBUF == 2) {
+            store_tile(buf ^ 1);             // unconditional (the buffer written after the last tile is never read)
+            __syncthreads();
+        } else {
+            __syncthreads();                 // every wave has finished reading the tile
+            if (kt + 1 < kt1) {
+                store_tile(0);
+                __syncthreads();
+            }
+        }
     }
 
     // ---- epilogue --------------------------------------------------------------------------
@@ -313,10 +352,14 @@ static int launch_kc_tile(KcParams& p, bool vecA, bool vecB, hipStream_t st, lon
         }
     }
     const dim3 grid((unsigned)(tiles * p.ksplit)), block(256);
-    if (vecA && vecB) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, p);
-    else if (vecA) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, p);
-    else if (vecB) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, p);
+    static const int nbuf_env = [] { const char* e = getenv("CSLGAN_KC_NBUF"); return e ? atoi(e) : 0; }();
+    const bool single = nbuf_env == 1;   // measured: the double buffer wins on every shape of the D-step
+    if (vecA && vecB) {
+        if (single) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, true, true, 1>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, true, true, 2>), grid, block, 0, st, p);
+    } else if (vecA) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, true, false, 2>), grid, block, 0, st, p);
+    else if (vecB) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, false, true, 2>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, false, false, 2>), grid, block, 0, st, p);
     return check_launch("igemm_kc_kernel");
 }
 
@@ -331,6 +374,30 @@ int launch_kc(KcParams& p, hipStream_t st, long long out_elems) {
     long long rows = 0;
     for (int c = 0; c < p.n_cls; ++c) rows += p.cls[c].M;
     if (rows <= 0 || p.Nn <= 0) return CSLGAN_OK;
+    {
+        const long long n_img = p.cls[0].M / ((long long)p.cls[0].OHc * p.cls[0].OWc);
+        const long long a_b = 4ll * n_img * p.AH * p.AW * p.AC;
+        long long w_end = 0;
+        for (int c = 0; c < p.n_cls; ++c) {
+            const long long e = (long long)p.cls[c].w_off + (long long)p.Nn * p.cls[c].Kdim;
+            w_end = e > w_end ? e : w_end;
+        }
+        if (a_b >= 0xFFFFFFF0ll || 4 * w_end >= 0xFFFFFFF0ll) {
+            set_error("igemm_kc: operand larger than 4 GB");
+            return CSLGAN_ERR_INVALID_ARG;
+        }
+        p.a_bytes = (unsigned)a_b;
+        p.w_bytes = (unsigned)(4 * w_end);
+        // k / AC as umulhi(k, ceil(2^32 / AC)): exact while k < 2^32 / AC
+        long long kmax = 0;
+        for (int c = 0; c < p.n_cls; ++c) kmax = p.cls[c].Kdim > kmax ? p.cls[c].Kdim : kmax;
+        if (p.AC < 2 || (kmax + IG_BK) * (long long)p.AC >= (1ll << 32)) {
+            if (p.AC == 1 && kmax + IG_BK < (1ll << 31)) p.ac_recip = 0xFFFFFFFFu;   // handled exactly below
+            else { set_error("igemm_kc: K too large for reciprocal division"); return CSLGAN_ERR_INVALID_ARG; }
+        } else {
+            p.ac_recip = (unsigned)(((1ull << 32) + (unsigned long long)p.AC - 1) / (unsigned long long)p.AC);
+        }
+    }
     bool kd4 = true;
     for (int c = 0; c < p.n_cls; ++c) kd4 = kd4 && (p.cls[c].Kdim % 4 == 0) && (p.cls[c].w_off % 4 == 0);
     const bool vecA = (p.AC % 4 == 0) && aligned16(p.a);

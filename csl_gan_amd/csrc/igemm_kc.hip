@@ -105,19 +105,22 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void igemm_kc_kernel(cons
     };
 
     int k_end = Kdim;            // exclusive K bound of this workgroup's slice (split-K), set below
-    auto load_tile = [&](int kt) {
+    // The loader is split in two so that no address arithmetic sits between a barrier and the loads it
+    // feeds: calc_offsets(kt) produces the byte offsets of tile kt (pure VALU, scheduled freely among the
+    // MFMAs of the previous tile), issue_loads() turns the stored offsets into buffer loads.
+    unsigned oa[VEC_A ? A_PASS : A_PASS * 4], ob[VEC_B ? B_PASS : B_PASS * 4];
+    auto calc_offsets = [&](int kt) {
         const int kb = kt * IG_BK + q * 4;
-        const int Kdim = k_end;  // shadows the class's Kdim inside the loader: beyond the slice everything is OOB
+        const int Kdim = k_end;  // shadows the class's Kdim: beyond this workgroup's K slice everything is OOB
         if (VEC_A) {
             const bool kin = kb < Kdim;
-            const int t = kin ? (p.AC == 1 ? kb : (int)__umulhi((unsigned)kb, p.ac_recip)) : 0;   // kb / AC by reciprocal (range checked on the host)
+            const int t = kin ? (p.AC == 1 ? kb : (int)__umulhi((unsigned)kb, p.ac_recip)) : 0;   // kb / AC (range checked on the host)
             const int c = kb - t * p.AC;
             const int tap = s_tap[t];
             const int ty = tap >> 16, tx = (int)(short)(tap & 0xffff);
 #pragma unroll
-            for (int i = 0; i < A_PASS; ++i) ra[i] = buf_load4(a_rsrc, a_offset(i, ty, tx, c, kin));
+            for (int i = 0; i < A_PASS; ++i) oa[i] = a_offset(i, ty, tx, c, kin);
         } else {
-            float tmp[A_PASS][4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int k = kb + e;
@@ -127,23 +130,30 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void igemm_kc_kernel(cons
                 const int tap = s_tap[t];
                 const int ty = tap >> 16, tx = (int)(short)(tap & 0xffff);
 #pragma unroll
-                for (int i = 0; i < A_PASS; ++i) tmp[i][e] = buf_load1(a_rsrc, a_offset(i, ty, tx, c, kin));
+                for (int i = 0; i < A_PASS; ++i) oa[i * 4 + e] = a_offset(i, ty, tx, c, kin);
             }
-#pragma unroll
-            for (int i = 0; i < A_PASS; ++i) ra[i] = make_float4(tmp[i][0], tmp[i][1], tmp[i][2], tmp[i][3]);
         }
         if (VEC_B) {
             const unsigned kofs = kb < Kdim ? 4u * (unsigned)kb : OOB;
 #pragma unroll
-            for (int i = 0; i < B_PASS; ++i) rb[i] = buf_load4(w_rsrc, (b_off[i] == OOB || kofs == OOB) ? OOB : b_off[i] + kofs);
+            for (int i = 0; i < B_PASS; ++i) ob[i] = (b_off[i] == OOB || kofs == OOB) ? OOB : b_off[i] + kofs;
         } else {
 #pragma unroll
-            for (int i = 0; i < B_PASS; ++i) {
-                float v[4];
+            for (int i = 0; i < B_PASS; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = buf_load1(w_rsrc, (b_off[i] != OOB && (kb + e) < Kdim) ? b_off[i] + 4u * (unsigned)(kb + e) : OOB);
-                rb[i] = make_float4(v[0], v[1], v[2], v[3]);
-            }
+                for (int e = 0; e < 4; ++e) ob[i * 4 + e] = (b_off[i] != OOB && (kb + e) < Kdim) ? b_off[i] + 4u * (unsigned)(kb + e) : OOB;
+        }
+    };
+    auto issue_loads = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_PASS; ++i) {
+            if (VEC_A) ra[i] = buf_load4(a_rsrc, oa[i]);
+            else ra[i] = make_float4(buf_load1(a_rsrc, oa[i * 4]), buf_load1(a_rsrc, oa[i * 4 + 1]), buf_load1(a_rsrc, oa[i * 4 + 2]), buf_load1(a_rsrc, oa[i * 4 + 3]));
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) {
+            if (VEC_B) rb[i] = buf_load4(w_rsrc, ob[i]);
+            else rb[i] = make_float4(buf_load1(w_rsrc, ob[i * 4]), buf_load1(w_rsrc, ob[i * 4 + 1]), buf_load1(w_rsrc, ob[i * 4 + 2]), buf_load1(w_rsrc, ob[i * 4 + 3]));
         }
     };
 
@@ -179,8 +189,10 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void igemm_kc_kernel(cons
         if (kt0 >= kt1) return;   // uniform across the workgroup
         k_end = kt1 * IG_BK < Kdim ? kt1 * IG_BK : Kdim;
     }
-    load_tile(kt0);
+    calc_offsets(kt0);
+    issue_loads();
     store_tile(0);
+    calc_offsets(kt0 + 1);
     __syncthreads();
 
     for (int kt = kt0; kt < kt1; ++kt) {
@@ -196,18 +208,17 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void igemm_kc_kernel(cons
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[slot][j] = *reinterpret_cast<const float4*>(&Bs[buf][ch * B_CH + (brow0 + j * 32) * 4]);
         };
+        issue_loads();       // tile kt+1 (offsets ready since the previous iteration; past the last tile all are OOB -> 0)
         load_frags(0, 0);
-        load_tile(kt + 1);   // past the last tile every offset is out of range: loads return 0, no branch
-#if CSLGAN_KC_INTERLEAVE
-        // one MFMA, a slice of the loader's address arithmetic, one buffer load — repeated over the first k-group
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);    // VALU
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read
-        }
-#else
         __builtin_amdgcn_sched_barrier(0);
+        calc_offsets(kt + 2);
+#if CSLGAN_KC_INTERLEAVE
+        // spread the offset arithmetic of tile kt+2 under the MFMAs of the first two k-groups
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);    // VALU | SALU
+        }
 #endif
 #pragma unroll
         for (int g = 0; g < 4; ++g) {

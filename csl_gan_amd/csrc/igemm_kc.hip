@@ -418,7 +418,8 @@ int launch_kc(KcParams& p, hipStream_t st, long long out_elems) {
         if (tiles_for(p, 128, 64) >= 192) return launch_kc_tile<128, 64, 2, 2>(p, vecA, vecB, st, out_elems);
         return launch_kc_tile<64, 64, 2, 2>(p, vecA, vecB, st, out_elems);
     }
-    if (tiles_for(p, 128, 128) >= 192) return launch_kc_tile<128, 128, 2, 2>(p, vecA, vecB, st, out_elems);
+    static const int t128 = [] { const char* e = getenv("CSLGAN_KC_T128"); return e ? atoi(e) : 300; }();
+    if (tiles_for(p, 128, 128) >= t128) return launch_kc_tile<128, 128, 2, 2>(p, vecA, vecB, st, out_elems);
     if (tiles_for(p, 64, 128) >= 192) return launch_kc_tile<64, 128, 1, 4>(p, vecA, vecB, st, out_elems);
     return launch_kc_tile<64, 64, 2, 2>(p, vecA, vecB, st, out_elems);
 }

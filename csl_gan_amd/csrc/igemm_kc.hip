@@ -19,9 +19,6 @@
 // Replaces (reference file:line): torch.nn.Conv2d / nn.Linear forward DCResNet_models.py:131-132,
 // 145, 13-17, 60-70, 95-104; MNIST_models.py:17-23, 41-46; and the autograd data-gradient of those.
 #include <stdlib.h>
-#ifndef CSLGAN_KC_INTERLEAVE
-#define CSLGAN_KC_INTERLEAVE 0
-#endif
 #include "common.h"
 #include "igemm.h"
 
@@ -109,9 +106,11 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void igemm_kc_kernel(cons
     // feeds: calc_offsets(kt) produces the byte offsets of tile kt (pure VALU, scheduled freely among the
     // MFMAs of the previous tile), issue_loads() turns the stored offsets into buffer loads.
     unsigned oa[VEC_A ? A_PASS : A_PASS * 4], ob[VEC_B ? B_PASS : B_PASS * 4];
-    auto calc_offsets = [&](int kt) {
+    // part: 0 = everything, 1 = A rows [0, A_PASS/2), 2 = A rows [A_PASS/2, A_PASS), 3 = B rows
+    auto calc_offsets = [&](int kt, int part = 0) {
         const int kb = kt * IG_BK + q * 4;
         const int Kdim = k_end;  // shadows the class's Kdim: beyond this workgroup's K slice everything is OOB
+        const int a_lo = part == 2 ? A_PASS / 2 : 0, a_hi = part == 1 ? A_PASS / 2 : (part == 3 ? 0 : A_PASS);
         if (VEC_A) {
             const bool kin = kb < Kdim;
             const int t = kin ? (p.AC == 1 ? kb : (int)__umulhi((unsigned)kb, p.ac_recip)) : 0;   // kb / AC (range checked on the host)
@@ -119,7 +118,8 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void igemm_kc_kernel(cons
             const int tap = s_tap[t];
             const int ty = tap >> 16, tx = (int)(short)(tap & 0xffff);
 #pragma unroll
-            for (int i = 0; i < A_PASS; ++i) oa[i] = a_offset(i, ty, tx, c, kin);
+            for (int i = 0; i < A_PASS; ++i)
+                if (i >= a_lo && i < a_hi) oa[i] = a_offset(i, ty, tx, c, kin);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -130,9 +130,11 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void igemm_kc_kernel(cons
                 const int tap = s_tap[t];
                 const int ty = tap >> 16, tx = (int)(short)(tap & 0xffff);
 #pragma unroll
-                for (int i = 0; i < A_PASS; ++i) oa[i * 4 + e] = a_offset(i, ty, tx, c, kin);
+                for (int i = 0; i < A_PASS; ++i)
+                    if (i >= a_lo && i < a_hi) oa[i * 4 + e] = a_offset(i, ty, tx, c, kin);
             }
         }
+        if (part == 1 || part == 2) return;
         if (VEC_B) {
             const unsigned kofs = kb < Kdim ? 4u * (unsigned)kb : OOB;
 #pragma unroll
@@ -211,15 +213,6 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void igemm_kc_kernel(cons
         issue_loads();       // tile kt+1 (offsets ready since the previous iteration; past the last tile all are OOB -> 0)
         load_frags(0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        calc_offsets(kt + 2);
-#if CSLGAN_KC_INTERLEAVE
-        // spread the offset arithmetic of tile kt+2 under the MFMAs of the first two k-groups
-#pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);    // VALU | SALU
-        }
-#endif
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int cur = g & 1;
@@ -233,6 +226,11 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void igemm_kc_kernel(cons
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].z, bf[cur][j].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].w, bf[cur][j].w, acc[i][j], 0, 0, 0);
                 }
+            // a third of tile kt+2's offset arithmetic rides behind each of the first three k-groups
+            if (g < 3) {
+                calc_offsets(kt + 2, g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (NBUF == 2) {
@@ -363,12 +361,10 @@ static int launch_kc_tile(KcParams& p, bool vecA, bool vecB, hipStream_t st, lon
         }
     }
     const dim3 grid((unsigned)(tiles * p.ksplit)), block(256);
-    static const int nbuf_env = [] { const char* e = getenv("CSLGAN_KC_NBUF"); return e ? atoi(e) : 0; }();
-    const bool single = nbuf_env == 1;   // measured: the double buffer wins on every shape of the D-step
-    if (vecA && vecB) {
-        if (single) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, true, true, 1>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, true, true, 2>), grid, block, 0, st, p);
-    } else if (vecA) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, true, false, 2>), grid, block, 0, st, p);
+    // NBUF = 1 (single LDS buffer, 4 workgroups/CU) was measured slower on every shape of the D-step
+    // (G b1: 59 vs 102 TF; G b4: 107 vs 105 TF), so only the double-buffered form is instantiated.
+    if (vecA && vecB) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, true, true, 2>), grid, block, 0, st, p);
+    else if (vecA) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, true, false, 2>), grid, block, 0, st, p);
     else if (vecB) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, false, true, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, false, false, 2>), grid, block, 0, st, p);
     return check_launch("igemm_kc_kernel");

@@ -474,3 +474,13 @@ class PrivacyEngine:
         delta = 1e-6 if target_delta is None else target_delta
         rdp = accountant.compute_rdp(self.sample_rate, self.noise_multiplier, self.steps, self.alphas)
         return accountant.get_privacy_spent(self.alphas, rdp, delta)
+
+    # -- checkpoint: the reference drops the engine state on resume (epsilon restarts from 0);
+    #    steps / seed / Philox call counter / clip norms are what must survive to keep the accounting honest
+    def state_dict(self):
+        return {"steps": self.steps, "seed": self.seed, "noise_calls": self._noise_calls, "max_grad_norm": self.max_grad_norm,
+                "noise_multiplier": self.noise_multiplier, "sample_rate": self.sample_rate}
+
+    def load_state_dict(self, st):
+        self.steps, self.seed, self._noise_calls = st["steps"], int(st["seed"]), int(st["noise_calls"])
+        self.set_max_grad_norm(st["max_grad_norm"])

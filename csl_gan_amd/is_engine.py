@@ -134,6 +134,14 @@ class ISPrivacyEngine:
         self.steps += 1
         self._sens_dev = None
 
+    def state_dict(self):
+        return {"steps": self.steps, "seed": self.seed, "noise_calls": self._noise_calls, "scaling_vec": self.scaling_vec,
+                "noise_multiplier": self.noise_multiplier, "sample_rate": self.sample_rate}
+
+    def load_state_dict(self, st):
+        self.steps, self.seed, self._noise_calls = st["steps"], int(st["seed"]), int(st["noise_calls"])
+        self.scaling_vec = st.get("scaling_vec")
+
     def get_privacy_spent(self, target_delta=None):
         delta = 1e-6 if target_delta is None else target_delta
         rdp = accountant.compute_rdp(self.sample_rate, self.noise_multiplier, self.steps, self.alphas)

@@ -41,6 +41,12 @@ def build_mean_sampler(opt, dataset):
     return ms, cost
 
 
+def _save_engine(tr, path):
+    if tr.privacy_engine is not None:
+        with open(path, "w") as f:
+            json.dump(tr.privacy_engine.state_dict(), f)
+
+
 def main(argv=None):
     opt = options.parse(argv)
     world, rank, local = dist_util.init() if getattr(opt, "dist", False) else (1, 0, 0)
@@ -78,7 +84,11 @@ def main(argv=None):
         tr.train(-1, it, img, labels if labels is not None else torch.zeros(len(img), dtype=torch.long), use_dp=False)
     tr.g_optimizer, tr.d_optimizer = tr.init_optimizers()  # train.py:572
     if opt.use_dp:
-        tr.setup_privacy_engine()
+        pe = tr.setup_privacy_engine()
+        pe_path = (opt.resume_path or "") + "saves/PE-" + str(opt.resume_epochs) + ".json"
+        if opt.resume_epochs > 0 and os.path.exists(pe_path):      # extension: the reference restarts epsilon at 0
+            with open(pe_path) as f:
+                pe.load_state_dict(json.load(f))
 
     iters, epoch, eps = 0, start_epoch, 0.0
     for epoch in range(opt.resume_epochs, opt.n_epochs):
@@ -101,6 +111,7 @@ def main(argv=None):
         if (epoch + 1) % opt.save_every == 0 and rank == 0:
             util.save_model(epoch, D, tr.d_optimizer, 0, opt.output_dir + "saves/D-" + str(epoch + 1))
             util.save_model(epoch, G, tr.g_optimizer, 0, opt.output_dir + "saves/G-" + str(epoch + 1))
+            _save_engine(tr, opt.output_dir + "saves/PE-" + str(epoch + 1) + ".json")
         if opt.max_iters and iters >= opt.max_iters:
             break
 
@@ -108,6 +119,7 @@ def main(argv=None):
     if rank == 0:
         util.save_model(opt.n_epochs, D, tr.d_optimizer, 0, opt.output_dir + "saves/D-" + str(epoch + 1))
         util.save_model(opt.n_epochs, G, tr.g_optimizer, 0, opt.output_dir + "saves/G-" + str(epoch + 1))
+        _save_engine(tr, opt.output_dir + "saves/PE-" + str(epoch + 1) + ".json")
     tr.flush_stats()
     tr.logger.close()
     return tr

@@ -147,6 +147,8 @@ class _LayerCollector:
         scale = float(B) if e.loss_reduction == "mean" else 1.0
         w = layer.weight
         K, Cc = gz.shape[-1], x.shape[-1]
+        if e.row_roles is not None:
+            return self._collect_roles(gz, x, R, S, stride, pad, has_bias)
         if e.norms_only:
             # adaptive-clipping pass (train.py:204-245): only the per-sample norms are consumed
             _, sq = e._buffers(w, n_pass, B, 0)
@@ -205,6 +207,47 @@ def _dense_bgrad(gz, scale):
     return out
 
 
+def _collect_roles(self, gz, x, R, S, stride, pad, has_bias):
+    """One fused forward carried several logical passes as consecutive row blocks (Trainer.train_D_fused):
+    ("norms", n) rows feed only per-sample norms, ("dense", n) rows only their sum, ("private", n) rows are
+    materialised per sample.  Each block is its own mean-reduced loss, hence its own x n scaling."""
+    e, layer = self.e, self.layer
+    w = layer.weight
+    K, Cc = gz.shape[-1], x.shape[-1]
+    r0 = 0
+    for role, n in e.row_roles:
+        g_, x_ = gz[r0:r0 + n], x[r0:r0 + n]
+        r0 += n
+        scale = float(n) if e.loss_reduction == "mean" else 1.0
+        if role == "norms":
+            _, sq = e._buffers(("norms", id(w)), 1, n, 0)
+            ops.conv2d_wgrad_grouped(g_, x_, R, S, stride=stride, pad=pad, group=1, alpha=scale, want_gw=False, sq=sq[0])
+            if has_bias:
+                _, bsq = e._buffers(("norms", id(layer.bias)), 1, n, 0)
+                ops.bias_grad_grouped(g_, group=1, alpha=scale, want_gb=False, sq=bsq[0])
+        elif role == "dense":
+            e._add_dense(w, _dense_wgrad(g_, x_, R, S, stride, pad, scale))
+            if has_bias:
+                e._add_dense(layer.bias, _dense_bgrad(g_, scale))
+        else:
+            buf, sq = e._buffers(w, 1, n, K * R * S * Cc)
+            ops.conv2d_wgrad_grouped(g_, x_, R, S, stride=stride, pad=pad, group=1, alpha=scale,
+                                     out=buf[0].view(n, K, R, S, Cc), sq=sq[0])
+            view = buf.view(1, n, K, R, S, Cc).permute(0, 1, 2, 5, 3, 4) if isinstance(layer, nn.Conv2d) else buf.view(1, n, K, Cc)
+            view._cslgan_rows = buf.view(n, -1)
+            w.grad_sample = view
+            if has_bias:
+                b = layer.bias
+                bbuf, bsq = e._buffers(b, 1, n, K)
+                ops.bias_grad_grouped(g_, group=1, alpha=scale, out=bbuf[0], sq=bsq[0])
+                bview = bbuf.view(1, n, K)
+                bview._cslgan_rows = bbuf.view(n, K)
+                b.grad_sample = bview
+
+
+_LayerCollector._collect_roles = _collect_roles
+
+
 class PrivacyEngine:
     """Gradient-clipping DP engine (train.py:110-116 constructor call).
 
@@ -221,6 +264,7 @@ class PrivacyEngine:
         if materialize not in ("all", "private"):
             raise ValueError("materialize must be 'all' or 'private'")
         self.materialize, self.norms_only = materialize, False
+        self.row_roles = None                   # set by Trainer.train_D_fused for one fused forward/backward
         self._dense = {}
         self.module = module
         self.batch_size, self.sample_size = batch_size, sample_size
@@ -272,8 +316,12 @@ class PrivacyEngine:
         cur = self._dense.get(id(p))
         self._dense[id(p)] = flat if cur is None else cur.add_(flat)
 
+    def norms_rows_sqnorms(self) -> torch.Tensor:
+        """[n_params, n] squared norms of the "norms" row block of a fused pass."""
+        return torch.stack([self._bufs[("norms", id(p))][1].reshape(-1) for p in self.params])
+
     def _buffers(self, p, n_pass, B, numel):
-        key = id(p)
+        key = p if isinstance(p, tuple) else id(p)
         cur = self._bufs.get(key)
         if cur is None or cur[0].shape != (n_pass, B, numel):
             cur = (torch.empty((n_pass, B, numel), device=p.device, dtype=torch.float32),
@@ -464,6 +512,7 @@ class PrivacyEngine:
             self._fwd_count[l] = 0
         self._bufs.clear()
         self._dense.clear()
+        self.row_roles = None
         for p in self.params:
             if hasattr(p, "grad_sample"):
                 del p.grad_sample

@@ -7,6 +7,8 @@ Additions of this build (all optional, none changes a reference default):
   --synthetic          use the synthetic in-memory dataset (the container has no MNIST/CelebA files)
   --max_iters N        stop after N training iterations (smoke runs)
   --dist               one process per GPU under torch.distributed (RCCL); see csl_gan_amd/distributed.py
+  --fuse_passes B      run the adaptive / generated / real discriminator passes as one forward+backward over the
+                       concatenated batch (same numbers, fewer and fuller launches); needs --materialize private
   --materialize M      per-sample gradients kept in HBM: "all" passes (the fork's p.grad_sample layout) or only
                        the "private" (clipped) passes — see csl_gan_amd.engine.PrivacyEngine
 Quirks kept on purpose: fill_defaults treats False like "unset" (options.py:95), so e.g. `-ispp False`
@@ -147,6 +149,7 @@ _ARGS = [
     (("--max_iters",), dict(type=int, default=0)),
     (("--dist",), dict(default=False, action="store_true")),
     (("--materialize",), dict(type=str, choices=["all", "private"], default="private")),
+    (("--fuse_passes",), dict(type=str2bool, default=True)),
 ]
 ALWAYS_KEEP = ["g_device", "d_device", "num_workers", "resume_path", "resume_epochs"]
 

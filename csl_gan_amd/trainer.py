@@ -218,6 +218,70 @@ class Trainer:
         aux = D.aux_loss(d_real_aux, labels, o.d_device, fake=False) if o.use_aux_loss else 0
         return d_real, d_real_aux, d_real_loss, aux
 
+    # ---- fused form of train.py:378-402 ---------------------------------------------------------
+    def _can_fuse(self, use_dp):
+        o, pe = self.opt, self.privacy_engine
+        return (use_dp and o.dp_mode == "gc" and o.grad_clip_split and getattr(pe, "materialize", "all") == "private"
+                and getattr(o, "fuse_passes", True) and not o.backprop_clip)
+
+    def _fused_passes(self, img, labels, z, y):
+        """[adaptive mean-sample pass] + generated pass + real pass as ONE discriminator forward/backward over the
+        concatenated batch.  D has no batch-coupled layer, every block keeps its own mean-reduced loss and the
+        engine treats the row blocks by role, so every number equals the three separate passes of the reference
+        (train.py:204-245, 382-389); the small layers simply see 3x more rows per launch."""
+        o, D, pe = self.opt, self.D, self.privacy_engine
+        B = img.size(0)
+        adaptive = o.grad_clip_mode.startswith("adaptive")
+        blocks, roles, lab = [], [], []
+        if adaptive:
+            if "ms_adapt" in self.explicit:
+                xa, ya = self.explicit["ms_adapt"], self.explicit.get("ms_adapt_labels")
+            elif o.public_set_size > 0:
+                xa, ya = next(iter(self.public_dataloader))
+                ya = ya if o.conditional else None
+            else:
+                xa, ya = self.mean_sampler.sample(o.batch_size)
+            xa = xa.to(o.d_device)
+            blocks.append(xa); roles.append(("norms", xa.size(0))); lab.append(None if ya is None else ya.to(o.d_device))
+        yg = None if y is None else y.to(o.g_device)
+        with torch.no_grad():
+            fake_img = self.G(z, yg).to(o.d_device)
+        blocks += [fake_img, img]
+        roles += [("dense", B), ("private", B)]
+        lab += [None if y is None else y.to(o.d_device), labels]
+        x_all = torch.cat(blocks, dim=0)
+        y_all = None if labels is None else torch.cat(lab, dim=0)
+        pe.enable_hooks()
+        pe.row_roles = roles
+        out_all, aux_all = D(x_all, y_all)
+        outs = torch.split(out_all, [n for _, n in roles])
+        auxs = [None] * len(roles) if aux_all is None else list(torch.split(aux_all, [n for _, n in roles]))
+        i0 = 1 if adaptive else 0
+        d_fake, d_real = outs[i0], outs[i0 + 1]
+        d_fake_aux, d_real_aux = auxs[i0], auxs[i0 + 1]
+        d_fake_loss = D.fake_loss(d_fake, o.d_device)
+        d_real_loss = D.real_loss(d_real, o.d_device)
+        d_fake_aux_loss = D.aux_loss(d_fake_aux, y.to(o.d_device), o.d_device, fake=True) if (o.use_aux_loss and o.d_fake_aux_loss) else 0
+        d_real_aux_loss = D.aux_loss(d_real_aux, labels, o.d_device, fake=False) if o.use_aux_loss else 0
+        total = d_real_loss + d_fake_loss + d_real_aux_loss + d_fake_aux_loss
+        if adaptive:
+            total = total + D.real_loss(outs[0], o.d_device)
+            if o.use_aux_loss:
+                total = total + D.aux_loss(auxs[0], lab[0], o.d_device, fake=False)
+        total.backward()
+        pe.disable_hooks()
+        if adaptive:
+            with torch.no_grad():
+                norms = pe.norms_rows_sqnorms().sqrt()
+                r = norms.mean(dim=1) if o.adaptive_stat == "mean" else norms.max(dim=1).values
+                if self.world_size > 1:
+                    from .distributed import average_across_ranks
+                    r = average_across_ranks(r.contiguous(), use_max=o.adaptive_stat == "max")
+                self.last["adaptive_stats"] = r
+                pe.set_max_grad_norm_device(r * o.adaptive_scalar if o.use_grad_clip_per_layer else (r.norm(2) * o.adaptive_scalar).reshape(1))
+        pe.row_roles = None
+        return d_fake, d_fake_aux, d_fake_loss, d_fake_aux_loss, fake_img.detach(), d_real, d_real_aux, d_real_loss, d_real_aux_loss
+
     # ---- train.py:360-500 ---------------------------------------------------------------------
     def train_D(self, img, labels, z, y, use_dp=False):
         o, D, G, pe = self.opt, self.D, self.G, self.privacy_engine
@@ -231,14 +295,20 @@ class Trainer:
             pe.enable_hooks()
         if use_imm_sens:
             img.requires_grad = True
-        if use_grad_clip and o.grad_clip_mode.startswith("adaptive"):
-            self.update_adaptive_clipping_params()
+        fused = self._can_fuse(use_dp)
+        if fused:
+            pe.zero_grad()
+            (d_fake, d_fake_aux, d_fake_loss, d_fake_aux_loss, fake_img,
+             d_real, d_real_aux, d_real_loss, d_real_aux_loss) = self._fused_passes(img, labels, z, y)
+            d_loss = d_real_loss + d_fake_loss + d_real_aux_loss + d_fake_aux_loss
+        else:
+            if use_grad_clip and o.grad_clip_mode.startswith("adaptive"):
+                self.update_adaptive_clipping_params()
+            d_fake, d_fake_aux, d_fake_loss, d_fake_aux_loss, fake_img = self.calc_d_fake_loss(img, labels, z, y)
+            d_real, d_real_aux, d_real_loss, d_real_aux_loss = self.calc_d_real_loss(img, labels)
+            d_loss = d_real_loss + d_fake_loss + d_real_aux_loss + d_fake_aux_loss
 
-        d_fake, d_fake_aux, d_fake_loss, d_fake_aux_loss, fake_img = self.calc_d_fake_loss(img, labels, z, y)
-        d_real, d_real_aux, d_real_loss, d_real_aux_loss = self.calc_d_real_loss(img, labels)
-        d_loss = d_real_loss + d_fake_loss + d_real_aux_loss + d_fake_aux_loss
-
-        if o.per_sample_grad and use_dp:
+        if o.per_sample_grad and use_dp and not fused:
             d_loss.backward()
             pe.disable_hooks()
         if use_grad_clip:

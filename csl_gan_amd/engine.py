@@ -324,8 +324,9 @@ class PrivacyEngine:
         key = p if isinstance(p, tuple) else id(p)
         cur = self._bufs.get(key)
         if cur is None or cur[0].shape != (n_pass, B, numel):
-            cur = (torch.empty((n_pass, B, numel), device=p.device, dtype=torch.float32),
-                   torch.zeros((n_pass, B), device=p.device, dtype=torch.float32))
+            dev = self.params[0].device
+            cur = (torch.empty((n_pass, B, numel), device=dev, dtype=torch.float32),
+                   torch.zeros((n_pass, B), device=dev, dtype=torch.float32))
             self._bufs[key] = cur
         return cur
 

@@ -143,3 +143,15 @@ def test_dp_engine_refuses_cpu_modules():
     from csl_gan_amd.MNIST_models import MNISTVanillaD
     with pytest.raises(RuntimeError, match="HIP device"):
         PrivacyEngine(MNISTVanillaD(), batch_size=4, sample_size=100, alphas=[2, 3], noise_multiplier=1.0, max_grad_norm=1.0)
+
+
+def test_budget_analysis_and_engine_state_roundtrip(tmp_path, capsys):
+    from csl_gan_amd import budget_analysis
+    o = options.parse(["CelebA", "-o", str(tmp_path), "-dpm", "gc", "-nms", "4", "--sigma", "1.0"])
+    with open(o.output_dir + "opt.txt", "w") as f:
+        json.dump(o.__dict__, f)
+    budget_analysis.main([str(tmp_path), "2"])
+    eps2 = float(capsys.readouterr().out.strip().strip("()").split(",")[0])
+    budget_analysis.main([str(tmp_path), "4"])
+    eps4 = float(capsys.readouterr().out.strip().strip("()").split(",")[0])
+    assert 0 < eps2 < eps4

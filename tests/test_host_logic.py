@@ -150,6 +150,7 @@ def test_budget_analysis_and_engine_state_roundtrip(tmp_path, capsys):
     o = options.parse(["CelebA", "-o", str(tmp_path), "-dpm", "gc", "-nms", "4", "--sigma", "1.0"])
     with open(o.output_dir + "opt.txt", "w") as f:
         json.dump(o.__dict__, f)
+    capsys.readouterr()
     budget_analysis.main([str(tmp_path), "2"])
     eps2 = float(capsys.readouterr().out.strip().strip("()").split(",")[0])
     budget_analysis.main([str(tmp_path), "4"])

@@ -6,6 +6,8 @@ the benchmark train on synthetic tensors of the right shape and range (SURVEY.md
 CelebA-like: clamp(N(0, 0.5^2), -1, 1), 3 x im_size x im_size, binary label ~ Bernoulli(0.42);
 MNIST-like:  U[0,1], 1 x 28 x 28, label ~ randint(10).  Real-data loaders are §8f item 4 (out of scope).
 """
+import os
+
 import torch
 from torch.utils.data import DataLoader, TensorDataset
 
@@ -29,8 +31,29 @@ class SyntheticImages(TensorDataset):
         return x[i], int(y[i])
 
 
+def init_real_data(opt):
+    """init_util.init_data (init_util.py:13-42) on the real files: returns (dataset, loader, public set, loader)."""
+    from . import datasets as ds
+    pub = None
+    if opt.dataset == "MNIST":
+        data = ds.MNISTDataset(opt.data_path, train=True, per_class=opt.train_set_size // 10)
+        if opt.public_set_size > 0:
+            pub = ds.MNISTDataset(opt.data_path, train=False)
+    else:
+        data = ds.CelebADataset(opt.data_path, im_size=opt.im_size, length=opt.train_set_size, attr_file=opt.label_path, attr=opt.label_attr)
+        if opt.public_set_size > 0:
+            pub = ds.CelebADataset(opt.data_path, im_size=opt.im_size, length=opt.public_set_size, offset=opt.train_set_size,
+                                   attr_file=opt.label_path, attr=opt.label_attr)
+    dl = DataLoader(data, num_workers=opt.num_workers, pin_memory=torch.cuda.is_available(), batch_size=opt.batch_size, shuffle=True)
+    pdl = DataLoader(pub, batch_size=opt.batch_size, num_workers=opt.num_workers, shuffle=True) if pub is not None else None
+    return data, dl, pub, pdl
+
+
 def init_data(opt):
-    """Synthetic counterpart of init_util.init_data: same return tuple, shuffle=True loaders."""
+    """Real files when --data_path exists and --synthetic is not given; otherwise the synthetic counterpart of
+    init_util.init_data: same return tuple, shuffle=True loaders."""
+    if not getattr(opt, "synthetic", False) and opt.data_path and os.path.isdir(opt.data_path):
+        return init_real_data(opt)
     n = min(opt.train_set_size, getattr(opt, "synthetic_cap", 4096))
     ds = SyntheticImages(opt.dataset, n, opt.im_size, seed=opt.manual_seed)
     pub = SyntheticImages(opt.dataset, min(opt.public_set_size, 2048), opt.im_size, seed=opt.manual_seed, offset=1) \

@@ -156,3 +156,48 @@ def test_budget_analysis_and_engine_state_roundtrip(tmp_path, capsys):
     budget_analysis.main([str(tmp_path), "4"])
     eps4 = float(capsys.readouterr().out.strip().strip("()").split(",")[0])
     assert 0 < eps2 < eps4
+
+
+def test_real_data_loaders_on_generated_files(tmp_path):
+    """CelebA-style JPEG folder + attribute file and MNIST idx files, generated here (no datasets in the image)."""
+    import struct
+    from PIL import Image
+    from csl_gan_amd import datasets as ds
+    root = tmp_path / "celeba"
+    root.mkdir()
+    rng = np.random.default_rng(0)
+    for i in range(1, 7):
+        arr = np.full((218, 178, 3), 20 * i, dtype=np.uint8)
+        arr[:, :89, 0] = 255                      # left half red: a flip is detectable
+        Image.fromarray(arr).save(str(root / ("%06d.jpg" % i)), quality=95)
+    attr = tmp_path / "attr.txt"
+    names = ["A", "Male", "Z"]
+    with open(attr, "w") as f:
+        f.write("6\n" + " ".join(names) + "\n")
+        for i in range(1, 7):
+            f.write("%06d.jpg  %d %d %d\n" % (i, -1, 1 if i % 2 == 0 else -1, 1))
+    d = ds.CelebADataset(str(root), im_size=64, length=4, offset=2, attr_file=str(attr), attr="Male", flip=False)
+    assert len(d) == 4 and d.labels.tolist() == [0, 1, 0, 1] and d.label_true_count == 2
+    img, lab = d[0]                                # file 000003.jpg, attribute row 3 -> odd -> 0
+    assert img.shape == (3, 64, 64) and lab == 0 and -1.0 <= img.min() and img.max() <= 1.0
+    assert abs(img[1, 32, 48].item() - (60 / 255 - 0.5) / 0.5) < 0.05          # right half keeps the grey level of file 3
+    assert img[0, 32, 5].item() > 0.9                                          # left half red, not flipped
+    got, lab1 = d.get_item_with_label(1)
+    assert lab1 == 1
+    flips = ds.CelebADataset(str(root), im_size=64, length=6, flip=True, seed=1)
+    assert flips.labels is None and len({float(flips[0][0][0, 32, 5] > 0.9) for _ in range(20)}) == 2
+
+    mroot = tmp_path / "mnist"
+    mroot.mkdir()
+    x = rng.integers(0, 256, size=(40, 28, 28), dtype=np.uint8)
+    y = (np.arange(40) % 10).astype(np.uint8)
+    for stem in ("train", "t10k"):
+        with open(mroot / (stem + "-images-idx3-ubyte"), "wb") as f:
+            f.write(struct.pack(">IIII", 0x00000803, 40, 28, 28) + x.tobytes())
+        with open(mroot / (stem + "-labels-idx1-ubyte"), "wb") as f:
+            f.write(struct.pack(">II", 0x00000801, 40) + y.tobytes())
+    m = ds.MNISTDataset(str(mroot), train=True, per_class=2)
+    assert len(m) == 20 and sorted(m.y.tolist()) == sorted(list(range(10)) * 2)
+    xi, yi = m[3]
+    assert xi.shape == (1, 28, 28) and 0.0 <= xi.min() and xi.max() <= 1.0
+    assert m.get_item_with_label(7)[1] == 7

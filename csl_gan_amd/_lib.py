@@ -14,7 +14,8 @@ MAX_SEGS = 16
 
 EXPORTS = [
     "cslgan_version", "cslgan_last_error", "cslgan_device_count",
-    "cslgan_sample_sqnorm_f32", "cslgan_clip_factors_f32", "cslgan_clip_accum_noise_f32",
+    "cslgan_sample_sqnorm_f32", "cslgan_sample_sqnorm_bf16", "cslgan_clip_factors_f32", "cslgan_clip_accum_noise_f32",
+    "cslgan_clip_accum_noise_bf16", "cslgan_conv2d_wgrad_grouped_bf16out_f32",
     "cslgan_l2_clip_rows_f32", "cslgan_row_l2norm_f32", "cslgan_row_l2norm_bwd_f32",
     "cslgan_conv2d_fwd_f32", "cslgan_conv2d_up_fwd_f32", "cslgan_conv2d_up_ws_floats", "cslgan_conv2d_up_dgrad_f32", "cslgan_conv2d_dgrad_f32", "cslgan_conv2d_wgrad_grouped_f32",
     "cslgan_bias_grad_grouped_f32", "cslgan_act_bwd_f32", "cslgan_groupnorm_act_f32", "cslgan_batchnorm_act_f32", "cslgan_norm_act_bwd_f32", "cslgan_norm_bwd_ws_floats", "cslgan_sum2x2_f32",
@@ -61,6 +62,9 @@ def lib():
         "cslgan_version": [],
         "cslgan_device_count": [],
         "cslgan_sample_sqnorm_f32": [C.POINTER(SegsT), i64, vp, vp],
+        "cslgan_sample_sqnorm_bf16": [C.POINTER(SegsT), i64, vp, vp],
+        "cslgan_clip_accum_noise_bf16": [C.POINTER(SegsT), i64, vp, i32, vp, u64, u64, f32, f32, vp],
+        "cslgan_conv2d_wgrad_grouped_bf16out_f32": [C.POINTER(ConvT), vp, vp, i32, f32, vp, vp, vp],
         "cslgan_clip_factors_f32": [vp, i32, i64, vp, i32, f32, i64, vp, vp, vp],
         "cslgan_clip_accum_noise_f32": [C.POINTER(SegsT), i64, vp, i32, vp, u64, u64, f32, f32, vp],
         "cslgan_l2_clip_rows_f32": [vp, vp, i64, i64, f32, vp, vp],

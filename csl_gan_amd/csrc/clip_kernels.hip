@@ -23,6 +23,24 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// 4 consecutive elements as floats: fp32 = one 16-byte load, bf16 = one 8-byte load widened by a 16-bit shift
+struct bf16x4 { unsigned short v[4]; };
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static __device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ float load1(const float* p) { return *p; }
+    static constexpr int align = 16;
+};
+template <> struct Elem<unsigned short> {
+    static __device__ __forceinline__ float4 load4(const unsigned short* p) {
+        const uint2 r = *reinterpret_cast<const uint2*>(p);
+        return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                           __uint_as_float(r.y & 0xffff0000u));
+    }
+    static __device__ __forceinline__ float load1(const unsigned short* p) { return __uint_as_float((unsigned)(*p) << 16); }
+    static constexpr int align = 8;
+};
+
 constexpr int SQ_THREADS = 256;
 constexpr int SQ_CHUNK = SQ_THREADS * 4 * 8;  // floats per block: 32 KB
 
@@ -35,6 +53,7 @@ struct SqArgs {
     int vec_ok[CSLGAN_MAX_SEGS];            // 16-byte loads allowed for this segment
 };
 
+template <typename T>
 __global__ __launch_bounds__(SQ_THREADS) void sample_sqnorm_kernel(SqArgs a, long long n_rows, float* __restrict__ out_sq) {
     __shared__ float red[4];
     const int bx = blockIdx.x;
@@ -46,23 +65,22 @@ __global__ __launch_bounds__(SQ_THREADS) void sample_sqnorm_kernel(SqArgs a, lon
     const long long len = a.len[s];
     long long n = len - off;
     if (n > SQ_CHUNK) n = SQ_CHUNK;
-    const float* __restrict__ p = a.in[s] + row * a.row_stride[s] + off;
+    const T* __restrict__ p = reinterpret_cast<const T*>(a.in[s]) + row * a.row_stride[s] + off;
     float acc = 0.f;
     if (a.vec_ok[s]) {
         const long long n4 = n >> 2;
-        const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
 #pragma unroll 8
         for (long long i = threadIdx.x; i < n4; i += SQ_THREADS) {
-            const float4 v = p4[i];
+            const float4 v = Elem<T>::load4(p + 4 * i);
             acc = fmaf(v.x, v.x, acc);
             acc = fmaf(v.y, v.y, acc);
             acc = fmaf(v.z, v.z, acc);
             acc = fmaf(v.w, v.w, acc);
         }
-        for (long long i = (n4 << 2) + threadIdx.x; i < n; i += SQ_THREADS) acc = fmaf(p[i], p[i], acc);
+        for (long long i = (n4 << 2) + threadIdx.x; i < n; i += SQ_THREADS) { const float v = Elem<T>::load1(p + i); acc = fmaf(v, v, acc); }
     } else {
 #pragma unroll 4
-        for (long long i = threadIdx.x; i < n; i += SQ_THREADS) acc = fmaf(p[i], p[i], acc);
+        for (long long i = threadIdx.x; i < n; i += SQ_THREADS) { const float v = Elem<T>::load1(p + i); acc = fmaf(v, v, acc); }
     }
     const float tot = block_sum_256(acc, red);
     if (threadIdx.x == 0) atomicAdd(out_sq + (long long)s * n_rows + row, tot);
@@ -133,6 +151,7 @@ struct CaArgs {
     int vec_ok[CSLGAN_MAX_SEGS];
 };
 
+template <typename T>
 __global__ __launch_bounds__(CA_THREADS) void clip_accum_noise_kernel(CaArgs a, long long n_rows,
                                                                       const float* __restrict__ factors,
                                                                       int factors_per_seg,
@@ -148,14 +167,14 @@ __global__ __launch_bounds__(CA_THREADS) void clip_accum_noise_kernel(CaArgs a, 
     const long long len = a.len[s];
     if (j0 >= len) return;
     const long long stride = a.row_stride[s];
-    const float* __restrict__ base = a.in[s] + j0;
+    const T* __restrict__ base = reinterpret_cast<const T*>(a.in[s]) + j0;
     const float* __restrict__ f = factors ? factors + (factors_per_seg ? (long long)s * n_rows : 0) : nullptr;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool full = (j0 + 4 <= len);
     if (full && a.vec_ok[s]) {
 #pragma unroll 8
         for (long long r = 0; r < n_rows; ++r) {
-            const float4 v = *reinterpret_cast<const float4*>(base + r * stride);
+            const float4 v = Elem<T>::load4(base + r * stride);
             const float fr = f ? f[r] : 1.f;
             acc.x = fmaf(fr, v.x, acc.x);
             acc.y = fmaf(fr, v.y, acc.y);
@@ -166,12 +185,12 @@ __global__ __launch_bounds__(CA_THREADS) void clip_accum_noise_kernel(CaArgs a, 
         const int nv = full ? 4 : (int)(len - j0);
 #pragma unroll 4
         for (long long r = 0; r < n_rows; ++r) {
-            const float* q = base + r * stride;
+            const T* q = base + r * stride;
             const float fr = f ? f[r] : 1.f;
-            acc.x = fmaf(fr, q[0], acc.x);
-            if (nv > 1) acc.y = fmaf(fr, q[1], acc.y);
-            if (nv > 2) acc.z = fmaf(fr, q[2], acc.z);
-            if (nv > 3) acc.w = fmaf(fr, q[3], acc.w);
+            acc.x = fmaf(fr, Elem<T>::load1(q), acc.x);
+            if (nv > 1) acc.y = fmaf(fr, Elem<T>::load1(q + 1), acc.y);
+            if (nv > 2) acc.z = fmaf(fr, Elem<T>::load1(q + 2), acc.z);
+            if (nv > 3) acc.w = fmaf(fr, Elem<T>::load1(q + 3), acc.w);
         }
     }
     float z[4] = {0.f, 0.f, 0.f, 0.f};
@@ -229,8 +248,10 @@ __global__ void row_l2norm_bwd_kernel(const float* __restrict__ in, const float*
         o[j] = p[j] * f;
 }
 
+static bool aligned_to(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(a - 1)) == 0; }
+
 static int launch_sqnorm(const float* const* in, const long long* len, const long long* stride, int n_seg,
-                         long long n_rows, float* out_sq, hipStream_t st) {
+                         long long n_rows, float* out_sq, hipStream_t st, bool bf16 = false) {
     SqArgs a;
     a.n_seg = n_seg;
     int tot = 0;
@@ -239,7 +260,7 @@ static int launch_sqnorm(const float* const* in, const long long* len, const lon
         a.len[s] = len[s];
         a.row_stride[s] = stride[s];
         a.chunk_prefix[s] = tot;
-        a.vec_ok[s] = aligned16(in[s]) && (stride[s] % 4 == 0);
+        a.vec_ok[s] = aligned_to(in[s], bf16 ? 8 : 16) && (stride[s] % 4 == 0);
         tot += (int)((len[s] + SQ_CHUNK - 1) / SQ_CHUNK);
     }
     a.chunk_prefix[n_seg] = tot;
@@ -249,7 +270,8 @@ static int launch_sqnorm(const float* const* in, const long long* len, const lon
         return CSLGAN_ERR_LAUNCH;
     }
     if (tot == 0 || n_rows == 0) return CSLGAN_OK;
-    hipLaunchKernelGGL(sample_sqnorm_kernel, dim3(tot, (unsigned)n_rows), dim3(SQ_THREADS), 0, st, a, n_rows, out_sq);
+    if (bf16) hipLaunchKernelGGL(sample_sqnorm_kernel<unsigned short>, dim3(tot, (unsigned)n_rows), dim3(SQ_THREADS), 0, st, a, n_rows, out_sq);
+    else hipLaunchKernelGGL(sample_sqnorm_kernel<float>, dim3(tot, (unsigned)n_rows), dim3(SQ_THREADS), 0, st, a, n_rows, out_sq);
     return check_launch("sample_sqnorm_kernel");
 }
 
@@ -271,7 +293,7 @@ int cslgan_device_count(void) {
     return n;
 }
 
-int cslgan_sample_sqnorm_f32(const cslgan_segs_t* segs, int64_t n_rows, float* out_sq, void* stream) {
+static int sample_sqnorm_impl(const cslgan_segs_t* segs, int64_t n_rows, float* out_sq, void* stream, bool bf16) {
     CSLGAN_REQUIRE(segs && out_sq, "sample_sqnorm: null argument");
     CSLGAN_REQUIRE(segs->n_seg >= 1 && segs->n_seg <= CSLGAN_MAX_SEGS, "sample_sqnorm: n_seg=%d out of range", segs->n_seg);
     CSLGAN_REQUIRE(n_rows >= 0 && n_rows <= 65535, "sample_sqnorm: n_rows=%lld out of range", (long long)n_rows);
@@ -282,7 +304,15 @@ int cslgan_sample_sqnorm_f32(const cslgan_segs_t* segs, int64_t n_rows, float* o
         CSLGAN_REQUIRE(segs->len[s] >= 0 && segs->row_stride[s] >= segs->len[s], "sample_sqnorm: bad len/stride in segment %d", s);
         in[s] = segs->in[s]; len[s] = segs->len[s]; stride[s] = segs->row_stride[s];
     }
-    return launch_sqnorm(in, len, stride, segs->n_seg, n_rows, out_sq, (hipStream_t)stream);
+    return launch_sqnorm(in, len, stride, segs->n_seg, n_rows, out_sq, (hipStream_t)stream, bf16);
+}
+
+int cslgan_sample_sqnorm_f32(const cslgan_segs_t* segs, int64_t n_rows, float* out_sq, void* stream) {
+    return sample_sqnorm_impl(segs, n_rows, out_sq, stream, false);
+}
+
+int cslgan_sample_sqnorm_bf16(const cslgan_segs_t* segs, int64_t n_rows, float* out_sq, void* stream) {
+    return sample_sqnorm_impl(segs, n_rows, out_sq, stream, true);
 }
 
 int cslgan_clip_factors_f32(const float* sq, int n_seg, int64_t n_rows, const float* max_norm, int flat, float eps,
@@ -296,9 +326,9 @@ int cslgan_clip_factors_f32(const float* sq, int n_seg, int64_t n_rows, const fl
     return check_launch("clip_factors_kernel");
 }
 
-int cslgan_clip_accum_noise_f32(const cslgan_segs_t* segs, int64_t n_rows, const float* factors, int factors_per_seg,
-                                const float* noise_std, uint64_t seed, uint64_t offset, float scale, float beta,
-                                void* stream) {
+static int clip_accum_noise_impl(const cslgan_segs_t* segs, int64_t n_rows, const float* factors, int factors_per_seg,
+                                 const float* noise_std, uint64_t seed, uint64_t offset, float scale, float beta,
+                                 void* stream, bool bf16) {
     CSLGAN_REQUIRE(segs, "clip_accum_noise: null segs");
     CSLGAN_REQUIRE(segs->n_seg >= 1 && segs->n_seg <= CSLGAN_MAX_SEGS, "clip_accum_noise: n_seg=%d out of range", segs->n_seg);
     CSLGAN_REQUIRE(n_rows >= 0, "clip_accum_noise: n_rows < 0");
@@ -312,7 +342,7 @@ int cslgan_clip_accum_noise_f32(const cslgan_segs_t* segs, int64_t n_rows, const
             CSLGAN_REQUIRE(segs->len[s] >= 0 && (n_rows == 0 || segs->row_stride[s] >= segs->len[s]), "clip_accum_noise: bad len/stride in segment %d", s);
             a.in[s] = segs->in[s]; a.out[s] = segs->out[s]; a.noise[s] = segs->noise[s];
             a.len[s] = segs->len[s]; a.row_stride[s] = segs->row_stride[s];
-            a.vec_ok[s] = aligned16(segs->in[s]) && (segs->row_stride[s] % 4 == 0);
+            a.vec_ok[s] = aligned_to(segs->in[s], bf16 ? 8 : 16) && (segs->row_stride[s] % 4 == 0);
             a.tile_prefix[s] = tot;
             tot += (int)((segs->len[s] + CA_COLS - 1) / CA_COLS);
         } else {
@@ -323,9 +353,21 @@ int cslgan_clip_accum_noise_f32(const cslgan_segs_t* segs, int64_t n_rows, const
     a.tile_prefix[CSLGAN_MAX_SEGS] = tot;
     for (int s = segs->n_seg; s <= CSLGAN_MAX_SEGS; ++s) a.tile_prefix[s] = tot;
     if (tot == 0) return CSLGAN_OK;
-    hipLaunchKernelGGL(clip_accum_noise_kernel, dim3(tot), dim3(CA_THREADS), 0, (hipStream_t)stream, a, (long long)n_rows,
-                       factors, factors_per_seg, noise_std, (unsigned long long)seed, (unsigned long long)offset, scale, beta);
+    if (bf16) hipLaunchKernelGGL(clip_accum_noise_kernel<unsigned short>, dim3(tot), dim3(CA_THREADS), 0, (hipStream_t)stream, a, (long long)n_rows,
+                                 factors, factors_per_seg, noise_std, (unsigned long long)seed, (unsigned long long)offset, scale, beta);
+    else hipLaunchKernelGGL(clip_accum_noise_kernel<float>, dim3(tot), dim3(CA_THREADS), 0, (hipStream_t)stream, a, (long long)n_rows,
+                            factors, factors_per_seg, noise_std, (unsigned long long)seed, (unsigned long long)offset, scale, beta);
     return check_launch("clip_accum_noise_kernel");
+}
+
+int cslgan_clip_accum_noise_f32(const cslgan_segs_t* segs, int64_t n_rows, const float* factors, int factors_per_seg,
+                                const float* noise_std, uint64_t seed, uint64_t offset, float scale, float beta, void* stream) {
+    return clip_accum_noise_impl(segs, n_rows, factors, factors_per_seg, noise_std, seed, offset, scale, beta, stream, false);
+}
+
+int cslgan_clip_accum_noise_bf16(const cslgan_segs_t* segs, int64_t n_rows, const float* factors, int factors_per_seg,
+                                 const float* noise_std, uint64_t seed, uint64_t offset, float scale, float beta, void* stream) {
+    return clip_accum_noise_impl(segs, n_rows, factors, factors_per_seg, noise_std, seed, offset, scale, beta, stream, true);
 }
 
 int cslgan_l2_clip_rows_f32(const float* in, float* out, int64_t n_rows, int64_t len, float C, float* norms_ws, void* stream) {

@@ -104,7 +104,8 @@ struct McParams {
     int group;           // samples per group
     int n_groups;
     float alpha;
-    float* gw;           // [n_groups][Kc][Ndim] or null
+    float* gw;           // [n_groups][Kc][Ndim] or null (bf16 elements when out_bf16)
+    int out_bf16;        // 1: gw is stored as bfloat16 (round-to-nearest-even); sq is taken over the ROUNDED values
     float* sq;           // [n_groups] or null
     int tiles_m, tiles_n;
     signed char ty[IG_MAX_TAPS], tx[IG_MAX_TAPS];   // kh-pad, kw-pad

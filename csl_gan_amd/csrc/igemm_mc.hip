@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
 
     // ---- epilogue: scale, store, per-group sum of squares ----------------------------------
     float ss = 0.f;
-    float* __restrict__ outg = p.gw ? p.gw + (long long)g * p.Kc * p.Ndim : nullptr;
+    float* __restrict__ outg = (p.gw && !p.out_bf16) ? p.gw + (long long)g * p.Kc * p.Ndim : nullptr;
+    unsigned short* __restrict__ outh = (p.gw && p.out_bf16) ? reinterpret_cast<unsigned short*>(p.gw) + (long long)g * p.Kc * p.Ndim : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * TN * 32 + j * 32 + r;
@@ -168,7 +169,13 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
             for (int v = 0; v < 16; ++v) {
                 const int m = m0 + wm * TM * 32 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
                 if (m >= p.Kc) continue;
-                const float val = p.alpha * acc[i][j][v];
+                float val = p.alpha * acc[i][j][v];
+                if (p.out_bf16) {      // what is stored is what gets clipped: norm of the rounded value
+                    unsigned u = __float_as_uint(val);
+                    u += 0x7FFFu + ((u >> 16) & 1u);
+                    if (outh) outh[(long long)m * p.Ndim + n] = (unsigned short)(u >> 16);
+                    val = __uint_as_float(u & 0xffff0000u);
+                }
                 ss = fmaf(val, val, ss);
                 if (outg) outg[(long long)m * p.Ndim + n] = val;
             }
@@ -227,8 +234,8 @@ using namespace cslgan;
 
 extern "C" {
 
-int cslgan_conv2d_wgrad_grouped_f32(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha,
-                                    float* gw, float* sq, void* stream) {
+static int wgrad_grouped_impl(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha,
+                              float* gw, float* sq, void* stream, int out_bf16) {
     CSLGAN_REQUIRE(c && gy && x, "conv2d_wgrad: null argument");
     CSLGAN_REQUIRE(gw || sq, "conv2d_wgrad: neither gw nor sq requested");
     CSLGAN_REQUIRE(group >= 1 && c->N % group == 0, "conv2d_wgrad: N=%d not divisible by group=%d", c->N, group);
@@ -239,7 +246,7 @@ int cslgan_conv2d_wgrad_grouped_f32(const cslgan_conv_t* c, const float* gy, con
     McParams p{};
     p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->P; p.Q = c->Q; p.Kc = c->K;
     p.T = c->R * c->S; p.Ndim = p.T * c->C; p.stride = c->stride; p.ups = c->upsample ? 1 : 0; p.group = group; p.n_groups = c->N / group;
-    p.alpha = alpha; p.gw = gw; p.sq = sq;
+    p.alpha = alpha; p.gw = gw; p.sq = sq; p.out_bf16 = out_bf16;
     for (int t = 0; t < IG_MAX_TAPS; ++t) { p.ty[t] = 0; p.tx[t] = 0; }
     for (int kh = 0; kh < c->R; ++kh)
         for (int kw = 0; kw < c->S; ++kw) { p.ty[kh * c->S + kw] = (signed char)(kh - c->pad); p.tx[kh * c->S + kw] = (signed char)(kw - c->pad); }
@@ -247,6 +254,16 @@ int cslgan_conv2d_wgrad_grouped_f32(const cslgan_conv_t* c, const float* gy, con
     const bool vecB = (c->C % 4 == 0) && aligned16(x);
     if (c->K > 64) return launch_mc_tile<128, 128, 2, 2>(p, vecA, vecB, (hipStream_t)stream);
     return launch_mc_tile<64, 128, 1, 4>(p, vecA, vecB, (hipStream_t)stream);
+}
+
+int cslgan_conv2d_wgrad_grouped_f32(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha,
+                                    float* gw, float* sq, void* stream) {
+    return wgrad_grouped_impl(c, gy, x, group, alpha, gw, sq, stream, 0);
+}
+
+int cslgan_conv2d_wgrad_grouped_bf16out_f32(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha,
+                                            void* gw_bf16, float* sq, void* stream) {
+    return wgrad_grouped_impl(c, gy, x, group, alpha, reinterpret_cast<float*>(gw_bf16), sq, stream, 1);
 }
 
 int cslgan_bias_grad_grouped_f32(const float* gy, int N, int PQ, int K, int group, float alpha, float* gb, float* sq,

@@ -166,7 +166,7 @@ class _LayerCollector:
             return
         if e.materialize == "private":
             pass_idx, n_pass = pass_idx - (n_pass - n_private), n_private
-        buf, sq = e._buffers(w, n_pass, B, K * R * S * Cc)
+        buf, sq = e._buffers(w, n_pass, B, K * R * S * Cc, e._gs_dtype)
         ops.conv2d_wgrad_grouped(gz, x, R, S, stride=stride, pad=pad, group=1, alpha=scale,
                                  out=buf[pass_idx].view(B, K, R, S, Cc), sq=sq[pass_idx])
         if isinstance(layer, nn.Conv2d):
@@ -230,7 +230,7 @@ def _collect_roles(self, gz, x, R, S, stride, pad, has_bias):
             if has_bias:
                 e._add_dense(layer.bias, _dense_bgrad(g_, scale))
         else:
-            buf, sq = e._buffers(w, 1, n, K * R * S * Cc)
+            buf, sq = e._buffers(w, 1, n, K * R * S * Cc, e._gs_dtype)
             ops.conv2d_wgrad_grouped(g_, x_, R, S, stride=stride, pad=pad, group=1, alpha=scale,
                                      out=buf[0].view(n, K, R, S, Cc), sq=sq[0])
             view = buf.view(1, n, K, R, S, Cc).permute(0, 1, 2, 5, 3, 4) if isinstance(layer, nn.Conv2d) else buf.view(1, n, K, Cc)
@@ -260,9 +260,15 @@ class PrivacyEngine:
 
     def __init__(self, module, batch_size, sample_size, alphas, noise_multiplier, max_grad_norm,
                  accum_passes=True, num_private_passes=None, auto_clip_and_accum_on_step=True,
-                 loss_reduction="mean", world_size=1, materialize="all", **_unused):
+                 loss_reduction="mean", world_size=1, materialize="all", grad_sample_dtype="fp32", **_unused):
         if materialize not in ("all", "private"):
             raise ValueError("materialize must be 'all' or 'private'")
+        if grad_sample_dtype not in ("fp32", "bf16"):
+            raise ValueError("grad_sample_dtype must be 'fp32' or 'bf16'")
+        # bf16: weight-tensor per-sample gradients are STORED as bfloat16 (fp32 MFMA accumulate, round-to-nearest
+        # on store; norms / clip read the rounded values) — half the HBM bytes of the clip passes.  Bias gradients
+        # (a few KB per sample) stay fp32.
+        self._gs_dtype = torch.bfloat16 if grad_sample_dtype == "bf16" else torch.float32
         self.materialize, self.norms_only = materialize, False
         self.row_roles = None                   # set by Trainer.train_D_fused for one fused forward/backward
         self._dense = {}
@@ -320,12 +326,12 @@ class PrivacyEngine:
         """[n_params, n] squared norms of the "norms" row block of a fused pass."""
         return torch.stack([self._bufs[("norms", id(p))][1].reshape(-1) for p in self.params])
 
-    def _buffers(self, p, n_pass, B, numel):
+    def _buffers(self, p, n_pass, B, numel, dtype=torch.float32):
         key = p if isinstance(p, tuple) else id(p)
         cur = self._bufs.get(key)
         if cur is None or cur[0].shape != (n_pass, B, numel):
             dev = self.params[0].device
-            cur = (torch.empty((n_pass, B, numel), device=dev, dtype=torch.float32),
+            cur = (torch.empty((n_pass, B, numel), device=dev, dtype=dtype),
                    torch.zeros((n_pass, B), device=dev, dtype=torch.float32))
             self._bufs[key] = cur
         return cur

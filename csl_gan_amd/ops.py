@@ -71,11 +71,11 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _chk(t: torch.Tensor, name: str):
+def _chk(t: torch.Tensor, name: str, allow_bf16=False):
     if not t.is_cuda:
         raise RuntimeError("%s must be a device tensor (csl_gan_amd.ops has no CPU path)" % name)
-    if t.dtype != torch.float32:
-        raise RuntimeError("%s must be float32, got %s" % (name, t.dtype))
+    if t.dtype != torch.float32 and not (allow_bf16 and t.dtype == torch.bfloat16):
+        raise RuntimeError("%s must be float32%s, got %s" % (name, " or bfloat16" if allow_bf16 else "", t.dtype))
     if not t.is_contiguous():
         raise RuntimeError("%s must be contiguous" % name)
     return t
@@ -164,14 +164,16 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
     gw = None
     if want_gw:
         gw = out if out is not None else torch.empty((G, K, R, S, Cc), device=x.device, dtype=torch.float32)
-        _chk(gw, "gw")
+        _chk(gw, "gw", allow_bf16=True)
     if sq is not None:
         _chk(sq, "sq")
     flop = 2.0 * N * P * Q * K * R * S * Cc
-    nbytes = 4.0 * (N * H * W * Cc + N * P * Q * K + (G * K * R * S * Cc if want_gw else 0))
+    esz = gw.element_size() if want_gw else 0
+    nbytes = 4.0 * (N * H * W * Cc + N * P * Q * K) + float(esz) * (G * K * R * S * Cc)
+    L = _lib.lib()
+    fn = L.cslgan_conv2d_wgrad_grouped_bf16out_f32 if (want_gw and gw.dtype == torch.bfloat16) else L.cslgan_conv2d_wgrad_grouped_f32
     _timed("conv2d_wgrad_grouped" + ("" if want_gw else "_normonly"), flop, nbytes, lambda: check(
-        _lib.lib().cslgan_conv2d_wgrad_grouped_f32(C.byref(d), _p(gy), _p(x), group, float(alpha), _p(gw), _p(sq), _stream()),
-        "conv2d_wgrad_grouped"))
+        fn(C.byref(d), _p(gy), _p(x), group, float(alpha), _p(gw), _p(sq), _stream()), "conv2d_wgrad_grouped"))
     return gw
 
 
@@ -235,7 +237,9 @@ def _segs(ins: Sequence[torch.Tensor], outs=None, noises=None):
     s.n_seg = len(ins)
     n_rows = ins[0].shape[0] if len(ins) else 0
     for i, t in enumerate(ins):
-        _chk(t, "segment %d" % i)
+        _chk(t, "segment %d" % i, allow_bf16=True)
+        if t.dtype != ins[0].dtype:
+            raise RuntimeError("segments of one launch must share a dtype")
         if t.dim() != 2 or t.shape[0] != n_rows:
             raise RuntimeError("segments must be 2-D [n_rows, len] with equal n_rows")
         s.inp[i] = t.data_ptr()
@@ -254,18 +258,30 @@ def _segs(ins: Sequence[torch.Tensor], outs=None, noises=None):
     return s, n_rows
 
 
+def _by_dtype(mats):
+    """Index lists of the fp32 and the bf16 segments (a launch handles one element type)."""
+    parts = {}
+    for i, m in enumerate(mats):
+        parts.setdefault(m.dtype, []).append(i)
+    return parts
+
+
 def sample_sqnorm(mats: Sequence[torch.Tensor]) -> torch.Tensor:
-    """mats: list of [n_rows, len_i] -> [n_seg, n_rows] squared row norms (all segments in one launch)."""
-    outs = []
-    for i in range(0, len(mats), _lib.MAX_SEGS):
-        chunk = list(mats[i:i + _lib.MAX_SEGS])
-        s, n_rows = _segs(chunk)
-        o = torch.empty((len(chunk), n_rows), device=chunk[0].device, dtype=torch.float32)
-        nbytes = 4.0 * sum(n_rows * m.shape[1] for m in chunk)
-        _timed("sample_sqnorm", 0.0, nbytes, lambda: check(
-            _lib.lib().cslgan_sample_sqnorm_f32(C.byref(s), n_rows, _p(o), _stream()), "sample_sqnorm"))
-        outs.append(o)
-    return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+    """mats: list of [n_rows, len_i] (fp32 or bf16) -> [n_seg, n_rows] squared row norms."""
+    n_rows = mats[0].shape[0]
+    out = torch.empty((len(mats), n_rows), device=mats[0].device, dtype=torch.float32)
+    L = _lib.lib()
+    for dt, idx in _by_dtype(mats).items():
+        fn = L.cslgan_sample_sqnorm_bf16 if dt == torch.bfloat16 else L.cslgan_sample_sqnorm_f32
+        for i in range(0, len(idx), _lib.MAX_SEGS):
+            sub = idx[i:i + _lib.MAX_SEGS]
+            chunk = [mats[j] for j in sub]
+            s, _ = _segs(chunk)
+            o = torch.empty((len(chunk), n_rows), device=chunk[0].device, dtype=torch.float32)
+            nbytes = float(sum(n_rows * m.shape[1] * m.element_size() for m in chunk))
+            _timed("sample_sqnorm", 0.0, nbytes, lambda: check(fn(C.byref(s), n_rows, _p(o), _stream()), "sample_sqnorm"))
+            out[torch.tensor(sub, device=out.device)] = o
+    return out
 
 
 def clip_factors(sq, max_norm, flat, eps=1e-6, first_private_row=0, want_norms=False):
@@ -283,27 +299,34 @@ def clip_factors(sq, max_norm, flat, eps=1e-6, first_private_row=0, want_norms=F
 
 
 def clip_accum_noise(mats, outs, factors=None, noise_std=None, noises=None, seed=0, offset=0, scale=1.0, beta=0.0):
-    """outs[i] = beta*outs[i] + scale*(sum_r f_r * mats[i][r] + noise_std[i]*z_i)."""
-    for i in range(0, len(mats), _lib.MAX_SEGS):
-        sl = slice(i, i + _lib.MAX_SEGS)
-        s, n_rows = _segs(list(mats[sl]), list(outs[sl]), None if noises is None else list(noises[sl]))
-        per_seg = 0
-        f = None
-        if factors is not None:
-            _chk(factors, "factors")
-            if factors.dim() == 2:
-                per_seg = 1
-                f = factors[sl].contiguous() if i or len(mats) > _lib.MAX_SEGS else factors
-            else:
-                f = factors
-        ns = None
-        if noise_std is not None:
-            _chk(noise_std, "noise_std")
-            ns = noise_std[sl].contiguous() if i or len(mats) > _lib.MAX_SEGS else noise_std
-        nbytes = 4.0 * sum((n_rows + 1) * m.shape[1] for m in mats[sl])
-        _timed("clip_accum_noise", 0.0, nbytes, lambda: check(
-            _lib.lib().cslgan_clip_accum_noise_f32(C.byref(s), n_rows, _p(f), per_seg, _p(ns), int(seed), int(offset) + i,
-                                                   float(scale), float(beta), _stream()), "clip_accum_noise"))
+    """outs[i] = beta*outs[i] + scale*(sum_r f_r * mats[i][r] + noise_std[i]*z_i).  mats may mix fp32 and bf16
+    segments (one launch per element type, fp32 accumulation either way)."""
+    L = _lib.lib()
+    if factors is not None:
+        _chk(factors, "factors")
+    if noise_std is not None:
+        _chk(noise_std, "noise_std")
+    for dt, idx in _by_dtype(mats).items():
+        fn = L.cslgan_clip_accum_noise_bf16 if dt == torch.bfloat16 else L.cslgan_clip_accum_noise_f32
+        for i in range(0, len(idx), _lib.MAX_SEGS):
+            sub = idx[i:i + _lib.MAX_SEGS]
+            whole = len(sub) == len(mats)
+            s, n_rows = _segs([mats[j] for j in sub], [outs[j] for j in sub], None if noises is None else [noises[j] for j in sub])
+            per_seg, f = 0, None
+            if factors is not None:
+                if factors.dim() == 2:
+                    per_seg = 1
+                    f = factors if whole else factors[torch.tensor(sub, device=factors.device)].contiguous()
+                else:
+                    f = factors
+            ns = None
+            if noise_std is not None:
+                ns = noise_std if whole else noise_std[torch.tensor(sub, device=noise_std.device)].contiguous()
+            nbytes = float(sum(n_rows * mats[j].shape[1] * mats[j].element_size() + 4 * mats[j].shape[1] for j in sub))
+            # the Philox stream is keyed by (offset, segment index within the launch): make it unique per launch
+            _timed("clip_accum_noise", 0.0, nbytes, lambda: check(
+                fn(C.byref(s), n_rows, _p(f), per_seg, _p(ns), int(seed), int(offset) * 64 + sub[0], float(scale), float(beta),
+                   _stream()), "clip_accum_noise"))
 
 
 def l2_clip_rows(t, Cval):

@@ -9,6 +9,7 @@ Additions of this build (all optional, none changes a reference default):
   --dist               one process per GPU under torch.distributed (RCCL); see csl_gan_amd/distributed.py
   --fuse_passes B      run the adaptive / generated / real discriminator passes as one forward+backward over the
                        concatenated batch (same numbers, fewer and fuller launches); needs --materialize private
+  --grad_sample_dtype  storage type of the materialised per-sample weight gradients (fp32 | bf16; fp32 accumulate)
   --materialize M      per-sample gradients kept in HBM: "all" passes (the fork's p.grad_sample layout) or only
                        the "private" (clipped) passes — see csl_gan_amd.engine.PrivacyEngine
 Quirks kept on purpose: fill_defaults treats False like "unset" (options.py:95), so e.g. `-ispp False`
@@ -150,6 +151,7 @@ _ARGS = [
     (("--dist",), dict(default=False, action="store_true")),
     (("--materialize",), dict(type=str, choices=["all", "private"], default="private")),
     (("--fuse_passes",), dict(type=str2bool, default=True)),
+    (("--grad_sample_dtype",), dict(type=str, choices=["fp32", "bf16"], default="fp32")),
 ]
 ALWAYS_KEEP = ["g_device", "d_device", "num_workers", "resume_path", "resume_epochs"]
 

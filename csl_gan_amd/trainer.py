@@ -60,7 +60,8 @@ class Trainer:
             pe = E.PrivacyEngine(self.D, **params, accum_passes=not o.grad_clip_split,
                                  num_private_passes=1 if o.grad_clip_split else None, auto_clip_and_accum_on_step=False,
                                  max_grad_norm=list(o.clipping_param_per_layer) if per_layer else o.clipping_param,
-                                 materialize=getattr(o, "materialize", "private"))
+                                 materialize=getattr(o, "materialize", "private"),
+                                 grad_sample_dtype=getattr(o, "grad_sample_dtype", "fp32"))
             pe.disable_hooks()
         elif o.dp_mode == "is":
             from .is_engine import ISPrivacyEngine

@@ -64,6 +64,11 @@ int cslgan_device_count(void);
  * privacy_engine.clip() (train.py:399).  out_sq is overwritten (zeroed on-stream first). */
 int cslgan_sample_sqnorm_f32(const cslgan_segs_t* segs, int64_t n_rows, float* out_sq, void* stream);
 
+/* bfloat16 storage of the materialised per-sample gradients (fp32 accumulate): segs->in[] point to bf16
+ * elements, everything else as the _f32 form.  Halves the HBM bytes of the norm / clip passes
+ * (17.3 MB/img/clipped pass for D64); BASELINE.json config 5. */
+int cslgan_sample_sqnorm_bf16(const cslgan_segs_t* segs, int64_t n_rows, float* out_sq, void* stream);
+
 /* Clip factors from squared norms:  f = min(1, C / (sqrt(sq) + eps)).
  *   flat != 0 : one factor per row from the all-segment norm; max_norm[0] is C; out_f is [n_rows]
  *   flat == 0 : per segment; max_norm[s] is C_s; out_f is [n_seg, n_rows]
@@ -82,6 +87,10 @@ int cslgan_clip_factors_f32(const float* sq, int n_seg, int64_t n_rows, const fl
 int cslgan_clip_accum_noise_f32(const cslgan_segs_t* segs, int64_t n_rows, const float* factors,
                                 int factors_per_seg, const float* noise_std, uint64_t seed, uint64_t offset,
                                 float scale, float beta, void* stream);
+
+int cslgan_clip_accum_noise_bf16(const cslgan_segs_t* segs, int64_t n_rows, const float* factors,
+                                 int factors_per_seg, const float* noise_std, uint64_t seed, uint64_t offset,
+                                 float scale, float beta, void* stream);
 
 /* backprop_clip.py:18-22 l2_clip: rows with ||t_r|| > C are scaled to norm C (no epsilon).
  * in/out may alias.  norms_ws: caller workspace [n_rows] floats. */
@@ -143,6 +152,11 @@ int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* p, const float* gy, const float
  * The dense gradient is group == N, or any group followed by cslgan_clip_accum_noise_f32. */
 int cslgan_conv2d_wgrad_grouped_f32(const cslgan_conv_t* p, const float* gy, const float* x, int group,
                                     float alpha, float* gw, float* sq, void* stream);
+
+/* Same, storing gw as bfloat16 (round-to-nearest-even); sq is the norm of the ROUNDED values, i.e. of what
+ * the clip kernels will read back. */
+int cslgan_conv2d_wgrad_grouped_bf16out_f32(const cslgan_conv_t* p, const float* gy, const float* x, int group,
+                                            float alpha, void* gw_bf16, float* sq, void* stream);
 
 /* Per-group bias gradient gb[g][k] = alpha * sum_{n in g, p, q} gy[n,p,q,k]; sq as above. */
 int cslgan_bias_grad_grouped_f32(const float* gy, int N, int PQ, int K, int group, float alpha,

@@ -375,3 +375,24 @@ def test_train_G_gradients_exact_without_activations(tmp_path):
             assert p.grad.abs().max().item() < 1e-4 * gscale, n
         else:
             _close(p.grad, g, "dL/d " + n, rtol=5e-4)
+
+
+def test_train_D_bf16_grad_sample_storage(tmp_path):
+    """--grad_sample_dtype bf16: per-sample weight gradients stored as bfloat16 (fp32 accumulate).  Norms and
+    clipped sums move by bf16 rounding only (<= 2^-9 per entry, averaging out in sums)."""
+    opt, tr, pe, oracle, Do = _setup(tmp_path, "CelebA", ["-gcm", "adaptive-pl", "--grad_sample_dtype", "bf16", "--materialize", "all"], 8, 128)
+    g = torch.Generator().manual_seed(78)
+    img = (torch.randn(8, 3, 64, 64, generator=g) * 0.5).clamp(-1, 1)
+    ms_a = (torch.randn(8, 3, 64, 64, generator=g) * 0.3).clamp(-1, 1)
+    ms_p = (torch.randn(8, 3, 64, 64, generator=g) * 0.3).clamp(-1, 1)
+    z, alpha = torch.randn(8, 128, generator=g), torch.rand(8, generator=g)
+    tr.explicit = dict(ms_adapt=ms_a, pen_real=ms_p, alpha=alpha, keep=True)
+    pe.noise_multiplier = 0.0
+    tr.train_D(img.cuda(), None, z.cuda(), None, use_dp=True)
+    assert tr.D.blocks[3].weight.grad is not None
+    oracle.cfg.sigma = 0.0
+    obs = oracle.step(img, None, z, None, ms_adapt=ms_a, pen_real=ms_p, alpha=alpha, apply_update=False)
+    n_o = obs["norms"]
+    _close(tr.last["norms"].reshape(9, -1), n_o.reshape(9, -1), "per-sample norms (bf16 storage)", rtol=5e-3)
+    for i, (a, b) in enumerate(zip(tr.last["summed_clipped"], obs["summed_clipped"])):
+        _close_grad(a, b, "summed_clipped[%d] (bf16 storage)" % i, l2_tol=1e-2, frac_tol=1.0)

@@ -336,3 +336,40 @@ def test_norm_act_backward(kind, N, H, C):
     _close(dx.permute(0, 3, 1, 2), gx_ref, rtol=2e-4, what="norm bwd dx")
     _close(dgam, gg_ref, rtol=2e-4, what="norm bwd dgamma")
     _close(dbet, gb_ref, rtol=2e-4, what="norm bwd dbeta")
+
+
+def test_bf16_grad_sample_storage_kernels():
+    """bf16-stored per-sample gradients: wgrad epilogue rounding (RNE), norms of the ROUNDED values, and the
+    bf16 norm / clip kernels (fp32 accumulate) against torch on the same rounded numbers."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    N, H, C, K, R = 4, 8, 16, 32, 5
+    x = torch.randn(N, C, H, H, generator=g)
+    gy = torch.randn(N, K, H // 2, H // 2, generator=g)
+    w = torch.zeros(K, C, R, R, requires_grad=True)
+    refs = []
+    for b in range(N):
+        y = F.conv2d(x[b:b + 1], w, None, stride=2, padding=2)
+        refs.append(torch.autograd.grad(y, w, gy[b:b + 1])[0] * 2.5)
+    ref = torch.stack(refs)
+    ref_bf = ref.to(torch.bfloat16)                                   # round-to-nearest-even, like the kernel
+    out = torch.empty(N, K, R, R, C, device="cuda", dtype=torch.bfloat16)
+    sq = torch.zeros(N, device="cuda")
+    ops.conv2d_wgrad_grouped(_nhwc(gy), _nhwc(x), R, R, stride=2, pad=2, group=1, alpha=2.5, out=out, sq=sq)
+    got = out.permute(0, 1, 4, 2, 3).float().cpu()
+    mism = (got != ref_bf.float()).float().mean().item()
+    assert mism < 2e-3, "bf16 rounding differs on %.3f%% of entries" % (100 * mism)   # only fp32 last-bit ties may differ
+    _close(got, ref, rtol=8e-3, what="bf16 wgrad")
+    _close(sq, got.reshape(N, -1).double().pow(2).sum(1).float(), rtol=1e-4, what="sq of rounded values")
+    # norm + clip kernels on mixed bf16 / fp32 segments
+    rows, lens = 6, [4803, 64, 1031]
+    mats = [torch.randn(rows, L, generator=g) for L in lens]
+    dm = [mats[0].to(torch.bfloat16).cuda(), mats[1].cuda(), mats[2].to(torch.bfloat16).cuda()]
+    as_f = [d.float().cpu() for d in dm]
+    sqn = ops.sample_sqnorm(dm)
+    _close(sqn, torch.stack([m.double().pow(2).sum(1).float() for m in as_f]), rtol=1e-4, what="bf16 sqnorm")
+    f = torch.rand(3, rows, generator=g)
+    outs = [torch.zeros(L, device="cuda") for L in lens]
+    ops.clip_accum_noise(dm, outs, factors=f.cuda(), scale=0.5)
+    for i in range(3):
+        _close(outs[i], 0.5 * (as_f[i] * f[i][:, None]).sum(0), rtol=1e-4, what="bf16 clip_accum %d" % i)

@@ -32,14 +32,14 @@ PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f
 B_PER_GPU = 128
 
 
-def build_trainer(rank, world, local, batch=B_PER_GPU, outdir=None):
+def build_trainer(rank, world, local, batch=B_PER_GPU, outdir=None, extra=()):
     from csl_gan_amd import distributed as D, init_util, options
     from csl_gan_amd.mean_sampler import MeanSampler
     from csl_gan_amd.trainer import Trainer
     dev = "cuda:%d" % local
     outdir = outdir or tempfile.mkdtemp(prefix="cslgan_bench_")
     opt = options.parse(["CelebA", "-dpm", "gc", "-gcm", "adaptive-pl", "-nms", "32", "-bs", str(batch), "-gd", dev, "-dd", dev,
-                         "-o", outdir, "--manual_seed", "1234", "--synthetic"])
+                         "-o", outdir, "--manual_seed", "1234", "--synthetic"] + list(extra))
     G, Dm = init_util.init_models(opt)
     g = torch.Generator().manual_seed(1234)
     # 32 mean samples: mean of 1000 synthetic images + N(0, 0.12^2)  (options.py:71-72)
@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", type=str, default="", help="extra train.py flags for experiments, e.g. '--grad_sample_dtype bf16' "
+                    "(the headline line is the run WITHOUT this)")
     a = ap.parse_args()
 
     from csl_gan_amd import distributed as D, ops
@@ -99,7 +101,7 @@ def main():
     torch.cuda.set_device(local)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):          # option parsing prints notices; stdout carries ONE JSON line
-        opt, tr, img = build_trainer(rank, world, local)
+        opt, tr, img = build_trainer(rank, world, local, extra=a.opt.split())
     B = img.shape[0]
 
     def step():
@@ -148,7 +150,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "CelebA DCResNet D-step: dp_mode=gc -gcm adaptive-pl -nms 32, WGAN-GP on mean samples, 3x64x64",
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                   "materialize": getattr(opt, "materialize", "all"),
+                   "materialize": getattr(opt, "materialize", "all"), "grad_sample_dtype": getattr(opt, "grad_sample_dtype", "fp32"),
+                   "fuse_passes": bool(getattr(opt, "fuse_passes", False)),
                    "step": "train_D (adaptive pass + G fwd + 2 D passes + per-sample grads + clip + GP + noise + Adam)"},
         "per_gpu": round(ips / world, 2),
         "step_tflops_algorithmic": round(FLOP_PER_IMG_STEP * ips / 1e12, 2),

@@ -75,6 +75,8 @@ CASES = [
     ("CelebA", ["-gcm", "adaptive-pl", "--materialize", "private"], 8, 128),
     ("MNIST", ["--model", "DeepConvResNet", "--penalty", "WGAN-GP", "-c", "3.0", "--materialize", "private"], 6, 16),
     ("MNIST", ["--model", "DeepConvResNet", "--penalty", "WGAN-GP", "-gcm", "adaptive", "-gcs", "False", "--materialize", "private"], 6, 16),
+    # BASELINE config 5 geometry (extension): 128x128 images, one more generator block, 8x8 critic head
+    ("CelebA", ["--im_size", "128", "-gcm", "adaptive-pl", "--materialize", "private"], 4, 128),
 ]
 
 
@@ -82,7 +84,7 @@ CASES = [
 def test_train_D_matches_oracle(tmp_path, dataset, extra, B, latent):
     opt, tr, pe, oracle, Do = _setup(tmp_path, dataset, extra, B, latent)
     g = torch.Generator().manual_seed(77)
-    ch, im = (1, 28) if dataset == "MNIST" else (3, 64)
+    ch, im = (1, 28) if dataset == "MNIST" else (3, opt.im_size)
     img = (torch.randn(B, ch, im, im, generator=g) * 0.5).clamp(-1, 1)
     ms_a = (torch.randn(B, ch, im, im, generator=g) * 0.3).clamp(-1, 1)
     ms_p = (torch.randn(B, ch, im, im, generator=g) * 0.3).clamp(-1, 1)

@@ -71,7 +71,8 @@ class ResBlockUp(nn.Module):
     def forward_nhwc(self, x):
         sc = self.shortcut.conv
         # 1x1 conv at low resolution; upsampled on the fly by the last conv's residual read
-        s_low = HF.Conv.apply(x, sc.weight.permute(0, 2, 3, 1).contiguous(), sc.bias, 1, 0, ops.ACT_NONE, False, None, 0)
+        w_sc = sc.weight.permute(0, 2, 3, 1).contiguous()
+        s_low = HF.Conv.apply(x, w_sc, sc.bias, 1, 0, ops.ACT_NONE, False, None, 0, sc._wkey(w_sc))
         o = self.convUp.conv.forward_nhwc(self.bn1.forward_nhwc(x))
         return self.conv.forward_nhwc(self.bn2.forward_nhwc(o), residual=s_low, res_shift=1)
 

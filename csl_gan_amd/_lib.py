@@ -71,9 +71,9 @@ def lib():
         "cslgan_row_l2norm_f32": [vp, i64, i64, vp, vp],
         "cslgan_row_l2norm_bwd_f32": [vp, vp, vp, i64, i64, vp, vp],
         "cslgan_conv2d_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, vp, i32, i32, vp, vp],
-        "cslgan_conv2d_up_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, vp, vp, i32, i32, vp, vp],
-        "cslgan_conv2d_dgrad_f32": [C.POINTER(ConvT), vp, vp, vp, vp, vp, vp],
-        "cslgan_conv2d_up_dgrad_f32": [C.POINTER(ConvT), vp, vp, vp, vp, vp],
+        "cslgan_conv2d_up_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, i32, vp, vp, i32, i32, vp, vp],
+        "cslgan_conv2d_dgrad_f32": [C.POINTER(ConvT), vp, vp, vp, i32, vp, vp, vp],
+        "cslgan_conv2d_up_dgrad_f32": [C.POINTER(ConvT), vp, vp, vp, i32, vp, vp],
         "cslgan_norm_act_bwd_f32": [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, i32, vp, vp, vp, vp, vp],
         "cslgan_sum2x2_f32": [vp, i32, i32, i32, i32, vp, vp],
         "cslgan_conv2d_wgrad_grouped_f32": [C.POINTER(ConvT), vp, vp, i32, f32, vp, vp, vp],

@@ -415,8 +415,12 @@ int launch_kc(KcParams& p, hipStream_t st, long long out_elems) {
         return launch_kc_tile<64, 64, 2, 2>(p, vecA, vecB, st, out_elems);
     }
     static const int t128 = [] { const char* e = getenv("CSLGAN_KC_T128"); return e ? atoi(e) : 300; }();
+    // classes of one launch have different K (9/6/6/4 taps for a 5x5 stride-2 data gradient): with about one
+    // workgroup per CU the launch lasts as long as its heaviest class, so multi-class launches want more, smaller tiles
+    static const int tmc = [] { const char* e = getenv("CSLGAN_KC_TMC"); return e ? atoi(e) : 520; }();
+    const int t64 = p.n_cls > 1 ? tmc : 192;
     if (tiles_for(p, 128, 128) >= t128) return launch_kc_tile<128, 128, 2, 2>(p, vecA, vecB, st, out_elems);
-    if (tiles_for(p, 64, 128) >= 192) return launch_kc_tile<64, 128, 1, 4>(p, vecA, vecB, st, out_elems);
+    if (tiles_for(p, 64, 128) >= t64) return launch_kc_tile<64, 128, 1, 4>(p, vecA, vecB, st, out_elems);
     return launch_kc_tile<64, 64, 2, 2>(p, vecA, vecB, st, out_elems);
 }
 
@@ -465,8 +469,8 @@ int cslgan_conv2d_fwd_f32(const cslgan_conv_t* c, const float* x, const float* w
     return launch_kc(p, (hipStream_t)stream, (long long)c->N * c->P * c->Q * c->K);
 }
 
-int cslgan_conv2d_up_fwd_f32(const cslgan_conv_t* c, const float* x, const float* w, float* wphase_ws, const float* bias,
-                             const float* residual, int res_shift, int act, float* y, void* stream) {
+int cslgan_conv2d_up_fwd_f32(const cslgan_conv_t* c, const float* x, const float* w, float* wphase_ws, int repack,
+                             const float* bias, const float* residual, int res_shift, int act, float* y, void* stream) {
     CSLGAN_REQUIRE(c && x && w && wphase_ws && y, "conv2d_up_fwd: null argument");
     int rc = check_conv(c, "conv2d_up_fwd");
     if (rc) return rc;
@@ -515,7 +519,7 @@ int cslgan_conv2d_up_fwd_f32(const cslgan_conv_t* c, const float* x, const float
                 }
             ra.cls_T[cls] = T; ra.cls_off[cls] = off; off += T * c->K * c->C;
         }
-    {
+    if (repack) {
         unsigned gxn = (unsigned)(((long long)c->K * c->C * 9 + 255) / 256);
         gxn = gxn > 1024 ? 1024 : (gxn < 1 ? 1 : gxn);
         hipLaunchKernelGGL(repack_filters_kernel, dim3(gxn, 4), dim3(256), 0, st, w, wphase_ws, ra);
@@ -535,7 +539,8 @@ int64_t cslgan_conv2d_up_ws_floats(int K, int R, int C) {
 //   gx[i] = sum_o w'(o) gy[2i + o],  o in [pad-R+1, pad+1] per axis, w'(o) = sum of the filter taps kh with
 //   kh in {pad-o, pad-o+1}: the 2x2 sum-pool of the dense data gradient folded into (R+1)^2 strided taps
 //   (36 instead of 4*25 MACs per low-res pixel for 5x5).
-int cslgan_conv2d_up_dgrad_f32(const cslgan_conv_t* c, const float* gy, const float* w, float* wt_ws, float* gx, void* stream) {
+int cslgan_conv2d_up_dgrad_f32(const cslgan_conv_t* c, const float* gy, const float* w, float* wt_ws, int repack, float* gx,
+                               void* stream) {
     CSLGAN_REQUIRE(c && gy && w && wt_ws && gx, "conv2d_up_dgrad: null argument");
     int rc = check_conv(c, "conv2d_up_dgrad");
     if (rc) return rc;
@@ -563,7 +568,7 @@ int cslgan_conv2d_up_dgrad_f32(const cslgan_conv_t* c, const float* gy, const fl
             ra.kw_lo[0][t] = (signed char)(xlo < 0 ? 0 : xlo); ra.kw_hi[0][t] = (signed char)(xlo + 2 > R ? R : xlo + 2);
         }
     ra.cls_T[0] = k.T; ra.cls_off[0] = 0;
-    {
+    if (repack) {
         unsigned gxn = (unsigned)(((long long)c->K * c->C * k.T + 255) / 256);
         gxn = gxn > 1024 ? 1024 : (gxn < 1 ? 1 : gxn);
         hipLaunchKernelGGL(repack_filters_kernel, dim3(gxn, 1), dim3(256), 0, st, w, wt_ws, ra);
@@ -573,8 +578,8 @@ int cslgan_conv2d_up_dgrad_f32(const cslgan_conv_t* c, const float* gy, const fl
     return launch_kc(p, st, (long long)c->N * c->H * c->W * c->C);
 }
 
-int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* c, const float* gy, const float* w, float* wt_ws, const float* mask,
-                            float* gx, void* stream) {
+int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* c, const float* gy, const float* w, float* wt_ws, int repack,
+                            const float* mask, float* gx, void* stream) {
     CSLGAN_REQUIRE(c && gy && w && wt_ws && gx, "conv2d_dgrad: null argument");
     int rc = check_conv(c, "conv2d_dgrad");
     if (rc) return rc;
@@ -614,7 +619,7 @@ int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* c, const float* gy, const float
             ra.cls_T[cls] = T; ra.cls_off[cls] = off; off += T * c->K * c->C;
         }
     p.n_cls = ncls; ra.n_class = ncls;
-    {
+    if (repack) {
         unsigned gxn = (unsigned)(((long long)c->K * c->C * c->R * c->S / (s * s) + 255) / 256);
         gxn = gxn > 1024 ? 1024 : (gxn < 1 ? 1 : gxn);
         hipLaunchKernelGGL(repack_filters_kernel, dim3(gxn, (unsigned)ncls), dim3(256), 0, st, w, wt_ws, ra);

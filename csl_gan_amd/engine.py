@@ -52,6 +52,8 @@ class HipAdam(torch.optim.Optimizer):
                         g = _like_layout(g, p)
                     ops.adam_step(_flat(p), _flat(g), _flat(st["exp_avg"]), _flat(st["exp_avg_sq"]), grp["lr"], b1, b2,
                                   grp["eps"], grp["weight_decay"], st["step"])
+                    # the kernel wrote p through its raw pointer: tell autograd (and ops.repack_cache) it changed
+                    torch.autograd.graph.increment_version(p)
                 else:
                     if grp["weight_decay"]:
                         g = g.add(p, alpha=grp["weight_decay"])

@@ -93,9 +93,10 @@ def _dense_group(N: int, tiles: int = 1) -> int:
 
 class Conv(Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, upsample, residual, res_shift):
+    def forward(ctx, x, w, b, stride, pad, act, upsample, residual, res_shift, wkey=None):
         y = ops.conv2d_fwd(x, w, b, stride=stride, pad=pad, upsample=upsample, residual=residual,
-                           res_shift=res_shift, act=act)
+                           res_shift=res_shift, act=act, wkey=wkey)
+        ctx.wkey = wkey            # id() of the owning nn.Parameter: lets ops reuse repacked filters while it is unchanged
         ctx.cfg = (stride, pad, act, upsample, res_shift)
         ctx.has_res = residual is not None
         ctx.input_only = _INPUT_GRADS_ONLY
@@ -116,12 +117,12 @@ class Conv(Function):
         gz = gz.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = Dgrad.apply(gz, w, x.shape[1], x.shape[2], stride, pad)
+            gx = Dgrad.apply(gz, w, x.shape[1], x.shape[2], stride, pad, ctx.wkey)
         if ctx.needs_input_grad[1] and not ctx.input_only:
             gw = Wgrad.apply(gz, x, w.shape[1], w.shape[2], stride, pad)
         if ctx.needs_input_grad[2] and not ctx.input_only:
             gb = BiasGrad.apply(gz)
-        return gx, gw, gb, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None
 
 
 def _conv_backward_generator(ctx, gy, x, w, y):
@@ -137,7 +138,8 @@ def _conv_backward_generator(ctx, gy, x, w, y):
         gx = gw = gb = gres = None
         R, S = w.shape[1], w.shape[2]
         if ctx.needs_input_grad[0]:
-            gx = ops.conv2d_up_dgrad(gz, w, pad) if upsample else ops.conv2d_dgrad(gz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad)
+            gx = (ops.conv2d_up_dgrad(gz, w, pad, wkey=ctx.wkey) if upsample
+                  else ops.conv2d_dgrad(gz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad, wkey=ctx.wkey))
         if ctx.needs_input_grad[1]:
             N = x.shape[0]
             tiles = ((gz.shape[-1] + 127) // 128) * ((R * S * x.shape[-1] + 127) // 128)
@@ -153,7 +155,7 @@ def _conv_backward_generator(ctx, gy, x, w, y):
             ops.clip_accum_noise([part], [gb])
         if ctx.has_res and ctx.needs_input_grad[7]:
             gres = ops.sum2x2(gz) if res_shift else gz
-    return gx, gw, gb, None, None, None, None, gres, None
+    return gx, gw, gb, None, None, None, None, gres, None, None
 
 
 Conv._backward_generator = staticmethod(_conv_backward_generator)
@@ -186,10 +188,11 @@ class NormAct(Function):
 
 class Dgrad(Function):
     @staticmethod
-    def forward(ctx, gy, w, H, W, stride, pad):
+    def forward(ctx, gy, w, H, W, stride, pad, wkey=None):
         ctx.cfg = (H, W, stride, pad)
+        ctx.wkey = wkey
         ctx.save_for_backward(gy, w)
-        return ops.conv2d_dgrad(gy, w, (H, W), stride=stride, pad=pad)
+        return ops.conv2d_dgrad(gy, w, (H, W), stride=stride, pad=pad, wkey=wkey)
 
     @staticmethod
     def backward(ctx, ggx):
@@ -198,10 +201,10 @@ class Dgrad(Function):
         ggx = ggx.contiguous()
         g_gy = g_w = None
         if ctx.needs_input_grad[0]:
-            g_gy = Conv.apply(ggx, w, None, stride, pad, ops.ACT_NONE, False, None, 0)
+            g_gy = Conv.apply(ggx, w, None, stride, pad, ops.ACT_NONE, False, None, 0, ctx.wkey)
         if ctx.needs_input_grad[1]:
             g_w = Wgrad.apply(gy, ggx, w.shape[1], w.shape[2], stride, pad)
-        return g_gy, g_w, None, None, None, None
+        return g_gy, g_w, None, None, None, None, None
 
 
 class Wgrad(Function):
@@ -239,8 +242,9 @@ class ConvPerSample(Function):
     store (the Opacus-hook replacement, train.py:373,387) and returns only the data gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, sink, pass_idx):
+    def forward(ctx, x, w, b, stride, pad, act, sink, pass_idx, wkey=None):
         y = ops.conv2d_fwd(x, w, b, stride=stride, pad=pad, act=act)
+        ctx.wkey = wkey
         ctx.cfg = (stride, pad, act)
         ctx.sink, ctx.pass_idx = sink, pass_idx
         ctx.has_bias = b is not None
@@ -260,8 +264,8 @@ class ConvPerSample(Function):
             ctx.sink.collect(ctx.pass_idx, gz, x, w.shape[1], w.shape[2], stride, pad, ctx.has_bias)
             gx = None
             if ctx.needs_input_grad[0]:
-                gx = ops.conv2d_dgrad(gz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad)
-        return gx, None, None, None, None, None, None, None
+                gx = ops.conv2d_dgrad(gz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad, wkey=ctx.wkey)
+        return gx, None, None, None, None, None, None, None, None
 
 
 class RowL2Norm(Function):

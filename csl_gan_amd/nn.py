@@ -55,9 +55,13 @@ class HipConv2d(nn.Conv2d, _PerSampleMixin):
         if self._per_sample_active() and residual is None and not self.upsample:
             sink = self._sink
             return HF.ConvPerSample.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act,
-                                          sink.collector(self), sink.next_pass(self))
+                                          sink.collector(self), sink.next_pass(self), self._wkey(w))
         return HF.Conv.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act, self.upsample,
-                             residual, res_shift)
+                             residual, res_shift, self._wkey(w))
+
+    def _wkey(self, w):
+        # only a zero-copy view of the parameter shares its version counter; a re-laid-out copy must not be cached
+        return id(self.weight) if w.data_ptr() == self.weight.data_ptr() else None
 
     def forward(self, x):
         if not x.is_cuda:
@@ -81,11 +85,12 @@ class HipLinear(nn.Linear, _PerSampleMixin):
         B = x.shape[0]
         x4 = x.contiguous().reshape(B, 1, 1, self.in_features)
         w4 = self.weight.reshape(self.out_features, 1, 1, self.in_features)
+        wkey = id(self.weight) if w4.data_ptr() == self.weight.data_ptr() else None
         if self._per_sample_active():
             sink = self._sink
-            y = HF.ConvPerSample.apply(x4, w4, self.bias, 1, 0, self.act, sink.collector(self), sink.next_pass(self))
+            y = HF.ConvPerSample.apply(x4, w4, self.bias, 1, 0, self.act, sink.collector(self), sink.next_pass(self), wkey)
         else:
-            y = HF.Conv.apply(x4, w4, self.bias, 1, 0, self.act, False, None, 0)
+            y = HF.Conv.apply(x4, w4, self.bias, 1, 0, self.act, False, None, 0, wkey)
         return y.reshape(B, self.out_features)
 
 

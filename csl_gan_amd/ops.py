@@ -21,6 +21,36 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _RepackCache:
+    """Repacked filter matrices (data-gradient classes, upsample phases) keyed by the filter tensor's storage and
+    autograd version counter: any in-place torch op bumps the counter, and HipAdam — which writes the weights
+    through raw pointers — bumps it explicitly (torch.autograd.graph.increment_version).  A D-step reuses each
+    critic layer's repack four times and the generator's phase filters until the next generator step."""
+
+    def __init__(self, max_entries=64):
+        self.d, self.max = {}, max_entries      # callers pass wkey=id(parameter) only for module-owned filters
+
+    def get(self, kind, w, numel, wkey=None):
+        if wkey is None:          # not known to be a live parameter (a temporary may reuse an address): never cache
+            return torch.empty(numel, device=w.device, dtype=torch.float32), 1
+        key = (kind, wkey, w.data_ptr(), tuple(w.shape))
+        ver = w._version
+        hit = self.d.get(key)
+        if hit is not None and hit[0] == ver and hit[1].numel() == numel and hit[1].device == w.device:
+            return hit[1], 0
+        if len(self.d) >= self.max:
+            self.d.clear()
+        ws = torch.empty(numel, device=w.device, dtype=torch.float32)
+        self.d[key] = (ver, ws)
+        return ws, 1
+
+    def clear(self):
+        self.d.clear()
+
+
+repack_cache = _RepackCache()
+
+
 class LaunchTimer:
     """HIP-event timing of individual C-ABI launches on the stream they are enqueued on (torch's
     current stream), for bench.py's live roofline figures.  Events are resolved once, after the
@@ -92,7 +122,7 @@ def _conv_desc(N, H, W, Cc, K, R, S, stride, pad, upsample):
 
 
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, upsample=False, residual=None, res_shift=0, act=ACT_NONE, out=None,
-               direct_upsample=False):
+               direct_upsample=False, wkey=None):
     """y[N,P,Q,K] = act(conv(x[N,H,W,C], w[K,R,S,C]) + bias [+ residual]).
 
     upsample=True: nearest-2x upsample of x first; computed by sub-pixel decomposition
@@ -116,9 +146,9 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, upsample=False, residual=None, 
     nbytes = 4.0 * (N * VH * VW * Cc + K * R * S * Cc + N * P * Q * K)
     if upsample and not direct_upsample and stride == 1 and R == S and R % 2 == 1 and pad == R // 2 and R > 1:
         L = _lib.lib()
-        ws = torch.empty(L.cslgan_conv2d_up_ws_floats(K, R, Cc), device=x.device, dtype=torch.float32)
+        ws, repack = repack_cache.get("up_fwd", w, L.cslgan_conv2d_up_ws_floats(K, R, Cc), wkey)
         _timed("conv2d_fwd", flop, nbytes, lambda: check(
-            L.cslgan_conv2d_up_fwd_f32(C.byref(d), _p(x), _p(w), _p(ws), _p(bias), _p(residual), res_shift, act, _p(y), _stream()),
+            L.cslgan_conv2d_up_fwd_f32(C.byref(d), _p(x), _p(w), _p(ws), repack, _p(bias), _p(residual), res_shift, act, _p(y), _stream()),
             "conv2d_up_fwd"))
         return y
     _timed("conv2d_fwd", flop, nbytes, lambda: check(
@@ -127,7 +157,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, upsample=False, residual=None, 
     return y
 
 
-def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None):
+def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None, wkey=None):
     """gx[N,H,W,C] = conv_transpose(gy[N,P,Q,K], w[K,R,S,C]) (* lrelu'(mask))."""
     _chk(gy, "gy"); _chk(w, "w")
     N, P, Q, K = gy.shape
@@ -137,7 +167,7 @@ def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None):
     if K2 != K or (P2, Q2) != (P, Q):
         raise RuntimeError("conv2d_dgrad: gy shape %s inconsistent with input %dx%d" % (tuple(gy.shape), H, W))
     gx = torch.empty((N, H, W, Cc), device=gy.device, dtype=torch.float32)
-    ws = torch.empty(w.numel(), device=gy.device, dtype=torch.float32)
+    ws, repack = repack_cache.get("dgrad%d" % stride, w, w.numel(), wkey)
     if mask is not None:
         _chk(mask, "mask")
         if tuple(mask.shape) != tuple(gx.shape):
@@ -145,7 +175,7 @@ def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None):
     flop = 2.0 * N * P * Q * K * R * S * Cc
     nbytes = 4.0 * (N * H * W * Cc + K * R * S * Cc + N * P * Q * K)
     _timed("conv2d_dgrad", flop, nbytes, lambda: check(
-        _lib.lib().cslgan_conv2d_dgrad_f32(C.byref(d), _p(gy), _p(w), _p(ws), _p(mask), _p(gx), _stream()), "conv2d_dgrad"))
+        _lib.lib().cslgan_conv2d_dgrad_f32(C.byref(d), _p(gy), _p(w), _p(ws), repack, _p(mask), _p(gx), _stream()), "conv2d_dgrad"))
     return gx
 
 
@@ -177,7 +207,7 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
     return gw
 
 
-def conv2d_up_dgrad(gy, w, pad):
+def conv2d_up_dgrad(gy, w, pad, wkey=None):
     """gx[N,H,W,C] for y = conv(nearest_up2(x), w[K,R,R,C]) ('same', stride 1) from gy[N,2H,2W,K]."""
     _chk(gy, "gy"); _chk(w, "w")
     N, P, Q, K = gy.shape
@@ -187,10 +217,10 @@ def conv2d_up_dgrad(gy, w, pad):
     if K2 != K or (P2, Q2) != (P, Q):
         raise RuntimeError("conv2d_up_dgrad: gy shape %s inconsistent" % (tuple(gy.shape),))
     gx = torch.empty((N, H, W, Cc), device=gy.device, dtype=torch.float32)
-    ws = torch.empty((R + 1) * (R + 1) * K * Cc, device=gy.device, dtype=torch.float32)
+    ws, repack = repack_cache.get("up_dgrad", w, (R + 1) * (R + 1) * K * Cc, wkey)
     flop = 2.0 * N * P * Q * K * R * S * Cc
     _timed("conv2d_dgrad", flop, 4.0 * (gy.numel() + gx.numel() + w.numel()), lambda: check(
-        _lib.lib().cslgan_conv2d_up_dgrad_f32(C.byref(d), _p(gy), _p(w), _p(ws), _p(gx), _stream()), "conv2d_up_dgrad"))
+        _lib.lib().cslgan_conv2d_up_dgrad_f32(C.byref(d), _p(gy), _p(w), _p(ws), repack, _p(gx), _stream()), "conv2d_up_dgrad"))
     return gx
 
 

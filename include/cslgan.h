@@ -125,9 +125,10 @@ int cslgan_conv2d_fwd_f32(const cslgan_conv_t* p, const float* x, const float* w
  * RxR stride-1 conv, DCResNet_models.py:13-17) computed by sub-pixel decomposition: each of the four
  * output phases is an (R/2+1)^2-tap conv of the LOW-resolution input with summed filter taps — 9
  * instead of 25 MACs per output for 5x5; the sums only re-associate the reference arithmetic.
- * wphase_ws: caller workspace of cslgan_conv2d_up_ws_floats(K,R,C) floats (folded filters, rebuilt
- * every call).  All four phases run in ONE launch. */
-int cslgan_conv2d_up_fwd_f32(const cslgan_conv_t* p, const float* x, const float* w, float* wphase_ws,
+ * wphase_ws: caller workspace of cslgan_conv2d_up_ws_floats(K,R,C) floats holding the folded filters; they are
+ * (re)built from w when repack != 0 — a caller that knows w is unchanged since its last call with the same
+ * workspace passes 0 and skips that launch.  All four phases run in ONE launch. */
+int cslgan_conv2d_up_fwd_f32(const cslgan_conv_t* p, const float* x, const float* w, float* wphase_ws, int repack,
                              const float* bias, const float* residual, int res_shift, int act, float* y,
                              void* stream);
 int64_t cslgan_conv2d_up_ws_floats(int K, int R, int C);
@@ -135,13 +136,14 @@ int64_t cslgan_conv2d_up_ws_floats(int K, int R, int C);
 /* Data gradient of the upsample+conv above with respect to its LOW-res input x[N][H][W][C], from
  * gy[N][2H][2W][K]: the 2x2 sum-pool of the dense data gradient folded into (R+1)^2 stride-2 taps.
  * wt_ws: caller workspace of (R+1)*(R+1)*K*C floats.  (Generator backward, train.py:502-511.) */
-int cslgan_conv2d_up_dgrad_f32(const cslgan_conv_t* p, const float* gy, const float* w, float* wt_ws, float* gx,
-                               void* stream);
+int cslgan_conv2d_up_dgrad_f32(const cslgan_conv_t* p, const float* gy, const float* w, float* wt_ws, int repack,
+                               float* gx, void* stream);
 
 /* gx = conv_transpose(gy, w) [* lrelu'(mask)]: the data gradient (autograd of the conv above;
  * "conv_transpose2d" in the north star).  wt_ws: caller workspace of K*R*S*C floats receiving
- * the repacked filters.  mask (nullable) has gx's shape: gx *= (mask > 0 ? 1 : 0.2). */
-int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* p, const float* gy, const float* w, float* wt_ws,
+ * the repacked filters (rebuilt when repack != 0, reused otherwise).  mask (nullable) has gx's shape:
+ * gx *= (mask > 0 ? 1 : 0.2). */
+int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* p, const float* gy, const float* w, float* wt_ws, int repack,
                             const float* mask, float* gx, void* stream);
 
 /* Grouped weight gradient:  gw[g][k][r][s][c] = alpha * sum_{n in group g} sum_{p,q} gy[n,p,q,k] x[n,..,c]

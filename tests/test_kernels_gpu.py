@@ -373,3 +373,43 @@ def test_bf16_grad_sample_storage_kernels():
     ops.clip_accum_noise(dm, outs, factors=f.cuda(), scale=0.5)
     for i in range(3):
         _close(outs[i], 0.5 * (as_f[i] * f[i][:, None]).sum(0), rtol=1e-4, what="bf16 clip_accum %d" % i)
+
+
+def test_repack_cache_follows_weight_updates():
+    """Repacked data-gradient / upsample-phase filters are cached per parameter + version counter: an in-place
+    torch update and a HipAdam step (raw-pointer kernel + explicit version bump) must both invalidate them."""
+    from csl_gan_amd import nn as hnn, ops, functional as HF
+    from csl_gan_amd.engine import HipAdam
+    torch.manual_seed(0)
+    conv = hnn.to_device_layout(hnn.HipConv2d(8, 16, 5, stride=2, padding=2).cuda())
+    up = hnn.to_device_layout(hnn.HipConv2d(8, 8, 5, padding="same", bias=False, upsample=True).cuda())
+    x = torch.randn(2, 8, 8, 8)
+
+    def run():
+        xd = x.clone().cuda().requires_grad_(True)
+        y = conv(xd)
+        gx, = torch.autograd.grad(y.sum(), xd)
+        with torch.no_grad():
+            yu = up(x.cuda())
+        return gx.cpu(), yu.cpu()
+
+    def ref():
+        xr = x.clone().requires_grad_(True)
+        y = F.conv2d(xr, conv.weight.detach().cpu(), conv.bias.detach().cpu(), stride=2, padding=2)
+        gx, = torch.autograd.grad(y.sum(), xr)
+        yu = F.conv2d(x.repeat_interleave(2, 2).repeat_interleave(2, 3), up.weight.detach().cpu(), None, padding=2)
+        return gx, yu
+    for step in range(3):
+        (g1, u1), (g0, u0) = run(), ref()
+        _close(g1, g0, what="dgrad step %d" % step); _close(u1, u0, what="up fwd step %d" % step)
+        (g2, u2) = run()                                          # second call: served from the cache
+        assert torch.equal(g1, g2) and torch.equal(u1, u2)
+        if step == 0:
+            with torch.no_grad():
+                conv.weight.mul_(1.5); up.weight.add_(0.1)       # in-place torch ops bump the version counter
+        elif step == 1:
+            opt = HipAdam(list(conv.parameters()) + list(up.parameters()), lr=0.05, betas=(0.0, 0.9))
+            for p in list(conv.parameters()) + list(up.parameters()):
+                p.grad = torch.ones_like(p, memory_format=torch.preserve_format)
+            opt.step()
+    assert len(ops.repack_cache.d) >= 2

@@ -75,10 +75,12 @@ def cpu_baseline():
         st.step(img, None, torch.randn(B, 128, generator=g), None, ms_adapt=ms, pen_real=ms, alpha=torch.rand(B, generator=g), noise_gen=g)
         return time.perf_counter() - t0
     one(8)                       # warm-up (allocator, thread pool)
-    Bs = 32
-    dt = one(Bs)
-    return {"value": round(Bs / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 oracle D-step (config 3) on a bs=%d slice of the bs=128 workload after a bs=8 warm-up, %.1f s" % (Bs, dt)}
+    n_steps, dt = 0, 0.0
+    while dt < 10.0 and n_steps < 4:          # about 10-20 s of host work
+        dt += one(B_PER_GPU)
+        n_steps += 1
+    return {"value": round(n_steps * B_PER_GPU / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d oracle D-step(s) (config 3) at bs=128 after a bs=8 warm-up, %.1f s" % (n_steps, dt)}
 
 
 def main():
@@ -141,7 +143,10 @@ def main():
         ach = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic if dom["name"].startswith("conv2d") else None,
-                "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]), "launches_per_step": dom["n"] / a.steps,
+                "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]),
+                "executed_tflops": round(dom["exec_flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
+                "note": "achieved counts the reference's algorithmic FLOP (25-tap upsample convs); the kernel executes 9 of those "
+                        "25 taps (sub-pixel decomposition), so frac can exceed 1 — executed_tflops is the hardware rate", "launches_per_step": dom["n"] / a.steps,
                 "avg_launch_ms": round(dom["ms"] / dom["n"], 4), "share_of_step": round(dom["ms"] / (dt * 1e3), 3)}
     line = {
         "metric": "images/sec/GPU CelebA DCResNet dp_mode=gc bs=128 at 1/2/4/8 MI355X",

@@ -64,17 +64,18 @@ class LaunchTimer:
         e.record()
         return e
 
-    def end(self, name, flop, nbytes, start):
+    def end(self, name, flop, nbytes, start, exec_flop=None):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        self.records.append((name, flop, nbytes, start, e))
+        self.records.append((name, flop, nbytes, start, e, flop if exec_flop is None else exec_flop))
 
     def summary(self):
         out = {}
-        for name, flop, nbytes, s, e in self.records:
-            d = out.setdefault(name, {"name": name, "ms": 0.0, "flop": 0.0, "bytes": 0.0, "n": 0})
+        for name, flop, nbytes, s, e, xf in self.records:
+            d = out.setdefault(name, {"name": name, "ms": 0.0, "flop": 0.0, "exec_flop": 0.0, "bytes": 0.0, "n": 0})
             d["ms"] += s.elapsed_time(e)
             d["flop"] += flop
+            d["exec_flop"] += xf
             d["bytes"] += nbytes
             d["n"] += 1
         return out
@@ -88,12 +89,14 @@ def set_launch_timer(t):
     _timer = t
 
 
-def _timed(name, flop, nbytes, fn):
+def _timed(name, flop, nbytes, fn, exec_flop=None):
+    """flop = algorithmic FLOP of the op as the reference executes it; exec_flop = FLOP the kernel really issues
+    (differs for the sub-pixel upsample convs)."""
     if _timer is None:
         return fn()
     s = _timer.begin()
     r = fn()
-    _timer.end(name, flop, nbytes, s)
+    _timer.end(name, flop, nbytes, s, exec_flop)
     return r
 
 
@@ -149,7 +152,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, upsample=False, residual=None, 
         ws, repack = repack_cache.get("up_fwd", w, L.cslgan_conv2d_up_ws_floats(K, R, Cc), wkey)
         _timed("conv2d_fwd", flop, nbytes, lambda: check(
             L.cslgan_conv2d_up_fwd_f32(C.byref(d), _p(x), _p(w), _p(ws), repack, _p(bias), _p(residual), res_shift, act, _p(y), _stream()),
-            "conv2d_up_fwd"))
+            "conv2d_up_fwd"), exec_flop=flop * (R // 2 + 1) ** 2 / float(R * S))
         return y
     _timed("conv2d_fwd", flop, nbytes, lambda: check(
         _lib.lib().cslgan_conv2d_fwd_f32(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), res_shift, act, _p(y), _stream()),

@@ -32,59 +32,74 @@ __global__ void act_bwd_kernel(const float* __restrict__ g, const float* __restr
 // consecutive channels:  s = (row / rows_per_stat) * n_groups + c / cpg.
 //   GroupNorm(G): rows_per_stat = H*W, cpg = C/G, n_groups = G        (per image, per group)
 //   BatchNorm   : rows_per_stat = R,   cpg = 1,   n_groups = C        (per channel over the batch)
-// PASS 0 accumulates sum(x) into stats[2s]; PASS 1 accumulates sum((x-mean_s)^2) into stats[2s+1]
-// (two-pass variance: no E[x^2]-mean^2 cancellation).  Rows are read with 16-byte loads, coalesced along
-// C; partial sums go thread -> LDS (one float per channel) -> one global atomic per channel per block.
+// ONE pass over x accumulates shifted moments  S1 = sum(x - k_s),  S2 = sum((x - k_s)^2)  with the shift k_s = the
+// statistic's first element (x[first row of s][first channel of s]): mean = k + S1/n, var = S2/n - (S1/n)^2.
+// The shift is a sample of the same distribution, so the subtraction loses about one bit instead of the
+// catastrophic cancellation of raw E[x^2] - mean^2, and x is read once instead of twice.  A tiny finalize
+// kernel turns (S1, S2) into the (sum, centred sum of squares) pair the apply / backward kernels consume.
+// Rows are read with 16-byte loads, coalesced along C; partial sums go thread -> LDS (per channel) -> one
+// global atomic per channel per block.
 constexpr int NS_ROWS = 64;   // rows per block
 
-template <int PASS, bool VEC>
+template <bool VEC>
 __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x, long long rows_per_stat, int C, int cpg,
                                                          int n_groups, float* __restrict__ stats) {
-    extern __shared__ float s_acc[];   // [C]
+    extern __shared__ float s_acc[];   // [2*C]: S1, S2 per channel
     const int tid = threadIdx.x;
-    for (int c = tid; c < C; c += 256) s_acc[c] = 0.f;
+    for (int c = tid; c < 2 * C; c += 256) s_acc[c] = 0.f;
     __syncthreads();
     const long long sr = blockIdx.y;                      // which row-group of statistics
-    const long long r0 = sr * rows_per_stat + (long long)blockIdx.x * NS_ROWS;
+    const long long row_first = sr * rows_per_stat;
+    const long long r0 = row_first + (long long)blockIdx.x * NS_ROWS;
     long long r1 = r0 + NS_ROWS;
-    const long long rend = (sr + 1) * rows_per_stat;
+    const long long rend = row_first + rows_per_stat;
     if (r1 > rend) r1 = rend;
-    const float inv_cnt = 1.f / ((float)rows_per_stat * (float)cpg);
     if (VEC) {
         const int c4n = C >> 2;
         const int c4 = tid % c4n, rl = tid / c4n, rstep = 256 / c4n;
-        float m[4] = {0.f, 0.f, 0.f, 0.f};
-        if (PASS == 1) {
+        float k[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) m[e] = stats[2 * (sr * n_groups + (4 * c4 + e) / cpg)] * inv_cnt;
-        }
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = 0; e < 4; ++e) k[e] = x[row_first * C + ((4 * c4 + e) / cpg) * cpg];
+        float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
         for (long long r = r0 + rl; r < r1; r += rstep) {
             const float4 v = *reinterpret_cast<const float4*>(x + r * C + 4 * c4);
-            if (PASS == 0) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
-            else {
-                const float a = v.x - m[0], b = v.y - m[1], c = v.z - m[2], d = v.w - m[3];
-                acc.x = fmaf(a, a, acc.x); acc.y = fmaf(b, b, acc.y); acc.z = fmaf(c, c, acc.z); acc.w = fmaf(d, d, acc.w);
-            }
+            const float d[4] = {v.x - k[0], v.y - k[1], v.z - k[2], v.w - k[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a1[e] += d[e]; a2[e] = fmaf(d[e], d[e], a2[e]); }
         }
-        atomicAdd(&s_acc[4 * c4 + 0], acc.x);
-        atomicAdd(&s_acc[4 * c4 + 1], acc.y);
-        atomicAdd(&s_acc[4 * c4 + 2], acc.z);
-        atomicAdd(&s_acc[4 * c4 + 3], acc.w);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(&s_acc[2 * (4 * c4 + e)], a1[e]);
+            atomicAdd(&s_acc[2 * (4 * c4 + e) + 1], a2[e]);
+        }
     } else {
         const long long n = (r1 - r0) * C;
         for (long long i = tid; i < n; i += 256) {
             const int c = (int)(i % C);
-            float v = x[r0 * C + i];
-            if (PASS == 1) {
-                v -= stats[2 * (sr * n_groups + c / cpg)] * inv_cnt;
-                v *= v;
-            }
-            atomicAdd(&s_acc[c], v);
+            const float d = x[r0 * C + i] - x[row_first * C + (c / cpg) * cpg];
+            atomicAdd(&s_acc[2 * c], d);
+            atomicAdd(&s_acc[2 * c + 1], d * d);
         }
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) atomicAdd(&stats[2 * (sr * n_groups + c / cpg) + PASS], s_acc[c]);
+    for (int c = tid; c < 2 * C; c += 256) atomicAdd(&stats[2 * (sr * n_groups + (c >> 1) / cpg) + (c & 1)], s_acc[c]);
+}
+
+// (S1, S2) about the shift k  ->  (sum x, sum (x-mean)^2)
+__global__ void norm_stats_finalize_kernel(const float* __restrict__ x, long long rows_per_stat, int C, int cpg, int n_groups,
+                                           long long n_stats, float* __restrict__ stats) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_stats) return;
+    const long long sr = s / n_groups;
+    const int g = (int)(s - sr * n_groups);
+    const float k = x[sr * rows_per_stat * C + g * cpg];
+    const float cnt = (float)rows_per_stat * (float)cpg;
+    const float S1 = stats[2 * s], S2 = stats[2 * s + 1];
+    const float m1 = S1 / cnt;
+    float css = S2 - S1 * m1;           // sum (x-mean)^2 = S2 - S1^2/n
+    if (css < 0.f) css = 0.f;
+    stats[2 * s] = (k + m1) * cnt;      // sum x
+    stats[2 * s + 1] = css;
 }
 
 // y = act((x - mean_s) * rstd_s * gamma[c] + beta[c])
@@ -267,17 +282,16 @@ static int launch_norm(const float* x, const float* gamma, const float* beta, lo
         set_error("norm: hipMemsetAsync failed");
         return CSLGAN_ERR_LAUNCH;
     }
-    const bool vec = (C % 4 == 0) && ((C / 4) <= 256) && (256 % (C / 4) == 0) && aligned16(x) && aligned16(y);
+    const bool vec = (C % 4 == 0) && ((C / 4) <= 256) && (256 % (C / 4) == 0) && (cpg % 4 == 0 || 4 % cpg == 0) && aligned16(x) && aligned16(y);
     const dim3 grid((unsigned)((rows_per_stat + NS_ROWS - 1) / NS_ROWS), (unsigned)n_row_groups), block(256);
     const size_t lds = sizeof(float) * C;
-    if (vec) {
-        hipLaunchKernelGGL((norm_stats_kernel<0, true>), grid, block, lds, st, x, rows_per_stat, C, cpg, n_groups, stats);
-        hipLaunchKernelGGL((norm_stats_kernel<1, true>), grid, block, lds, st, x, rows_per_stat, C, cpg, n_groups, stats);
-    } else {
-        hipLaunchKernelGGL((norm_stats_kernel<0, false>), grid, block, lds, st, x, rows_per_stat, C, cpg, n_groups, stats);
-        hipLaunchKernelGGL((norm_stats_kernel<1, false>), grid, block, lds, st, x, rows_per_stat, C, cpg, n_groups, stats);
-    }
+    if (vec) hipLaunchKernelGGL((norm_stats_kernel<true>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, stats);
+    else hipLaunchKernelGGL((norm_stats_kernel<false>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, stats);
     int rc = check_launch("norm_stats_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(norm_stats_finalize_kernel, dim3((unsigned)((n_stats + 127) / 128)), dim3(128), 0, st, x, rows_per_stat, C, cpg,
+                       n_groups, n_stats, stats);
+    rc = check_launch("norm_stats_finalize_kernel");
     if (rc) return rc;
     const long long total = R * C;
     long long nb = (total / 4 + 255) / 256;

@@ -33,8 +33,9 @@ def _close_grad(got, exp, what, l2_tol=5e-3, frac_tol=0.03, abs_floor=0.0):
     l2 = ((got - exp).norm() / (exp.norm() + 1e-30)).item()
     assert l2 <= l2_tol, "%s: relative L2 error %.3e" % (what, l2)
     scale = exp.abs().max().item() + 1e-30
-    frac = ((got - exp).abs() > RTOL * scale).double().mean().item()
-    assert frac <= frac_tol, "%s: %.2f%% of entries off by more than 1e-3 of scale" % (what, 100 * frac)
+    n_off = ((got - exp).abs() > RTOL * scale).double().sum().item()
+    allowed = max(frac_tol * got.numel(), 4)       # a single flipped unit touches a handful of entries even in a 64-entry bias
+    assert n_off <= allowed, "%s: %d of %d entries off by more than 1e-3 of scale" % (what, n_off, got.numel())
 
 
 def _setup(tmp_path, dataset, extra, B, latent):

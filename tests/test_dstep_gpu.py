@@ -19,14 +19,16 @@ def _close(got, exp, what, rtol=RTOL):
     assert err <= rtol * scale, "%s: max abs err %.3e, scale %.3e, rel %.3e" % (what, err, scale, err / scale)
 
 
-def _close_grad(got, exp, what, l2_tol=2e-2, frac_tol=0.10, abs_floor=0.0):
+def _close_grad(got, exp, what, l2_tol=2e-2, frac_tol=1.0, abs_floor=0.0):
     """Gradient TENSORS of a LeakyReLU network are discontinuous in the activations: a unit whose
     pre-activation is within fp32 rounding of zero takes a different slope on CPU and GPU and shifts the
     gradient entries it feeds by a whole term (entries are sums of hundreds of cancelling terms, so that is
     percent-level on a few rows).  Which units flip also varies from run to run (GroupNorm statistics and
-    norms are reduced with float atomics), so the bounds leave room for a few flips: 2e-2 in relative L2 and at
-    most 10% of the entries beyond 1e-3 of the tensor's scale.  The activation-free tests below check the same
-    wiring to 1e-4 / 5e-4, and losses, penalty, per-sample norms and clip factors are held to 1e-3."""
+    norms are reduced with float atomics) and one flipped unit of one sample shifts EVERY entry of that sample's
+    upstream gradients slightly, so a per-entry count is not a stable criterion (observed: 0 or 12 of the 64
+    entries of the conv0 bias sum beyond 1e-3, run to run).  The bound is 2e-2 in relative L2; the activation-free
+    tests below check the same wiring to 1e-4 / 5e-4, and losses, penalty, per-sample norms and clip factors
+    are held to 1e-3."""
     got = torch.as_tensor(got).detach().cpu().double().reshape(-1)
     exp = torch.as_tensor(exp).detach().cpu().double().reshape(-1)
     assert got.shape == exp.shape, (what, got.shape, exp.shape)

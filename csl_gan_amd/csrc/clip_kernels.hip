@@ -275,6 +275,21 @@ static int launch_sqnorm(const float* const* in, const long long* len, const lon
     return check_launch("sample_sqnorm_kernel");
 }
 
+// sq_accum[r] += ||in[r, :]||^2  (no zeroing: the caller's accumulator semantics, as the wgrad epilogue has)
+int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, float* sq_accum, hipStream_t st) {
+    if (n_rows <= 0 || len <= 0) return CSLGAN_OK;
+    if (n_rows > 65535) { set_error("sqnorm_rows_accumulate: too many rows"); return CSLGAN_ERR_INVALID_ARG; }
+    SqArgs a;
+    for (int s = 0; s < CSLGAN_MAX_SEGS; ++s) { a.in[s] = nullptr; a.len[s] = 0; a.row_stride[s] = 0; a.vec_ok[s] = 0; a.chunk_prefix[s] = 0; }
+    a.n_seg = 1;
+    a.in[0] = in; a.len[0] = len; a.row_stride[0] = len;
+    a.vec_ok[0] = aligned_to(in, 16) && (len % 4 == 0);
+    const int tot = (int)((len + SQ_CHUNK - 1) / SQ_CHUNK);
+    for (int s = 1; s <= CSLGAN_MAX_SEGS; ++s) a.chunk_prefix[s] = tot;
+    hipLaunchKernelGGL(sample_sqnorm_kernel<float>, dim3(tot, (unsigned)n_rows), dim3(SQ_THREADS), 0, st, a, n_rows, sq_accum);
+    return check_launch("sample_sqnorm_kernel");
+}
+
 }  // namespace cslgan
 
 using namespace cslgan;

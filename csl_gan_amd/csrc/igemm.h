@@ -108,6 +108,7 @@ struct McParams {
     int out_bf16;        // 1: gw is stored as bfloat16 (round-to-nearest-even); sq is taken over the ROUNDED values
     float* sq;           // [n_groups] or null
     int tiles_m, tiles_n;
+    int ksplit;          // >1: the group's pixels are divided over ksplit workgroups that atomically add into zeroed gw
     signed char ty[IG_MAX_TAPS], tx[IG_MAX_TAPS];   // kh-pad, kw-pad
 };
 

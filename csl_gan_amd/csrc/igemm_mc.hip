@@ -32,8 +32,10 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
 
     const int tid = threadIdx.x;
     const int per_g = p.tiles_m * p.tiles_n;
-    const int g = blockIdx.x / per_g;
-    const int tl = blockIdx.x - g * per_g;
+    const int split = p.ksplit > 1 ? blockIdx.x % p.ksplit : 0;
+    const int bid = p.ksplit > 1 ? blockIdx.x / p.ksplit : blockIdx.x;
+    const int g = bid / per_g;
+    const int tl = bid - g * per_g;
     const int tile_m = tl / p.tiles_n, tile_n = tl - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int PQ = p.P * p.Q;
@@ -125,12 +127,19 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-    const int nk = (Ktot + MC_BK - 1) / MC_BK;
-    load_tile(0);
+    const int nk_all = (Ktot + MC_BK - 1) / MC_BK;
+    int kt0 = 0, nk = nk_all;
+    if (p.ksplit > 1) {
+        const int per = (nk_all + p.ksplit - 1) / p.ksplit;
+        kt0 = split * per;
+        nk = kt0 + per < nk_all ? kt0 + per : nk_all;
+        if (kt0 >= nk) return;      // uniform
+    }
+    load_tile(kt0);
     store_tile(0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int buf = (kt - kt0) & 1;
         if (kt + 1 < nk) load_tile(kt + 1);
         int krem = Ktot - kt * MC_BK;
         if (krem > MC_BK) krem = MC_BK;
@@ -177,11 +186,14 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
                     val = __uint_as_float(u & 0xffff0000u);
                 }
                 ss = fmaf(val, val, ss);
-                if (outg) outg[(long long)m * p.Ndim + n] = val;
+                if (outg) {
+                    if (p.ksplit > 1) atomicAdd(&outg[(long long)m * p.Ndim + n], val);
+                    else outg[(long long)m * p.Ndim + n] = val;
+                }
             }
         }
     }
-    if (p.sq) {
+    if (p.sq && p.ksplit <= 1) {
         const float tot = block_sum_256(ss, s_red);
         if (tid == 0) atomicAdd(p.sq + g, tot);
     }
@@ -214,18 +226,45 @@ __global__ __launch_bounds__(256) void bias_grad_grouped_kernel(const float* __r
     }
 }
 
+int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, float* sq_accum, hipStream_t st);   // clip_kernels.hip
+
 template <int BM, int BN, int WM, int WN>
 static int launch_mc_tile(McParams& p, bool vecA, bool vecB, hipStream_t st) {
     p.tiles_m = (p.Kc + BM - 1) / BM;
     p.tiles_n = (p.Ndim + BN - 1) / BN;
-    const long long nb = (long long)p.n_groups * p.tiles_m * p.tiles_n;
+    // few workgroups with a long pixel loop (the 3-channel first layer: one 64x75 tile per sample, 1024+ pixels):
+    // split the pixels over workgroups that atomically add into the zeroed fp32 output
+    p.ksplit = 1;
+    {
+        const long long base = (long long)p.n_groups * p.tiles_m * p.tiles_n;
+        const int nk_all = (p.group * p.P * p.Q + MC_BK - 1) / MC_BK;
+        if (p.gw && !p.out_bf16 && base < 192 && nk_all >= 32) {
+            long long want = (512 + base - 1) / base;
+            const long long cap = nk_all / 8;
+            p.ksplit = (int)(want < cap ? want : cap);
+            if (p.ksplit < 1) p.ksplit = 1;
+        }
+    }
+    if (p.ksplit > 1) {
+        if (hipMemsetAsync(p.gw, 0, sizeof(float) * (size_t)p.n_groups * p.Kc * p.Ndim, st) != hipSuccess) {
+            set_error("wgrad: hipMemsetAsync failed");
+            return CSLGAN_ERR_LAUNCH;
+        }
+    }
+    const long long nb = (long long)p.n_groups * p.tiles_m * p.tiles_n * p.ksplit;
     if (nb > 0x7fffffffll) { set_error("wgrad: grid too large"); return CSLGAN_ERR_INVALID_ARG; }
     const dim3 grid((unsigned)nb), block(256);
     if (vecA && vecB) hipLaunchKernelGGL((igemm_mc_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, p);
     else if (vecA) hipLaunchKernelGGL((igemm_mc_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, p);
     else if (vecB) hipLaunchKernelGGL((igemm_mc_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((igemm_mc_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, p);
-    return check_launch("igemm_mc_kernel");
+    int rc = check_launch("igemm_mc_kernel");
+    if (rc) return rc;
+    if (p.ksplit > 1 && p.sq) {
+        // the per-group norm needs the completed sums: one pass of the contract norm kernel over the (small) result
+        rc = sqnorm_rows_accumulate(p.gw, p.n_groups, (long long)p.Kc * p.Ndim, p.sq, st);
+    }
+    return rc;
 }
 
 }  // namespace cslgan

@@ -195,6 +195,13 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
         raise RuntimeError("conv2d_wgrad: N=%d not divisible by group=%d" % (N, group))
     G = N // group
     gw = None
+    scratch = False
+    if not want_gw and sq is not None:
+        # norms only, but a layer with a handful of tiles and a long pixel loop (the 3-channel first conv) runs several
+        # times faster when its pixels are split over workgroups, which needs a (small) output to accumulate into
+        tiles = ((K + 63) // 64) * ((R * S * Cc + 127) // 128) * G
+        if tiles < 192 and group * P * Q >= 512 and G * K * R * S * Cc <= (1 << 22):
+            want_gw, scratch = True, True
     if want_gw:
         gw = out if out is not None else torch.empty((G, K, R, S, Cc), device=x.device, dtype=torch.float32)
         _chk(gw, "gw", allow_bf16=True)
@@ -205,9 +212,9 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
     nbytes = 4.0 * (N * H * W * Cc + N * P * Q * K) + float(esz) * (G * K * R * S * Cc)
     L = _lib.lib()
     fn = L.cslgan_conv2d_wgrad_grouped_bf16out_f32 if (want_gw and gw.dtype == torch.bfloat16) else L.cslgan_conv2d_wgrad_grouped_f32
-    _timed("conv2d_wgrad_grouped" + ("" if want_gw else "_normonly"), flop, nbytes, lambda: check(
+    _timed("conv2d_wgrad_grouped" + ("" if (want_gw and not scratch) else "_normonly"), flop, nbytes, lambda: check(
         fn(C.byref(d), _p(gy), _p(x), group, float(alpha), _p(gw), _p(sq), _stream()), "conv2d_wgrad_grouped"))
-    return gw
+    return None if scratch else gw
 
 
 def conv2d_up_dgrad(gy, w, pad, wkey=None):

@@ -27,6 +27,7 @@ constexpr int IG_MAX_TAPS = 40;
 constexpr int IG_MAX_CLS = 4;
 struct KcClass {
     int M, OHc, OWc;     // rows and per-image grid of this class
+    int patch;           // 1: rows enumerate 8x8 patches (needs OHc % 8 == 0 && OWc % 8 == 0)
     int T, Kdim;         // taps, T*AC
     int w_off;           // float offset of this class's [Nn][Kdim] filter matrix from KcParams::w
     int oy0, ox0;        // output phase: out[img][oy*osy+oy0][ox*osx+ox0][n]
@@ -61,13 +62,25 @@ struct RowCoord {
     int img, oy, ox;
 };
 
-CSL_HD RowCoord kc_decode_row(int m, int OHc, int OWc) {
+// Row index -> output coordinate.  patch == 0: row-major over the image (a 128-row tile is a 2-row strip of a 64-wide
+// image: 5x5 taps then read (2+4)/2 = 3x the tile's own pixels).  patch == 1 (grid dims multiples of 8): rows are
+// enumerated 8x8 patch by patch, so a 64-row tile is an 8x8 square and a 128-row tile an 8x16 rectangle — halo
+// factor (12x20)/128 = 1.9 for 5x5 — which is what cuts the L2 / Infinity-Cache re-reads of the input.
+CSL_HD RowCoord kc_decode_row(int m, int OHc, int OWc, int patch = 0) {
     RowCoord r;
     const int per = OHc * OWc;
     r.img = m / per;
     const int rem = m - r.img * per;
-    r.oy = rem / OWc;
-    r.ox = rem - r.oy * OWc;
+    if (patch) {
+        const int pid = rem >> 6, q = rem & 63;
+        const int gw = OWc >> 3;
+        const int gy = pid / gw, gx = pid - gy * gw;
+        r.oy = (gy << 3) + (q >> 3);
+        r.ox = (gx << 3) + (q & 7);
+    } else {
+        r.oy = rem / OWc;
+        r.ox = rem - r.oy * OWc;
+    }
     return r;
 }
 

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void igemm_kc_kernel(cons
     for (int i = 0; i < A_PASS; ++i) {
         const int m = m0 + lrow + 32 * i;
         const bool ok = m < M;
-        const RowCoord rc = kc_decode_row(ok ? m : 0, OHc, OWc);
+        const RowCoord rc = kc_decode_row(ok ? m : 0, OHc, OWc, kc.patch);
         a_img[i] = rc.img * p.AH * p.AW * p.AC;
         a_iy[i] = ok ? rc.oy * p.sy : -(1 << 20);
         a_ix[i] = rc.ox * p.sx;
@@ -250,10 +250,10 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void igemm_kc_kernel(cons
         const int m = m0 + tid;
         int off = -1, roff = 0;
         if (m < M) {
-            if (p.dense_out && !p.res) {
+            if (p.dense_out && !p.res && !kc.patch) {
                 off = m * p.ldo;
             } else {
-                const RowCoord rc = kc_decode_row(m, OHc, OWc);
+                const RowCoord rc = kc_decode_row(m, OHc, OWc, kc.patch);
                 off = kc_out_offset(p, kc, rc);
                 if (p.res) roff = kc_res_offset(p, kc, rc);
             }
@@ -404,6 +404,11 @@ int launch_kc(KcParams& p, hipStream_t st, long long out_elems) {
         } else {
             p.ac_recip = (unsigned)(((1ull << 32) + (unsigned long long)p.AC - 1) / (unsigned long long)p.AC);
         }
+    }
+    static const int patch_env = [] { const char* e = getenv("CSLGAN_KC_PATCH"); return e ? atoi(e) : 1; }();
+    for (int c = 0; c < p.n_cls; ++c) {
+        KcClass& k = p.cls[c];
+        k.patch = (patch_env && k.T > 1 && k.OHc % 8 == 0 && k.OWc % 8 == 0) ? 1 : 0;
     }
     bool kd4 = true;
     for (int c = 0; c < p.n_cls; ++c) kd4 = kd4 && (p.cls[c].Kdim % 4 == 0) && (p.cls[c].w_off % 4 == 0);

@@ -32,6 +32,7 @@ struct KcClass {
     int w_off;           // float offset of this class's [Nn][Kdim] filter matrix from KcParams::w
     int oy0, ox0;        // output phase: out[img][oy*osy+oy0][ox*osx+ox0][n]
     int tile0;           // first m-tile (in the launch's concatenated m-tile space)
+    int ty_min, tx_min, halo_h, halo_w;   // igemm_halo: tap offset range and the (8+range) halo of an 8x8 patch
     signed char ty[IG_MAX_TAPS], tx[IG_MAX_TAPS];
 };
 struct KcParams {

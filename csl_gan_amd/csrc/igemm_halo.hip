@@ -1,0 +1,249 @@
+// fp32 MFMA convolution with an LDS-resident input halo, for the stride-1 tap classes (5x5 "same" convs,
+// the 3x3 phases of the upsample convs, the parity classes of the strided data gradient).  gfx950 only.
+//
+// igemm_kc_kernel re-gathers the A operand from global memory once per filter tap: 25 (or 9) passes over the
+// same input window, each with its own address arithmetic, 16-byte loads and ds_write_b128.  rocprofv3 showed
+// those re-reads overflowing the XCD's L2 (FETCH_SIZE = 3x the algorithmic bytes, served by the Infinity
+// Cache) and the loader occupying a fifth of every K tile.  Here a workgroup owns two 8x8 output patches
+// (128 rows) x BN channels; for every 32-channel chunk it stages the (8+R-1) x (8+S-1) input halo of each patch
+// in LDS ONCE, and all taps read their A fragments straight from that image with a per-tap LDS offset — the
+// global->LDS traffic of A drops by the tap count, and a K step (one tap of one chunk) only streams its 32 x BN
+// filter slice.  Pixels are padded to 36 floats in LDS so the 16 lanes of a ds_read_b128 group hit distinct banks.
+//
+// Same MFMA schedule as igemm_kc (v_mfma_f32_32x32x2_f32, half-wave h owns k = 8g+4h+e), same epilogue.
+#include "common.h"
+#include "igemm.h"
+
+namespace cslgan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned HOOB = 0xFFFFFFF0u;
+constexpr int PIX = 36;                // floats per halo pixel in LDS (32 channels + 4 pad)
+constexpr int HALO_MAX = 12 * 12;      // pixels per patch halo (8+4 squared: up to 5x5 taps)
+
+__device__ __forceinline__ float4 hbuf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
+    constexpr int BM = 128, TM = 2, TN = BN / 64;            // waves 2 (M) x 2 (N); each wave = one patch x BN/2 channels
+    constexpr int B_CH = BN * 4 + 4, B_PASS = BN / 32;
+    __shared__ __attribute__((aligned(16))) float Hs[2 * HALO_MAX * PIX];
+    __shared__ __attribute__((aligned(16))) float Bs[2][8 * B_CH];
+    __shared__ int s_tapoff[IG_MAX_TAPS];
+    __shared__ int s_off[BM];
+    __shared__ int s_roff[BM];
+
+    const int tid = threadIdx.x;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int tile_mg = wg / p.tiles_n, tile_n = wg - tile_mg * p.tiles_n;
+    int ci = 0;
+#pragma unroll 1
+    while (ci + 1 < p.n_cls && tile_mg >= p.cls[ci + 1].tile0) ++ci;
+    const KcClass& kc = p.cls[ci];
+    const int M = kc.M, OHc = kc.OHc, OWc = kc.OWc, T = kc.T;
+    const int m0 = (tile_mg - kc.tile0) * BM, n0 = tile_n * BN;
+    const int HW_ = kc.halo_w, HH_ = kc.halo_h;
+    const int hpix = HH_ * HW_;
+
+    if (tid < IG_MAX_TAPS) s_tapoff[tid] = (((int)kc.ty[tid] - kc.ty_min) * HW_ + ((int)kc.tx[tid] - kc.tx_min)) * PIX;
+
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w + kc.w_off), 0,
+                                                                             p.w_bytes - 4u * (unsigned)kc.w_off, 0x00020000);
+    // ---- the two patches of this tile: image and origin of their halos ----------------------------------
+    int p_img[2], p_y0[2], p_x0[2];
+    bool p_ok[2];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        const int m = m0 + 64 * pp;
+        p_ok[pp] = m < M;
+        const RowCoord rc = kc_decode_row(p_ok[pp] ? m : 0, OHc, OWc, 1);   // first row of the patch = its top-left pixel
+        p_img[pp] = rc.img * p.AH * p.AW * p.AC;
+        p_y0[pp] = rc.oy + kc.ty_min;
+        p_x0[pp] = rc.ox + kc.tx_min;
+    }
+    // ---- B loader coordinates (filter slice of one tap, one 32-channel chunk) ----------------------------
+    const int lrow = tid >> 3, q = tid & 7;
+    unsigned b_off[B_PASS];
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i) {
+        const int n = n0 + lrow + 32 * i;
+        b_off[i] = n < p.Nn ? 4u * ((unsigned)n * (unsigned)kc.Kdim + (unsigned)(q * 4)) : HOOB;
+    }
+    float4 rb[B_PASS];
+    auto load_b = [&](int kbase) {       // kbase = t*AC + cc*32, or -1 past the end
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i)
+            rb[i] = hbuf_load4(w_rsrc, (kbase < 0 || b_off[i] == HOOB) ? HOOB : b_off[i] + 4u * (unsigned)kbase);
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) *reinterpret_cast<float4*>(&Bs[buf][q * B_CH + (lrow + 32 * i) * 4]) = rb[i];
+    };
+    // ---- halo staging: 2 patches x hpix pixels x 8 chunks of 4 channels ----------------------------------
+    auto stage_halo = [&](int cc) {
+        const int total = 2 * hpix * 8;
+        for (int idx = tid; idx < total; idx += 256) {
+            const int ch = idx & 7, pixg = idx >> 3;
+            const int pp = pixg >= hpix ? 1 : 0;
+            const int pix = pixg - pp * hpix;
+            const int hy = pix / HW_, hx = pix - hy * HW_;
+            const int iy = p_y0[pp] + hy, ix = p_x0[pp] + hx;
+            const bool ok = p_ok[pp] && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
+            const unsigned off = ok ? 4u * (unsigned)(p_img[pp] + (iy * p.AW + ix) * p.AC + cc * 32 + ch * 4) : HOOB;
+            *reinterpret_cast<float4*>(&Hs[(pp * HALO_MAX + pix) * PIX + ch * 4]) = hbuf_load4(a_rsrc, off);
+        }
+    };
+
+    // ---- MFMA coordinates ---------------------------------------------------------------------------------
+    const int lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;                   // wm = patch index
+    int a_base[TM];                                          // LDS float offset of this lane's pixel (tap 0,0 corner) per MFMA tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int qq = i * 32 + r;                           // row within the patch
+        a_base[i] = (wm * HALO_MAX + (qq >> 3) * HW_ + (qq & 7)) * PIX + h * 4;
+    }
+    const int brow0 = wn * TN * 32 + r;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    const int n_cc = p.AC >> 5;
+    const int n_steps = n_cc * T;
+    // prologue: halo of chunk 0, filter slice of step 0
+    stage_halo(0);
+    load_b(0);
+    store_b(0);
+    __syncthreads();
+
+    int t = 0, cc = 0;
+    for (int s = 0; s < n_steps; ++s) {
+        const int buf = s & 1;
+        int tn = t + 1, ccn = cc;
+        if (tn == T) { tn = 0; ccn = cc + 1; }
+        load_b(s + 1 < n_steps ? tn * p.AC + ccn * 32 : -1);
+        const int toff = s_tapoff[t];
+        float4 af[2][TM], bf[2][TN];
+        auto load_frags = [&](int g, int slot) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[slot][i] = *reinterpret_cast<const float4*>(&Hs[a_base[i] + toff + g * 8]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[slot][j] = *reinterpret_cast<const float4*>(&Bs[buf][(2 * g + h) * B_CH + (brow0 + j * 32) * 4]);
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cur = g & 1;
+            if (g < 3) load_frags(g + 1, cur ^ 1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].x, bf[cur][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].y, bf[cur][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].z, bf[cur][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i].w, bf[cur][j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        store_b(buf ^ 1);
+        __syncthreads();
+        if (ccn != cc && s + 1 < n_steps) {      // all taps of this chunk are done (uniform): restage the halo
+            stage_halo(ccn);
+            __syncthreads();
+        }
+        t = tn;
+        cc = ccn;
+    }
+
+    // ---- epilogue (as igemm_kc) ---------------------------------------------------------------------------
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int off = -1, roff = 0;
+        if (m < M) {
+            const RowCoord rc = kc_decode_row(m, OHc, OWc, 1);
+            off = kc_out_offset(p, kc, rc);
+            if (p.res) roff = kc_res_offset(p, kc, rc);
+        }
+        s_off[tid] = off;
+        s_roff[tid] = roff;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + r;
+        if (n >= p.Nn) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                const int off = s_off[row];
+                if (off < 0) continue;
+                float val = acc[i][j][v] + bv;
+                if (p.res) val += p.res[s_roff[row] + n];
+                if (p.act == CSLGAN_ACT_LRELU02) val = val > 0.f ? val : 0.2f * val;
+                else if (p.act == CSLGAN_ACT_RELU) val = val > 0.f ? val : 0.f;
+                else if (p.act == CSLGAN_ACT_TANH) val = tanhf(val);
+                if (p.mask) val *= (p.mask[off + n] > 0.f ? 1.f : 0.2f);
+                p.out[off + n] = val;
+            }
+        }
+    }
+}
+
+// Eligibility: every class stride 1, no upsample-on-read, 8x8-patchable grid, channel count a multiple of 32,
+// 2..25 taps within a 12x12 halo, enough output channels to fill the 64-wide N tile.
+bool halo_eligible(const KcParams& p) {
+    if (p.sy != 1 || p.sx != 1 || p.ups != 0 || (p.AC & 31) || p.Nn < 64 || p.ksplit > 1) return false;
+    for (int c = 0; c < p.n_cls; ++c) {
+        const KcClass& k = p.cls[c];
+        if (k.T < 2 || (k.OHc & 7) || (k.OWc & 7) || (k.M & 63)) return false;
+        int ymin = 127, ymax = -128, xmin = 127, xmax = -128;
+        for (int t = 0; t < k.T; ++t) {
+            ymin = k.ty[t] < ymin ? k.ty[t] : ymin; ymax = k.ty[t] > ymax ? k.ty[t] : ymax;
+            xmin = k.tx[t] < xmin ? k.tx[t] : xmin; xmax = k.tx[t] > xmax ? k.tx[t] : xmax;
+        }
+        if (ymax - ymin > 4 || xmax - xmin > 4) return false;
+    }
+    return true;
+}
+
+int launch_halo(KcParams& p, hipStream_t st) {
+    int tm = 0;
+    for (int c = 0; c < p.n_cls; ++c) {
+        KcClass& k = p.cls[c];
+        int ymin = 127, ymax = -128, xmin = 127, xmax = -128;
+        for (int t = 0; t < k.T; ++t) {
+            ymin = k.ty[t] < ymin ? k.ty[t] : ymin; ymax = k.ty[t] > ymax ? k.ty[t] : ymax;
+            xmin = k.tx[t] < xmin ? k.tx[t] : xmin; xmax = k.tx[t] > xmax ? k.tx[t] : xmax;
+        }
+        k.ty_min = ymin; k.tx_min = xmin; k.halo_h = 8 + ymax - ymin; k.halo_w = 8 + xmax - xmin;
+        k.patch = 1;
+        k.tile0 = tm;
+        tm += (k.M + 127) / 128;
+    }
+    p.tiles_m = tm;
+    p.ksplit = 1;
+    const bool wide = p.Nn > 64;
+    p.tiles_n = wide ? (p.Nn + 127) / 128 : 1;
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);
+    if (wide) hipLaunchKernelGGL((igemm_halo_kernel<128>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_halo_kernel<64>), grid, block, 0, st, p);
+    return check_launch("igemm_halo_kernel");
+}
+
+}  // namespace cslgan

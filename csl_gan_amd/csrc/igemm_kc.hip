@@ -376,6 +376,9 @@ static long long tiles_for(const KcParams& p, int BM, int BN) {
     return tm * ((p.Nn + BN - 1) / BN);
 }
 
+bool halo_eligible(const KcParams& p);          // igemm_halo.hip
+int launch_halo(KcParams& p, hipStream_t st);
+
 // out_elems: total floats of the output tensor (needed to zero it when K is split), or 0 to forbid splitting
 int launch_kc(KcParams& p, hipStream_t st, long long out_elems) {
     long long rows = 0;
@@ -405,6 +408,8 @@ int launch_kc(KcParams& p, hipStream_t st, long long out_elems) {
             p.ac_recip = (unsigned)(((1ull << 32) + (unsigned long long)p.AC - 1) / (unsigned long long)p.AC);
         }
     }
+    static const int halo_env = [] { const char* e = getenv("CSLGAN_KC_HALO"); return e ? atoi(e) : 1; }();
+    if (halo_env && halo_eligible(p)) return launch_halo(p, st);
     static const int patch_env = [] { const char* e = getenv("CSLGAN_KC_PATCH"); return e ? atoi(e) : 1; }();
     for (int c = 0; c < p.n_cls; ++c) {
         KcClass& k = p.cls[c];

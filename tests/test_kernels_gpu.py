@@ -50,6 +50,13 @@ FWD_CASES = [
     (128, 1, 1, 8192, 1, 1, 1, 0, True, 0, False, None),
     (3, 1, 1, 1000, 10, 1, 1, 0, True, 0, False, None),
     (2, 8, 8, 32, 48, 5, 1, 2, True, 0, False, 1),
+    # shapes that take the LDS-halo kernel (stride 1, C % 32 == 0, 8x8-patchable grid, K >= 64)
+    (2, 16, 16, 64, 128, 5, 1, 2, True, 1, False, None),
+    (3, 8, 8, 32, 64, 3, 1, 1, True, 0, False, None),
+    (2, 8, 8, 64, 128, 5, 1, 2, False, 0, True, None),
+    (2, 8, 8, 64, 192, 5, 1, 2, True, 2, True, 1),
+    (3, 16, 24, 96, 80, 5, 1, 2, True, 0, False, 0),
+    (2, 32, 32, 128, 128, 5, 1, 2, True, 0, False, None),
     (2, 8, 8, 32, 48, 1, 1, 0, True, 0, False, 0),
     (7, 1, 1, 794, 128, 1, 1, 0, True, 2, False, None),
     (5, 1, 1, 128, 1, 1, 1, 0, True, 0, False, None),
@@ -98,6 +105,9 @@ DGRAD_CASES = [
     (2, 8, 8, 16, 24, 3, 1, 1, False),
     (6, 1, 1, 794, 128, 1, 1, 0, False),
     (2, 32, 32, 64, 128, 5, 2, 2, True),
+    (3, 16, 16, 128, 64, 5, 2, 2, False),
+    (2, 16, 16, 64, 96, 3, 1, 1, True),
+    (2, 32, 32, 64, 256, 5, 2, 2, True),
 ]
 
 

@@ -86,18 +86,36 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
 #pragma unroll
         for (int i = 0; i < B_PASS; ++i) *reinterpret_cast<float4*>(&Bs[buf][q * B_CH + (lrow + 32 * i) * 4]) = rb[i];
     };
-    // ---- halo staging: 2 patches x hpix pixels x 8 chunks of 4 channels ----------------------------------
-    auto stage_halo = [&](int cc) {
-        const int total = 2 * hpix * 8;
-        for (int idx = tid; idx < total; idx += 256) {
+    // ---- halo staging: 2 patches x hpix pixels x 8 chunks of 4 channels; <= 2*144*8/256 = 9 float4 per thread.
+    // fetch_halo() issues the loads into registers (called at the top of a chunk's LAST tap step, so the global
+    // latency hides under that step's MFMAs); commit_halo() writes them to LDS once every wave has left the chunk.
+    constexpr int HREG = (2 * HALO_MAX * 8 + 255) / 256;
+    float4 rh[HREG];
+    const int h_total = 2 * hpix * 8;
+    auto fetch_halo = [&](int cc) {
+#pragma unroll
+        for (int j = 0; j < HREG; ++j) {
+            const int idx = tid + 256 * j;
             const int ch = idx & 7, pixg = idx >> 3;
             const int pp = pixg >= hpix ? 1 : 0;
             const int pix = pixg - pp * hpix;
             const int hy = pix / HW_, hx = pix - hy * HW_;
             const int iy = p_y0[pp] + hy, ix = p_x0[pp] + hx;
-            const bool ok = p_ok[pp] && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
+            const bool ok = idx < h_total && p_ok[pp] && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
             const unsigned off = ok ? 4u * (unsigned)(p_img[pp] + (iy * p.AW + ix) * p.AC + cc * 32 + ch * 4) : HOOB;
-            *reinterpret_cast<float4*>(&Hs[(pp * HALO_MAX + pix) * PIX + ch * 4]) = hbuf_load4(a_rsrc, off);
+            rh[j] = hbuf_load4(a_rsrc, off);
+        }
+    };
+    auto commit_halo = [&]() {
+#pragma unroll
+        for (int j = 0; j < HREG; ++j) {
+            const int idx = tid + 256 * j;
+            if (idx < h_total) {
+                const int ch = idx & 7, pixg = idx >> 3;
+                const int pp = pixg >= hpix ? 1 : 0;
+                const int pix = pixg - pp * hpix;
+                *reinterpret_cast<float4*>(&Hs[(pp * HALO_MAX + pix) * PIX + ch * 4]) = rh[j];
+            }
         }
     };
 
@@ -124,7 +142,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
     const int n_cc = p.AC >> 5;
     const int n_steps = n_cc * T;
     // prologue: halo of chunk 0, filter slice of step 0
-    stage_halo(0);
+    fetch_halo(0);
+    commit_halo();
     load_b(0);
     store_b(0);
     __syncthreads();
@@ -135,6 +154,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
         int tn = t + 1, ccn = cc;
         if (tn == T) { tn = 0; ccn = cc + 1; }
         load_b(s + 1 < n_steps ? tn * p.AC + ccn * 32 : -1);
+        const bool restage = ccn != cc && s + 1 < n_steps;    // uniform: this is the chunk's last tap
+        if (restage) fetch_halo(ccn);
         const int toff = s_tapoff[t];
         float4 af[2][TM], bf[2][TN];
         auto load_frags = [&](int g, int slot) {
@@ -160,8 +181,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
         }
         store_b(buf ^ 1);
         __syncthreads();
-        if (ccn != cc && s + 1 < n_steps) {      // all taps of this chunk are done (uniform): restage the halo
-            stage_halo(ccn);
+        if (restage) {       // every wave has finished the chunk's taps: replace the halo image
+            commit_halo();
             __syncthreads();
         }
         t = tn;

@@ -85,7 +85,7 @@ CSL_HD RowCoord kc_decode_row(int m, int OHc, int OWc, int patch = 0) {
     return r;
 }
 
-// Element offset into `a` of A(row, k) or -1 when the tap falls outside the image / k >= Kdim.
+// Element offsets of an output row (and of its residual operand) in the NHWC output tensor.
 CSL_HD int kc_out_offset(const KcParams& p, const KcClass& k, const RowCoord& rc) {
     return ((rc.img * p.OHf + rc.oy * p.osy + k.oy0) * p.OWf + rc.ox * p.osx + k.ox0) * p.ldo;
 }

@@ -21,7 +21,7 @@ import torch
 from torch import nn
 
 from . import accountant, ops
-from .nn import HipConv2d, HipLinear
+from .nn import HipConv2d, HipLinear, PerSampleSink
 
 CLIP_EPS = 1e-6
 
@@ -250,7 +250,7 @@ def _collect_roles(self, gz, x, R, S, stride, pad, has_bias):
 _LayerCollector._collect_roles = _collect_roles
 
 
-class PrivacyEngine:
+class PrivacyEngine(PerSampleSink):
     """Gradient-clipping DP engine (train.py:110-116 constructor call).
 
     materialize="all"     every pass's per-sample gradients are written to p.grad_sample[pass] (fork layout);

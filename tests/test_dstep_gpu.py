@@ -403,3 +403,60 @@ def test_train_D_bf16_grad_sample_storage(tmp_path):
     _close(tr.last["norms"].reshape(9, -1), n_o.reshape(9, -1), "per-sample norms (bf16 storage)", rtol=5e-3)
     for i, (a, b) in enumerate(zip(tr.last["summed_clipped"], obs["summed_clipped"])):
         _close_grad(a, b, "summed_clipped[%d] (bf16 storage)" % i, l2_tol=1e-2, frac_tol=1.0)
+
+
+@pytest.mark.parametrize("dataset,extra,B,latent", [
+    ("MNIST", ["--model", "Vanilla", "-c", "0.5", "--sigma", "10"], 16, 100),                       # BASELINE configs[1] (bs scaled down)
+    ("CelebA", ["-gcm", "adaptive-pl"], 8, 128),                                                    # ACGAN critic head + aux-logit penalties
+    ("MNIST", ["--model", "DeepConvResNet", "--penalty", "WGAN-GP", "-c", "3.0", "--conditional_arch", "CGAN"], 6, 16),   # label planes concatenated
+])
+def test_train_D_conditional_matches_oracle(tmp_path, dataset, extra, B, latent):
+    """Conditional models: one-hot label concatenation in G (and in D for CGAN), the ACGAN auxiliary head with its
+    cross-entropy / wasserstein aux losses on real and generated batches, and the per-aux-logit gradient penalties
+    (gradient_penalty.py:56-63)."""
+    from csl_gan_amd import init_util, options
+    from csl_gan_amd.trainer import Trainer
+    from oracle.dstep import OracleDStep, StepConfig
+    from oracle.nets import build_models
+    argv = [dataset, "-dpm", "gc", "-nms", "4", "-bs", str(B), "-gd", "cuda:0", "-dd", "cuda:0", "-o", str(tmp_path), "--manual_seed", "1",
+            "--g_latent_dim", str(latent), "--conditional", "--materialize", "all"] + extra
+    if "--sigma" not in extra:
+        argv += ["--sigma", "0.5"]
+    opt = options.parse(argv)
+    G, D = init_util.init_models(opt)
+    tr = Trainer(opt, G, D, log_to=str(tmp_path / "log.csv"))
+    pe = tr.setup_privacy_engine()
+    pe.noise_multiplier = 0.0
+    Go, Do = build_models(dataset=dataset, model=opt.model, im_size=opt.im_size, weights_seed=opt.weights_seed, manual_seed=1,
+                          per_sample_grad=True, g_latent_dim=latent, conditional=True, n_classes=opt.n_classes,
+                          conditional_arch=opt.conditional_arch, aux_loss_type=opt.aux_loss_type, aux_loss_scalar=opt.aux_loss_scalar)
+    for (n1, p1), (n2, p2) in zip(D.named_parameters(), Do.named_parameters()):
+        assert n1 == n2 and torch.equal(p1.detach().cpu(), p2.detach())
+    n = len(list(Do.parameters()))
+    cfg = StepConfig(dp_mode="gc", grad_clip_mode=opt.grad_clip_mode, grad_clip_split=True, clipping_param=opt.clipping_param,
+                     clipping_param_per_layer=[1.0] * n, adaptive_scalar=opt.adaptive_scalar, sigma=0.0, penalty=tuple(opt.penalty),
+                     lr=opt.d_lr, adam_b1=opt.adam_b1, adam_b2=opt.adam_b2, aux_penalty=opt.aux_penalty,
+                     use_aux_loss=opt.use_aux_loss, d_fake_aux_loss=opt.d_fake_aux_loss)
+    oracle = OracleDStep(Go, Do, cfg)
+    g = torch.Generator().manual_seed(91)
+    ch, im = (1, 28) if dataset == "MNIST" else (3, 64)
+    img = torch.rand(B, ch, im, im, generator=g) * 2 - 1
+    labels = torch.randint(0, opt.n_classes, (B,), generator=g)
+    labels[:opt.n_classes] = torch.arange(opt.n_classes)[:B]            # every class present (aux wasserstein divides by class counts)
+    ms_a, ms_p = torch.rand(B, ch, im, im, generator=g) - 0.5, torch.rand(B, ch, im, im, generator=g) - 0.5
+    z, alpha = torch.randn(B, latent, generator=g), torch.rand(B, generator=g)
+    tr.explicit = dict(ms_adapt=ms_a, ms_adapt_labels=labels, pen_real=ms_p, alpha=alpha, keep=True)
+    tr.train_D(img.cuda(), labels.cuda(), z.cuda(), labels.cuda(), use_dp=True)
+    torch.cuda.synchronize()
+    obs = oracle.step(img, labels, z, labels, ms_adapt=ms_a, ms_adapt_labels=labels, pen_real=ms_p if opt.penalty else None,
+                      pen_labels=labels, alpha=alpha, apply_update=False)
+    last = tr.last
+    _close(last["fake_img"], obs["fake_img"], "conditional generator forward")
+    _close(last["d_real_loss"], obs["d_real_loss"], "d_real_loss")
+    _close(last["d_fake_loss"], obs["d_fake_loss"], "d_fake_loss")
+    if opt.penalty:
+        _close(last["penalty"], obs["penalty"], "penalty (with aux-logit terms)" if opt.use_aux_loss else "penalty", rtol=2e-3)
+    n_o = obs["norms"]
+    _close(last["norms"].reshape(n_o.shape[0], -1), n_o.reshape(n_o.shape[0], -1), "per-sample norms")
+    for i, (a, b) in enumerate(zip(last["summed_grad"], obs["summed_grad"])):
+        _close_grad(a, b, "summed_grad[%d]" % i)

@@ -407,7 +407,7 @@ def test_train_D_bf16_grad_sample_storage(tmp_path):
 
 @pytest.mark.parametrize("dataset,extra,B,latent", [
     ("MNIST", ["--model", "Vanilla", "-c", "0.5", "--sigma", "10"], 16, 100),                       # BASELINE configs[1] (bs scaled down)
-    ("CelebA", ["-gcm", "adaptive-pl"], 8, 128),                                                    # ACGAN critic head + aux-logit penalties
+    ("CelebA", ["-gcm", "adaptive-pl", "-cpl"] + ["1"] * 11, 8, 128),                                                    # ACGAN critic head + aux-logit penalties
     ("MNIST", ["--model", "DeepConvResNet", "--penalty", "WGAN-GP", "-c", "3.0", "--conditional_arch", "CGAN"], 6, 16),   # label planes concatenated
 ])
 def test_train_D_conditional_matches_oracle(tmp_path, dataset, extra, B, latent):

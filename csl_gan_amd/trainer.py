@@ -393,11 +393,30 @@ class Trainer:
             (g_adv_loss + g_aux_loss).backward()
         finally:
             util.unfreeze(D)
+        if self.world_size > 1:
+            self._average_G_grads()
         self.g_optimizer.step()
         self._acc("G Adv Loss", g_adv_loss.detach())
         if o.is_acgan:
             self._acc("G Aux Loss", g_aux_loss.detach())
             self._acc("G Aux Acc", 100 * (d_fake_aux.detach().argmax(dim=1) == y.to(o.d_device)).float().mean())
+
+    def _average_G_grads(self):
+        """G is replicated; its (non-private) gradients are averaged over ranks with ONE flat
+        all-reduce (G64: 84 MB).  p.grad tensors are re-pointed at slices of the bucket, like the D side."""
+        ps = [p for p in self.G.parameters() if p.grad is not None]
+        flat = getattr(self, "_g_flat", None)
+        n = sum(p.numel() for p in ps)
+        if flat is None or flat.numel() != n or flat.device != ps[0].device:
+            flat = self._g_flat = torch.empty(n, device=ps[0].device, dtype=torch.float32)
+        off = 0
+        for p in ps:
+            v = torch.as_strided(flat, p.size(), p.stride(), storage_offset=off)
+            v.copy_(p.grad)
+            p.grad = v
+            off += p.numel()
+        from .distributed import average_across_ranks
+        average_across_ranks(flat)
 
     # ---- train.py:521-546 ---------------------------------------------------------------------
     def train(self, epoch, batch_i, real_images_batch, real_labels_batch, use_dp=False):
@@ -408,6 +427,9 @@ class Trainer:
         self.train_D(img, labels, self.gen_z(n), labels, use_dp=use_dp)
         if batch_i % o.n_d_steps == 0:
             gate = self.dev_stats.pop("_d_adv_gate", None)
+            if gate is not None and self.world_size > 1:           # every rank must take the same branch
+                from .distributed import average_across_ranks
+                gate = average_across_ranks(gate.detach().reshape(1).clone())
             d_adv = 0.0 if gate is None else float(gate)           # the one host sync, every n_d_steps iterations
             if d_adv / o.n_d_steps < o.train_d_until_threshold:
                 lg.log_g_iter += 1

@@ -76,3 +76,41 @@ def test_single_process_helpers_are_noops():
     assert torch.equal(D.average_across_ranks(t.clone()), t)
     r = D.FlatGradReducer()
     assert r.world == 1 and torch.equal(r(t.clone()), t)
+
+
+def _g_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from csl_gan_amd import distributed as D
+    from csl_gan_amd import init_util, options
+    from csl_gan_amd.trainer import Trainer
+    D.init("gloo")
+    opt = options.parse(["MNIST", "--model", "Vanilla", "-bs", "4", "-gd", "cpu", "-dd", "cpu", "-o", out_dir,
+                         "--manual_seed", "1", "--g_latent_dim", "8", "--log_every", "100000"])
+    G, Dm = init_util.init_models(opt)
+    tr = Trainer(opt, G, Dm, log_to=os.path.join(out_dir, "log%d.csv" % rank), world_size=world, rank=rank)
+    g = torch.Generator().manual_seed(5 + rank)                # each rank sees its own shard and its own z
+    torch.manual_seed(100 + rank)
+    before = [p.detach().clone() for p in G.parameters()]
+    img = torch.rand(4, 1, 28, 28, generator=g) * 2 - 1
+    tr.train(0, 0, img, torch.zeros(4, dtype=torch.long), use_dp=False)
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, G.parameters())), "the G step did not run"
+    flat = torch.cat([p.detach().reshape(-1) for p in G.parameters()])
+    grads = torch.cat([p.grad.reshape(-1) for p in G.parameters()])
+    both = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    gb = [torch.empty_like(grads) for _ in range(world)]
+    dist.all_gather(gb, grads)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "g.npy"), np.stack([t.numpy() for t in both] + [t.numpy() for t in gb]))
+    dist.destroy_process_group()
+
+
+def test_G_step_keeps_replicas_identical(tmp_path):
+    """G is replicated; after a G step on different per-rank shards every rank holds the same G
+    (one flat all-reduce of the G gradients, and a rank-consistent threshold gate)."""
+    world = 2
+    mp.spawn(_g_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a = np.load(tmp_path / "g.npy")
+    assert np.array_equal(a[0], a[1]), "generator replicas diverged"
+    assert np.array_equal(a[2], a[3]) and np.abs(a[2]).max() > 0, "ranks stepped with different G gradients"

@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--loop-steps", type=int, default=10, help="iterations of the full train() loop timed for the secondary metric (0 = skip)")
     ap.add_argument("--opt", type=str, default="", help="extra train.py flags for experiments, e.g. '--grad_sample_dtype bf16' "
                     "(the headline line is the run WITHOUT this)")
     a = ap.parse_args()
@@ -127,6 +128,27 @@ def main():
         t = torch.tensor([dt], device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
+    # secondary metric: the full train() loop, a G step forced on every n_d_steps-th iteration
+    loop = None
+    if a.loop_steps > 0:
+        opt.train_d_until_threshold = float("inf")
+        lbl = torch.zeros(B, dtype=torch.long)
+        for i in range(opt.n_d_steps):
+            tr.train(0, i, img, lbl, use_dp=True)
+        torch.cuda.synchronize()
+        D.barrier()
+        t1 = time.perf_counter()
+        for i in range(a.loop_steps):
+            tr.train(0, i, img, lbl, use_dp=True)
+        torch.cuda.synchronize()
+        D.barrier()
+        dl = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dl], device="cuda")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dl = float(t)
+        loop = {"metric": "full train() loop, G step every %d iterations" % opt.n_d_steps, "value": round(world * B * a.loop_steps / dl, 2),
+                "unit": "images/sec", "iterations": a.loop_steps, "ms_per_iteration": round(dl / a.loop_steps * 1e3, 3)}
     if rank != 0:
         return
     ips = world * B * a.steps / dt
@@ -162,6 +184,7 @@ def main():
         "step_tflops_algorithmic": round(FLOP_PER_IMG_STEP * ips / 1e12, 2),
         "step_frac_of_fp32_mfma_peak": round(FLOP_PER_IMG_STEP * ips / world / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
         "roofline": roof,
+        "secondary": loop,
         "kernels_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},
     }
     if world == 1 and not a.no_cpu_baseline:

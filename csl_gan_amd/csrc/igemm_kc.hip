@@ -378,6 +378,8 @@ static long long tiles_for(const KcParams& p, int BM, int BN) {
 
 bool halo_eligible(const KcParams& p);          // igemm_halo.hip
 int launch_halo(KcParams& p, hipStream_t st);
+bool skinny_eligible(const KcParams& p);        // igemm_skinny.hip
+int launch_skinny(KcParams& p, hipStream_t st);
 
 // out_elems: total floats of the output tensor (needed to zero it when K is split), or 0 to forbid splitting
 int launch_kc(KcParams& p, hipStream_t st, long long out_elems) {
@@ -408,6 +410,8 @@ int launch_kc(KcParams& p, hipStream_t st, long long out_elems) {
             p.ac_recip = (unsigned)(((1ull << 32) + (unsigned long long)p.AC - 1) / (unsigned long long)p.AC);
         }
     }
+    static const int skinny_env = [] { const char* e = getenv("CSLGAN_KC_SKINNY"); return e ? atoi(e) : 1; }();
+    if (skinny_env && skinny_eligible(p)) return launch_skinny(p, st);
     static const int halo_env = [] { const char* e = getenv("CSLGAN_KC_HALO"); return e ? atoi(e) : 1; }();
     if (halo_env && halo_eligible(p)) return launch_halo(p, st);
     static const int patch_env = [] { const char* e = getenv("CSLGAN_KC_PATCH"); return e ? atoi(e) : 1; }();

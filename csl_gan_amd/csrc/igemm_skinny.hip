@@ -1,0 +1,168 @@
+// fp32 convolution with 1..4 output channels (the generator's 64 -> 3 output conv, the data gradient of the
+// critic's 3 -> 64 first conv), on the vector ALU with an LDS-resident input halo.  gfx950 only.
+//
+// A 32-wide MFMA tile spends 29/32 of its work on padding when the GEMM's N is 3 (rocprofv3: 0.22 ms for the
+// 1.8 GFLOP output conv, 5.9 TFLOP/s for the first layer's data gradient).  With N this small the op is a
+// stream over the input: every input value meets only NJ filter values.  One workgroup owns one 8x8 output
+// patch: it stages the patch's (8+range)^2 x 64-channel halo in LDS once, and 16 lanes share each output pixel
+// (4 channels per lane, one ds_read_b128 per tap) with that lane's T x NJ filter float4s held in registers; the
+// 16 partial sums meet in a 4-step butterfly.  Same KcParams classes / epilogue contract as igemm_kc.
+#include "common.h"
+#include "igemm.h"
+
+namespace cslgan {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned SOOB = 0xFFFFFFF0u;
+constexpr int SK_MAXT = 9;             // taps per class held in registers
+constexpr int SK_C = 64;               // input channels (16 lanes x float4)
+constexpr int SK_HALO = 12 * 12;
+
+__device__ __forceinline__ float4 sbuf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+template <int NJ>
+__global__ __launch_bounds__(256) void igemm_skinny_kernel(const KcParams p) {
+    __shared__ float4 Hs[SK_HALO * 16];
+
+    const int tid = threadIdx.x;
+    const int b = xcd_remap(blockIdx.x, p.tiles_m);
+    int ci = 0;
+#pragma unroll 1
+    while (ci + 1 < p.n_cls && b >= p.cls[ci + 1].tile0) ++ci;
+    const KcClass& kc = p.cls[ci];
+    const int T = kc.T, HW_ = kc.halo_w, hpix = kc.halo_h * kc.halo_w;
+    const RowCoord rc0 = kc_decode_row((b - kc.tile0) * 64, kc.OHc, kc.OWc, 1);     // the patch's top-left pixel
+    const int y0 = rc0.oy + kc.ty_min, x0 = rc0.ox + kc.tx_min;
+    const int img_base = rc0.img * p.AH * p.AW * SK_C;
+
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w + kc.w_off), 0,
+                                                                             p.w_bytes - 4u * (unsigned)kc.w_off, 0x00020000);
+    // ---- halo: hpix pixels x 16 float4 ------------------------------------------------------------------
+    constexpr int HREG = (SK_HALO * 16 + 255) / 256;
+    float4 rh[HREG];
+#pragma unroll
+    for (int j = 0; j < HREG; ++j) {
+        const int idx = tid + 256 * j;
+        const int c4 = idx & 15, pix = idx >> 4;
+        const int hy = pix / HW_, hx = pix - hy * HW_;
+        const int iy = y0 + hy, ix = x0 + hx;
+        const bool ok = pix < hpix && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
+        rh[j] = sbuf_load4(a_rsrc, ok ? 4u * (unsigned)(img_base + (iy * p.AW + ix) * SK_C + c4 * 4) : SOOB);
+    }
+    // ---- this lane's filter values: 4 channels x T taps x NJ outputs ------------------------------------
+    const int cl = tid & 15;
+    float4 wr[SK_MAXT][NJ];
+    int toff[SK_MAXT];
+#pragma unroll
+    for (int t = 0; t < SK_MAXT; ++t) {
+        toff[t] = t < T ? (((int)kc.ty[t] - kc.ty_min) * HW_ + ((int)kc.tx[t] - kc.tx_min)) * 16 : 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            wr[t][j] = sbuf_load4(w_rsrc, (t < T && j < p.Nn) ? 4u * (unsigned)(j * kc.Kdim + t * SK_C + cl * 4) : SOOB);
+    }
+#pragma unroll
+    for (int j = 0; j < HREG; ++j) {
+        const int idx = tid + 256 * j;
+        if ((idx >> 4) < hpix) Hs[idx] = rh[j];
+    }
+    __syncthreads();
+
+    const int wid = tid >> 6, pg = (tid & 63) >> 4;
+    float bv = 0.f;
+    if (p.bias && cl < p.Nn) bv = p.bias[cl];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int q = wid * 16 + it * 4 + pg;            // pixel of the patch: 16 lanes each
+        const int qy = q >> 3, qx = q & 7;
+        const int base = (qy * HW_ + qx) * 16 + cl;
+        float acc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < SK_MAXT; ++t) {
+            if (t < T) {                                  // uniform
+                const float4 a = Hs[base + toff[t]];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[j] = fmaf(a.x, wr[t][j].x, acc[j]);
+                    acc[j] = fmaf(a.y, wr[t][j].y, acc[j]);
+                    acc[j] = fmaf(a.z, wr[t][j].z, acc[j]);
+                    acc[j] = fmaf(a.w, wr[t][j].w, acc[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            acc[j] += __shfl_xor(acc[j], 1);
+            acc[j] += __shfl_xor(acc[j], 2);
+            acc[j] += __shfl_xor(acc[j], 4);
+            acc[j] += __shfl_xor(acc[j], 8);
+        }
+        if (cl < p.Nn) {
+            float val = acc[0];
+#pragma unroll
+            for (int j = 1; j < NJ; ++j) val = cl == j ? acc[j] : val;
+            val += bv;
+            const RowCoord rc = {rc0.img, rc0.oy + qy, rc0.ox + qx};
+            const int off = kc_out_offset(p, kc, rc);
+            if (p.res) val += p.res[kc_res_offset(p, kc, rc) + cl];
+            if (p.act == CSLGAN_ACT_LRELU02) val = val > 0.f ? val : 0.2f * val;
+            else if (p.act == CSLGAN_ACT_RELU) val = val > 0.f ? val : 0.f;
+            else if (p.act == CSLGAN_ACT_TANH) val = tanhf(val);
+            if (p.mask) val *= (p.mask[off + cl] > 0.f ? 1.f : 0.2f);
+            p.out[off + cl] = val;
+        }
+    }
+}
+
+// Eligibility: at most 4 output channels, 64 input channels, stride 1, 8x8-patchable class grids, at most 9 taps per
+// class within a 12x12 halo.
+bool skinny_eligible(const KcParams& p) {
+    if (p.Nn > 4 || p.Nn < 1 || p.sy != 1 || p.sx != 1 || p.ups != 0 || p.AC != SK_C) return false;
+    if (!aligned16(p.a) || !aligned16(p.w)) return false;
+    for (int c = 0; c < p.n_cls; ++c) {
+        const KcClass& k = p.cls[c];
+        if (k.T < 1 || k.T > SK_MAXT || (k.OHc & 7) || (k.OWc & 7) || (k.M & 63) || (k.w_off & 3)) return false;
+        int ymin = 127, ymax = -128, xmin = 127, xmax = -128;
+        for (int t = 0; t < k.T; ++t) {
+            ymin = k.ty[t] < ymin ? k.ty[t] : ymin; ymax = k.ty[t] > ymax ? k.ty[t] : ymax;
+            xmin = k.tx[t] < xmin ? k.tx[t] : xmin; xmax = k.tx[t] > xmax ? k.tx[t] : xmax;
+        }
+        if (ymax - ymin > 4 || xmax - xmin > 4) return false;
+    }
+    return true;
+}
+
+int launch_skinny(KcParams& p, hipStream_t st) {
+    int tm = 0;
+    for (int c = 0; c < p.n_cls; ++c) {
+        KcClass& k = p.cls[c];
+        int ymin = 127, ymax = -128, xmin = 127, xmax = -128;
+        for (int t = 0; t < k.T; ++t) {
+            ymin = k.ty[t] < ymin ? k.ty[t] : ymin; ymax = k.ty[t] > ymax ? k.ty[t] : ymax;
+            xmin = k.tx[t] < xmin ? k.tx[t] : xmin; xmax = k.tx[t] > xmax ? k.tx[t] : xmax;
+        }
+        k.ty_min = ymin; k.tx_min = xmin; k.halo_h = 8 + ymax - ymin; k.halo_w = 8 + xmax - xmin;
+        k.patch = 1;
+        k.tile0 = tm;                  // in 8x8 patches
+        tm += k.M / 64;
+    }
+    p.tiles_m = tm;
+    p.tiles_n = 1;
+    p.ksplit = 1;
+    const dim3 grid((unsigned)tm), block(256);
+    switch (p.Nn) {
+        case 1: hipLaunchKernelGGL((igemm_skinny_kernel<1>), grid, block, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((igemm_skinny_kernel<2>), grid, block, 0, st, p); break;
+        case 3: hipLaunchKernelGGL((igemm_skinny_kernel<3>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((igemm_skinny_kernel<4>), grid, block, 0, st, p); break;
+    }
+    return check_launch("igemm_skinny_kernel");
+}
+
+}  // namespace cslgan

@@ -64,14 +64,16 @@ class LaunchTimer:
         e.record()
         return e
 
-    def end(self, name, flop, nbytes, start, exec_flop=None):
+    def end(self, name, flop, nbytes, start, exec_flop=None, tag=None):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        self.records.append((name, flop, nbytes, start, e, flop if exec_flop is None else exec_flop))
+        self.records.append((name, flop, nbytes, start, e, flop if exec_flop is None else exec_flop, tag))
 
-    def summary(self):
+    def summary(self, by_shape=False):
         out = {}
-        for name, flop, nbytes, s, e, xf in self.records:
+        for name, flop, nbytes, s, e, xf, tag in self.records:
+            if by_shape and tag:
+                name = "%s %s" % (name, tag)
             d = out.setdefault(name, {"name": name, "ms": 0.0, "flop": 0.0, "exec_flop": 0.0, "bytes": 0.0, "n": 0})
             d["ms"] += s.elapsed_time(e)
             d["flop"] += flop
@@ -89,14 +91,14 @@ def set_launch_timer(t):
     _timer = t
 
 
-def _timed(name, flop, nbytes, fn, exec_flop=None):
+def _timed(name, flop, nbytes, fn, exec_flop=None, tag=None):
     """flop = algorithmic FLOP of the op as the reference executes it; exec_flop = FLOP the kernel really issues
     (differs for the sub-pixel upsample convs)."""
     if _timer is None:
         return fn()
     s = _timer.begin()
     r = fn()
-    _timer.end(name, flop, nbytes, s, exec_flop)
+    _timer.end(name, flop, nbytes, s, exec_flop, tag() if callable(tag) else tag)
     return r
 
 
@@ -152,11 +154,12 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, upsample=False, residual=None, 
         ws, repack = repack_cache.get("up_fwd", w, L.cslgan_conv2d_up_ws_floats(K, R, Cc), wkey)
         _timed("conv2d_fwd", flop, nbytes, lambda: check(
             L.cslgan_conv2d_up_fwd_f32(C.byref(d), _p(x), _p(w), _p(ws), repack, _p(bias), _p(residual), res_shift, act, _p(y), _stream()),
-            "conv2d_up_fwd"), exec_flop=flop * (R // 2 + 1) ** 2 / float(R * S))
+            "conv2d_up_fwd"), exec_flop=flop * (R // 2 + 1) ** 2 / float(R * S),
+            tag=lambda: "up N%d %dx%d C%d K%d R%d" % (N, H, W, Cc, K, R))
         return y
     _timed("conv2d_fwd", flop, nbytes, lambda: check(
         _lib.lib().cslgan_conv2d_fwd_f32(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), res_shift, act, _p(y), _stream()),
-        "conv2d_fwd"))
+        "conv2d_fwd"), tag=lambda: "N%d %dx%d C%d K%d R%d s%d" % (N, H, W, Cc, K, R, stride))
     return y
 
 
@@ -178,7 +181,8 @@ def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None, wkey=None):
     flop = 2.0 * N * P * Q * K * R * S * Cc
     nbytes = 4.0 * (N * H * W * Cc + K * R * S * Cc + N * P * Q * K)
     _timed("conv2d_dgrad", flop, nbytes, lambda: check(
-        _lib.lib().cslgan_conv2d_dgrad_f32(C.byref(d), _p(gy), _p(w), _p(ws), repack, _p(mask), _p(gx), _stream()), "conv2d_dgrad"))
+        _lib.lib().cslgan_conv2d_dgrad_f32(C.byref(d), _p(gy), _p(w), _p(ws), repack, _p(mask), _p(gx), _stream()), "conv2d_dgrad"),
+        tag=lambda: "N%d %dx%d C%d K%d R%d s%d" % (N, H, W, Cc, K, R, stride))
     return gx
 
 
@@ -213,7 +217,8 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
     L = _lib.lib()
     fn = L.cslgan_conv2d_wgrad_grouped_bf16out_f32 if (want_gw and gw.dtype == torch.bfloat16) else L.cslgan_conv2d_wgrad_grouped_f32
     _timed("conv2d_wgrad_grouped" + ("" if (want_gw and not scratch) else "_normonly"), flop, nbytes, lambda: check(
-        fn(C.byref(d), _p(gy), _p(x), group, float(alpha), _p(gw), _p(sq), _stream()), "conv2d_wgrad_grouped"))
+        fn(C.byref(d), _p(gy), _p(x), group, float(alpha), _p(gw), _p(sq), _stream()), "conv2d_wgrad_grouped"),
+        tag=lambda: "N%d %dx%d C%d K%d R%d s%d g%d%s" % (N, H, W, Cc, K, R, stride, group, " up" if upsample else ""))
     return None if scratch else gw
 
 
@@ -230,7 +235,8 @@ def conv2d_up_dgrad(gy, w, pad, wkey=None):
     ws, repack = repack_cache.get("up_dgrad", w, (R + 1) * (R + 1) * K * Cc, wkey)
     flop = 2.0 * N * P * Q * K * R * S * Cc
     _timed("conv2d_dgrad", flop, 4.0 * (gy.numel() + gx.numel() + w.numel()), lambda: check(
-        _lib.lib().cslgan_conv2d_up_dgrad_f32(C.byref(d), _p(gy), _p(w), _p(ws), repack, _p(gx), _stream()), "conv2d_up_dgrad"))
+        _lib.lib().cslgan_conv2d_up_dgrad_f32(C.byref(d), _p(gy), _p(w), _p(ws), repack, _p(gx), _stream()), "conv2d_up_dgrad"),
+        tag=lambda: "up N%d %dx%d C%d K%d R%d" % (N, H, W, Cc, K, R))
     return gx
 
 

@@ -39,19 +39,19 @@ __global__ void act_bwd_kernel(const float* __restrict__ g, const float* __restr
 // kernel turns (S1, S2) into the (sum, centred sum of squares) pair the apply / backward kernels consume.
 // Rows are read with 16-byte loads, coalesced along C; partial sums go thread -> LDS (per channel) -> one
 // global atomic per channel per block.
-constexpr int NS_ROWS = 64;   // rows per block
+constexpr int NS_ROWS_MIN = 64;   // rows per block, lower bound (the launch picks a multiple: ~1024 blocks in all)
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x, long long rows_per_stat, int C, int cpg,
-                                                         int n_groups, float* __restrict__ stats) {
+                                                         int n_groups, int rows_per_block, float* __restrict__ stats) {
     extern __shared__ float s_acc[];   // [2*C]: S1, S2 per channel
     const int tid = threadIdx.x;
     for (int c = tid; c < 2 * C; c += 256) s_acc[c] = 0.f;
     __syncthreads();
     const long long sr = blockIdx.y;                      // which row-group of statistics
     const long long row_first = sr * rows_per_stat;
-    const long long r0 = row_first + (long long)blockIdx.x * NS_ROWS;
-    long long r1 = r0 + NS_ROWS;
+    const long long r0 = row_first + (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
     const long long rend = row_first + rows_per_stat;
     if (r1 > rend) r1 = rend;
     if (VEC) {
@@ -61,7 +61,19 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
 #pragma unroll
         for (int e = 0; e < 4; ++e) k[e] = x[row_first * C + ((4 * c4 + e) / cpg) * cpg];
         float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
-        for (long long r = r0 + rl; r < r1; r += rstep) {
+        long long r = r0 + rl;
+        for (; r + 3 * rstep < r1; r += 4 * rstep) {      // four independent 16-byte loads in flight
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + (r + u * rstep) * C + 4 * c4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float d[4] = {v[u].x - k[0], v[u].y - k[1], v[u].z - k[2], v[u].w - k[3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a1[e] += d[e]; a2[e] = fmaf(d[e], d[e], a2[e]); }
+            }
+        }
+        for (; r < r1; r += rstep) {
             const float4 v = *reinterpret_cast<const float4*>(x + r * C + 4 * c4);
             const float d[4] = {v.x - k[0], v.y - k[1], v.z - k[2], v.w - k[3]};
 #pragma unroll
@@ -82,7 +94,13 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
         }
     }
     __syncthreads();
-    for (int c = tid; c < 2 * C; c += 256) atomicAdd(&stats[2 * (sr * n_groups + (c >> 1) / cpg) + (c & 1)], s_acc[c]);
+    // the channels of a group share the shift: fold them in LDS, one global atomic per (group, moment)
+    for (int i = tid; i < 2 * n_groups; i += 256) {
+        const int g = i >> 1, which = i & 1;
+        float t = 0.f;
+        for (int j = 0; j < cpg; ++j) t += s_acc[2 * (g * cpg + j) + which];
+        atomicAdd(&stats[2 * (sr * n_groups + g) + which], t);
+    }
 }
 
 // (S1, S2) about the shift k  ->  (sum x, sum (x-mean)^2)
@@ -150,14 +168,14 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void norm_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                              const float* __restrict__ y, const float* __restrict__ stats,
                                                              long long rows_per_stat, int C, int cpg, int n_groups, float eps,
-                                                             int relu, float* __restrict__ ab) {
+                                                             int relu, int rows_per_block, float* __restrict__ ab) {
     extern __shared__ float s_acc[];   // [2*C]
     const int tid = threadIdx.x;
     for (int c = tid; c < 2 * C; c += 256) s_acc[c] = 0.f;
     __syncthreads();
     const long long sr = blockIdx.y;
-    const long long r0 = sr * rows_per_stat + (long long)blockIdx.x * NS_ROWS;
-    long long r1 = r0 + NS_ROWS;
+    const long long r0 = sr * rows_per_stat + (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
     const long long rend = (sr + 1) * rows_per_stat;
     if (r1 > rend) r1 = rend;
     const float inv_cnt = 1.f / ((float)rows_per_stat * (float)cpg);
@@ -283,10 +301,13 @@ static int launch_norm(const float* x, const float* gamma, const float* beta, lo
         return CSLGAN_ERR_LAUNCH;
     }
     const bool vec = (C % 4 == 0) && ((C / 4) <= 256) && (256 % (C / 4) == 0) && (cpg % 4 == 0 || 4 % cpg == 0) && aligned16(x) && aligned16(y);
-    const dim3 grid((unsigned)((rows_per_stat + NS_ROWS - 1) / NS_ROWS), (unsigned)n_row_groups), block(256);
+    // about 1024 workgroups in all, each with at least NS_ROWS_MIN rows: fewer, longer blocks mean fewer global atomics
+    long long rpb = (rows_per_stat * n_row_groups / 1024 + NS_ROWS_MIN - 1) / NS_ROWS_MIN * NS_ROWS_MIN;
+    rpb = rpb < NS_ROWS_MIN ? NS_ROWS_MIN : (rpb > 4096 ? 4096 : rpb);
+    const dim3 grid((unsigned)((rows_per_stat + rpb - 1) / rpb), (unsigned)n_row_groups), block(256);
     const size_t lds = sizeof(float) * C;
-    if (vec) hipLaunchKernelGGL((norm_stats_kernel<true>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, stats);
-    else hipLaunchKernelGGL((norm_stats_kernel<false>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, stats);
+    if (vec) hipLaunchKernelGGL((norm_stats_kernel<true>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, stats);
+    else hipLaunchKernelGGL((norm_stats_kernel<false>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, stats);
     int rc = check_launch("norm_stats_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(norm_stats_finalize_kernel, dim3((unsigned)((n_stats + 127) / 128)), dim3(128), 0, st, x, rows_per_stat, C, cpg,
@@ -376,9 +397,11 @@ int cslgan_norm_act_bwd_f32(const float* x, const float* dy, const float* y, con
     float* gs = ws + nrg * C * 2;           // [nrg*groups][2]
     if (hipMemsetAsync(ab, 0, sizeof(float) * nrg * C * 2, st) != hipSuccess) { set_error("norm_bwd: memset failed"); return CSLGAN_ERR_LAUNCH; }
     const bool vec = (C % 4 == 0) && ((C / 4) <= 256) && (256 % (C / 4) == 0) && aligned16(x) && aligned16(dy) && (!relu || aligned16(y));
-    const dim3 grid((unsigned)((rows_per_stat + NS_ROWS - 1) / NS_ROWS), (unsigned)nrg), block(256);
-    if (vec) hipLaunchKernelGGL((norm_bwd_stats_kernel<true>), grid, block, sizeof(float) * 2 * C, st, x, dy, y, stats, (long long)rows_per_stat, C, cpg, groups, eps, relu, ab);
-    else hipLaunchKernelGGL((norm_bwd_stats_kernel<false>), grid, block, sizeof(float) * 2 * C, st, x, dy, y, stats, (long long)rows_per_stat, C, cpg, groups, eps, relu, ab);
+    long long rpb = (rows / 1024 + NS_ROWS_MIN - 1) / NS_ROWS_MIN * NS_ROWS_MIN;
+    rpb = rpb < NS_ROWS_MIN ? NS_ROWS_MIN : (rpb > 4096 ? 4096 : rpb);
+    const dim3 grid((unsigned)((rows_per_stat + rpb - 1) / rpb), (unsigned)nrg), block(256);
+    if (vec) hipLaunchKernelGGL((norm_bwd_stats_kernel<true>), grid, block, sizeof(float) * 2 * C, st, x, dy, y, stats, (long long)rows_per_stat, C, cpg, groups, eps, relu, (int)rpb, ab);
+    else hipLaunchKernelGGL((norm_bwd_stats_kernel<false>), grid, block, sizeof(float) * 2 * C, st, x, dy, y, stats, (long long)rows_per_stat, C, cpg, groups, eps, relu, (int)rpb, ab);
     int rc = check_launch("norm_bwd_stats_kernel");
     if (rc) return rc;
     const long long nfin = nrg * groups > C ? nrg * groups : C;

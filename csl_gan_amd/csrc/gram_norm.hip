@@ -1,0 +1,184 @@
+// Per-sample weight-gradient norms of a conv layer WITHOUT forming the gradient ("ghost" norms), for layers
+// with at most 64 output pixels per sample.  gfx950 only.
+//
+//   gW_b = alpha * GY_b^T XU_b          GY_b: [PQ x K] output gradient, XU_b: [PQ x T*C] unfolded input
+//   ||gW_b||^2 = alpha^2 * sum_{p,p'} (GY_b GY_b^T)[p,p'] * (XU_b XU_b^T)[p,p']
+//
+// The critic's last conv has PQ = 16 output pixels and K x T*C = 512 x 6400: the direct product costs
+// 2*16*512*6400 = 105 MFLOP per sample, the two PQ x PQ Gram matrices 2*16*16*(512+6400) = 3.5 MFLOP (30x less;
+// 3.7x less for the 64-pixel layer before it).  Rows of both operands are contiguous in k, so the loader and the
+// MFMA fragment reads are igemm_kc's: 16-byte loads into a [row][32+4] LDS image, ds_read_b128 fragments with
+// k = 8g+4h+e (both factors of A A^T use the same k permutation, so the sum over k is unchanged).
+//
+// One workgroup per sample.  PQ <= 32: one 32x32 tile, the four wavefronts take every fourth 32-deep K chunk and
+// their partial Gram matrices are added in LDS.  32 < PQ <= 64: four 32x32 tiles, one per wavefront.
+#include "common.h"
+#include "igemm.h"
+
+namespace cslgan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GramParams {
+    const float* gy;     // [N][P][Q][K]
+    const float* x;      // [N][H][W][C]
+    int N, H, W, C, K, PQ, Q, T, stride;
+    int n1, n2;          // 32-deep chunks of GY rows (K/32) and of XU rows (T*C/32)
+    float alpha2;
+    float* sq;           // [N], accumulated
+    signed char ty[IG_MAX_TAPS], tx[IG_MAX_TAPS];
+};
+
+constexpr int GR_LD = 36;
+
+template <int TILES>
+__global__ __launch_bounds__(256) void gram_sqnorm_kernel(const GramParams p) {
+    constexpr int ROWS = TILES == 1 ? 128 : 64;      // LDS rows per buffer: 4 K-chunks x 32 pixels, or 1 chunk x 64 pixels
+    constexpr int LPT = ROWS * 8 / 256;              // float4 loads per thread per iteration
+    __shared__ __attribute__((aligned(16))) float As[2][ROWS * GR_LD];
+    __shared__ float s_red[TILES == 1 ? 2 * 1024 : 4];
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int cpc = p.C >> 5;                        // 32-channel chunks per tap
+    const int n_chunks = p.n1 + p.n2;
+    const int n_iter = TILES == 1 ? (n_chunks + 3) / 4 : n_chunks;
+
+    // loader coordinates: row -> (chunk slot, pixel), fixed per thread
+    int l_pix[LPT], l_slot[LPT], l_py[LPT], l_px[LPT];
+    const int j4 = (tid & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        l_slot[i] = TILES == 1 ? row >> 5 : 0;
+        l_pix[i] = TILES == 1 ? row & 31 : row;
+        l_py[i] = l_pix[i] / p.Q;
+        l_px[i] = l_pix[i] - l_py[i] * p.Q;
+    }
+    float4 rg[LPT];
+    auto load = [&](int it) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int c = TILES == 1 ? 4 * it + l_slot[i] : it;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (l_pix[i] < p.PQ && c < n_chunks) {
+                if (c < p.n1) {
+                    v = *reinterpret_cast<const float4*>(p.gy + ((long long)b * p.PQ + l_pix[i]) * p.K + c * 32 + j4);
+                } else {
+                    const int c2 = c - p.n1;
+                    const int t = c2 / cpc, cc = c2 - t * cpc;
+                    const int iy = l_py[i] * p.stride + p.ty[t], ix = l_px[i] * p.stride + p.tx[t];
+                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                        v = *reinterpret_cast<const float4*>(p.x + (((long long)b * p.H + iy) * p.W + ix) * p.C + cc * 32 + j4);
+                }
+            }
+            rg[i] = v;
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            *reinterpret_cast<float4*>(&As[buf][row * GR_LD + j4]) = rg[i];
+        }
+    };
+
+    const int lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int rowA = TILES == 1 ? wid * 32 + r : (wid >> 1) * 32 + r;
+    const int rowB = TILES == 1 ? wid * 32 + r : (wid & 1) * 32 + r;
+
+    f32x16 acc1, acc2;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { acc1[v] = 0.f; acc2[v] = 0.f; }
+
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int it = 0; it < n_iter; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < n_iter) load(it + 1);
+        const int c = TILES == 1 ? 4 * it + wid : it;      // this wavefront's chunk
+        if (c < n_chunks) {
+            float4 af[4], bf[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                af[g] = *reinterpret_cast<const float4*>(&As[buf][rowA * GR_LD + 8 * g + 4 * h]);
+                bf[g] = *reinterpret_cast<const float4*>(&As[buf][rowB * GR_LD + 8 * g + 4 * h]);
+            }
+            if (c < p.n1) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].x, bf[g].x, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].y, bf[g].y, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].z, bf[g].z, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].w, bf[g].w, acc1, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].x, bf[g].x, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].y, bf[g].y, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].z, bf[g].z, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].w, bf[g].w, acc2, 0, 0, 0);
+                }
+            }
+        }
+        if (it + 1 < n_iter) store(buf ^ 1);
+        __syncthreads();
+    }
+
+    float prod = 0.f;
+    if (TILES == 1) {
+        // add the four wavefronts' partial Gram matrices, then multiply them entry by entry
+        for (int i = tid; i < 2 * 1024; i += 256) s_red[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = (v & 3) + 8 * (v >> 2) + 4 * h;
+            atomicAdd(&s_red[row * 32 + r], acc1[v]);
+            atomicAdd(&s_red[1024 + row * 32 + r], acc2[v]);
+        }
+        __syncthreads();
+        for (int i = tid; i < 1024; i += 256) prod = fmaf(s_red[i], s_red[1024 + i], prod);
+        __syncthreads();
+        const float tot = block_sum_256(prod, s_red);
+        if (tid == 0) atomicAdd(p.sq + b, p.alpha2 * tot);
+    } else {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) prod = fmaf(acc1[v], acc2[v], prod);
+        const float tot = block_sum_256(prod, s_red);
+        if (tid == 0) atomicAdd(p.sq + b, p.alpha2 * tot);
+    }
+}
+
+}  // namespace cslgan
+
+using namespace cslgan;
+
+extern "C" {
+
+int cslgan_conv2d_wgrad_sqnorm_gram_f32(const cslgan_conv_t* c, const float* gy, const float* x, float alpha, float* sq,
+                                        void* stream) {
+    CSLGAN_REQUIRE(c && gy && x && sq, "wgrad_sqnorm_gram: null argument");
+    CSLGAN_REQUIRE(c->N > 0 && c->H > 0 && c->W > 0 && c->R > 0 && c->S > 0 && c->stride > 0 && c->pad >= 0, "wgrad_sqnorm_gram: non-positive dimension");
+    CSLGAN_REQUIRE(!c->upsample, "wgrad_sqnorm_gram: upsampled input not supported");
+    CSLGAN_REQUIRE(c->R * c->S <= IG_MAX_TAPS, "wgrad_sqnorm_gram: too many taps");
+    const int P = (c->H + 2 * c->pad - c->R) / c->stride + 1, Q = (c->W + 2 * c->pad - c->S) / c->stride + 1;
+    CSLGAN_REQUIRE(P == c->P && Q == c->Q, "wgrad_sqnorm_gram: output %dx%d does not match P,Q=%d,%d", P, Q, c->P, c->Q);
+    CSLGAN_REQUIRE(P * Q >= 1 && P * Q <= 64, "wgrad_sqnorm_gram: needs at most 64 output pixels per sample, got %d", P * Q);
+    CSLGAN_REQUIRE(c->K % 32 == 0 && c->C % 32 == 0, "wgrad_sqnorm_gram: K=%d and C=%d must be multiples of 32", c->K, c->C);
+    CSLGAN_REQUIRE(aligned16(gy) && aligned16(x), "wgrad_sqnorm_gram: operands must be 16-byte aligned");
+    GramParams p{};
+    p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.K = c->K; p.PQ = P * Q; p.Q = Q; p.T = c->R * c->S;
+    p.stride = c->stride; p.n1 = c->K / 32; p.n2 = p.T * (c->C / 32); p.alpha2 = alpha * alpha; p.sq = sq;
+    for (int t = 0; t < IG_MAX_TAPS; ++t) { p.ty[t] = 0; p.tx[t] = 0; }
+    for (int kh = 0; kh < c->R; ++kh)
+        for (int kw = 0; kw < c->S; ++kw) { p.ty[kh * c->S + kw] = (signed char)(kh - c->pad); p.tx[kh * c->S + kw] = (signed char)(kw - c->pad); }
+    const dim3 grid((unsigned)c->N), block(256);
+    if (p.PQ <= 32) hipLaunchKernelGGL((gram_sqnorm_kernel<1>), grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gram_sqnorm_kernel<4>), grid, block, 0, (hipStream_t)stream, p);
+    return check_launch("gram_sqnorm_kernel");
+}
+
+}  // extern "C"

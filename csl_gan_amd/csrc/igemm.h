@@ -123,6 +123,7 @@ struct McParams {
     float* sq;           // [n_groups] or null
     int tiles_m, tiles_n;
     int ksplit;          // >1: the group's pixels are divided over ksplit workgroups that atomically add into zeroed gw
+    const float* row_scale;   // nullable [N]: gy of sample n is multiplied by row_scale[n] on load (clip-weighted sums)
     signed char ty[IG_MAX_TAPS], tx[IG_MAX_TAPS];   // kh-pad, kw-pad
 };
 

@@ -75,6 +75,10 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
                     if (m0 + a_mc + 2 < p.Kc) v.z = src[2];
                     if (m0 + a_mc + 3 < p.Kc) v.w = src[3];
                 }
+                if (p.row_scale) {
+                    const float sc = p.row_scale[(pix_base + kk) / PQ];
+                    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+                }
             }
             ra[i] = v;
         }
@@ -274,7 +278,7 @@ using namespace cslgan;
 extern "C" {
 
 static int wgrad_grouped_impl(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha,
-                              float* gw, float* sq, void* stream, int out_bf16) {
+                              float* gw, float* sq, void* stream, int out_bf16, const float* row_scale = nullptr) {
     CSLGAN_REQUIRE(c && gy && x, "conv2d_wgrad: null argument");
     CSLGAN_REQUIRE(gw || sq, "conv2d_wgrad: neither gw nor sq requested");
     CSLGAN_REQUIRE(group >= 1 && c->N % group == 0, "conv2d_wgrad: N=%d not divisible by group=%d", c->N, group);
@@ -285,7 +289,7 @@ static int wgrad_grouped_impl(const cslgan_conv_t* c, const float* gy, const flo
     McParams p{};
     p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->P; p.Q = c->Q; p.Kc = c->K;
     p.T = c->R * c->S; p.Ndim = p.T * c->C; p.stride = c->stride; p.ups = c->upsample ? 1 : 0; p.group = group; p.n_groups = c->N / group;
-    p.alpha = alpha; p.gw = gw; p.sq = sq; p.out_bf16 = out_bf16;
+    p.alpha = alpha; p.gw = gw; p.sq = sq; p.out_bf16 = out_bf16; p.row_scale = row_scale;
     for (int t = 0; t < IG_MAX_TAPS; ++t) { p.ty[t] = 0; p.tx[t] = 0; }
     for (int kh = 0; kh < c->R; ++kh)
         for (int kw = 0; kw < c->S; ++kw) { p.ty[kh * c->S + kw] = (signed char)(kh - c->pad); p.tx[kh * c->S + kw] = (signed char)(kw - c->pad); }
@@ -303,6 +307,12 @@ int cslgan_conv2d_wgrad_grouped_f32(const cslgan_conv_t* c, const float* gy, con
 int cslgan_conv2d_wgrad_grouped_bf16out_f32(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha,
                                             void* gw_bf16, float* sq, void* stream) {
     return wgrad_grouped_impl(c, gy, x, group, alpha, reinterpret_cast<float*>(gw_bf16), sq, stream, 1);
+}
+
+int cslgan_conv2d_wgrad_scaled_f32(const cslgan_conv_t* c, const float* gy, const float* x, const float* row_scale, int group,
+                                   float alpha, float* gw, void* stream) {
+    CSLGAN_REQUIRE(row_scale && gw, "conv2d_wgrad_scaled: null argument");
+    return wgrad_grouped_impl(c, gy, x, group, alpha, gw, nullptr, stream, 0, row_scale);
 }
 
 int cslgan_bias_grad_grouped_f32(const float* gy, int N, int PQ, int K, int group, float alpha, float* gb, float* sq,

@@ -154,20 +154,23 @@ class _LayerCollector:
         if e.norms_only:
             # adaptive-clipping pass (train.py:204-245): only the per-sample norms are consumed
             _, sq = e._buffers(w, n_pass, B, 0)
-            ops.conv2d_wgrad_grouped(gz, x, R, S, stride=stride, pad=pad, group=1, alpha=scale, want_gw=False, sq=sq[pass_idx])
+            _weight_sqnorms(gz, x, R, S, stride, pad, scale, sq[pass_idx])
             if has_bias:
                 _, bsq = e._buffers(layer.bias, n_pass, B, 0)
                 ops.bias_grad_grouped(gz, group=1, alpha=scale, want_gb=False, sq=bsq[pass_idx])
             return
         n_private = e._n_private(n_pass)
-        if e.materialize == "private" and pass_idx < n_pass - n_private:
+        if e.lean and pass_idx < n_pass - n_private:
             # a pass that is never clipped (generated data in split mode): only its SUM is needed
             e._add_dense(w, _dense_wgrad(gz, x, R, S, stride, pad, scale))
             if has_bias:
                 e._add_dense(layer.bias, _dense_bgrad(gz, scale))
             return
-        if e.materialize == "private":
+        if e.lean:
             pass_idx, n_pass = pass_idx - (n_pass - n_private), n_private
+        if e._ghost_layer(gz, x):
+            self._ghost_rows(pass_idx, n_pass, gz, x, R, S, stride, pad, scale, has_bias)
+            return
         buf, sq = e._buffers(w, n_pass, B, K * R * S * Cc, e._gs_dtype)
         ops.conv2d_wgrad_grouped(gz, x, R, S, stride=stride, pad=pad, group=1, alpha=scale,
                                  out=buf[pass_idx].view(B, K, R, S, Cc), sq=sq[pass_idx])
@@ -186,7 +189,39 @@ class _LayerCollector:
             b.grad_sample = bview
 
 
-def _dense_wgrad(gz, x, R, S, stride, pad, scale):
+def _weight_sqnorms(gz, x, R, S, stride, pad, scale, sq_row):
+    """sq_row[n] += ||scale * per-sample weight gradient||^2 without storing the gradient: from the two pixel-Gram
+    matrices where that is the cheaper form (few output pixels), else from the product kernel's epilogue."""
+    if ops.gram_norms_eligible(gz.shape, x.shape):
+        ops.conv2d_wgrad_sqnorm_gram(gz, x, R, S, stride=stride, pad=pad, alpha=scale, sq=sq_row)
+    else:
+        ops.conv2d_wgrad_grouped(gz, x, R, S, stride=stride, pad=pad, group=1, alpha=scale, want_gw=False, sq=sq_row)
+
+
+def _ghost_rows(self, pass_idx, n_pass, gz, x, R, S, stride, pad, scale, has_bias):
+    """materialize="ghost": a clipped pass of a layer whose norms come from the Gram kernel.  Only the norms are
+    computed now; (gz, x) are kept until clip() knows the factors and forms sum_b f_b g_b with ONE weighted dense
+    wgrad — the per-sample gradient tensor (1.7 GB for the critic's last conv at B=128) is never written or re-read."""
+    e, layer = self.e, self.layer
+    w = layer.weight
+    n = x.shape[0]
+    _, sq = e._buffers(w, n_pass, n, 0)
+    ops.conv2d_wgrad_sqnorm_gram(gz, x, R, S, stride=stride, pad=pad, alpha=scale, sq=sq[pass_idx])
+    e._ghost.setdefault(id(w), {})[pass_idx] = (gz, x, R, S, stride, pad, scale)
+    if has_bias:
+        b = layer.bias
+        K = gz.shape[-1]
+        bbuf, bsq = e._buffers(b, n_pass, n, K)
+        ops.bias_grad_grouped(gz, group=1, alpha=scale, out=bbuf[pass_idx], sq=bsq[pass_idx])
+        bview = bbuf.view(n_pass, n, K)
+        bview._cslgan_rows = bbuf.view(n_pass * n, K)
+        b.grad_sample = bview
+
+
+_LayerCollector._ghost_rows = _ghost_rows
+
+
+def _dense_wgrad(gz, x, R, S, stride, pad, scale, row_scale=None):
     N = x.shape[0]
     tiles = ((gz.shape[-1] + 127) // 128) * ((R * S * x.shape[-1] + 127) // 128)
     group = 1
@@ -194,7 +229,7 @@ def _dense_wgrad(gz, x, R, S, stride, pad, scale):
         if N % g == 0 and (N // g) * tiles >= 512:
             group = g
             break
-    slabs = ops.conv2d_wgrad_grouped(gz, x, R, S, stride=stride, pad=pad, group=group, alpha=scale)
+    slabs = ops.conv2d_wgrad_grouped(gz, x, R, S, stride=stride, pad=pad, group=group, alpha=scale, row_scale=row_scale)
     if slabs.shape[0] == 1:
         return slabs[0].reshape(-1)
     out = torch.empty(slabs[0].numel(), device=x.device, dtype=torch.float32)
@@ -223,7 +258,7 @@ def _collect_roles(self, gz, x, R, S, stride, pad, has_bias):
         scale = float(n) if e.loss_reduction == "mean" else 1.0
         if role == "norms":
             _, sq = e._buffers(("norms", id(w)), 1, n, 0)
-            ops.conv2d_wgrad_grouped(g_, x_, R, S, stride=stride, pad=pad, group=1, alpha=scale, want_gw=False, sq=sq[0])
+            _weight_sqnorms(g_, x_, R, S, stride, pad, scale, sq[0])
             if has_bias:
                 _, bsq = e._buffers(("norms", id(layer.bias)), 1, n, 0)
                 ops.bias_grad_grouped(g_, group=1, alpha=scale, want_gb=False, sq=bsq[0])
@@ -231,6 +266,8 @@ def _collect_roles(self, gz, x, R, S, stride, pad, has_bias):
             e._add_dense(w, _dense_wgrad(g_, x_, R, S, stride, pad, scale))
             if has_bias:
                 e._add_dense(layer.bias, _dense_bgrad(g_, scale))
+        elif e._ghost_layer(g_, x_):
+            self._ghost_rows(0, 1, g_, x_, R, S, stride, pad, scale, has_bias)
         else:
             buf, sq = e._buffers(w, 1, n, K * R * S * Cc, e._gs_dtype)
             ops.conv2d_wgrad_grouped(g_, x_, R, S, stride=stride, pad=pad, group=1, alpha=scale,
@@ -257,14 +294,18 @@ class PrivacyEngine(PerSampleSink):
     materialize="private" only the passes that are clipped are materialised; never-clipped passes (generated
                           data under grad_clip_split) contribute a dense sum computed by the same MFMA kernel
                           with coarse groups — 2.2 GB less written and re-read per pass for D64 at B=128.
+    materialize="ghost"   as "private", and layers with few output pixels per sample (the critic's last two convs)
+                          are never materialised at all: their norms come from the pixel-Gram kernel and their
+                          clipped sum from one clip-weighted dense wgrad inside clip() ("ghost clipping").  Those
+                          parameters have no p.grad_sample.  Needs split clipping (accum_passes=False).
     `norms_only` (set around the adaptive-clipping pass) computes per-sample norms without storing gradients.
     """
 
     def __init__(self, module, batch_size, sample_size, alphas, noise_multiplier, max_grad_norm,
                  accum_passes=True, num_private_passes=None, auto_clip_and_accum_on_step=True,
                  loss_reduction="mean", world_size=1, materialize="all", grad_sample_dtype="fp32", **_unused):
-        if materialize not in ("all", "private"):
-            raise ValueError("materialize must be 'all' or 'private'")
+        if materialize not in ("all", "private", "ghost"):
+            raise ValueError("materialize must be 'all', 'private' or 'ghost'")
         if grad_sample_dtype not in ("fp32", "bf16"):
             raise ValueError("grad_sample_dtype must be 'fp32' or 'bf16'")
         # bf16: weight-tensor per-sample gradients are STORED as bfloat16 (fp32 MFMA accumulate, round-to-nearest
@@ -274,6 +315,7 @@ class PrivacyEngine(PerSampleSink):
         self.materialize, self.norms_only = materialize, False
         self.row_roles = None                   # set by Trainer.train_D_fused for one fused forward/backward
         self._dense = {}
+        self._ghost = {}                        # id(weight) -> {pass: (gz, x, R, S, stride, pad, scale)} awaiting clip()
         self.module = module
         self.batch_size, self.sample_size = batch_size, sample_size
         self.alphas = list(alphas)
@@ -316,6 +358,13 @@ class PrivacyEngine(PerSampleSink):
 
     def collector(self, layer):
         return self._collectors[layer]
+
+    @property
+    def lean(self):
+        return self.materialize in ("private", "ghost")
+
+    def _ghost_layer(self, gz, x):
+        return self.materialize == "ghost" and not self.accum_passes and ops.gram_norms_eligible(gz.shape, x.shape)
 
     def _n_private(self, n_pass):
         return n_pass if (self.accum_passes or self.num_private_passes is None) else min(self.num_private_passes, n_pass)
@@ -399,17 +448,21 @@ class PrivacyEngine(PerSampleSink):
         """[n_params, n_passes*B] squared per-sample norms.  Default: the values the wgrad epilogue
         accumulated; recompute=True re-reads the materialised grad_sample (cslgan_sample_sqnorm_f32),
         which is what must be used after a caller edited p.grad_sample in place (train.py:447)."""
+        stored = [self._bufs[id(p)][1].reshape(-1) for p in self.params]
         if recompute:
-            return ops.sample_sqnorm([_rows(p.grad_sample) for p in self.params])
-        return torch.stack([self._bufs[id(p)][1].reshape(-1) for p in self.params])
+            mat = [i for i, p in enumerate(self.params) if id(p) not in self._ghost]
+            fresh = ops.sample_sqnorm([_rows(self.params[i].grad_sample) for i in mat])
+            for j, i in enumerate(mat):
+                stored[i] = fresh[j]
+        return torch.stack(stored)
 
     # -- train.py:399-402, 417 -----------------------------------------------------------------
     def clip(self, recompute_norms=False):
         """Per-sample clip factors + clipped sum into p.summed_grad (a SUM over samples)."""
         ps = self.params
-        mats = [_rows(p.grad_sample) for p in ps]
-        n_pass = ps[0].grad_sample.shape[0]
-        B = ps[0].grad_sample.shape[1]
+        mat_idx = [i for i, p in enumerate(ps) if id(p) not in self._ghost]
+        mats = [_rows(ps[i].grad_sample) for i in mat_idx]
+        n_pass, B = self._bufs[id(ps[0])][1].shape
         if self.accum_passes and n_pass > 1:
             # passes are added per sample before clipping: column-sum over the pass axis
             summed_ps = [torch.empty((B, m.shape[1]), device=m.device, dtype=torch.float32) for m in mats]
@@ -427,7 +480,21 @@ class PrivacyEngine(PerSampleSink):
         for p in ps:
             p.summed_grad = torch.empty_like(p, memory_format=torch.preserve_format)
             outs.append(_flat(p.summed_grad))
-        ops.clip_accum_noise(mats, outs, factors=f)
+        if len(mat_idx) == len(ps):
+            ops.clip_accum_noise(mats, outs, factors=f)
+        else:
+            f_mat = f[torch.tensor(mat_idx, device=f.device)].contiguous() if per_layer else f
+            ops.clip_accum_noise(mats, [outs[i] for i in mat_idx], factors=f_mat)
+            for i, p in enumerate(ps):       # ghost layers: sum_b f_b g_b as one clip-weighted dense wgrad per pass
+                stash = self._ghost.get(id(p))
+                if stash is None:
+                    continue
+                fi = (f[i] if per_layer else f).reshape(n_pass, B)
+                total = None
+                for k, (gz, x, R, S, stride, pad, scale) in sorted(stash.items()):
+                    part = _dense_wgrad(gz, x, R, S, stride, pad, scale, row_scale=fi[k].contiguous())
+                    total = part if total is None else total.add_(part)
+                outs[i].copy_(total)
         if self._dense:       # sums of the never-clipped passes (materialize="private")
             ops.clip_accum_noise([self._dense[id(p)].view(1, -1) for p in ps], outs, beta=1.0)
         self._accumulated = False
@@ -521,6 +588,7 @@ class PrivacyEngine(PerSampleSink):
             self._fwd_count[l] = 0
         self._bufs.clear()
         self._dense.clear()
+        self._ghost.clear()
         self.row_roles = None
         for p in self.params:
             if hasattr(p, "grad_sample"):

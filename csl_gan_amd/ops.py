@@ -186,9 +186,37 @@ def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None, wkey=None):
     return gx
 
 
-def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_gw=True, sq=None, out=None, upsample=False):
+def gram_norms_eligible(gy_shape, x_shape, upsample=False):
+    """Shapes cslgan_conv2d_wgrad_sqnorm_gram_f32 accepts (and where the Gram form is cheaper than the product)."""
+    _, P, Q, K = gy_shape
+    return (not upsample) and P * Q <= 64 and K % 32 == 0 and x_shape[-1] % 32 == 0
+
+
+def conv2d_wgrad_sqnorm_gram(gy, x, R, S, stride=1, pad=0, alpha=1.0, sq=None):
+    """sq[N] += ||alpha * per-sample weight gradient||^2 from the two PQ x PQ Gram matrices (no gradient formed)."""
+    _chk(gy, "gy"); _chk(x, "x")
+    N, H, W, Cc = x.shape
+    N2, P, Q, K = gy.shape
+    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, False)
+    if N2 != N or (P2, Q2) != (P, Q):
+        raise RuntimeError("conv2d_wgrad_sqnorm_gram: gy %s inconsistent with x %s" % (tuple(gy.shape), tuple(x.shape)))
+    if sq is None:
+        sq = torch.zeros(N, device=x.device, dtype=torch.float32)
+    _chk(sq, "sq")
+    if sq.numel() != N:
+        raise RuntimeError("conv2d_wgrad_sqnorm_gram: sq needs %d entries" % N)
+    flop = 2.0 * N * (P * Q) ** 2 * (K + R * S * Cc)
+    _timed("conv2d_wgrad_gram_norms", flop, 4.0 * (gy.numel() + x.numel()), lambda: check(
+        _lib.lib().cslgan_conv2d_wgrad_sqnorm_gram_f32(C.byref(d), _p(gy), _p(x), float(alpha), _p(sq), _stream()),
+        "conv2d_wgrad_sqnorm_gram"), tag=lambda: "N%d %dx%d C%d K%d R%d s%d" % (N, H, W, Cc, K, R, stride))
+    return sq
+
+
+def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_gw=True, sq=None, out=None, upsample=False,
+                         row_scale=None):
     """gw[N/group,K,R,S,C] (per-group weight gradients) and/or sq[N/group] += ||alpha*gw_g||^2.
-    upsample=True: x is the LOW-res input of an upsample+conv (read through the nearest-2x map)."""
+    upsample=True: x is the LOW-res input of an upsample+conv (read through the nearest-2x map).
+    row_scale [N]: gy of sample n is weighted by row_scale[n] (clip-weighted sums; fp32 output, no sq)."""
     _chk(gy, "gy"); _chk(x, "x")
     N, H, W, Cc = x.shape
     N2, P, Q, K = gy.shape
@@ -198,6 +226,17 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
     if N % group:
         raise RuntimeError("conv2d_wgrad: N=%d not divisible by group=%d" % (N, group))
     G = N // group
+    if row_scale is not None:
+        _chk(row_scale, "row_scale")
+        if row_scale.numel() != N or sq is not None or not want_gw:
+            raise RuntimeError("conv2d_wgrad: row_scale needs [N] factors, a gradient output and no sq")
+        gw = out if out is not None else torch.empty((G, K, R, S, Cc), device=x.device, dtype=torch.float32)
+        _chk(gw, "gw")
+        flop = 2.0 * N * P * Q * K * R * S * Cc
+        _timed("conv2d_wgrad_grouped", flop, 4.0 * (N * H * W * Cc + N * P * Q * K + G * K * R * S * Cc), lambda: check(
+            _lib.lib().cslgan_conv2d_wgrad_scaled_f32(C.byref(d), _p(gy), _p(x), _p(row_scale), group, float(alpha), _p(gw), _stream()),
+            "conv2d_wgrad_scaled"), tag=lambda: "N%d %dx%d C%d K%d R%d s%d g%d scaled" % (N, H, W, Cc, K, R, stride, group))
+        return gw
     gw = None
     scratch = False
     if not want_gw and sq is not None:

@@ -8,10 +8,11 @@ Additions of this build (all optional, none changes a reference default):
   --max_iters N        stop after N training iterations (smoke runs)
   --dist               one process per GPU under torch.distributed (RCCL); see csl_gan_amd/distributed.py
   --fuse_passes B      run the adaptive / generated / real discriminator passes as one forward+backward over the
-                       concatenated batch (same numbers, fewer and fuller launches); needs --materialize private
+                       concatenated batch (same numbers, fewer and fuller launches); needs --materialize private|ghost
   --grad_sample_dtype  storage type of the materialised per-sample weight gradients (fp32 | bf16; fp32 accumulate)
   --materialize M      per-sample gradients kept in HBM: "all" passes (the fork's p.grad_sample layout) or only
-                       the "private" (clipped) passes — see csl_gan_amd.engine.PrivacyEngine
+                       the "private" (clipped) passes; "ghost" additionally never materialises layers with few
+                       output pixels (Gram norms + clip-weighted dense wgrad) — see csl_gan_amd.engine.PrivacyEngine
 Quirks kept on purpose: fill_defaults treats False like "unset" (options.py:95), so e.g. `-ispp False`
 on CelebA still becomes True; --mean_sample_noise_std is parsed as int (options.py:166).
 """
@@ -149,7 +150,7 @@ _ARGS = [
     (("--synthetic",), dict(default=False, action="store_true")),
     (("--max_iters",), dict(type=int, default=0)),
     (("--dist",), dict(default=False, action="store_true")),
-    (("--materialize",), dict(type=str, choices=["all", "private"], default="private")),
+    (("--materialize",), dict(type=str, choices=["all", "private", "ghost"], default="private")),
     (("--fuse_passes",), dict(type=str2bool, default=True)),
     (("--grad_sample_dtype",), dict(type=str, choices=["fp32", "bf16"], default="fp32")),
 ]

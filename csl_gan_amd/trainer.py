@@ -146,7 +146,7 @@ class Trainer:
             z = self.explicit["z_adapt"] if "z_adapt" in self.explicit else self.gen_z(o.batch_size)
             _, _, d_fake_loss, d_fake_aux_loss, _ = self.calc_d_fake_loss(img, labels, z, labels)
         _, _, d_real_loss, d_real_aux_loss = self.calc_d_real_loss(img, labels)
-        pe.norms_only = pe.materialize == "private"      # this pass only feeds the per-sample norms below
+        pe.norms_only = pe.lean      # this pass only feeds the per-sample norms below
         try:
             (d_real_loss + d_fake_loss + d_real_aux_loss + d_fake_aux_loss).backward()
         finally:
@@ -222,7 +222,7 @@ class Trainer:
     # ---- fused form of train.py:378-402 ---------------------------------------------------------
     def _can_fuse(self, use_dp):
         o, pe = self.opt, self.privacy_engine
-        return (use_dp and o.dp_mode == "gc" and o.grad_clip_split and getattr(pe, "materialize", "all") == "private"
+        return (use_dp and o.dp_mode == "gc" and o.grad_clip_split and getattr(pe, "lean", False)
                 and getattr(o, "fuse_passes", True) and not o.backprop_clip)
 
     def _fused_passes(self, img, labels, z, y):

@@ -155,6 +155,19 @@ int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* p, const float* gy, const float
 int cslgan_conv2d_wgrad_grouped_f32(const cslgan_conv_t* p, const float* gy, const float* x, int group,
                                     float alpha, float* gw, float* sq, void* stream);
 
+/* Clip-weighted grouped weight gradient: as cslgan_conv2d_wgrad_grouped_f32 with gy of sample n multiplied by
+ * row_scale[n] on load.  With row_scale = the per-sample clip factors f_b and group = N this is the clipped sum
+ * sum_b f_b g_b (privacy_engine.clip() + accumulate, train.py:399-417) without materialising p.grad_sample. */
+int cslgan_conv2d_wgrad_scaled_f32(const cslgan_conv_t* p, const float* gy, const float* x, const float* row_scale,
+                                   int group, float alpha, float* gw, void* stream);
+
+/* Per-sample squared norms of the weight gradient WITHOUT forming it:  sq[n] += alpha^2 * sum_{p,p'}
+ * (GY_n GY_n^T)[p,p'] (XU_n XU_n^T)[p,p']  — the same value cslgan_conv2d_wgrad_grouped_f32(group=1, gw=NULL)
+ * accumulates (opacus calc_sample_norms, train.py:311-314), 30x fewer FLOP for the critic's last conv.
+ * Needs P*Q <= 64, K % 32 == 0, C % 32 == 0, no upsample.  sq: [N], caller zeroes. */
+int cslgan_conv2d_wgrad_sqnorm_gram_f32(const cslgan_conv_t* p, const float* gy, const float* x, float alpha, float* sq,
+                                        void* stream);
+
 /* Same, storing gw as bfloat16 (round-to-nearest-even); sq is the norm of the ROUNDED values, i.e. of what
  * the clip kernels will read back. */
 int cslgan_conv2d_wgrad_grouped_bf16out_f32(const cslgan_conv_t* p, const float* gy, const float* x, int group,

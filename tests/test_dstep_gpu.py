@@ -80,6 +80,11 @@ CASES = [
     ("CelebA", ["-gcm", "adaptive-pl", "--materialize", "private"], 8, 128),
     ("MNIST", ["--model", "DeepConvResNet", "--penalty", "WGAN-GP", "-c", "3.0", "--materialize", "private"], 6, 16),
     ("MNIST", ["--model", "DeepConvResNet", "--penalty", "WGAN-GP", "-gcm", "adaptive", "-gcs", "False", "--materialize", "private"], 6, 16),
+    # ghost clipping: the last two critic convs are never materialised (Gram norms + clip-weighted dense wgrad)
+    ("CelebA", ["-gcm", "adaptive-pl", "--materialize", "ghost"], 8, 128),
+    ("CelebA", ["-c", "2.0", "--materialize", "ghost"], 8, 128),
+    ("CelebA", ["-gcm", "adaptive-pl", "--materialize", "ghost", "--fuse_passes", "False"], 8, 128),
+    ("MNIST", ["--model", "DeepConvResNet", "--penalty", "WGAN-GP", "-gcm", "adaptive", "-gcs", "False", "--materialize", "ghost"], 6, 16),
     # BASELINE config 5 geometry (extension): 128x128 images, one more generator block, 8x8 critic head
     ("CelebA", ["--im_size", "128", "-gcm", "adaptive-pl", "--materialize", "private"], 4, 128),
 ]
@@ -132,7 +137,7 @@ def test_train_D_matches_oracle(tmp_path, dataset, extra, B, latent):
         _close(last["adaptive_stats"], torch.tensor(obs["adaptive_stats"]), "adaptive stats")
     _close(last["clip_params"], torch.tensor(Cfin if isinstance(Cfin, list) else [Cfin]), "clip params")
     n_o, f_o = obs["norms"], obs["clip_factors"]          # [L or 1, passes, B]
-    if opt.grad_clip_split and opt.materialize == "private":   # only the clipped (real) pass has per-sample state
+    if opt.grad_clip_split and opt.materialize in ("private", "ghost"):   # only the clipped (real) pass has per-sample state
         _close(last["norms"], n_o[:, 1], "per-sample norms (private pass)")
         _close(last["clip_factors"].reshape(f_o.shape[0], -1), f_o[:, 1], "clip factors (private pass)")
         assert tr.D.blocks[0].weight.grad is not None

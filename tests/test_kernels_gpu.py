@@ -433,3 +433,52 @@ def test_repack_cache_follows_weight_updates():
                 p.grad = torch.ones_like(p, memory_format=torch.preserve_format)
             opt.step()
     assert len(ops.repack_cache.d) >= 2
+
+
+@pytest.mark.parametrize("case", [
+    # N, H, W, C, K, R, stride, pad
+    (5, 8, 8, 256, 512, 5, 2, 2),      # critic conv4: 16 output pixels
+    (3, 16, 16, 128, 256, 5, 2, 2),    # critic conv3: 64 output pixels
+    (7, 1, 1, 64, 32, 1, 1, 0),        # a linear layer: 1 pixel
+    (4, 6, 6, 32, 64, 3, 1, 1),        # 36 pixels, stride 1
+    (3, 4, 4, 32, 32, 3, 1, 1),
+    (2, 7, 5, 64, 96, 5, 2, 2),        # ragged: 4x3 outputs
+])
+def test_wgrad_gram_norms_and_scaled_sum(case):
+    """Ghost clipping pieces: per-sample ||gW_b||^2 from the pixel-Gram matrices equals the norm of the materialised
+    per-sample gradient; the clip-weighted dense wgrad equals sum_b f_b gW_b."""
+    ops = _ops()
+    N, H, W, C, K, R, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.zeros(K, C, R, R, requires_grad=True)
+    alpha = 2.5
+    gy = torch.randn(F.conv2d(x, w, None, stride=s, padding=p).shape, generator=g)
+    per = []
+    for b in range(N):
+        y = F.conv2d(x[b:b + 1], w, None, stride=s, padding=p)
+        per.append(torch.autograd.grad(y, w, gy[b:b + 1])[0] * alpha)
+    per = torch.stack(per)
+    sq_ref = per.double().pow(2).flatten(1).sum(1).float()
+    assert ops.gram_norms_eligible(_nhwc(gy).shape, _nhwc(x).shape)
+    sq = ops.conv2d_wgrad_sqnorm_gram(_nhwc(gy), _nhwc(x), R, R, stride=s, pad=p, alpha=alpha)
+    _close(sq, sq_ref, rtol=1e-4, what="gram norms %s" % (case,))
+    sq2 = torch.full((N,), 3.0, device="cuda")                       # accumulates into the caller's buffer
+    ops.conv2d_wgrad_sqnorm_gram(_nhwc(gy), _nhwc(x), R, R, stride=s, pad=p, alpha=alpha, sq=sq2)
+    _close(sq2 - 3.0, sq_ref, rtol=1e-4, what="gram norms accumulate")
+    f = torch.rand(N, generator=g)
+    ref = (per * f.view(-1, 1, 1, 1, 1)).sum(0)
+    got = ops.conv2d_wgrad_grouped(_nhwc(gy), _nhwc(x), R, R, stride=s, pad=p, group=N, alpha=alpha, row_scale=_dev(f))
+    _close(got[0].permute(0, 3, 1, 2), ref, what="clip-weighted dense wgrad %s" % (case,))
+    with pytest.raises(RuntimeError):
+        ops.conv2d_wgrad_grouped(_nhwc(gy), _nhwc(x), R, R, stride=s, pad=p, group=N, row_scale=_dev(f[:-1]))
+
+
+def test_wgrad_gram_rejects_unsupported_shapes():
+    ops = _ops()
+    gy, x = torch.zeros(2, 16, 16, 64, device="cuda"), torch.zeros(2, 32, 32, 32, device="cuda")
+    assert not ops.gram_norms_eligible(gy.shape, x.shape)
+    with pytest.raises(RuntimeError, match="at most 64 output pixels"):
+        ops.conv2d_wgrad_sqnorm_gram(gy, x, 5, 5, stride=2, pad=2)
+    with pytest.raises(RuntimeError, match="multiples of 32"):
+        ops.conv2d_wgrad_sqnorm_gram(torch.zeros(2, 4, 4, 24, device="cuda"), torch.zeros(2, 8, 8, 32, device="cuda"), 5, 5, stride=2, pad=2)

@@ -55,8 +55,11 @@ __global__ __launch_bounds__(256) void gram_sqnorm_kernel(const GramParams p) {
         l_py[i] = l_pix[i] / p.Q;
         l_px[i] = l_pix[i] - l_py[i] * p.Q;
     }
-    float4 rg[LPT];
-    auto load = [&](int it) {
+    // DEPTH chunk-iterations are in flight in registers: with one workgroup per sample and ~1 us of global latency per
+    // gather, a single prefetched iteration left the MFMAs idle nine tenths of the time (rocprofv3: 0.13 ms per launch).
+    constexpr int DEPTH = TILES == 1 ? 4 : 6;
+    float4 rg[DEPTH][LPT];
+    auto load = [&](int it, float4* dst) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const int c = TILES == 1 ? 4 * it + l_slot[i] : it;
@@ -72,14 +75,14 @@ __global__ __launch_bounds__(256) void gram_sqnorm_kernel(const GramParams p) {
                         v = *reinterpret_cast<const float4*>(p.x + (((long long)b * p.H + iy) * p.W + ix) * p.C + cc * 32 + j4);
                 }
             }
-            rg[i] = v;
+            dst[i] = v;
         }
     };
-    auto store = [&](int buf) {
+    auto store = [&](int buf, const float4* src) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const int row = (tid >> 3) + 32 * i;
-            *reinterpret_cast<float4*>(&As[buf][row * GR_LD + j4]) = rg[i];
+            *reinterpret_cast<float4*>(&As[buf][row * GR_LD + j4]) = src[i];
         }
     };
 
@@ -92,41 +95,48 @@ __global__ __launch_bounds__(256) void gram_sqnorm_kernel(const GramParams p) {
 #pragma unroll
     for (int v = 0; v < 16; ++v) { acc1[v] = 0.f; acc2[v] = 0.f; }
 
-    load(0);
-    store(0);
-    __syncthreads();
-    for (int it = 0; it < n_iter; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < n_iter) load(it + 1);
-        const int c = TILES == 1 ? 4 * it + wid : it;      // this wavefront's chunk
-        if (c < n_chunks) {
-            float4 af[4], bf[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                af[g] = *reinterpret_cast<const float4*>(&As[buf][rowA * GR_LD + 8 * g + 4 * h]);
-                bf[g] = *reinterpret_cast<const float4*>(&As[buf][rowB * GR_LD + 8 * g + 4 * h]);
-            }
-            if (c < p.n1) {
+    for (int d = 0; d < DEPTH; ++d) load(d, rg[d]);          // past-the-end iterations load zeros
+    int buf = 0;
+    for (int it0 = 0; it0 < n_iter; it0 += DEPTH) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].x, bf[g].x, acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].y, bf[g].y, acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].z, bf[g].z, acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].w, bf[g].w, acc1, 0, 0, 0);
+        for (int d = 0; d < DEPTH; ++d) {
+            const int it = it0 + d;
+            if (it < n_iter) {                                // uniform
+                store(buf, rg[d]);
+                load(it + DEPTH, rg[d]);
+                __syncthreads();                              // also orders this store after every wave's reads two iterations back
+                const int c = TILES == 1 ? 4 * it + wid : it; // this wavefront's chunk
+                if (c < n_chunks) {
+                    float4 af[4], bf[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        af[g] = *reinterpret_cast<const float4*>(&As[buf][rowA * GR_LD + 8 * g + 4 * h]);
+                        bf[g] = *reinterpret_cast<const float4*>(&As[buf][rowB * GR_LD + 8 * g + 4 * h]);
+                    }
+                    if (c < p.n1) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].x, bf[g].x, acc1, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].y, bf[g].y, acc1, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].z, bf[g].z, acc1, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].w, bf[g].w, acc1, 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].x, bf[g].x, acc2, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].y, bf[g].y, acc2, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].z, bf[g].z, acc2, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].w, bf[g].w, acc2, 0, 0, 0);
+                        }
+                    }
                 }
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].x, bf[g].x, acc2, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].y, bf[g].y, acc2, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].z, bf[g].z, acc2, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].w, bf[g].w, acc2, 0, 0, 0);
-                }
+                buf ^= 1;
             }
         }
-        if (it + 1 < n_iter) store(buf ^ 1);
-        __syncthreads();
     }
+    __syncthreads();
 
     float prod = 0.f;
     if (TILES == 1) {

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
                     if (m0 + a_mc + 3 < p.Kc) v.w = src[3];
                 }
                 if (p.row_scale) {
-                    const float sc = p.row_scale[(pix_base + kk) / PQ];
+                    const float sc = p.row_scale[g * p.group + kk / PQ];
                     v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
                 }
             }

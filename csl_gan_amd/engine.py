@@ -198,7 +198,7 @@ def _weight_sqnorms(gz, x, R, S, stride, pad, scale, sq_row):
         ops.conv2d_wgrad_grouped(gz, x, R, S, stride=stride, pad=pad, group=1, alpha=scale, want_gw=False, sq=sq_row)
 
 
-def _ghost_rows(self, pass_idx, n_pass, gz, x, R, S, stride, pad, scale, has_bias):
+def _ghost_rows(self, pass_idx, n_pass, gz, x, R, S, stride, pad, scale, has_bias, joint=None):
     """materialize="ghost": a clipped pass of a layer whose norms come from the Gram kernel.  Only the norms are
     computed now; (gz, x) are kept until clip() knows the factors and forms sum_b f_b g_b with ONE weighted dense
     wgrad — the per-sample gradient tensor (1.7 GB for the critic's last conv at B=128) is never written or re-read."""
@@ -207,7 +207,9 @@ def _ghost_rows(self, pass_idx, n_pass, gz, x, R, S, stride, pad, scale, has_bia
     n = x.shape[0]
     _, sq = e._buffers(w, n_pass, n, 0)
     ops.conv2d_wgrad_sqnorm_gram(gz, x, R, S, stride=stride, pad=pad, alpha=scale, sq=sq[pass_idx])
-    e._ghost.setdefault(id(w), {})[pass_idx] = (gz, x, R, S, stride, pad, scale)
+    # joint = (gz, x, n_dense, scale_dense): the never-clipped rows that sit right before these rows in a fused batch;
+    # their dense sum rides in the same clip-weighted launch (weight scale_dense instead of f_b * scale)
+    e._ghost.setdefault(id(w), {})[pass_idx] = (gz, x, R, S, stride, pad, scale, joint)
     if has_bias:
         b = layer.bias
         K = gz.shape[-1]
@@ -252,8 +254,11 @@ def _collect_roles(self, gz, x, R, S, stride, pad, has_bias):
     w = layer.weight
     K, Cc = gz.shape[-1], x.shape[-1]
     r0 = 0
+    ghost = e._ghost_layer(gz, x)
+    held = None                       # ghost layer: ("dense" rows start, count, scale) waiting for the private rows after them
     for role, n in e.row_roles:
         g_, x_ = gz[r0:r0 + n], x[r0:r0 + n]
+        row0 = r0
         r0 += n
         scale = float(n) if e.loss_reduction == "mean" else 1.0
         if role == "norms":
@@ -263,11 +268,21 @@ def _collect_roles(self, gz, x, R, S, stride, pad, has_bias):
                 _, bsq = e._buffers(("norms", id(layer.bias)), 1, n, 0)
                 ops.bias_grad_grouped(g_, group=1, alpha=scale, want_gb=False, sq=bsq[0])
         elif role == "dense":
-            e._add_dense(w, _dense_wgrad(g_, x_, R, S, stride, pad, scale))
+            if held is not None:
+                e._add_dense(w, _dense_wgrad(gz[held[0]:held[0] + held[1]], x[held[0]:held[0] + held[1]], R, S, stride, pad, held[2]))
+                held = None
+            if ghost:
+                held = (row0, n, scale)
+            else:
+                e._add_dense(w, _dense_wgrad(g_, x_, R, S, stride, pad, scale))
             if has_bias:
                 e._add_dense(layer.bias, _dense_bgrad(g_, scale))
-        elif e._ghost_layer(g_, x_):
-            self._ghost_rows(0, 1, g_, x_, R, S, stride, pad, scale, has_bias)
+        elif ghost:
+            joint = None
+            if held is not None and held[0] + held[1] == row0:
+                joint = (gz[held[0]:r0], x[held[0]:r0], held[1], held[2])
+                held = None
+            self._ghost_rows(0, 1, g_, x_, R, S, stride, pad, scale, has_bias, joint=joint)
         else:
             buf, sq = e._buffers(w, 1, n, K * R * S * Cc, e._gs_dtype)
             ops.conv2d_wgrad_grouped(g_, x_, R, S, stride=stride, pad=pad, group=1, alpha=scale,
@@ -282,6 +297,9 @@ def _collect_roles(self, gz, x, R, S, stride, pad, has_bias):
                 bview = bbuf.view(1, n, K)
                 bview._cslgan_rows = bbuf.view(n, K)
                 b.grad_sample = bview
+
+    if held is not None:
+        e._add_dense(w, _dense_wgrad(gz[held[0]:held[0] + held[1]], x[held[0]:held[0] + held[1]], R, S, stride, pad, held[2]))
 
 
 _LayerCollector._collect_roles = _collect_roles
@@ -491,12 +509,18 @@ class PrivacyEngine(PerSampleSink):
                     continue
                 fi = (f[i] if per_layer else f).reshape(n_pass, B)
                 total = None
-                for k, (gz, x, R, S, stride, pad, scale) in sorted(stash.items()):
-                    part = _dense_wgrad(gz, x, R, S, stride, pad, scale, row_scale=fi[k].contiguous())
+                for k, (gz, x, R, S, stride, pad, scale, joint) in sorted(stash.items()):
+                    if joint is None:
+                        part = _dense_wgrad(gz, x, R, S, stride, pad, scale, row_scale=fi[k].contiguous())
+                    else:
+                        gzj, xj, n_d, scale_d = joint
+                        rs = torch.cat([torch.full((n_d,), float(scale_d), device=f.device, dtype=torch.float32), fi[k] * float(scale)])
+                        part = _dense_wgrad(gzj, xj, R, S, stride, pad, 1.0, row_scale=rs)
                     total = part if total is None else total.add_(part)
                 outs[i].copy_(total)
-        if self._dense:       # sums of the never-clipped passes (materialize="private")
-            ops.clip_accum_noise([self._dense[id(p)].view(1, -1) for p in ps], outs, beta=1.0)
+        if self._dense:       # sums of the never-clipped passes (lean modes)
+            idx = [i for i, p in enumerate(ps) if id(p) in self._dense]
+            ops.clip_accum_noise([self._dense[id(ps[i])].view(1, -1) for i in idx], [outs[i] for i in idx], beta=1.0)
         self._accumulated = False
 
     def accum_grads_across_passes(self):

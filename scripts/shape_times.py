@@ -6,8 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from csl_gan_amd import ops
 
+extra = sys.argv[sys.argv.index("--opt") + 1].split() if "--opt" in sys.argv else []
 with contextlib.redirect_stdout(sys.stderr):
-    opt, tr, img = bench.build_trainer(0, 1, 0)
+    opt, tr, img = bench.build_trainer(0, 1, 0, extra=extra)
 B = img.shape[0]
 g_mode = "--g" in sys.argv
 

@@ -162,6 +162,106 @@ __global__ __launch_bounds__(256) void gram_sqnorm_kernel(const GramParams p) {
     }
 }
 
+
+// ---- layers with at most 16 output pixels AND at most 16 input pixels per stride-parity class ------------------
+// (the critic's last conv: 8x8x256 -> 4x4x512, 5x5 stride 2).  The unfolded Gram matrix is assembled from the
+// pixel-pair Gram matrices of the input instead of being multiplied out tap by tap:
+//   (XU XU^T)[p,p'] = sum_t < x[s*p + t], x[s*p' + t] >  and  s*p + t, s*p' + t always share their parity class,
+// so with XX_c = X_c X_c^T (X_c: the <= 16 pixels of class c, K = C) the sum over the T taps is T lookups.
+// Work per sample: s^2 * 2*16*16*C + 2*16*16*K FLOP (0.8 MFLOP for the last critic conv; the tap-by-tap Gram form
+// needs 3.5, the product 105).  One wavefront per parity class on v_mfma_f32_16x16x4_f32 with the operands loaded
+// straight into fragment registers (A and B of X X^T are the same registers); K of GY GY^T is split over the four
+// wavefronts.  ~100 KB read per sample: the kernel is a stream over gy and x.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct GramSmallParams {
+    const float* gy;     // [N][PQ][K]
+    const float* x;      // [N][H][W][C]
+    int N, H, W, C, K, PQ, Q, T, s;
+    float alpha2;
+    float* sq;
+    signed char tcls[IG_MAX_TAPS], tdy[IG_MAX_TAPS], tdx[IG_MAX_TAPS];   // tap -> parity class, offsets on the class grid
+    int Hc[4], Wc[4];    // class grid dims
+};
+
+__global__ __launch_bounds__(256) void gram_sqnorm_small_kernel(const GramSmallParams p) {
+    __shared__ float XXs[4][16 * 17];
+    __shared__ float G1s[16 * 17];
+    __shared__ float s_red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int b = blockIdx.x;
+    const int row = lane & 15, q = lane >> 4;
+    for (int i = tid; i < 16 * 17; i += 256) G1s[i] = 0.f;
+    __syncthreads();
+
+    // ---- XX_c for class c = wid ---------------------------------------------------------------------------
+    const int nc = p.s * p.s;
+    f32x4 accx = {0.f, 0.f, 0.f, 0.f};
+    if (wid < nc) {
+        const int cy = wid / p.s, cx = wid - cy * p.s;
+        const int Hc = p.Hc[wid], Wc = p.Wc[wid];
+        const int ly = row / Wc, lx = row - ly * Wc;
+        const bool ok = row < Hc * Wc;
+        const float* src = p.x + (((long long)b * p.H + (ly * p.s + cy)) * p.W + (lx * p.s + cx)) * p.C + 4 * q;
+        for (int j0 = 0; j0 < p.C; j0 += 128) {          // 8 float4 per lane in flight
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = (ok && j0 + 16 * j < p.C) ? *reinterpret_cast<const float4*>(src + j0 + 16 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                accx = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j].x, v[j].x, accx, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j].y, v[j].y, accx, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j].z, v[j].z, accx, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j].w, v[j].w, accx, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) XXs[wid][(4 * q + i) * 17 + row] = accx[i];
+    }
+    // ---- this wavefront's quarter of GY GY^T ------------------------------------------------------------
+    {
+        f32x4 accg = {0.f, 0.f, 0.f, 0.f};
+        const int kq = p.K >> 2;
+        const bool ok = row < p.PQ;
+        const float* src = p.gy + ((long long)b * p.PQ + row) * p.K + wid * kq + 4 * q;
+        for (int j0 = 0; j0 < kq; j0 += 128) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = (ok && j0 + 16 * j < kq) ? *reinterpret_cast<const float4*>(src + j0 + 16 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                accg = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j].x, v[j].x, accg, 0, 0, 0);
+                accg = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j].y, v[j].y, accg, 0, 0, 0);
+                accg = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j].z, v[j].z, accg, 0, 0, 0);
+                accg = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j].w, v[j].w, accg, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(&G1s[(4 * q + i) * 17 + row], accg[i]);
+    }
+    __syncthreads();
+    // ---- sum_{p,p'} G1[p,p'] * sum_t XX_{c(t)}[loc(p,t), loc(p',t)] --------------------------------------
+    float prod = 0.f;
+    {
+        const int pa = tid >> 4, pb = tid & 15;
+        if (pa < p.PQ && pb < p.PQ) {
+            const int ay = pa / p.Q, ax = pa - ay * p.Q, by = pb / p.Q, bx = pb - by * p.Q;
+            float g2 = 0.f;
+            for (int t = 0; t < p.T; ++t) {
+                const int c = p.tcls[t], Hc = p.Hc[c], Wc = p.Wc[c];
+                const int ya = ay + p.tdy[t], xa = ax + p.tdx[t], yb = by + p.tdy[t], xb = bx + p.tdx[t];
+                if ((unsigned)ya < (unsigned)Hc && (unsigned)xa < (unsigned)Wc && (unsigned)yb < (unsigned)Hc && (unsigned)xb < (unsigned)Wc)
+                    g2 += XXs[c][(ya * Wc + xa) * 17 + yb * Wc + xb];
+            }
+            prod = G1s[pa * 17 + pb] * g2;
+        }
+    }
+    const float tot = block_sum_256(prod, s_red);
+    if (tid == 0) atomicAdd(p.sq + b, p.alpha2 * tot);
+}
+
 }  // namespace cslgan
 
 using namespace cslgan;
@@ -179,6 +279,31 @@ int cslgan_conv2d_wgrad_sqnorm_gram_f32(const cslgan_conv_t* c, const float* gy,
     CSLGAN_REQUIRE(P * Q >= 1 && P * Q <= 64, "wgrad_sqnorm_gram: needs at most 64 output pixels per sample, got %d", P * Q);
     CSLGAN_REQUIRE(c->K % 32 == 0 && c->C % 32 == 0, "wgrad_sqnorm_gram: K=%d and C=%d must be multiples of 32", c->K, c->C);
     CSLGAN_REQUIRE(aligned16(gy) && aligned16(x), "wgrad_sqnorm_gram: operands must be 16-byte aligned");
+    {   // few pixels per stride-parity class: assemble the unfolded Gram matrix from pixel-pair Gram matrices
+        const int st = c->stride;
+        bool small = P * Q <= 16 && st >= 1 && st <= 2 && c->K % 64 == 0 && c->C % 16 == 0;
+        GramSmallParams sp{};
+        for (int cls = 0; small && cls < st * st; ++cls) {
+            const int cy = cls / st, cx = cls % st;
+            sp.Hc[cls] = c->H > cy ? (c->H - cy + st - 1) / st : 0;
+            sp.Wc[cls] = c->W > cx ? (c->W - cx + st - 1) / st : 0;
+            small = small && sp.Hc[cls] * sp.Wc[cls] <= 16 && sp.Hc[cls] * sp.Wc[cls] >= 1;
+        }
+        if (small) {
+            auto fl = [](int v, int d) { return v >= 0 ? v / d : -((-v + d - 1) / d); };
+            sp.gy = gy; sp.x = x; sp.N = c->N; sp.H = c->H; sp.W = c->W; sp.C = c->C; sp.K = c->K; sp.PQ = P * Q; sp.Q = Q;
+            sp.T = c->R * c->S; sp.s = st; sp.alpha2 = alpha * alpha; sp.sq = sq;
+            for (int kh = 0; kh < c->R; ++kh)
+                for (int kw = 0; kw < c->S; ++kw) {
+                    const int t = kh * c->S + kw, oy = kh - c->pad, ox = kw - c->pad;
+                    const int dy = fl(oy, st), dx = fl(ox, st);
+                    sp.tdy[t] = (signed char)dy; sp.tdx[t] = (signed char)dx;
+                    sp.tcls[t] = (signed char)((oy - dy * st) * st + (ox - dx * st));
+                }
+            hipLaunchKernelGGL(gram_sqnorm_small_kernel, dim3((unsigned)c->N), dim3(256), 0, (hipStream_t)stream, sp);
+            return check_launch("gram_sqnorm_small_kernel");
+        }
+    }
     GramParams p{};
     p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.K = c->K; p.PQ = P * Q; p.Q = Q; p.T = c->R * c->S;
     p.stride = c->stride; p.n1 = c->K / 32; p.n2 = p.T * (c->C / 32); p.alpha2 = alpha * alpha; p.sq = sq;

@@ -168,7 +168,7 @@ class _LayerCollector:
             return
         if e.lean:
             pass_idx, n_pass = pass_idx - (n_pass - n_private), n_private
-        if e._ghost_layer(gz, x):
+        if e._ghost_layer(gz, x, stride):
             self._ghost_rows(pass_idx, n_pass, gz, x, R, S, stride, pad, scale, has_bias)
             return
         buf, sq = e._buffers(w, n_pass, B, K * R * S * Cc, e._gs_dtype)
@@ -192,7 +192,7 @@ class _LayerCollector:
 def _weight_sqnorms(gz, x, R, S, stride, pad, scale, sq_row):
     """sq_row[n] += ||scale * per-sample weight gradient||^2 without storing the gradient: from the two pixel-Gram
     matrices where that is the cheaper form (few output pixels), else from the product kernel's epilogue."""
-    if ops.gram_norms_eligible(gz.shape, x.shape):
+    if ops.gram_norms_preferred(gz.shape, x.shape, stride):
         ops.conv2d_wgrad_sqnorm_gram(gz, x, R, S, stride=stride, pad=pad, alpha=scale, sq=sq_row)
     else:
         ops.conv2d_wgrad_grouped(gz, x, R, S, stride=stride, pad=pad, group=1, alpha=scale, want_gw=False, sq=sq_row)
@@ -227,7 +227,7 @@ def _dense_wgrad(gz, x, R, S, stride, pad, scale, row_scale=None):
     N = x.shape[0]
     tiles = ((gz.shape[-1] + 127) // 128) * ((R * S * x.shape[-1] + 127) // 128)
     group = 1
-    for g in (16, 8, 4, 2):
+    for g in (64, 32, 16, 8, 4, 2):
         if N % g == 0 and (N // g) * tiles >= 512:
             group = g
             break
@@ -254,7 +254,7 @@ def _collect_roles(self, gz, x, R, S, stride, pad, has_bias):
     w = layer.weight
     K, Cc = gz.shape[-1], x.shape[-1]
     r0 = 0
-    ghost = e._ghost_layer(gz, x)
+    ghost = e._ghost_layer(gz, x, stride)
     held = None                       # ghost layer: ("dense" rows start, count, scale) waiting for the private rows after them
     for role, n in e.row_roles:
         g_, x_ = gz[r0:r0 + n], x[r0:r0 + n]
@@ -312,8 +312,8 @@ class PrivacyEngine(PerSampleSink):
     materialize="private" only the passes that are clipped are materialised; never-clipped passes (generated
                           data under grad_clip_split) contribute a dense sum computed by the same MFMA kernel
                           with coarse groups — 2.2 GB less written and re-read per pass for D64 at B=128.
-    materialize="ghost"   as "private", and layers with few output pixels per sample (the critic's last two convs)
-                          are never materialised at all: their norms come from the pixel-Gram kernel and their
+    materialize="ghost"   as "private", and layers with at most 16 output pixels per sample (the critic's last conv,
+                          76 % of its parameters) are never materialised at all: their norms come from the pixel-Gram kernel and their
                           clipped sum from one clip-weighted dense wgrad inside clip() ("ghost clipping").  Those
                           parameters have no p.grad_sample.  Needs split clipping (accum_passes=False).
     `norms_only` (set around the adaptive-clipping pass) computes per-sample norms without storing gradients.
@@ -381,8 +381,8 @@ class PrivacyEngine(PerSampleSink):
     def lean(self):
         return self.materialize in ("private", "ghost")
 
-    def _ghost_layer(self, gz, x):
-        return self.materialize == "ghost" and not self.accum_passes and ops.gram_norms_eligible(gz.shape, x.shape)
+    def _ghost_layer(self, gz, x, stride):
+        return self.materialize == "ghost" and not self.accum_passes and ops.gram_norms_preferred(gz.shape, x.shape, stride)
 
     def _n_private(self, n_pass):
         return n_pass if (self.accum_passes or self.num_private_passes is None) else min(self.num_private_passes, n_pass)

@@ -192,6 +192,16 @@ def gram_norms_eligible(gy_shape, x_shape, upsample=False):
     return (not upsample) and P * Q <= 64 and K % 32 == 0 and x_shape[-1] % 32 == 0
 
 
+def gram_norms_preferred(gy_shape, x_shape, stride, upsample=False):
+    """Shapes where the Gram form runs on the pixel-pair kernel (<= 16 output pixels and <= 16 input pixels per
+    stride-parity class): there it is far cheaper than the product, so the engine uses it for norms and ghost clipping."""
+    _, P, Q, K = gy_shape
+    _, H, W, Cc = x_shape
+    if upsample or stride not in (1, 2) or P * Q > 16 or K % 64 or Cc % 32:
+        return False
+    return ((H + stride - 1) // stride) * ((W + stride - 1) // stride) <= 16
+
+
 def conv2d_wgrad_sqnorm_gram(gy, x, R, S, stride=1, pad=0, alpha=1.0, sq=None):
     """sq[N] += ||alpha * per-sample weight gradient||^2 from the two PQ x PQ Gram matrices (no gradient formed)."""
     _chk(gy, "gy"); _chk(x, "x")

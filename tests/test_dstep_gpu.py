@@ -80,7 +80,7 @@ CASES = [
     ("CelebA", ["-gcm", "adaptive-pl", "--materialize", "private"], 8, 128),
     ("MNIST", ["--model", "DeepConvResNet", "--penalty", "WGAN-GP", "-c", "3.0", "--materialize", "private"], 6, 16),
     ("MNIST", ["--model", "DeepConvResNet", "--penalty", "WGAN-GP", "-gcm", "adaptive", "-gcs", "False", "--materialize", "private"], 6, 16),
-    # ghost clipping: the last two critic convs are never materialised (Gram norms + clip-weighted dense wgrad)
+    # ghost clipping: the last critic conv is never materialised (Gram norms + clip-weighted dense wgrad)
     ("CelebA", ["-gcm", "adaptive-pl", "--materialize", "ghost"], 8, 128),
     ("CelebA", ["-c", "2.0", "--materialize", "ghost"], 8, 128),
     ("CelebA", ["-gcm", "adaptive-pl", "--materialize", "ghost", "--fuse_passes", "False"], 8, 128),

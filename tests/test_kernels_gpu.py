@@ -443,6 +443,12 @@ def test_repack_cache_follows_weight_updates():
     (4, 6, 6, 32, 64, 3, 1, 1),        # 36 pixels, stride 1
     (3, 4, 4, 32, 32, 3, 1, 1),
     (2, 7, 5, 64, 96, 5, 2, 2),        # ragged: 4x3 outputs
+    # pixel-pair kernel (<= 16 output pixels, <= 16 input pixels per parity class, K % 64 == 0)
+    (3, 4, 4, 32, 64, 3, 1, 1),        # stride 1: one class
+    (2, 7, 5, 64, 128, 5, 2, 2),       # odd input: four classes of different sizes
+    (4, 2, 2, 64, 64, 3, 1, 1),
+    (6, 8, 8, 32, 192, 3, 2, 1),
+    (2, 1, 1, 64, 64, 1, 1, 0),
 ])
 def test_wgrad_gram_norms_and_scaled_sum(case):
     """Ghost clipping pieces: per-sample ||gW_b||^2 from the pixel-Gram matrices equals the norm of the materialised

@@ -227,7 +227,7 @@ def _dense_wgrad(gz, x, R, S, stride, pad, scale, row_scale=None):
     N = x.shape[0]
     tiles = ((gz.shape[-1] + 127) // 128) * ((R * S * x.shape[-1] + 127) // 128)
     group = 1
-    for g in (64, 32, 16, 8, 4, 2):
+    for g in (16, 8, 4, 2):
         if N % g == 0 and (N // g) * tiles >= 512:
             group = g
             break

@@ -197,6 +197,8 @@ def gram_norms_preferred(gy_shape, x_shape, stride, upsample=False):
     stride-parity class): there it is far cheaper than the product, so the engine uses it for norms and ghost clipping."""
     _, P, Q, K = gy_shape
     _, H, W, Cc = x_shape
+    if not upsample and P * Q == 1 and H * W == 1:
+        return True              # a linear layer: ||gy_b x_b^T||^2 = ||gy_b||^2 ||x_b||^2
     if upsample or stride not in (1, 2) or P * Q > 16 or K % 64 or Cc % 32:
         return False
     return ((H + stride - 1) // stride) * ((W + stride - 1) // stride) <= 16
@@ -215,6 +217,11 @@ def conv2d_wgrad_sqnorm_gram(gy, x, R, S, stride=1, pad=0, alpha=1.0, sq=None):
     _chk(sq, "sq")
     if sq.numel() != N:
         raise RuntimeError("conv2d_wgrad_sqnorm_gram: sq needs %d entries" % N)
+    if P * Q == 1 and H * W == 1 and R == 1 and S == 1:
+        # linear layer: the 1x1 Gram matrices are the two row norms (one pass of the contract norm kernel over gy and x)
+        both = sample_sqnorm([gy.reshape(N, K), x.reshape(N, Cc)])
+        sq.view(-1).addcmul_(both[0], both[1], value=float(alpha) ** 2)
+        return sq
     flop = 2.0 * N * (P * Q) ** 2 * (K + R * S * Cc)
     _timed("conv2d_wgrad_gram_norms", flop, 4.0 * (gy.numel() + x.numel()), lambda: check(
         _lib.lib().cslgan_conv2d_wgrad_sqnorm_gram_f32(C.byref(d), _p(gy), _p(x), float(alpha), _p(sq), _stream()),
@@ -375,6 +382,8 @@ def sample_sqnorm(mats: Sequence[torch.Tensor]) -> torch.Tensor:
             o = torch.empty((len(chunk), n_rows), device=chunk[0].device, dtype=torch.float32)
             nbytes = float(sum(n_rows * m.shape[1] * m.element_size() for m in chunk))
             _timed("sample_sqnorm", 0.0, nbytes, lambda: check(fn(C.byref(s), n_rows, _p(o), _stream()), "sample_sqnorm"))
+            if len(sub) == len(mats):
+                return o
             out[torch.tensor(sub, device=out.device)] = o
     return out
 

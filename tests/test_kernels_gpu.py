@@ -449,6 +449,8 @@ def test_repack_cache_follows_weight_updates():
     (4, 2, 2, 64, 64, 3, 1, 1),
     (6, 8, 8, 32, 192, 3, 2, 1),
     (2, 1, 1, 64, 64, 1, 1, 0),
+    (9, 1, 1, 8192, 1, 1, 1, 0),       # the critic's linear head (norm product)
+    (5, 1, 1, 794, 128, 1, 1, 0),
 ])
 def test_wgrad_gram_norms_and_scaled_sum(case):
     """Ghost clipping pieces: per-sample ||gW_b||^2 from the pixel-Gram matrices equals the norm of the materialised
@@ -466,7 +468,7 @@ def test_wgrad_gram_norms_and_scaled_sum(case):
         per.append(torch.autograd.grad(y, w, gy[b:b + 1])[0] * alpha)
     per = torch.stack(per)
     sq_ref = per.double().pow(2).flatten(1).sum(1).float()
-    assert ops.gram_norms_eligible(_nhwc(gy).shape, _nhwc(x).shape)
+    assert ops.gram_norms_eligible(_nhwc(gy).shape, _nhwc(x).shape) or ops.gram_norms_preferred(_nhwc(gy).shape, _nhwc(x).shape, s)
     sq = ops.conv2d_wgrad_sqnorm_gram(_nhwc(gy), _nhwc(x), R, R, stride=s, pad=p, alpha=alpha)
     _close(sq, sq_ref, rtol=1e-4, what="gram norms %s" % (case,))
     sq2 = torch.full((N,), 3.0, device="cuda")                       # accumulates into the caller's buffer

@@ -150,7 +150,7 @@ _ARGS = [
     (("--synthetic",), dict(default=False, action="store_true")),
     (("--max_iters",), dict(type=int, default=0)),
     (("--dist",), dict(default=False, action="store_true")),
-    (("--materialize",), dict(type=str, choices=["all", "private", "ghost"], default="private")),
+    (("--materialize",), dict(type=str, choices=["all", "private", "ghost"], default="ghost")),
     (("--fuse_passes",), dict(type=str2bool, default=True)),
     (("--grad_sample_dtype",), dict(type=str, choices=["fp32", "bf16"], default="fp32")),
 ]

@@ -124,6 +124,9 @@ struct McParams {
     int tiles_m, tiles_n;
     int ksplit;          // >1: the group's pixels are divided over ksplit workgroups that atomically add into zeroed gw
     const float* row_scale;   // nullable [N]: gy of sample n is multiplied by row_scale[n] on load (clip-weighted sums)
+    int gy_phase;        // 1: sub-pixel form of an upsample+conv weight gradient.  P,Q are the LOW-res grid, gy is the full
+                         // [N][2P][2Q][Kc] tensor read at (2*oy+a, 2*ox+b); n -> (phase a*2+b, tap, c) with Ndim = 4*T*C, and
+                         // every BN-wide n-tile lies inside one phase (T*C % BN == 0)
     signed char ty[IG_MAX_TAPS], tx[IG_MAX_TAPS];   // kh-pad, kw-pad
 };
 

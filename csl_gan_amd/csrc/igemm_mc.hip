@@ -48,12 +48,16 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
     // B columns are fixed per thread: decode (tap, c) once
     int b_ty[4], b_tx[4], b_c[4];
     bool b_nok[4];
+    const int per_phase = p.T * p.C;
+    const int phase = p.gy_phase ? n0 / per_phase : 0;          // uniform: an n-tile never straddles phases
+    const int ph_a = phase >> 1, ph_b = phase & 1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int n = n0 + b_nc + e;
         b_nok[e] = n < p.Ndim;
-        const int t = b_nok[e] ? n / p.C : 0;
-        b_c[e] = n - t * p.C;
+        const int nl = n - phase * per_phase;
+        const int t = b_nok[e] ? nl / p.C : 0;
+        b_c[e] = nl - t * p.C;
         b_ty[e] = p.ty[t];
         b_tx[e] = p.tx[t];
     }
@@ -67,6 +71,11 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (kk < Ktot) {
                 const float* src = p.gy + (pix_base + kk) * p.Kc + m0 + a_mc;
+                if (p.gy_phase) {
+                    const int il = kk / PQ, pix = kk - il * PQ;
+                    const int oy = pix / p.Q, ox = pix - oy * p.Q;
+                    src = p.gy + ((((long long)g * p.group + il) * (2 * p.P) + 2 * oy + ph_a) * (2 * p.Q) + 2 * ox + ph_b) * p.Kc + m0 + a_mc;
+                }
                 if (VEC_A) {
                     if (m0 + a_mc < p.Kc) v = *reinterpret_cast<const float4*>(src);
                 } else {
@@ -313,6 +322,25 @@ int cslgan_conv2d_wgrad_scaled_f32(const cslgan_conv_t* c, const float* gy, cons
                                    float alpha, float* gw, void* stream) {
     CSLGAN_REQUIRE(row_scale && gw, "conv2d_wgrad_scaled: null argument");
     return wgrad_grouped_impl(c, gy, x, group, alpha, gw, nullptr, stream, 0, row_scale);
+}
+
+int cslgan_conv2d_up_wgrad_phases_f32(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha,
+                                      float* gwp, void* stream) {
+    CSLGAN_REQUIRE(c && gy && x && gwp, "conv2d_up_wgrad_phases: null argument");
+    CSLGAN_REQUIRE(c->upsample == 1 && c->stride == 1 && c->R == 5 && c->S == 5 && c->pad == 2, "conv2d_up_wgrad_phases: needs a 5x5 'same' upsample conv");
+    CSLGAN_REQUIRE(c->P == 2 * c->H && c->Q == 2 * c->W, "conv2d_up_wgrad_phases: output must be 2H x 2W");
+    CSLGAN_REQUIRE(c->C % 128 == 0 && c->K % 4 == 0, "conv2d_up_wgrad_phases: needs C %% 128 == 0 and K %% 4 == 0");
+    CSLGAN_REQUIRE(group >= 1 && c->N % group == 0, "conv2d_up_wgrad_phases: N=%d not divisible by group=%d", c->N, group);
+    CSLGAN_REQUIRE(aligned16(gy) && aligned16(x), "conv2d_up_wgrad_phases: operands must be 16-byte aligned");
+    McParams p{};
+    p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->H; p.Q = c->W; p.Kc = c->K;
+    p.T = 9; p.Ndim = 4 * 9 * c->C; p.stride = 1; p.ups = 0; p.group = group; p.n_groups = c->N / group;
+    p.alpha = alpha; p.gw = gwp; p.sq = nullptr; p.out_bf16 = 0; p.row_scale = nullptr; p.gy_phase = 1;
+    for (int t = 0; t < IG_MAX_TAPS; ++t) { p.ty[t] = 0; p.tx[t] = 0; }
+    for (int u = 0; u < 3; ++u)
+        for (int v = 0; v < 3; ++v) { p.ty[u * 3 + v] = (signed char)(u - 1); p.tx[u * 3 + v] = (signed char)(v - 1); }
+    if (c->K > 64) return launch_mc_tile<128, 128, 2, 2>(p, true, true, (hipStream_t)stream);
+    return launch_mc_tile<64, 128, 1, 4>(p, true, true, (hipStream_t)stream);
 }
 
 int cslgan_bias_grad_grouped_f32(const float* gy, int N, int PQ, int K, int group, float alpha, float* gb, float* sq,

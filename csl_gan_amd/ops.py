@@ -243,6 +243,21 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
     if N % group:
         raise RuntimeError("conv2d_wgrad: N=%d not divisible by group=%d" % (N, group))
     G = N // group
+    if (upsample and R == 5 and S == 5 and stride == 1 and pad == 2 and Cc % 128 == 0 and K % 4 == 0 and want_gw and sq is None
+            and row_scale is None and (out is None or out.dtype == torch.float32)):
+        # sub-pixel form: 36 MACs per low-res pixel instead of 100, then fold the four phases onto the 25 taps
+        L = _lib.lib()
+        gwp = torch.empty((G, K, 36, Cc), device=x.device, dtype=torch.float32)
+        gw = out if out is not None else torch.empty((G, K, R, S, Cc), device=x.device, dtype=torch.float32)
+        _chk(gw, "gw")
+        flop = 2.0 * N * P * Q * K * R * S * Cc
+
+        def run():
+            check(L.cslgan_conv2d_up_wgrad_phases_f32(C.byref(d), _p(gy), _p(x), group, float(alpha), _p(gwp), _stream()), "conv2d_up_wgrad_phases")
+            check(L.cslgan_fold_up_wgrad_f32(_p(gwp), G * K, Cc, _p(gw), _stream()), "fold_up_wgrad")
+        _timed("conv2d_wgrad_grouped", flop, 4.0 * (N * H * W * Cc + N * P * Q * K + G * K * R * S * Cc), run, exec_flop=flop * 9.0 / 25.0,
+               tag=lambda: "N%d %dx%d C%d K%d R%d g%d up-phases" % (N, H, W, Cc, K, R, group))
+        return gw
     if row_scale is not None:
         _chk(row_scale, "row_scale")
         if row_scale.numel() != N or sq is not None or not want_gw:

@@ -161,6 +161,16 @@ int cslgan_conv2d_wgrad_grouped_f32(const cslgan_conv_t* p, const float* gy, con
 int cslgan_conv2d_wgrad_scaled_f32(const cslgan_conv_t* p, const float* gy, const float* x, const float* row_scale,
                                    int group, float alpha, float* gw, void* stream);
 
+/* Weight gradient of y = conv5x5(nearest_up2(x)) ('same', stride 1; UpsampleConv, DCResNet_models.py:13-16) in
+ * sub-pixel form: the four output phases (a,b) of gy each see a 3x3 window of the LOW-res x, so
+ *   gwp[g][k][a*2+b][u][v][c] = alpha * sum_{n in group g} sum_{i,j} gy[n,2i+a,2j+b,k] x[n,i+u-1,j+v-1,c]
+ * costs 36 MACs per low-res pixel where the direct form costs 100 (train_G backward, train.py:502-517).
+ * cslgan_fold_up_wgrad_f32 adds the phases back onto the 25 filter taps: gw[gk][r][s][c], GK = groups*K.
+ * Needs C % 128 == 0, K % 4 == 0. */
+int cslgan_conv2d_up_wgrad_phases_f32(const cslgan_conv_t* p, const float* gy, const float* x, int group, float alpha,
+                                      float* gwp, void* stream);
+int cslgan_fold_up_wgrad_f32(const float* gwp, int64_t GK, int C, float* gw, void* stream);
+
 /* Per-sample squared norms of the weight gradient WITHOUT forming it:  sq[n] += alpha^2 * sum_{p,p'}
  * (GY_n GY_n^T)[p,p'] (XU_n XU_n^T)[p,p']  — the same value cslgan_conv2d_wgrad_grouped_f32(group=1, gw=NULL)
  * accumulates (opacus calc_sample_norms, train.py:311-314), 30x fewer FLOP for the critic's last conv.

@@ -314,7 +314,9 @@ def test_act_bwd_groupnorm_adam():
     _close(dp, pr, rtol=1e-5, what="adam")
 
 
-@pytest.mark.parametrize("case", [(2, 4, 4, 32, 48, 5), (3, 5, 7, 12, 20, 3), (2, 8, 8, 64, 64, 5), (1, 3, 3, 8, 8, 1)])
+@pytest.mark.parametrize("case", [(2, 4, 4, 32, 48, 5), (3, 5, 7, 12, 20, 3), (2, 8, 8, 64, 64, 5), (1, 3, 3, 8, 8, 1),
+                                  # C % 128 == 0: the weight gradient takes the sub-pixel (phase) form
+                                  (2, 4, 4, 128, 64, 5), (3, 8, 8, 128, 160, 5), (2, 5, 3, 256, 36, 5)])
 def test_upsample_conv_backward(case):
     """Data and weight gradients of nearest-2x upsample + 'same' conv (generator backward)."""
     ops = _ops()

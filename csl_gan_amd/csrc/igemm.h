@@ -28,6 +28,7 @@ constexpr int IG_MAX_CLS = 4;
 struct KcClass {
     int M, OHc, OWc;     // rows and per-image grid of this class
     int patch;           // 1: rows enumerate 8x8 patches (needs OHc % 8 == 0 && OWc % 8 == 0)
+                         // 2 (igemm_halo only): a 4x4 grid; 64 consecutive rows = the 4x4 grids of four consecutive images
     int T, Kdim;         // taps, T*AC
     int w_off;           // float offset of this class's [Nn][Kdim] filter matrix from KcParams::w
     int oy0, ox0;        // output phase: out[img][oy*osy+oy0][ox*osx+ox0][n]
@@ -56,6 +57,9 @@ struct KcParams {
     int n_cls;
     int tiles_m, tiles_n;   // total m-tiles over all classes, n-tiles
     int ksplit;             // >1: K tiles are divided over ksplit workgroups that atomically add into zeroed out
+    int pair_mode;          // igemm_halo: 1 = a workgroup runs TWO classes back to back on the same m-tile index (heaviest with
+    int pair_cls[2][2];     // lightest: the 9+4 / 6+6 tap classes of a 5x5 stride-2 data gradient), tiles_m = 2 * tiles_per_cls
+    int tiles_per_cls;
     KcClass cls[IG_MAX_CLS];
 };
 

@@ -42,14 +42,27 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
     const int nwg = p.tiles_m * p.tiles_n;
     const int wg = xcd_remap(blockIdx.x, nwg);
     const int tile_mg = wg / p.tiles_n, tile_n = wg - tile_mg * p.tiles_n;
-    int ci = 0;
+    const int n_sub = p.pair_mode ? 2 : 1;
 #pragma unroll 1
-    while (ci + 1 < p.n_cls && tile_mg >= p.cls[ci + 1].tile0) ++ci;
+    for (int sub = 0; sub < n_sub; ++sub) {
+    int ci = 0, tile_in_cls;
+    if (p.pair_mode) {
+        const int pg = tile_mg / p.tiles_per_cls;
+        ci = p.pair_cls[pg][sub];
+        tile_in_cls = tile_mg - pg * p.tiles_per_cls;
+    } else {
+#pragma unroll 1
+        while (ci + 1 < p.n_cls && tile_mg >= p.cls[ci + 1].tile0) ++ci;
+        tile_in_cls = tile_mg - p.cls[ci].tile0;
+    }
     const KcClass& kc = p.cls[ci];
     const int M = kc.M, OHc = kc.OHc, OWc = kc.OWc, T = kc.T;
-    const int m0 = (tile_mg - kc.tile0) * BM, n0 = tile_n * BN;
+    const int m0 = tile_in_cls * BM, n0 = tile_n * BN;
     const int HW_ = kc.halo_w, HH_ = kc.halo_h;
-    const int hpix = HH_ * HW_;
+    const bool quad = kc.patch == 2;                 // 4x4 grids: a 64-row patch = four consecutive images
+    const int hpix_img = HH_ * HW_;
+    const int hpix = quad ? 4 * hpix_img : hpix_img;
+    const int img_stride = p.AH * p.AW * p.AC;
 
     if (tid < IG_MAX_TAPS) s_tapoff[tid] = (((int)kc.ty[tid] - kc.ty_min) * HW_ + ((int)kc.tx[tid] - kc.tx_min)) * PIX;
 
@@ -63,8 +76,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
     for (int pp = 0; pp < 2; ++pp) {
         const int m = m0 + 64 * pp;
         p_ok[pp] = m < M;
-        const RowCoord rc = kc_decode_row(p_ok[pp] ? m : 0, OHc, OWc, 1);   // first row of the patch = its top-left pixel
-        p_img[pp] = rc.img * p.AH * p.AW * p.AC;
+        const RowCoord rc = kc_decode_row(p_ok[pp] ? m : 0, OHc, OWc, quad ? 0 : 1);   // first row of the patch = its top-left pixel
+        p_img[pp] = rc.img * img_stride;
         p_y0[pp] = rc.oy + kc.ty_min;
         p_x0[pp] = rc.ox + kc.tx_min;
     }
@@ -99,10 +112,12 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
             const int ch = idx & 7, pixg = idx >> 3;
             const int pp = pixg >= hpix ? 1 : 0;
             const int pix = pixg - pp * hpix;
-            const int hy = pix / HW_, hx = pix - hy * HW_;
+            const int si = quad ? pix / hpix_img : 0;         // sub-image of a quad patch
+            const int rem = pix - si * hpix_img;
+            const int hy = rem / HW_, hx = rem - hy * HW_;
             const int iy = p_y0[pp] + hy, ix = p_x0[pp] + hx;
             const bool ok = idx < h_total && p_ok[pp] && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
-            const unsigned off = ok ? 4u * (unsigned)(p_img[pp] + (iy * p.AW + ix) * p.AC + cc * 32 + ch * 4) : HOOB;
+            const unsigned off = ok ? 4u * (unsigned)(p_img[pp] + si * img_stride + (iy * p.AW + ix) * p.AC + cc * 32 + ch * 4) : HOOB;
             rh[j] = hbuf_load4(a_rsrc, off);
         }
     };
@@ -127,7 +142,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int qq = i * 32 + r;                           // row within the patch
-        a_base[i] = (wm * HALO_MAX + (qq >> 3) * HW_ + (qq & 7)) * PIX + h * 4;
+        const int lpix = quad ? (qq >> 4) * hpix_img + ((qq >> 2) & 3) * HW_ + (qq & 3) : (qq >> 3) * HW_ + (qq & 7);
+        a_base[i] = (wm * HALO_MAX + lpix) * PIX + h * 4;
     }
     const int brow0 = wn * TN * 32 + r;
 
@@ -194,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
         const int m = m0 + tid;
         int off = -1, roff = 0;
         if (m < M) {
-            const RowCoord rc = kc_decode_row(m, OHc, OWc, 1);
+            const RowCoord rc = kc_decode_row(m, OHc, OWc, quad ? 0 : 1);
             off = kc_out_offset(p, kc, rc);
             if (p.res) roff = kc_res_offset(p, kc, rc);
         }
@@ -224,6 +240,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
             }
         }
     }
+    __syncthreads();          // the next class of a pair reuses every LDS array
+    }   // sub
 }
 
 // Eligibility: every class stride 1, no upsample-on-read, 8x8-patchable grid, channel count a multiple of 32,
@@ -232,13 +250,16 @@ bool halo_eligible(const KcParams& p) {
     if (p.sy != 1 || p.sx != 1 || p.ups != 0 || (p.AC & 31) || p.Nn < 64 || p.ksplit > 1) return false;
     for (int c = 0; c < p.n_cls; ++c) {
         const KcClass& k = p.cls[c];
-        if (k.T < 2 || (k.OHc & 7) || (k.OWc & 7) || (k.M & 63)) return false;
+        const bool quad = k.OHc == 4 && k.OWc == 4;
+        if (k.T < 2 || (k.M & 63)) return false;
+        if (!quad && ((k.OHc & 7) || (k.OWc & 7))) return false;
         int ymin = 127, ymax = -128, xmin = 127, xmax = -128;
         for (int t = 0; t < k.T; ++t) {
             ymin = k.ty[t] < ymin ? k.ty[t] : ymin; ymax = k.ty[t] > ymax ? k.ty[t] : ymax;
             xmin = k.tx[t] < xmin ? k.tx[t] : xmin; xmax = k.tx[t] > xmax ? k.tx[t] : xmax;
         }
-        if (ymax - ymin > 4 || xmax - xmin > 4) return false;
+        const int lim = quad ? 2 : 4;       // four 6x6 halos fill the 144-pixel LDS image
+        if (ymax - ymin > lim || xmax - xmin > lim) return false;
     }
     return true;
 }
@@ -252,13 +273,34 @@ int launch_halo(KcParams& p, hipStream_t st) {
             ymin = k.ty[t] < ymin ? k.ty[t] : ymin; ymax = k.ty[t] > ymax ? k.ty[t] : ymax;
             xmin = k.tx[t] < xmin ? k.tx[t] : xmin; xmax = k.tx[t] > xmax ? k.tx[t] : xmax;
         }
-        k.ty_min = ymin; k.tx_min = xmin; k.halo_h = 8 + ymax - ymin; k.halo_w = 8 + xmax - xmin;
-        k.patch = 1;
+        const bool quad = k.OHc == 4 && k.OWc == 4;
+        const int side = quad ? 4 : 8;
+        k.ty_min = ymin; k.tx_min = xmin; k.halo_h = side + ymax - ymin; k.halo_w = side + xmax - xmin;
+        k.patch = quad ? 2 : 1;
         k.tile0 = tm;
         tm += (k.M + 127) / 128;
     }
     p.tiles_m = tm;
     p.ksplit = 1;
+    // classes with unequal tap counts (9/6/6/4 for a 5x5 stride-2 data gradient): pair the heaviest with the lightest and
+    // run each pair in one workgroup, so every workgroup carries the same number of K steps
+    p.pair_mode = 0;
+    static const int pair_env = [] { const char* e = getenv("CSLGAN_HALO_PAIR"); return e ? atoi(e) : 1; }();
+    if (pair_env && p.n_cls == 4) {
+        bool same_m = true, same_t = true;
+        for (int c = 1; c < 4; ++c) { same_m = same_m && p.cls[c].M == p.cls[0].M; same_t = same_t && p.cls[c].T == p.cls[0].T; }
+        if (same_m && !same_t) {
+            int o[4] = {0, 1, 2, 3};
+            for (int i = 0; i < 4; ++i)
+                for (int j = i + 1; j < 4; ++j)
+                    if (p.cls[o[j]].T > p.cls[o[i]].T) { const int t = o[i]; o[i] = o[j]; o[j] = t; }
+            p.pair_mode = 1;
+            p.pair_cls[0][0] = o[0]; p.pair_cls[0][1] = o[3];
+            p.pair_cls[1][0] = o[1]; p.pair_cls[1][1] = o[2];
+            p.tiles_per_cls = (p.cls[0].M + 127) / 128;
+            p.tiles_m = 2 * p.tiles_per_cls;
+        }
+    }
     const bool wide = p.Nn > 64;
     p.tiles_n = wide ? (p.Nn + 127) / 128 : 1;
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);

@@ -63,6 +63,9 @@ FWD_CASES = [
     (2, 16, 16, 64, 3, 3, 1, 1, True, 3, False, None),
     (2, 7, 7, 12, 20, 5, 2, 2, True, 1, False, None),
     (1, 6, 6, 5, 7, 3, 1, 1, False, 0, False, None),
+    # 4x4 grids with N % 4 == 0: halo kernel, four images per 64-row patch
+    (4, 4, 4, 64, 128, 5, 1, 2, True, 2, True, 1),
+    (8, 4, 4, 96, 64, 3, 1, 1, True, 0, False, None),
     # 1..4 output channels from 64 input channels: the vector-ALU kernel (igemm_skinny)
     (2, 8, 8, 64, 1, 3, 1, 1, False, 0, False, None),
     (3, 16, 8, 64, 2, 3, 1, 1, True, 1, False, 0),
@@ -113,6 +116,10 @@ DGRAD_CASES = [
     (3, 16, 16, 128, 64, 5, 2, 2, False),
     (2, 16, 16, 64, 96, 3, 1, 1, True),
     (2, 32, 32, 64, 256, 5, 2, 2, True),
+    # 4x4 parity-class grids (halo kernel, four images per patch; classes paired 9+4 / 6+6 taps)
+    (4, 8, 8, 64, 128, 5, 2, 2, True),
+    (8, 8, 8, 256, 512, 5, 2, 2, False),
+    (12, 8, 8, 128, 96, 5, 2, 2, True),
     # data gradients with 1..4 input channels and 64 output channels (igemm_skinny)
     (2, 32, 32, 4, 64, 5, 2, 2, False),
     (2, 16, 16, 1, 64, 5, 2, 2, True),

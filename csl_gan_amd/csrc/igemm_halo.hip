@@ -28,7 +28,9 @@ __device__ __forceinline__ float4 hbuf_load4(__amdgpu_buffer_rsrc_t r, unsigned 
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int BN>
+// GEN = false: the lean instantiation for single-class / equal-class launches on 8x8 patches (the generator's convs);
+// GEN = true adds class pairs and four-image patches (their index arithmetic costs the big convs 1-4 % when compiled in).
+template <int BN, bool GEN>
 __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
     constexpr int BM = 128, TM = 2, TN = BN / 64;            // waves 2 (M) x 2 (N); each wave = one patch x BN/2 channels
     constexpr int B_CH = BN * 4 + 4, B_PASS = BN / 32;
@@ -42,11 +44,11 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
     const int nwg = p.tiles_m * p.tiles_n;
     const int wg = xcd_remap(blockIdx.x, nwg);
     const int tile_mg = wg / p.tiles_n, tile_n = wg - tile_mg * p.tiles_n;
-    const int n_sub = p.pair_mode ? 2 : 1;
+    const int n_sub = (GEN && p.pair_mode) ? 2 : 1;
 #pragma unroll 1
     for (int sub = 0; sub < n_sub; ++sub) {
     int ci = 0, tile_in_cls;
-    if (p.pair_mode) {
+    if (GEN && p.pair_mode) {
         const int pg = tile_mg / p.tiles_per_cls;
         ci = p.pair_cls[pg][sub];
         tile_in_cls = tile_mg - pg * p.tiles_per_cls;
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
     const int M = kc.M, OHc = kc.OHc, OWc = kc.OWc, T = kc.T;
     const int m0 = tile_in_cls * BM, n0 = tile_n * BN;
     const int HW_ = kc.halo_w, HH_ = kc.halo_h;
-    const bool quad = kc.patch == 2;                 // 4x4 grids: a 64-row patch = four consecutive images
+    const bool quad = GEN && kc.patch == 2;          // 4x4 grids: a 64-row patch = four consecutive images
     const int hpix_img = HH_ * HW_;
     const int hpix = quad ? 4 * hpix_img : hpix_img;
     const int img_stride = p.AH * p.AW * p.AC;
@@ -252,6 +254,7 @@ bool halo_eligible(const KcParams& p) {
         const KcClass& k = p.cls[c];
         const bool quad = k.OHc == 4 && k.OWc == 4;
         if (k.T < 2 || (k.M & 63)) return false;
+        if (quad && k.M < 4096) return false;       // too few four-image patches to fill the chip: igemm_kc's small tiles win
         if (!quad && ((k.OHc & 7) || (k.OWc & 7))) return false;
         int ymin = 127, ymax = -128, xmin = 127, xmax = -128;
         for (int t = 0; t < k.T; ++t) {
@@ -282,14 +285,20 @@ int launch_halo(KcParams& p, hipStream_t st) {
     }
     p.tiles_m = tm;
     p.ksplit = 1;
-    // classes with unequal tap counts (9/6/6/4 for a 5x5 stride-2 data gradient): pair the heaviest with the lightest and
-    // run each pair in one workgroup, so every workgroup carries the same number of K steps
+    // Equal classes (forward convs, upsample phases): 128-wide N tiles.  Unequal classes (9/6/6/4 taps of a 5x5 stride-2 data
+    // gradient): 64-wide tiles, and the heaviest class is paired with the lightest in ONE workgroup so every workgroup
+    // carries the same number of K steps — when the halved grid still fills the chip.  Measured on the critic's data
+    // gradients at 128 / 384 rows (scripts/dgrad_sweep.py): 63 -> 81, 68 -> 75, 76 -> 96, 83 -> 98, 65 -> 79 TF.
+    bool same_m = true, same_t = true;
+    for (int c = 1; c < p.n_cls; ++c) { same_m = same_m && p.cls[c].M == p.cls[0].M; same_t = same_t && p.cls[c].T == p.cls[0].T; }
+    static const int wide_min = [] { const char* e = getenv("CSLGAN_HALO_WIDE_MIN"); return e ? atoi(e) : 0; }();
+    const bool wide = p.Nn > 64 && same_t && (long long)tm * ((p.Nn + 127) / 128) >= wide_min;
     p.pair_mode = 0;
-    static const int pair_env = [] { const char* e = getenv("CSLGAN_HALO_PAIR"); return e ? atoi(e) : 1; }();
-    if (pair_env && p.n_cls == 4) {
-        bool same_m = true, same_t = true;
-        for (int c = 1; c < 4; ++c) { same_m = same_m && p.cls[c].M == p.cls[0].M; same_t = same_t && p.cls[c].T == p.cls[0].T; }
-        if (same_m && !same_t) {
+    static const int pair_min = [] { const char* e = getenv("CSLGAN_HALO_PAIR_MIN"); return e ? atoi(e) : 256; }();
+    if (p.n_cls == 4 && same_m && !same_t) {
+        const int tpc = (p.cls[0].M + 127) / 128;
+        const long long paired = 2ll * tpc * (wide ? (p.Nn + 127) / 128 : (p.Nn + 63) / 64);
+        if (paired >= pair_min) {
             int o[4] = {0, 1, 2, 3};
             for (int i = 0; i < 4; ++i)
                 for (int j = i + 1; j < 4; ++j)
@@ -297,15 +306,18 @@ int launch_halo(KcParams& p, hipStream_t st) {
             p.pair_mode = 1;
             p.pair_cls[0][0] = o[0]; p.pair_cls[0][1] = o[3];
             p.pair_cls[1][0] = o[1]; p.pair_cls[1][1] = o[2];
-            p.tiles_per_cls = (p.cls[0].M + 127) / 128;
-            p.tiles_m = 2 * p.tiles_per_cls;
+            p.tiles_per_cls = tpc;
+            p.tiles_m = 2 * tpc;
         }
     }
-    const bool wide = p.Nn > 64;
-    p.tiles_n = wide ? (p.Nn + 127) / 128 : 1;
+    p.tiles_n = wide ? (p.Nn + 127) / 128 : (p.Nn + 63) / 64;
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);
-    if (wide) hipLaunchKernelGGL((igemm_halo_kernel<128>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((igemm_halo_kernel<64>), grid, block, 0, st, p);
+    bool gen = p.pair_mode != 0;
+    for (int c = 0; c < p.n_cls; ++c) gen = gen || p.cls[c].patch == 2;
+    if (wide && gen) hipLaunchKernelGGL((igemm_halo_kernel<128, true>), grid, block, 0, st, p);
+    else if (wide) hipLaunchKernelGGL((igemm_halo_kernel<128, false>), grid, block, 0, st, p);
+    else if (gen) hipLaunchKernelGGL((igemm_halo_kernel<64, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_halo_kernel<64, false>), grid, block, 0, st, p);
     return check_launch("igemm_halo_kernel");
 }
 

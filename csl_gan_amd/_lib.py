@@ -18,7 +18,7 @@ EXPORTS = [
     "cslgan_clip_accum_noise_bf16", "cslgan_conv2d_wgrad_grouped_bf16out_f32",
     "cslgan_l2_clip_rows_f32", "cslgan_row_l2norm_f32", "cslgan_row_l2norm_bwd_f32",
     "cslgan_conv2d_fwd_f32", "cslgan_conv2d_up_fwd_f32", "cslgan_conv2d_up_ws_floats", "cslgan_conv2d_up_dgrad_f32", "cslgan_conv2d_dgrad_f32", "cslgan_conv2d_wgrad_grouped_f32",
-    "cslgan_conv2d_wgrad_scaled_f32", "cslgan_conv2d_wgrad_sqnorm_gram_f32", "cslgan_conv2d_up_wgrad_phases_f32", "cslgan_fold_up_wgrad_f32",
+    "cslgan_conv2d_wgrad_scaled_f32", "cslgan_conv2d_wgrad_sqnorm_gram_f32", "cslgan_conv2d_up_wgrad_phases_f32", "cslgan_fold_up_wgrad_f32", "cslgan_conv2d_up_wgrad_phase_stride",
     "cslgan_bias_grad_grouped_f32", "cslgan_act_bwd_f32", "cslgan_groupnorm_act_f32", "cslgan_batchnorm_act_f32", "cslgan_norm_act_bwd_f32", "cslgan_norm_bwd_ws_floats", "cslgan_sum2x2_f32",
     "cslgan_adam_step_f32",
 ]
@@ -94,6 +94,8 @@ def lib():
         fn.restype = C.c_int
     L.cslgan_conv2d_up_ws_floats.argtypes = [i32, i32, i32]
     L.cslgan_conv2d_up_ws_floats.restype = C.c_int64
+    L.cslgan_conv2d_up_wgrad_phase_stride.argtypes = [i32]
+    L.cslgan_conv2d_up_wgrad_phase_stride.restype = C.c_int64
     L.cslgan_norm_bwd_ws_floats.argtypes = [i64, i64, i32, i32]
     L.cslgan_norm_bwd_ws_floats.restype = C.c_int64
     if L.cslgan_version() != 1:

@@ -130,7 +130,8 @@ struct McParams {
     const float* row_scale;   // nullable [N]: gy of sample n is multiplied by row_scale[n] on load (clip-weighted sums)
     int gy_phase;        // 1: sub-pixel form of an upsample+conv weight gradient.  P,Q are the LOW-res grid, gy is the full
                          // [N][2P][2Q][Kc] tensor read at (2*oy+a, 2*ox+b); n -> (phase a*2+b, tap, c) with Ndim = 4*T*C, and
-                         // every BN-wide n-tile lies inside one phase (T*C % BN == 0)
+                         // every BN-wide n-tile lies inside one phase: phases are phase_stride (a multiple of 256) columns apart
+    int phase_stride;
     signed char ty[IG_MAX_TAPS], tx[IG_MAX_TAPS];   // kh-pad, kw-pad
 };
 

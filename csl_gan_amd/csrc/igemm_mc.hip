@@ -48,14 +48,14 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
     // B columns are fixed per thread: decode (tap, c) once
     int b_ty[4], b_tx[4], b_c[4];
     bool b_nok[4];
-    const int per_phase = p.T * p.C;
+    const int per_phase = p.gy_phase ? p.phase_stride : p.T * p.C;
     const int phase = p.gy_phase ? n0 / per_phase : 0;          // uniform: an n-tile never straddles phases
     const int ph_a = phase >> 1, ph_b = phase & 1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int n = n0 + b_nc + e;
-        b_nok[e] = n < p.Ndim;
         const int nl = n - phase * per_phase;
+        b_nok[e] = n < p.Ndim && nl < p.T * p.C;
         const int t = b_nok[e] ? nl / p.C : 0;
         b_c[e] = nl - t * p.C;
         b_ty[e] = p.ty[t];
@@ -305,6 +305,10 @@ static int wgrad_grouped_impl(const cslgan_conv_t* c, const float* gy, const flo
     const bool vecA = (c->K % 4 == 0) && aligned16(gy);
     const bool vecB = (c->C % 4 == 0) && aligned16(x);
     if (c->K > 64) return launch_mc_tile<128, 128, 2, 2>(p, vecA, vecB, (hipStream_t)stream);
+    // 64 output channels: a 64x256 tile reads 20 KB per K tile for the MACs a 64x128 tile does with 12 KB twice
+    static const int wide64 = [] { const char* e = getenv("CSLGAN_MC_WIDE64"); return e ? atoi(e) : 1; }();
+    if (wide64 && c->K > 32 && p.Ndim >= 1024 && (long long)p.n_groups * ((p.Ndim + 255) / 256) >= 256)
+        return launch_mc_tile<64, 256, 1, 4>(p, vecA, vecB, (hipStream_t)stream);
     return launch_mc_tile<64, 128, 1, 4>(p, vecA, vecB, (hipStream_t)stream);
 }
 
@@ -334,12 +338,15 @@ int cslgan_conv2d_up_wgrad_phases_f32(const cslgan_conv_t* c, const float* gy, c
     CSLGAN_REQUIRE(aligned16(gy) && aligned16(x), "conv2d_up_wgrad_phases: operands must be 16-byte aligned");
     McParams p{};
     p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->H; p.Q = c->W; p.Kc = c->K;
-    p.T = 9; p.Ndim = 4 * 9 * c->C; p.stride = 1; p.ups = 0; p.group = group; p.n_groups = c->N / group;
+    p.phase_stride = (9 * c->C + 255) / 256 * 256;
+    p.T = 9; p.Ndim = 4 * p.phase_stride; p.stride = 1; p.ups = 0; p.group = group; p.n_groups = c->N / group;
     p.alpha = alpha; p.gw = gwp; p.sq = nullptr; p.out_bf16 = 0; p.row_scale = nullptr; p.gy_phase = 1;
     for (int t = 0; t < IG_MAX_TAPS; ++t) { p.ty[t] = 0; p.tx[t] = 0; }
     for (int u = 0; u < 3; ++u)
         for (int v = 0; v < 3; ++v) { p.ty[u * 3 + v] = (signed char)(u - 1); p.tx[u * 3 + v] = (signed char)(v - 1); }
     if (c->K > 64) return launch_mc_tile<128, 128, 2, 2>(p, true, true, (hipStream_t)stream);
+    if (c->K > 32 && (long long)p.n_groups * ((p.Ndim + 255) / 256) >= 256)
+        return launch_mc_tile<64, 256, 1, 4>(p, true, true, (hipStream_t)stream);
     return launch_mc_tile<64, 128, 1, 4>(p, true, true, (hipStream_t)stream);
 }
 

@@ -283,7 +283,7 @@ __global__ void sum2x2_kernel(const float* __restrict__ in, int N, int H, int W,
 
 // Fold the four sub-pixel phase gradients of a 5x5 upsample conv back onto its 25 taps:
 //   gw[gk][r][s][c] = sum_{a,b in {0,1}} gwp[gk][a*2+b][u(a,r)][v(b,s)][c],   u(a,r) = floor((a + r - 2) / 2) + 1 in {0,1,2}
-__global__ void fold_up_wgrad_kernel(const float* __restrict__ gwp, long long GK, int C, float* __restrict__ gw) {
+__global__ void fold_up_wgrad_kernel(const float* __restrict__ gwp, long long GK, int C, int phase_stride, float* __restrict__ gw) {
     const long long total = GK * 25 * C;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
@@ -291,14 +291,14 @@ __global__ void fold_up_wgrad_kernel(const float* __restrict__ gwp, long long GK
         const int rs = (int)(q % 25);
         const long long gk = q / 25;
         const int r = rs / 5, s = rs - r * 5;
-        const float* base = gwp + gk * 36 * C + c;
+        const float* base = gwp + gk * 4 * phase_stride + c;
         float acc = 0.f;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 const int u = ((a + r) >> 1), v = ((b + s) >> 1);          // floor((a+r-2)/2)+1 == (a+r)>>1
-                acc += base[((a * 2 + b) * 9 + u * 3 + v) * C];
+                acc += base[(a * 2 + b) * phase_stride + (u * 3 + v) * C];
             }
         gw[i] = acc;
     }
@@ -373,10 +373,13 @@ using namespace cslgan;
 
 extern "C" {
 
+int64_t cslgan_conv2d_up_wgrad_phase_stride(int C) { return ((int64_t)9 * C + 255) / 256 * 256; }
+
 int cslgan_fold_up_wgrad_f32(const float* gwp, int64_t GK, int C, float* gw, void* stream) {
     CSLGAN_REQUIRE(gwp && gw, "fold_up_wgrad: null argument");
     CSLGAN_REQUIRE(GK > 0 && C > 0, "fold_up_wgrad: bad sizes");
-    hipLaunchKernelGGL(fold_up_wgrad_kernel, dim3(grid_for(GK * 25 * C)), dim3(256), 0, (hipStream_t)stream, gwp, (long long)GK, C, gw);
+    hipLaunchKernelGGL(fold_up_wgrad_kernel, dim3(grid_for(GK * 25 * C)), dim3(256), 0, (hipStream_t)stream, gwp, (long long)GK, C,
+                       (int)cslgan_conv2d_up_wgrad_phase_stride(C), gw);
     return check_launch("fold_up_wgrad_kernel");
 }
 

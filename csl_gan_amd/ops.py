@@ -247,7 +247,7 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
             and row_scale is None and (out is None or out.dtype == torch.float32)):
         # sub-pixel form: 36 MACs per low-res pixel instead of 100, then fold the four phases onto the 25 taps
         L = _lib.lib()
-        gwp = torch.empty((G, K, 36, Cc), device=x.device, dtype=torch.float32)
+        gwp = torch.empty((G, K, 4 * L.cslgan_conv2d_up_wgrad_phase_stride(Cc)), device=x.device, dtype=torch.float32)
         gw = out if out is not None else torch.empty((G, K, R, S, Cc), device=x.device, dtype=torch.float32)
         _chk(gw, "gw")
         flop = 2.0 * N * P * Q * K * R * S * Cc

@@ -170,6 +170,9 @@ int cslgan_conv2d_wgrad_scaled_f32(const cslgan_conv_t* p, const float* gy, cons
 int cslgan_conv2d_up_wgrad_phases_f32(const cslgan_conv_t* p, const float* gy, const float* x, int group, float alpha,
                                       float* gwp, void* stream);
 int cslgan_fold_up_wgrad_f32(const float* gwp, int64_t GK, int C, float* gw, void* stream);
+/* Columns per phase in gwp: 9*C rounded up to a multiple of 256 (n-tiles never straddle a phase);
+ * gwp holds groups * K * 4 * phase_stride floats, laid out [g][k][phase][u*3+v][c] with that stride. */
+int64_t cslgan_conv2d_up_wgrad_phase_stride(int C);
 
 /* Per-sample squared norms of the weight gradient WITHOUT forming it:  sq[n] += alpha^2 * sum_{p,p'}
  * (GY_n GY_n^T)[p,p'] (XU_n XU_n^T)[p,p']  — the same value cslgan_conv2d_wgrad_grouped_f32(group=1, gw=NULL)

@@ -158,7 +158,7 @@ def main():
     traffic = None
     try:        # HBM bytes per launch of the conv kernel family, from the committed rocprofv3 PMC passes
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            traffic = round(json.load(f)["igemm_kc_all_instantiations"]["MB_per_launch"] * 1e6)
+            traffic = round(json.load(f)["conv_family"]["MB_per_launch"] * 1e6)
     except Exception:
         traffic = None
     if dom:

@@ -62,9 +62,10 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
         b_tx[e] = p.tx[t];
     }
 
-    float4 ra[A_PASS], rb[B_PASS];
+    // two K tiles are in flight in registers: one tile of MFMAs (~1 us) does not cover the global latency of the gathers
+    float4 ra[2][A_PASS], rb[2][B_PASS];
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, int slot) {
 #pragma unroll
         for (int i = 0; i < A_PASS; ++i) {
             const int kk = kt * MC_BK + a_kr + A_ROWS * i;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
                     v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
                 }
             }
-            ra[i] = v;
+            ra[slot][i] = v;
         }
 #pragma unroll
         for (int i = 0; i < B_PASS; ++i) {
@@ -117,14 +118,14 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
                     v = make_float4(t4[0], t4[1], t4[2], t4[3]);
                 }
             }
-            rb[i] = v;
+            rb[slot][i] = v;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, int slot) {
 #pragma unroll
-        for (int i = 0; i < A_PASS; ++i) *reinterpret_cast<float4*>(&As[buf][(a_kr + A_ROWS * i) * BM + a_mc]) = ra[i];
+        for (int i = 0; i < A_PASS; ++i) *reinterpret_cast<float4*>(&As[buf][(a_kr + A_ROWS * i) * BM + a_mc]) = ra[slot][i];
 #pragma unroll
-        for (int i = 0; i < B_PASS; ++i) *reinterpret_cast<float4*>(&Bs[buf][(b_kr + B_ROWS * i) * BN + b_nc]) = rb[i];
+        for (int i = 0; i < B_PASS; ++i) *reinterpret_cast<float4*>(&Bs[buf][(b_kr + B_ROWS * i) * BN + b_nc]) = rb[slot][i];
     };
 
     const int lane = tid & 63, wid = tid >> 6;
@@ -148,12 +149,11 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
         nk = kt0 + per < nk_all ? kt0 + per : nk_all;
         if (kt0 >= nk) return;      // uniform
     }
-    load_tile(kt0);
-    store_tile(0);
+    load_tile(kt0, 0);
+    store_tile(0, 0);
+    if (kt0 + 1 < nk) load_tile(kt0 + 1, 1);
     __syncthreads();
-    for (int kt = kt0; kt < nk; ++kt) {
-        const int buf = (kt - kt0) & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+    auto compute_tile = [&](int kt, int buf) {
         int krem = Ktot - kt * MC_BK;
         if (krem > MC_BK) krem = MC_BK;
         const int nsteps = (krem + 1) >> 1;
@@ -173,8 +173,20 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+    };
+    // tile kt is computed from LDS buffer (kt-kt0)&1 while tile kt+1 waits in register slot (kt+1-kt0)&1 and the
+    // loads of tile kt+2 are issued into the slot tile kt came through
+    for (int kt = kt0; kt < nk; kt += 2) {
+        if (kt + 2 < nk) load_tile(kt + 2, 0);
+        compute_tile(kt, 0);
+        if (kt + 1 < nk) store_tile(1, 1);
         __syncthreads();
+        if (kt + 1 < nk) {
+            if (kt + 3 < nk) load_tile(kt + 3, 1);
+            compute_tile(kt + 1, 1);
+            if (kt + 2 < nk) store_tile(0, 0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: scale, store, per-group sum of squares ----------------------------------

@@ -224,13 +224,7 @@ _LayerCollector._ghost_rows = _ghost_rows
 
 
 def _dense_wgrad(gz, x, R, S, stride, pad, scale, row_scale=None):
-    N = x.shape[0]
-    tiles = ((gz.shape[-1] + 127) // 128) * ((R * S * x.shape[-1] + 127) // 128)
-    group = 1
-    for g in (16, 8, 4, 2):
-        if N % g == 0 and (N // g) * tiles >= 512:
-            group = g
-            break
+    group = ops.dense_wgrad_group(x.shape[0], gz.shape[-1], x.shape[-1], R, S, gz.shape[1] * gz.shape[2])
     slabs = ops.conv2d_wgrad_grouped(gz, x, R, S, stride=stride, pad=pad, group=group, alpha=scale, row_scale=row_scale)
     if slabs.shape[0] == 1:
         return slabs[0].reshape(-1)

@@ -141,9 +141,8 @@ def _conv_backward_generator(ctx, gy, x, w, y):
             gx = (ops.conv2d_up_dgrad(gz, w, pad, wkey=ctx.wkey) if upsample
                   else ops.conv2d_dgrad(gz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad, wkey=ctx.wkey))
         if ctx.needs_input_grad[1]:
-            N = x.shape[0]
-            tiles = ((gz.shape[-1] + 127) // 128) * ((R * S * x.shape[-1] + 127) // 128)
-            slabs = ops.conv2d_wgrad_grouped(gz, x, R, S, stride=stride, pad=pad, group=_dense_group(N, tiles), upsample=upsample)
+            group = ops.dense_wgrad_group(x.shape[0], gz.shape[-1], x.shape[-1], R, S, gz.shape[1] * gz.shape[2], upsample=upsample)
+            slabs = ops.conv2d_wgrad_grouped(gz, x, R, S, stride=stride, pad=pad, group=group, upsample=upsample)
             if slabs.shape[0] == 1:
                 gw = slabs[0]
             else:
@@ -214,9 +213,7 @@ class Wgrad(Function):
     def forward(ctx, gy, x, R, S, stride, pad):
         ctx.cfg = (R, S, stride, pad)
         ctx.save_for_backward(gy, x)
-        N = x.shape[0]
-        tiles = ((gy.shape[-1] + 127) // 128) * ((R * S * x.shape[-1] + 127) // 128)
-        group = _dense_group(N, tiles)
+        group = ops.dense_wgrad_group(x.shape[0], gy.shape[-1], x.shape[-1], R, S, gy.shape[1] * gy.shape[2])
         slabs = ops.conv2d_wgrad_grouped(gy, x, R, S, stride=stride, pad=pad, group=group)
         if slabs.shape[0] == 1:
             return slabs[0]

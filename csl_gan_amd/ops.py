@@ -186,6 +186,31 @@ def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None, wkey=None):
     return gx
 
 
+def dense_wgrad_group(N, K, Cc, R, S, PQ, upsample=False):
+    """Samples per slab for a dense (summed) weight gradient.  The slab count sets the workgroup count, and the launch
+    time follows how well that count fills 256 CUs x 3 resident workgroups (800 workgroups take two rounds, 3200 take
+    4.2: measured 1.45 vs 1.16 ms on the same 55 GFLOP); more slabs cost their write + re-read by the column sum.
+    Model: t(g) = FLOP / (100 TF x fill(g)) + 2 x slab bytes / 4 TB/s, minimised over g | N."""
+    phases = upsample and R == 5 and S == 5 and Cc % 128 == 0
+    ndim = 4 * ((9 * Cc + 255) // 256 * 256) if phases else R * S * Cc
+    bn = 256 if (32 < K <= 64 and ndim >= 1024) else 128
+    tiles = ((K + 127) // 128 if K > 64 else 1) * ((ndim + bn - 1) // bn)
+    flop = 2.0 * N * PQ * K * ndim
+    out_bytes = 4.0 * K * ndim
+    best, best_t = 1, None
+    g = 1
+    while g <= N:
+        if N % g == 0:
+            blocks = (N // g) * tiles
+            if blocks >= 1024 or g == 1:
+                rounds = -(-blocks // 768)
+                t = flop / (100e12 * blocks / (rounds * 768.0)) + (2.0 * (N // g) * out_bytes / 4e12 if N // g > 1 else 0.0)
+                if best_t is None or t < best_t:
+                    best, best_t = g, t
+        g *= 2
+    return best
+
+
 def gram_norms_eligible(gy_shape, x_shape, upsample=False):
     """Shapes cslgan_conv2d_wgrad_sqnorm_gram_f32 accepts (and where the Gram form is cheaper than the product)."""
     _, P, Q, K = gy_shape

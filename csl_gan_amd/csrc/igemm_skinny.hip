@@ -165,4 +165,146 @@ int launch_skinny(KcParams& p, hipStream_t st) {
     return check_launch("igemm_skinny_kernel");
 }
 
+
+// ---- dense weight gradient of a conv with 1..4 output channels (the generator's 64 -> 3 output conv, G step) ----------
+//   gw[j][t][c] = alpha * sum_{img, pixel} gy[img][pixel][j] * x[img][pixel + t][c]
+// As an MFMA GEMM this has M = 3 (1.8 TFLOP/s, 1.0 ms).  Same stream as the forward: a workgroup walks a strided list of
+// 8x8 patches, stages each patch's x halo (64 channels) and its 64 x NJ gy values in LDS, and every lane keeps
+// T x NJ float4 accumulators (its 4 channels) over ALL its patches; the workgroup's 16 pixel slots are added at the
+// end (shuffle within a wavefront, then LDS) and each workgroup writes ONE partial [NJ][T][64] row, which the caller
+// column-sums (deterministic: no float atomics).
+struct SkinnyWgradParams {
+    const float* gy;     // [N][P][Q][NJ]
+    const float* x;      // [N][H][W][64]
+    int N, H, W, P, Q, T, n_patches;
+    unsigned x_bytes;
+    float alpha;
+    float* partial;      // [gridDim.x][NJ*T*64]
+    signed char ty[SK_MAXT], tx[SK_MAXT];
+    int ty_min, tx_min, halo_h, halo_w;
+};
+
+template <int NJ>
+__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const SkinnyWgradParams p) {
+    __shared__ float4 Hs[SK_HALO * 16];
+    __shared__ float Gs[64 * 4];
+    const int tid = threadIdx.x;
+    const int T = p.T, HW_ = p.halo_w, hpix = p.halo_h * p.halo_w;
+    const int cl = tid & 15, wid = tid >> 6, pg = (tid & 63) >> 4;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    int toff[SK_MAXT];
+#pragma unroll
+    for (int t = 0; t < SK_MAXT; ++t) toff[t] = t < T ? (((int)p.ty[t] - p.ty_min) * HW_ + ((int)p.tx[t] - p.tx_min)) * 16 : 0;
+    float4 acc[SK_MAXT][NJ];
+#pragma unroll
+    for (int t = 0; t < SK_MAXT; ++t)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[t][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    constexpr int HREG = (SK_HALO * 16 + 255) / 256;
+    const int per_img = (p.P >> 3) * (p.Q >> 3);
+    for (int pt = blockIdx.x; pt < p.n_patches; pt += gridDim.x) {
+        const int img = pt / per_img, rem = pt - img * per_img;
+        const int gyy = rem / (p.Q >> 3), gxx = rem - gyy * (p.Q >> 3);
+        const int oy0 = gyy << 3, ox0 = gxx << 3;
+        float4 rh[HREG];
+#pragma unroll
+        for (int j = 0; j < HREG; ++j) {
+            const int idx = tid + 256 * j;
+            const int c4 = idx & 15, pix = idx >> 4;
+            const int hy = pix / HW_, hx = pix - hy * HW_;
+            const int iy = oy0 + p.ty_min + hy, ix = ox0 + p.tx_min + hx;
+            const bool ok = pix < hpix && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            rh[j] = sbuf_load4(x_rsrc, ok ? 4u * (unsigned)(((img * p.H + iy) * p.W + ix) * SK_C + c4 * 4) : SOOB);
+        }
+        float gv = 0.f;
+        if (tid < 64 * NJ) {
+            const int q = tid / NJ, j = tid - q * NJ;
+            gv = p.gy[((long long)(img * p.P + oy0 + (q >> 3)) * p.Q + ox0 + (q & 7)) * NJ + j];
+        }
+        __syncthreads();                 // every lane has finished the previous patch
+#pragma unroll
+        for (int j = 0; j < HREG; ++j) {
+            const int idx = tid + 256 * j;
+            if ((idx >> 4) < hpix) Hs[idx] = rh[j];
+        }
+        if (tid < 64 * NJ) Gs[(tid / NJ) * 4 + (tid % NJ)] = gv;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int q = wid * 16 + it * 4 + pg;
+            const int base = ((q >> 3) * HW_ + (q & 7)) * 16 + cl;
+            float g[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) g[j] = Gs[q * 4 + j];
+#pragma unroll
+            for (int t = 0; t < SK_MAXT; ++t) {
+                if (t < T) {
+                    const float4 a = Hs[base + toff[t]];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        acc[t][j].x = fmaf(g[j], a.x, acc[t][j].x);
+                        acc[t][j].y = fmaf(g[j], a.y, acc[t][j].y);
+                        acc[t][j].z = fmaf(g[j], a.z, acc[t][j].z);
+                        acc[t][j].w = fmaf(g[j], a.w, acc[t][j].w);
+                    }
+                }
+            }
+        }
+    }
+    // ---- add the 16 pixel slots (4 per wavefront x 4 wavefronts) that share a channel group ---------------------
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(Hs);          // [4 waves][NJ*T][64]  (<= 4*36*64*4 B = 36.9 KB)
+#pragma unroll
+    for (int t = 0; t < SK_MAXT; ++t) {
+        if (t < T) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float4 v = acc[t][j];
+                v.x += __shfl_xor(v.x, 16); v.y += __shfl_xor(v.y, 16); v.z += __shfl_xor(v.z, 16); v.w += __shfl_xor(v.w, 16);
+                v.x += __shfl_xor(v.x, 32); v.y += __shfl_xor(v.y, 32); v.z += __shfl_xor(v.z, 32); v.w += __shfl_xor(v.w, 32);
+                if (pg == 0) *reinterpret_cast<float4*>(&red[((wid * NJ + j) * T + t) * 64 + cl * 4]) = v;
+            }
+        }
+    }
+    __syncthreads();
+    const int n_out = NJ * T * 64;
+    float* dst = p.partial + (long long)blockIdx.x * n_out;
+    for (int i = tid; i < n_out; i += 256)
+        dst[i] = p.alpha * (red[i] + red[n_out + i] + red[2 * n_out + i] + red[3 * n_out + i]);
+}
+
 }  // namespace cslgan
+
+using namespace cslgan;
+
+extern "C" {
+
+int cslgan_conv2d_wgrad_skinny_f32(const cslgan_conv_t* c, const float* gy, const float* x, float alpha, float* partial,
+                                   int n_blocks, void* stream) {
+    CSLGAN_REQUIRE(c && gy && x && partial, "conv2d_wgrad_skinny: null argument");
+    CSLGAN_REQUIRE(c->K >= 1 && c->K <= 4 && c->C == SK_C, "conv2d_wgrad_skinny: needs 1..4 output and 64 input channels");
+    CSLGAN_REQUIRE(c->stride == 1 && !c->upsample && c->R * c->S <= SK_MAXT && c->R <= 5 && c->S <= 5, "conv2d_wgrad_skinny: needs stride 1 and at most 9 taps");
+    CSLGAN_REQUIRE(c->N > 0 && c->P == c->H + 2 * c->pad - c->R + 1 && c->Q == c->W + 2 * c->pad - c->S + 1, "conv2d_wgrad_skinny: inconsistent output size");
+    CSLGAN_REQUIRE((c->P & 7) == 0 && (c->Q & 7) == 0, "conv2d_wgrad_skinny: output grid must be a multiple of 8x8");
+    CSLGAN_REQUIRE(n_blocks >= 1 && aligned16(x), "conv2d_wgrad_skinny: bad workspace / alignment");
+    CSLGAN_REQUIRE(4ll * c->N * c->H * c->W * SK_C < 0xFFFFFFF0ll, "conv2d_wgrad_skinny: input larger than 4 GB");
+    SkinnyWgradParams p{};
+    p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.P = c->P; p.Q = c->Q; p.T = c->R * c->S;
+    p.n_patches = c->N * (c->P >> 3) * (c->Q >> 3);
+    p.x_bytes = (unsigned)(4ll * c->N * c->H * c->W * SK_C);
+    p.alpha = alpha; p.partial = partial;
+    for (int kh = 0; kh < c->R; ++kh)
+        for (int kw = 0; kw < c->S; ++kw) { p.ty[kh * c->S + kw] = (signed char)(kh - c->pad); p.tx[kh * c->S + kw] = (signed char)(kw - c->pad); }
+    p.ty_min = -c->pad; p.tx_min = -c->pad; p.halo_h = 8 + c->R - 1; p.halo_w = 8 + c->S - 1;
+    const dim3 grid((unsigned)n_blocks), block(256);
+    switch (c->K) {
+        case 1: hipLaunchKernelGGL((skinny_wgrad_kernel<1>), grid, block, 0, (hipStream_t)stream, p); break;
+        case 2: hipLaunchKernelGGL((skinny_wgrad_kernel<2>), grid, block, 0, (hipStream_t)stream, p); break;
+        case 3: hipLaunchKernelGGL((skinny_wgrad_kernel<3>), grid, block, 0, (hipStream_t)stream, p); break;
+        default: hipLaunchKernelGGL((skinny_wgrad_kernel<4>), grid, block, 0, (hipStream_t)stream, p); break;
+    }
+    return check_launch("skinny_wgrad_kernel");
+}
+
+}  // extern "C"

@@ -224,13 +224,7 @@ _LayerCollector._ghost_rows = _ghost_rows
 
 
 def _dense_wgrad(gz, x, R, S, stride, pad, scale, row_scale=None):
-    group = ops.dense_wgrad_group(x.shape[0], gz.shape[-1], x.shape[-1], R, S, gz.shape[1] * gz.shape[2])
-    slabs = ops.conv2d_wgrad_grouped(gz, x, R, S, stride=stride, pad=pad, group=group, alpha=scale, row_scale=row_scale)
-    if slabs.shape[0] == 1:
-        return slabs[0].reshape(-1)
-    out = torch.empty(slabs[0].numel(), device=x.device, dtype=torch.float32)
-    ops.clip_accum_noise([slabs.reshape(slabs.shape[0], -1)], [out])
-    return out
+    return ops.conv2d_wgrad_dense(gz, x, R, S, stride=stride, pad=pad, alpha=scale, row_scale=row_scale).reshape(-1)
 
 
 def _dense_bgrad(gz, scale):

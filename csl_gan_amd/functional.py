@@ -141,13 +141,7 @@ def _conv_backward_generator(ctx, gy, x, w, y):
             gx = (ops.conv2d_up_dgrad(gz, w, pad, wkey=ctx.wkey) if upsample
                   else ops.conv2d_dgrad(gz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad, wkey=ctx.wkey))
         if ctx.needs_input_grad[1]:
-            group = ops.dense_wgrad_group(x.shape[0], gz.shape[-1], x.shape[-1], R, S, gz.shape[1] * gz.shape[2], upsample=upsample)
-            slabs = ops.conv2d_wgrad_grouped(gz, x, R, S, stride=stride, pad=pad, group=group, upsample=upsample)
-            if slabs.shape[0] == 1:
-                gw = slabs[0]
-            else:
-                gw = torch.empty(slabs.shape[1:], device=x.device, dtype=torch.float32)
-                ops.clip_accum_noise([slabs.reshape(slabs.shape[0], -1)], [gw])
+            gw = ops.conv2d_wgrad_dense(gz, x, R, S, stride=stride, pad=pad, upsample=upsample)
         if ctx.needs_input_grad[2]:
             part = ops.bias_grad_grouped(gz, group=1)
             gb = torch.empty(part.shape[1], device=x.device, dtype=torch.float32)
@@ -213,13 +207,7 @@ class Wgrad(Function):
     def forward(ctx, gy, x, R, S, stride, pad):
         ctx.cfg = (R, S, stride, pad)
         ctx.save_for_backward(gy, x)
-        group = ops.dense_wgrad_group(x.shape[0], gy.shape[-1], x.shape[-1], R, S, gy.shape[1] * gy.shape[2])
-        slabs = ops.conv2d_wgrad_grouped(gy, x, R, S, stride=stride, pad=pad, group=group)
-        if slabs.shape[0] == 1:
-            return slabs[0]
-        out = torch.empty(slabs.shape[1:], device=x.device, dtype=torch.float32)
-        ops.clip_accum_noise([slabs.reshape(slabs.shape[0], -1)], [out])
-        return out
+        return ops.conv2d_wgrad_dense(gy, x, R, S, stride=stride, pad=pad)
 
     @staticmethod
     def backward(ctx, ggw):

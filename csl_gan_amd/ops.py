@@ -137,6 +137,11 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, upsample=False, residual=None, 
     K, R, S, C2 = w.shape
     if C2 != Cc:
         raise RuntimeError("conv2d_fwd: channel mismatch x C=%d, w C=%d" % (Cc, C2))
+    if Cc == 3 and R * S > 1:
+        # RGB input (the critic's first conv): a zero 4th channel makes every tap one aligned 16-byte load
+        # (scalar gathers ran at 22-32 TF); the zero channel adds nothing to the sums
+        x, w, Cc, wkey = _pad_c4(x), _pad_c4(w), 4, None
+    c_alg = C2                    # channels the reference convolves (FLOP accounting)
     d, P, Q = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, upsample)
     y = out if out is not None else torch.empty((N, P, Q, K), device=x.device, dtype=torch.float32)
     if bias is not None:
@@ -147,8 +152,8 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, upsample=False, residual=None, 
         if tuple(residual.shape) != exp:
             raise RuntimeError("conv2d_fwd: residual shape %s, expected %s" % (tuple(residual.shape), exp))
     VH, VW = (2 * H, 2 * W) if upsample else (H, W)
-    flop = 2.0 * N * P * Q * K * R * S * Cc       # the dense conv the reference executes on the (up-sampled) input
-    nbytes = 4.0 * (N * VH * VW * Cc + K * R * S * Cc + N * P * Q * K)
+    flop = 2.0 * N * P * Q * K * R * S * c_alg    # the dense conv the reference executes on the (up-sampled) input
+    nbytes = 4.0 * (N * VH * VW * c_alg + K * R * S * c_alg + N * P * Q * K)
     if upsample and not direct_upsample and stride == 1 and R == S and R % 2 == 1 and pad == R // 2 and R > 1:
         L = _lib.lib()
         ws, repack = repack_cache.get("up_fwd", w, L.cslgan_conv2d_up_ws_floats(K, R, Cc), wkey)
@@ -159,8 +164,15 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, upsample=False, residual=None, 
         return y
     _timed("conv2d_fwd", flop, nbytes, lambda: check(
         _lib.lib().cslgan_conv2d_fwd_f32(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), res_shift, act, _p(y), _stream()),
-        "conv2d_fwd"), tag=lambda: "N%d %dx%d C%d K%d R%d s%d" % (N, H, W, Cc, K, R, stride))
+        "conv2d_fwd"), exec_flop=flop * Cc / float(c_alg), tag=lambda: "N%d %dx%d C%d K%d R%d s%d" % (N, H, W, Cc, K, R, stride))
     return y
+
+
+def _pad_c4(t):
+    """[..., 3] -> [..., 4] with a zero last channel (one small elementwise pass)."""
+    out = torch.zeros(t.shape[:-1] + (4,), device=t.device, dtype=t.dtype)
+    out[..., :3] = t
+    return out
 
 
 def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None, wkey=None):
@@ -262,6 +274,16 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
     _chk(gy, "gy"); _chk(x, "x")
     N, H, W, Cc = x.shape
     N2, P, Q, K = gy.shape
+    if Cc == 3 and R * S > 1 and row_scale is None and (out is None or out.dtype == torch.float32):
+        # RGB input: run on a zero-padded 4th channel (aligned 16-byte gathers), then drop that channel's (zero) gradients
+        g4 = conv2d_wgrad_grouped(gy, _pad_c4(x), R, S, stride=stride, pad=pad, group=group, alpha=alpha, want_gw=want_gw, sq=sq,
+                                  upsample=upsample)
+        if g4 is None:
+            return None
+        if out is not None:
+            out.view(g4.shape[:-1] + (3,)).copy_(g4[..., :3])
+            return out
+        return g4[..., :3].contiguous()
     d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, upsample)
     if N2 != N or (P2, Q2) != (P, Q):
         raise RuntimeError("conv2d_wgrad: gy %s inconsistent with x %s" % (tuple(gy.shape), tuple(x.shape)))
@@ -316,6 +338,34 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
         fn(C.byref(d), _p(gy), _p(x), group, float(alpha), _p(gw), _p(sq), _stream()), "conv2d_wgrad_grouped"),
         tag=lambda: "N%d %dx%d C%d K%d R%d s%d g%d%s" % (N, H, W, Cc, K, R, stride, group, " up" if upsample else ""))
     return None if scratch else gw
+
+
+def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, upsample=False, alpha=1.0, row_scale=None):
+    """The summed weight gradient [K,R,S,C] of a batch: slabs of the grouped MFMA kernel + a column sum, or the
+    vector-ALU kernel for 1..4 output channels."""
+    N, H, W, Cc = x.shape
+    _, P, Q, K = gy.shape
+    if (K <= 4 and Cc == 64 and stride == 1 and not upsample and R * S <= 9 and P % 8 == 0 and Q % 8 == 0 and row_scale is None):
+        _chk(gy, "gy"); _chk(x, "x")
+        d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, False)
+        if (P2, Q2) != (P, Q):
+            raise RuntimeError("conv2d_wgrad_dense: gy %s inconsistent with x %s" % (tuple(gy.shape), tuple(x.shape)))
+        nb = min(512, N * (P // 8) * (Q // 8))
+        partial = torch.empty((nb, K * R * S * Cc), device=x.device, dtype=torch.float32)
+        flop = 2.0 * N * P * Q * K * R * S * Cc
+        _timed("conv2d_wgrad_grouped", flop, 4.0 * (x.numel() + gy.numel()), lambda: check(
+            _lib.lib().cslgan_conv2d_wgrad_skinny_f32(C.byref(d), _p(gy), _p(x), float(alpha), _p(partial), nb, _stream()),
+            "conv2d_wgrad_skinny"), tag=lambda: "N%d %dx%d C%d K%d R%d skinny" % (N, H, W, Cc, K, R))
+        out = torch.empty(K * R * S * Cc, device=x.device, dtype=torch.float32)
+        clip_accum_noise([partial], [out])
+        return out.view(K, R, S, Cc)
+    group = dense_wgrad_group(N, K, Cc, R, S, P * Q, upsample=upsample)
+    slabs = conv2d_wgrad_grouped(gy, x, R, S, stride=stride, pad=pad, group=group, alpha=alpha, upsample=upsample, row_scale=row_scale)
+    if slabs.shape[0] == 1:
+        return slabs[0]
+    out = torch.empty(slabs.shape[1:], device=x.device, dtype=torch.float32)
+    clip_accum_noise([slabs.reshape(slabs.shape[0], -1)], [out.view(-1)])
+    return out
 
 
 def conv2d_up_dgrad(gy, w, pad, wkey=None):

@@ -174,6 +174,13 @@ int cslgan_fold_up_wgrad_f32(const float* gwp, int64_t GK, int C, float* gw, voi
  * gwp holds groups * K * 4 * phase_stride floats, laid out [g][k][phase][u*3+v][c] with that stride. */
 int64_t cslgan_conv2d_up_wgrad_phase_stride(int C);
 
+/* Dense weight gradient of a stride-1 conv with 1..4 output channels and 64 input channels (G's output conv in
+ * train_G, train.py:502-511), on the vector ALU.  Each of the n_blocks workgroups writes one partial [K][R*S][64]
+ * row into partial[n_blocks][K*R*S*64]; the caller sums the rows (cslgan_clip_accum_noise_f32).  Needs P, Q
+ * multiples of 8 and at most 9 taps. */
+int cslgan_conv2d_wgrad_skinny_f32(const cslgan_conv_t* p, const float* gy, const float* x, float alpha, float* partial,
+                                   int n_blocks, void* stream);
+
 /* Per-sample squared norms of the weight gradient WITHOUT forming it:  sq[n] += alpha^2 * sum_{p,p'}
  * (GY_n GY_n^T)[p,p'] (XU_n XU_n^T)[p,p']  — the same value cslgan_conv2d_wgrad_grouped_f32(group=1, gw=NULL)
  * accumulates (opacus calc_sample_norms, train.py:311-314), 30x fewer FLOP for the critic's last conv.

@@ -499,3 +499,18 @@ def test_wgrad_gram_rejects_unsupported_shapes():
         ops.conv2d_wgrad_sqnorm_gram(gy, x, 5, 5, stride=2, pad=2)
     with pytest.raises(RuntimeError, match="multiples of 32"):
         ops.conv2d_wgrad_sqnorm_gram(torch.zeros(2, 4, 4, 24, device="cuda"), torch.zeros(2, 8, 8, 32, device="cuda"), 5, 5, stride=2, pad=2)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 3, 3), (3, 8, 16, 1, 3), (2, 8, 8, 4, 3), (5, 64, 64, 3, 3), (2, 8, 8, 2, 1), (130, 8, 8, 3, 3)])
+def test_wgrad_dense_skinny(case):
+    """Dense weight gradient of a 64 -> K (K <= 4) stride-1 conv on the vector-ALU kernel (G's output conv in train_G)."""
+    ops = _ops()
+    N, H, W, K, R = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, 64, H, W, generator=g)
+    w = torch.zeros(K, 64, R, R, requires_grad=True)
+    y = F.conv2d(x, w, None, padding=R // 2)
+    gy = torch.randn(y.shape, generator=g)
+    ref, = torch.autograd.grad(y, w, gy)
+    got = ops.conv2d_wgrad_dense(_nhwc(gy), _nhwc(x), R, R, stride=1, pad=R // 2, alpha=1.5)
+    _close(got.permute(0, 3, 1, 2), ref * 1.5, what="skinny dense wgrad %s" % (case,))

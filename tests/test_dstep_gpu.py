@@ -465,3 +465,9 @@ def test_train_D_conditional_matches_oracle(tmp_path, dataset, extra, B, latent)
     _close(last["norms"].reshape(n_o.shape[0], -1), n_o.reshape(n_o.shape[0], -1), "per-sample norms")
     for i, (a, b) in enumerate(zip(last["summed_grad"], obs["summed_grad"])):
         _close_grad(a, b, "summed_grad[%d]" % i)
+
+
+def test_graft_entry_smoke():
+    """The driver's smoke entry point: one small D-step on cuda:0 checked against the oracle."""
+    import __graft_entry__ as entry
+    entry.smoke()

@@ -296,7 +296,7 @@ def test_train_D_immediate_sensitivity_matches_oracle(tmp_path, per_param):
         return zv.view(p.shape)
     for i, (p, go, zv, po) in enumerate(zip(tr.D.parameters(), obs["is_param_grads"], zs, params_o)):
         exp = go + to_logical(zv, po) * (opt.sigma * float(sens[i]) / B)
-        _close_grad(p.grad, exp, "IS noised grad[%d]" % i, l2_tol=2e-2, frac_tol=0.1)
+        _close_grad(p.grad, exp, "IS noised grad[%d]" % i, l2_tol=2e-2)
     assert pe.steps == 1
     # running statistics of the BatchNorm generator were updated like torch's
     for (n1, b1), (n2, b2) in zip(G.named_buffers(), Go.named_buffers()):

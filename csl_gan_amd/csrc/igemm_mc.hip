@@ -251,6 +251,50 @@ __global__ __launch_bounds__(256) void bias_grad_grouped_kernel(const float* __r
     }
 }
 
+// Same for K % 4 == 0, K <= 1024, 256 % (K/4) == 0: one workgroup per group, 16-byte loads (K/4 lanes cover a pixel's
+// channels, 256/(K/4) pixel slices), four loads in flight per lane.  The scalar kernel above read one float per lane per
+// iteration with a dependent add: 0.69 TB/s by rocprofv3 (0.28 ms per step for 190 MB).
+__global__ __launch_bounds__(256) void bias_grad_grouped_vec_kernel(const float* __restrict__ gy, int PQ, int K, int group,
+                                                                    float alpha, float* __restrict__ gb, float* __restrict__ sq) {
+    extern __shared__ float s_part[];            // [K]
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int c4n = K >> 2, c4 = tid % c4n, sl = tid / c4n, nsl = 256 / c4n;
+    const int g = blockIdx.x;
+    const long long npix = (long long)group * PQ;
+    const float* base = gy + (long long)g * npix * K + 4 * c4;
+    for (int i = tid; i < K; i += 256) s_part[i] = 0.f;
+    __syncthreads();
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    long long px = sl;
+    for (; px + 3 * nsl < npix; px += 4 * nsl) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(base + (px + u * nsl) * K);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    for (; px < npix; px += nsl) {
+        const float4 v = *reinterpret_cast<const float4*>(base + px * K);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    atomicAdd(&s_part[4 * c4 + 0], acc.x);
+    atomicAdd(&s_part[4 * c4 + 1], acc.y);
+    atomicAdd(&s_part[4 * c4 + 2], acc.z);
+    atomicAdd(&s_part[4 * c4 + 3], acc.w);
+    __syncthreads();
+    float ss = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        const float v = alpha * s_part[k];
+        if (gb) gb[(long long)g * K + k] = v;
+        ss = fmaf(v, v, ss);
+    }
+    if (sq) {
+        const float tot = block_sum_256(ss, red);
+        if (tid == 0) atomicAdd(sq + g, tot);
+    }
+}
+
 int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, float* sq_accum, hipStream_t st);   // clip_kernels.hip
 
 template <int BM, int BN, int WM, int WN>
@@ -367,6 +411,11 @@ int cslgan_bias_grad_grouped_f32(const float* gy, int N, int PQ, int K, int grou
     CSLGAN_REQUIRE(gy && (gb || sq), "bias_grad: null argument");
     CSLGAN_REQUIRE(N > 0 && PQ > 0 && K > 0 && group >= 1 && N % group == 0, "bias_grad: bad sizes");
     CSLGAN_REQUIRE(N / group <= 65535, "bias_grad: too many groups");
+    if (K % 4 == 0 && K <= 1024 && 256 % (K / 4) == 0 && aligned16(gy)) {
+        hipLaunchKernelGGL(bias_grad_grouped_vec_kernel, dim3((unsigned)(N / group)), dim3(256), sizeof(float) * K, (hipStream_t)stream,
+                           gy, PQ, K, group, alpha, gb, sq);
+        return check_launch("bias_grad_grouped_vec_kernel");
+    }
     hipLaunchKernelGGL(bias_grad_grouped_kernel, dim3((unsigned)((K + 63) / 64), (unsigned)(N / group)), dim3(256), 0,
                        (hipStream_t)stream, gy, PQ, K, group, alpha, gb, sq);
     return check_launch("bias_grad_grouped_kernel");

@@ -96,7 +96,7 @@ class Conv(Function):
     def forward(ctx, x, w, b, stride, pad, act, upsample, residual, res_shift, wkey=None):
         y = ops.conv2d_fwd(x, w, b, stride=stride, pad=pad, upsample=upsample, residual=residual,
                            res_shift=res_shift, act=act, wkey=wkey)
-        ctx.wkey = wkey            # id() of the owning nn.Parameter: lets ops reuse repacked filters while it is unchanged
+        ctx.wkey = wkey            # the owning layer's cache token: lets ops reuse repacked filters while the parameter is unchanged
         ctx.cfg = (stride, pad, act, upsample, res_shift)
         ctx.has_res = residual is not None
         ctx.input_only = _INPUT_GRADS_ONLY

@@ -8,12 +8,20 @@ that mode exists only for BASELINE.json configs[0] ("-gd cpu -dd cpu", plumbing 
 """
 from __future__ import annotations
 
+import itertools
+
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from . import functional as HF
 from . import ops
+
+
+# Cache keys for repacked filters (ops.repack_cache).  id(parameter) is NOT safe: CPython reuses ids and the caching
+# allocator reuses addresses, so a model built later in the same process (a test suite, a resumed run) could collide with
+# a dead one's entry — same id, same data_ptr, same shape, same version counter, different weights.  A token is never reused.
+_tokens = itertools.count(1)
 
 
 class PerSampleSink:
@@ -48,6 +56,7 @@ class HipConv2d(nn.Conv2d, _PerSampleMixin):
             padding = k // 2
         super().__init__(cin, cout, k, stride=stride, padding=padding, bias=bias)
         self.act, self.upsample = act, upsample
+        self._wtoken = next(_tokens)
 
     def forward_nhwc(self, x, residual=None, res_shift=0):
         """x: NHWC-contiguous device tensor -> NHWC output."""
@@ -61,7 +70,7 @@ class HipConv2d(nn.Conv2d, _PerSampleMixin):
 
     def _wkey(self, w):
         # only a zero-copy view of the parameter shares its version counter; a re-laid-out copy must not be cached
-        return id(self.weight) if w.data_ptr() == self.weight.data_ptr() else None
+        return self._wtoken if w.data_ptr() == self.weight.data_ptr() else None
 
     def forward(self, x):
         if not x.is_cuda:
@@ -78,6 +87,7 @@ class HipLinear(nn.Linear, _PerSampleMixin):
     def __init__(self, fin, fout, bias=True, act=ops.ACT_NONE):
         super().__init__(fin, fout, bias=bias)
         self.act = act
+        self._wtoken = next(_tokens)
 
     def forward(self, x):
         if not x.is_cuda:
@@ -85,7 +95,7 @@ class HipLinear(nn.Linear, _PerSampleMixin):
         B = x.shape[0]
         x4 = x.contiguous().reshape(B, 1, 1, self.in_features)
         w4 = self.weight.reshape(self.out_features, 1, 1, self.in_features)
-        wkey = id(self.weight) if w4.data_ptr() == self.weight.data_ptr() else None
+        wkey = self._wtoken if w4.data_ptr() == self.weight.data_ptr() else None
         if self._per_sample_active():
             sink = self._sink
             y = HF.ConvPerSample.apply(x4, w4, self.bias, 1, 0, self.act, sink.collector(self), sink.next_pass(self), wkey)

@@ -28,7 +28,7 @@ class _RepackCache:
     critic layer's repack four times and the generator's phase filters until the next generator step."""
 
     def __init__(self, max_entries=64):
-        self.d, self.max = {}, max_entries      # callers pass wkey=id(parameter) only for module-owned filters
+        self.d, self.max = {}, max_entries      # callers pass wkey (a never-reused per-module token, csl_gan_amd.nn) only for module-owned filters
 
     def get(self, kind, w, numel, wkey=None):
         if wkey is None:          # not known to be a live parameter (a temporary may reuse an address): never cache

@@ -67,4 +67,7 @@ def average_across_ranks(t: torch.Tensor, use_max=False, group=None):
 
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":      # name the device: RCCL otherwise guesses it from the rank
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()

@@ -18,7 +18,7 @@ EXPORTS = [
     "cslgan_clip_accum_noise_bf16", "cslgan_conv2d_wgrad_grouped_bf16out_f32",
     "cslgan_l2_clip_rows_f32", "cslgan_row_l2norm_f32", "cslgan_row_l2norm_bwd_f32",
     "cslgan_conv2d_fwd_f32", "cslgan_conv2d_up_fwd_f32", "cslgan_conv2d_up_ws_floats", "cslgan_conv2d_up_dgrad_f32", "cslgan_conv2d_dgrad_f32", "cslgan_conv2d_wgrad_grouped_f32",
-    "cslgan_conv2d_wgrad_scaled_f32", "cslgan_conv2d_wgrad_sqnorm_gram_f32", "cslgan_conv2d_up_wgrad_phases_f32", "cslgan_fold_up_wgrad_f32", "cslgan_conv2d_up_wgrad_phase_stride", "cslgan_conv2d_wgrad_skinny_f32",
+    "cslgan_conv2d_wgrad_scaled_f32", "cslgan_conv2d_wgrad_sqnorm_gram_f32", "cslgan_conv2d_up_wgrad_phases_f32", "cslgan_fold_up_wgrad_f32", "cslgan_conv2d_up_wgrad_phase_stride", "cslgan_conv2d_wgrad_skinny_f32", "cslgan_conv2d_s2_fwd_f32",
     "cslgan_bias_grad_grouped_f32", "cslgan_act_bwd_f32", "cslgan_groupnorm_act_f32", "cslgan_batchnorm_act_f32", "cslgan_norm_act_bwd_f32", "cslgan_norm_bwd_ws_floats", "cslgan_sum2x2_f32",
     "cslgan_adam_step_f32",
 ]
@@ -83,6 +83,7 @@ def lib():
         "cslgan_conv2d_up_wgrad_phases_f32": [C.POINTER(ConvT), vp, vp, i32, f32, vp, vp],
         "cslgan_fold_up_wgrad_f32": [vp, i64, i32, vp, vp],
         "cslgan_conv2d_wgrad_skinny_f32": [C.POINTER(ConvT), vp, vp, f32, vp, i32, vp],
+        "cslgan_conv2d_s2_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, i32, vp, i32, vp, vp],
         "cslgan_bias_grad_grouped_f32": [vp, i32, i32, i32, i32, f32, vp, vp, vp],
         "cslgan_act_bwd_f32": [vp, vp, i64, f32, vp, vp],
         "cslgan_groupnorm_act_f32": [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp],

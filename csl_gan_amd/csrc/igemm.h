@@ -34,6 +34,8 @@ struct KcClass {
     int oy0, ox0;        // output phase: out[img][oy*osy+oy0][ox*osx+ox0][n]
     int tile0;           // first m-tile (in the launch's concatenated m-tile space)
     int ty_min, tx_min, halo_h, halo_w;   // igemm_halo: tap offset range and the (8+range) halo of an 8x8 patch
+    int ay_mul, ay_off, ax_mul, ax_off;   // igemm_halo, sub-image view of a: class pixel (y,x) is a[y*ay_mul+ay_off][x*ax_mul+ax_off]
+                                          // (0 = unset = identity); the parity sub-images of a stride-2 forward conv
     signed char ty[IG_MAX_TAPS], tx[IG_MAX_TAPS];
 };
 struct KcParams {
@@ -60,6 +62,8 @@ struct KcParams {
     int pair_mode;          // igemm_halo: 1 = a workgroup runs TWO classes back to back on the same m-tile index (heaviest with
     int pair_cls[2][2];     // lightest: the 9+4 / 6+6 tap classes of a 5x5 stride-2 data gradient), tiles_m = 2 * tiles_per_cls
     int tiles_per_cls;
+    int acc_classes;        // igemm_halo: 1 = every workgroup runs ALL classes on its m-tile into ONE accumulator (the classes are
+                            // partial sums of the same output: a stride-2 conv as four stride-1 convs over parity sub-images)
     KcClass cls[IG_MAX_CLS];
 };
 

@@ -44,11 +44,16 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
     const int nwg = p.tiles_m * p.tiles_n;
     const int wg = xcd_remap(blockIdx.x, nwg);
     const int tile_mg = wg / p.tiles_n, tile_n = wg - tile_mg * p.tiles_n;
-    const int n_sub = (GEN && p.pair_mode) ? 2 : 1;
+    const bool accumulate = GEN && p.acc_classes;
+    const int n_sub = accumulate ? p.n_cls : ((GEN && p.pair_mode) ? 2 : 1);
+    f32x16 acc[TM][TN];
 #pragma unroll 1
     for (int sub = 0; sub < n_sub; ++sub) {
     int ci = 0, tile_in_cls;
-    if (GEN && p.pair_mode) {
+    if (accumulate) {
+        ci = sub;
+        tile_in_cls = tile_mg;
+    } else if (GEN && p.pair_mode) {
         const int pg = tile_mg / p.tiles_per_cls;
         ci = p.pair_cls[pg][sub];
         tile_in_cls = tile_mg - pg * p.tiles_per_cls;
@@ -65,6 +70,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
     const int hpix_img = HH_ * HW_;
     const int hpix = quad ? 4 * hpix_img : hpix_img;
     const int img_stride = p.AH * p.AW * p.AC;
+    const int ay_mul = (GEN && kc.ay_mul) ? kc.ay_mul : 1, ay_off = GEN ? kc.ay_off : 0;
+    const int ax_mul = (GEN && kc.ax_mul) ? kc.ax_mul : 1, ax_off = GEN ? kc.ax_off : 0;
 
     if (tid < IG_MAX_TAPS) s_tapoff[tid] = (((int)kc.ty[tid] - kc.ty_min) * HW_ + ((int)kc.tx[tid] - kc.tx_min)) * PIX;
 
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
             const int si = quad ? pix / hpix_img : 0;         // sub-image of a quad patch
             const int rem = pix - si * hpix_img;
             const int hy = rem / HW_, hx = rem - hy * HW_;
-            const int iy = p_y0[pp] + hy, ix = p_x0[pp] + hx;
+            const int iy = (p_y0[pp] + hy) * ay_mul + ay_off, ix = (p_x0[pp] + hx) * ax_mul + ax_off;
             const bool ok = idx < h_total && p_ok[pp] && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
             const unsigned off = ok ? 4u * (unsigned)(p_img[pp] + si * img_stride + (iy * p.AW + ix) * p.AC + cc * 32 + ch * 4) : HOOB;
             rh[j] = hbuf_load4(a_rsrc, off);
@@ -149,13 +156,14 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
     }
     const int brow0 = wn * TN * 32 + r;
 
-    f32x16 acc[TM][TN];
+    if (!accumulate || sub == 0) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+                for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    }
 
     const int n_cc = p.AC >> 5;
     const int n_steps = n_cc * T;
@@ -208,6 +216,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
     }
 
     // ---- epilogue (as igemm_kc) ---------------------------------------------------------------------------
+    if (accumulate && sub + 1 < n_sub) { __syncthreads(); continue; }
     if (tid < BM) {
         const int m = m0 + tid;
         int off = -1, roff = 0;
@@ -292,10 +301,14 @@ int launch_halo(KcParams& p, hipStream_t st) {
     bool same_m = true, same_t = true;
     for (int c = 1; c < p.n_cls; ++c) { same_m = same_m && p.cls[c].M == p.cls[0].M; same_t = same_t && p.cls[c].T == p.cls[0].T; }
     static const int wide_min = [] { const char* e = getenv("CSLGAN_HALO_WIDE_MIN"); return e ? atoi(e) : 0; }();
-    const bool wide = p.Nn > 64 && same_t && (long long)tm * ((p.Nn + 127) / 128) >= wide_min;
+    bool wide = p.Nn > 64 && same_t && (long long)tm * ((p.Nn + 127) / 128) >= wide_min;
     p.pair_mode = 0;
+    if (p.acc_classes) {        // all classes in every workgroup: one class's tiles, balanced by construction
+        p.tiles_m = (p.cls[0].M + 127) / 128;
+        wide = p.Nn > 64 && (long long)p.tiles_m * ((p.Nn + 127) / 128) >= 256;
+    }
     static const int pair_min = [] { const char* e = getenv("CSLGAN_HALO_PAIR_MIN"); return e ? atoi(e) : 256; }();
-    if (p.n_cls == 4 && same_m && !same_t) {
+    if (!p.acc_classes && p.n_cls == 4 && same_m && !same_t) {
         const int tpc = (p.cls[0].M + 127) / 128;
         const long long paired = 2ll * tpc * (wide ? (p.Nn + 127) / 128 : (p.Nn + 63) / 64);
         if (paired >= pair_min) {
@@ -312,8 +325,8 @@ int launch_halo(KcParams& p, hipStream_t st) {
     }
     p.tiles_n = wide ? (p.Nn + 127) / 128 : (p.Nn + 63) / 64;
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);
-    bool gen = p.pair_mode != 0;
-    for (int c = 0; c < p.n_cls; ++c) gen = gen || p.cls[c].patch == 2;
+    bool gen = p.pair_mode != 0 || p.acc_classes != 0;
+    for (int c = 0; c < p.n_cls; ++c) gen = gen || p.cls[c].patch == 2 || p.cls[c].ay_mul > 1 || p.cls[c].ax_mul > 1;
     if (wide && gen) hipLaunchKernelGGL((igemm_halo_kernel<128, true>), grid, block, 0, st, p);
     else if (wide) hipLaunchKernelGGL((igemm_halo_kernel<128, false>), grid, block, 0, st, p);
     else if (gen) hipLaunchKernelGGL((igemm_halo_kernel<64, true>), grid, block, 0, st, p);

@@ -543,6 +543,64 @@ int cslgan_conv2d_up_fwd_f32(const cslgan_conv_t* c, const float* x, const float
     return launch_kc(p, st, 0);
 }
 
+// Stride-2 forward conv as four stride-1 convs over the parity sub-images of x (class (a,b) = input pixels (2i+a, 2j+b)),
+// all accumulating into the same output tile inside one igemm_halo workgroup.  igemm_kc re-gathers the 2-strided input
+// window once per tap (the critic's forward convs ran at 82-105 TF); per class the window is a <= 10x10 halo in LDS.
+// Falls back to cslgan_conv2d_fwd_f32 for shapes the halo kernel does not take.
+int cslgan_conv2d_s2_fwd_f32(const cslgan_conv_t* c, const float* x, const float* w, float* wcls_ws, int repack,
+                             const float* bias, int act, float* y, void* stream) {
+    CSLGAN_REQUIRE(c && x && w && wcls_ws && y, "conv2d_s2_fwd: null argument");
+    int rc = check_conv(c, "conv2d_s2_fwd");
+    if (rc) return rc;
+    CSLGAN_REQUIRE(c->stride == 2 && !c->upsample && c->R == c->S, "conv2d_s2_fwd: needs stride 2, a square filter, no upsample");
+    CSLGAN_REQUIRE(act >= 0 && act <= 3, "conv2d_s2_fwd: unknown activation %d", act);
+    hipStream_t st = (hipStream_t)stream;
+    const int R = c->R, pad = c->pad;
+    auto fl = [](int v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); };
+    RepackArgs ra{};
+    ra.K = c->K; ra.R = R; ra.S = R; ra.C = c->C; ra.transposed = 0;
+    KcParams p{};
+    p.a = x; p.AH = c->H; p.AW = c->W; p.AC = c->C; p.VH = c->H; p.VW = c->W; p.ups = 0; p.sy = p.sx = 1;
+    p.w = wcls_ws; p.Nn = c->K; p.out = y; p.OHf = c->P; p.OWf = c->Q; p.osy = p.osx = 1; p.ldo = c->K; p.dense_out = 0;
+    p.bias = bias; p.res = nullptr; p.res_shift = 0; p.mask = nullptr; p.act = act; p.acc_classes = 1;
+    int n = 0, off = 0;
+    bool ok = R * R <= IG_MAX_TAPS;
+    for (int a = 0; ok && a < 2; ++a)
+        for (int b = 0; ok && b < 2; ++b) {
+            KcClass& k = p.cls[n];
+            clear_taps(k);
+            int T = 0;
+            for (int kh = 0; kh < R; ++kh)
+                for (int kw = 0; kw < R; ++kw) {
+                    const int du = fl(kh - pad), dv = fl(kw - pad);
+                    if ((kh - pad) - 2 * du != a || (kw - pad) - 2 * dv != b) continue;
+                    k.ty[T] = (signed char)du; k.tx[T] = (signed char)dv;
+                    ra.kh_lo[n][T] = (signed char)kh; ra.kh_hi[n][T] = (signed char)(kh + 1);
+                    ra.kw_lo[n][T] = (signed char)kw; ra.kw_hi[n][T] = (signed char)(kw + 1);
+                    ++T;
+                }
+            if (T == 0) continue;
+            k.M = c->N * c->P * c->Q; k.OHc = c->P; k.OWc = c->Q; k.T = T; k.Kdim = T * c->C; k.w_off = off; k.oy0 = k.ox0 = 0;
+            k.ay_mul = 2; k.ay_off = a; k.ax_mul = 2; k.ax_off = b;
+            ra.cls_T[n] = T; ra.cls_off[n] = off; off += T * c->K * c->C;
+            ++n;
+        }
+    p.n_cls = n; ra.n_class = n;
+    static const int halo_env = [] { const char* e = getenv("CSLGAN_KC_HALO"); return e ? atoi(e) : 1; }();
+    static const int s2_env = [] { const char* e = getenv("CSLGAN_S2_HALO"); return e ? atoi(e) : 1; }();
+    if (!ok || n == 0 || !halo_env || !s2_env || !halo_eligible(p))
+        return cslgan_conv2d_fwd_f32(c, x, w, bias, nullptr, 0, act, y, stream);
+    if (repack) {
+        const long long per = (long long)c->C * 9 * c->K;
+        unsigned gxn = (unsigned)((per + 255) / 256);
+        gxn = gxn > 1024 ? 1024 : (gxn < 1 ? 1 : gxn);
+        hipLaunchKernelGGL(repack_filters_kernel, dim3(gxn, (unsigned)n), dim3(256), 0, st, w, wcls_ws, ra);
+        rc = check_launch("repack_filters_kernel");
+        if (rc) return rc;
+    }
+    return launch_kc(p, st, 0);
+}
+
 // floats of workspace cslgan_conv2d_up_fwd_f32 needs for a K x R x R x C filter
 int64_t cslgan_conv2d_up_ws_floats(int K, int R, int C) {
     const int n = R / 2 + 1;   // folded taps per axis (upper bound over both phases)

@@ -162,6 +162,13 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, upsample=False, residual=None, 
             "conv2d_up_fwd"), exec_flop=flop * (R // 2 + 1) ** 2 / float(R * S),
             tag=lambda: "up N%d %dx%d C%d K%d R%d" % (N, H, W, Cc, K, R))
         return y
+    if stride == 2 and not upsample and R == S and R % 2 == 1 and R > 1 and Cc % 32 == 0 and K >= 64 and residual is None:
+        # parity sub-images through the LDS-halo kernel (the C entry falls back to the generic kernel for other grids)
+        ws, repack = repack_cache.get("s2_fwd", w, w.numel(), wkey)
+        _timed("conv2d_fwd", flop, nbytes, lambda: check(
+            _lib.lib().cslgan_conv2d_s2_fwd_f32(C.byref(d), _p(x), _p(w), _p(ws), repack, _p(bias), act, _p(y), _stream()),
+            "conv2d_s2_fwd"), tag=lambda: "N%d %dx%d C%d K%d R%d s2 halo" % (N, H, W, Cc, K, R))
+        return y
     _timed("conv2d_fwd", flop, nbytes, lambda: check(
         _lib.lib().cslgan_conv2d_fwd_f32(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), res_shift, act, _p(y), _stream()),
         "conv2d_fwd"), exec_flop=flop * Cc / float(c_alg), tag=lambda: "N%d %dx%d C%d K%d R%d s%d" % (N, H, W, Cc, K, R, stride))

@@ -155,6 +155,13 @@ int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* p, const float* gy, const float
 int cslgan_conv2d_wgrad_grouped_f32(const cslgan_conv_t* p, const float* gy, const float* x, int group,
                                     float alpha, float* gw, float* sq, void* stream);
 
+/* Stride-2 forward conv (the critic's convs, DCResNet_models.py:131) through the LDS-halo kernel: the four parity
+ * sub-images of x are convolved at stride 1 and accumulated in one workgroup.  wcls_ws: K*R*R*C floats receiving the
+ * filters regrouped by parity class (rebuilt when repack != 0).  Same result as cslgan_conv2d_fwd_f32, to which it falls
+ * back for shapes the halo kernel does not take (C % 32, K >= 64, 8x8-patchable or 4x4 output grid). */
+int cslgan_conv2d_s2_fwd_f32(const cslgan_conv_t* p, const float* x, const float* w, float* wcls_ws, int repack,
+                             const float* bias, int act, float* y, void* stream);
+
 /* Clip-weighted grouped weight gradient: as cslgan_conv2d_wgrad_grouped_f32 with gy of sample n multiplied by
  * row_scale[n] on load.  With row_scale = the per-sample clip factors f_b and group = N this is the clipped sum
  * sum_b f_b g_b (privacy_engine.clip() + accumulate, train.py:399-417) without materialising p.grad_sample. */

@@ -588,7 +588,11 @@ int cslgan_conv2d_s2_fwd_f32(const cslgan_conv_t* c, const float* x, const float
     p.n_cls = n; ra.n_class = n;
     static const int halo_env = [] { const char* e = getenv("CSLGAN_KC_HALO"); return e ? atoi(e) : 1; }();
     static const int s2_env = [] { const char* e = getenv("CSLGAN_S2_HALO"); return e ? atoi(e) : 1; }();
-    if (!ok || n == 0 || !halo_env || !s2_env || !halo_eligible(p))
+    // Measured on the critic (B=128 and the fused 384 rows, scripts/shape_times.py): 92 -> 109 TF on the 768-tile conv2
+    // launch, no gain or a loss below ~500 tiles (four halo stagings per chunk for 2-9 taps each) -> igemm_kc keeps those.
+    static const int s2_min_tiles = [] { const char* e = getenv("CSLGAN_S2_MIN_TILES"); return e ? atoi(e) : 512; }();
+    const long long wide_tiles = ((long long)c->N * c->P * c->Q + 127) / 128 * ((c->K + 127) / 128);
+    if (!ok || n == 0 || !halo_env || !s2_env || wide_tiles < s2_min_tiles || !halo_eligible(p))
         return cslgan_conv2d_fwd_f32(c, x, w, bias, nullptr, 0, act, y, stream);
     if (repack) {
         const long long per = (long long)c->C * 9 * c->K;

@@ -63,12 +63,13 @@ FWD_CASES = [
     (2, 16, 16, 64, 3, 3, 1, 1, True, 3, False, None),
     (2, 7, 7, 12, 20, 5, 2, 2, True, 1, False, None),
     (1, 6, 6, 5, 7, 3, 1, 1, False, 0, False, None),
-    # stride 2 through the halo kernel: four parity sub-images accumulated in one workgroup
+    # stride 2 through the halo kernel (>= 512 tiles): four parity sub-images accumulated in one workgroup
+    (64, 32, 32, 32, 64, 5, 2, 2, True, 0, False, None),
+    (72, 32, 32, 64, 128, 5, 2, 2, True, 1, False, None),
+    (16, 32, 64, 96, 288, 5, 2, 2, True, 3, False, None),
+    (2048, 8, 8, 32, 128, 5, 2, 2, False, 1, False, None),    # 4x4 outputs: four-image patches
+    # stride 2, too few tiles for it: generic kernel through the same entry
     (2, 16, 16, 64, 128, 5, 2, 2, True, 1, False, None),
-    (3, 32, 32, 32, 64, 5, 2, 2, True, 0, False, None),
-    (4, 16, 16, 96, 160, 5, 2, 2, True, 3, False, None),
-    (256, 8, 8, 64, 64, 5, 2, 2, False, 1, False, None),     # 4x4 outputs: four-image patches
-    (2, 16, 32, 64, 192, 5, 2, 2, False, 2, False, None),
     # 4x4 grids with N % 4 == 0: halo kernel, four images per 64-row patch
     (4, 4, 4, 64, 128, 5, 1, 2, True, 2, True, 1),
     (8, 4, 4, 96, 64, 3, 1, 1, True, 0, False, None),

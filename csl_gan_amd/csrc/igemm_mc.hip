@@ -297,6 +297,9 @@ __global__ __launch_bounds__(256) void bias_grad_grouped_vec_kernel(const float*
 
 int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, float* sq_accum, hipStream_t st);   // clip_kernels.hip
 
+bool wgh_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const void* x);      // igemm_wgh.hip
+int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st);
+
 template <int BM, int BN, int WM, int WN>
 static int launch_mc_tile(McParams& p, bool vecA, bool vecB, hipStream_t st) {
     p.tiles_m = (p.Kc + BM - 1) / BM;
@@ -351,6 +354,9 @@ static int wgrad_grouped_impl(const cslgan_conv_t* c, const float* gy, const flo
     const int VH = c->upsample ? 2 * c->H : c->H, VW = c->upsample ? 2 * c->W : c->W;
     const int P = (VH + 2 * c->pad - c->R) / c->stride + 1, Q = (VW + 2 * c->pad - c->S) / c->stride + 1;
     CSLGAN_REQUIRE(P == c->P && Q == c->Q, "conv2d_wgrad: output %dx%d does not match P,Q=%d,%d", P, Q, c->P, c->Q);
+    static const int wgh_env = [] { const char* e = getenv("CSLGAN_WGH"); return e ? atoi(e) : 1; }();
+    if (wgh_env && !row_scale && wgh_eligible(c, out_bf16, gy, x))
+        return launch_wgh(c, gy, x, group, alpha, gw, sq, (hipStream_t)stream);
     McParams p{};
     p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->P; p.Q = c->Q; p.Kc = c->K;
     p.T = c->R * c->S; p.Ndim = p.T * c->C; p.stride = c->stride; p.ups = c->upsample ? 1 : 0; p.group = group; p.n_groups = c->N / group;

@@ -1,0 +1,194 @@
+// fp32 MFMA grouped weight gradient with LDS-resident operands, for 8x8-patchable outputs.  gfx950 only.
+//
+//   gw[g][m][r][s][c] = alpha * sum_{img in group g} sum_{pixel} GY[img][pixel][m] * X[img][pixel*stride + (r,s) - pad][c]
+//
+// igemm_mc streams a [16 pixels x 128] slice of each operand per K tile and re-reads the input window once per filter
+// tap (32 FLOP per byte moved into LDS; 60-77 TF, the weakest MFMA kernel of the step).  Here a workgroup owns
+// 128 output channels x 64 input channels x the S taps of ONE filter row: per 8x8 output patch it stages the 64 x 128
+// output-gradient patch and the 8-row input slab that row needs ((8-1)*stride + S columns x 64 channels) in LDS ONCE and
+// runs all S taps from it — 2 + S fragment reads for 2*S MFMAs per k step, S x fewer input bytes per MAC.
+// Both operands have the pixel (the reduction index) as the slow dimension, so fragments are ds_read_b32 of 32
+// consecutive channels: conflict-free, no transposes.  v_mfma_f32_32x32x2_f32, exact fp32; 4 wavefronts = 2 (m) x 2 (c).
+#include "common.h"
+#include "igemm.h"
+
+namespace cslgan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WG_BM = 128, WG_BC = 64, WG_MAXS = 5;
+constexpr int WG_LDG = WG_BM + 4;      // floats per pixel row of the gy patch in LDS
+constexpr int WG_LDX = WG_BC + 4;      // floats per pixel of the input slab in LDS
+constexpr int WG_MAXW = 7 * 2 + WG_MAXS;   // staged columns at stride 2
+
+struct WghParams {
+    const float* gy;     // [N][P][Q][K]
+    const float* x;      // [N][H][W][C]
+    float* gw;           // [n_groups][K][R][S][C] or null
+    float* sq;           // [n_groups] or null
+    int N, H, W, C, P, Q, K, R, S, stride, pad, group, n_groups;
+    float alpha;
+    int tiles_m, tiles_c, ppi;   // K/128, C/64, patches per image
+    int ksplit;                  // workgroups per (group, tile, filter row): they take every ksplit-th patch and add atomically
+    int xw;                      // staged columns: 7*stride + S
+};
+
+template <int S>
+__global__ __launch_bounds__(256, 2) void igemm_wgh_kernel(const WghParams p) {
+    __shared__ __attribute__((aligned(16))) float Gs[64 * WG_LDG];
+    __shared__ __attribute__((aligned(16))) float Xs[8 * WG_MAXW * WG_LDX];
+    __shared__ float s_red[4];
+
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int split = bid % p.ksplit; bid /= p.ksplit;
+    const int r = bid % p.R; bid /= p.R;
+    const int tc = bid % p.tiles_c; bid /= p.tiles_c;
+    const int tm = bid % p.tiles_m;
+    const int g = bid / p.tiles_m;
+    const int m0 = tm * WG_BM, c0 = tc * WG_BC;
+
+    const int lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    f32x16 acc[2][S];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][s][v] = 0.f;
+
+    const int n_patch = p.group * p.ppi;
+    const int pq8 = p.Q >> 3;
+    const int x_slots = 8 * p.xw * 16;          // float4 slots of the input slab
+    for (int pi = split; pi < n_patch; pi += p.ksplit) {
+        const int il = pi / p.ppi, pr = pi - il * p.ppi;
+        const long long img = (long long)g * p.group + il;
+        const int py0 = (pr / pq8) << 3, px0 = (pr - (pr / pq8) * pq8) << 3;
+        __syncthreads();                        // every wavefront is done with the previous patch
+        // ---- gy patch: 64 pixels x 128 channels, 8 float4 per thread, staged four at a time --------------------
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = tid + 256 * (half * 4 + j);
+                const int pix = idx >> 5, m4 = idx & 31;
+                v[j] = *reinterpret_cast<const float4*>(p.gy + ((img * p.P + py0 + (pix >> 3)) * p.Q + px0 + (pix & 7)) * p.K + m0 + m4 * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = tid + 256 * (half * 4 + j);
+                *reinterpret_cast<float4*>(&Gs[(idx >> 5) * WG_LDG + (idx & 31) * 4]) = v[j];
+            }
+        }
+        // ---- input slab of filter row r: 8 rows x xw columns x 64 channels ------------------------------------
+        for (int base = 0; base < x_slots; base += 256 * 4) {
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = base + tid + 256 * j;
+                const int c4 = idx & 15, pc = idx >> 4;
+                const int row = pc / p.xw, col = pc - row * p.xw;
+                const int iy = (py0 + row) * p.stride + r - p.pad, ix = px0 * p.stride - p.pad + col;
+                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < x_slots && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                    v[j] = *reinterpret_cast<const float4*>(p.x + ((img * p.H + iy) * p.W + ix) * p.C + c0 + c4 * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = base + tid + 256 * j;
+                if (idx < x_slots) *reinterpret_cast<float4*>(&Xs[(idx >> 4) * WG_LDX + (idx & 15) * 4]) = v[j];
+            }
+        }
+        __syncthreads();
+        // ---- 32 k steps of two pixels: 2 + S fragment reads, 2*S MFMAs ------------------------------------------
+#pragma unroll 4
+        for (int ks = 0; ks < 32; ++ks) {
+            const int q = 2 * ks + h;
+            const int qy = q >> 3, qx = q & 7;
+            float a[2], b[S];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = Gs[q * WG_LDG + wm * 64 + i * 32 + l31];
+            const float* xrow = &Xs[(qy * p.xw + qx * p.stride) * WG_LDX + wn * 32 + l31];
+#pragma unroll
+            for (int s = 0; s < S; ++s) b[s] = xrow[s * WG_LDX];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    acc[i][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[s], acc[i][s], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------
+    float ss = 0.f;
+    float* __restrict__ outg = p.gw ? p.gw + (long long)g * p.K * p.R * S * p.C : nullptr;
+    const int c = c0 + wn * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                const float val = p.alpha * acc[i][s][v];
+                ss = fmaf(val, val, ss);
+                if (outg) {
+                    float* dst = outg + (((long long)m * p.R + r) * S + s) * p.C + c;
+                    if (p.ksplit > 1) atomicAdd(dst, val);
+                    else *dst = val;
+                }
+            }
+    if (p.sq && p.ksplit <= 1) {
+        const float tot = block_sum_256(ss, s_red);
+        if (tid == 0) atomicAdd(p.sq + g, tot);
+    }
+}
+
+int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, float* sq_accum, hipStream_t st);   // clip_kernels.hip
+
+// Shapes this kernel takes (the rest stays on igemm_mc).
+bool wgh_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const void* x) {
+    return !out_bf16 && !c->upsample && (c->stride == 1 || c->stride == 2) && c->S >= 2 && c->S <= WG_MAXS && c->K % WG_BM == 0 &&
+           c->C % WG_BC == 0 && (c->P & 7) == 0 && (c->Q & 7) == 0 && aligned16(gy) && aligned16(x);
+}
+
+int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st) {
+    WghParams p{};
+    p.gy = gy; p.x = x; p.gw = gw; p.sq = sq;
+    p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->P; p.Q = c->Q; p.K = c->K; p.R = c->R; p.S = c->S;
+    p.stride = c->stride; p.pad = c->pad; p.group = group; p.n_groups = c->N / group; p.alpha = alpha;
+    p.tiles_m = c->K / WG_BM; p.tiles_c = c->C / WG_BC; p.ppi = (c->P >> 3) * (c->Q >> 3);
+    p.xw = 7 * c->stride + c->S;
+    const long long base = (long long)p.n_groups * p.tiles_m * p.tiles_c * c->R;
+    const int n_patch = group * p.ppi;
+    p.ksplit = 1;
+    if (gw && base < 384 && n_patch >= 8) {      // few tiles, long patch loops: split the patches, add atomically
+        long long want = (768 + base - 1) / base;
+        const long long cap = n_patch / 4;
+        p.ksplit = (int)(want < cap ? want : cap);
+        if (p.ksplit < 1) p.ksplit = 1;
+    }
+    if (p.ksplit > 1 && hipMemsetAsync(gw, 0, sizeof(float) * (size_t)p.n_groups * c->K * c->R * c->S * c->C, st) != hipSuccess) {
+        set_error("wgrad: hipMemsetAsync failed");
+        return CSLGAN_ERR_LAUNCH;
+    }
+    const long long nb = base * p.ksplit;
+    if (nb > 0x7fffffffll) { set_error("wgrad: grid too large"); return CSLGAN_ERR_INVALID_ARG; }
+    const dim3 grid((unsigned)nb), block(256);
+    switch (c->S) {
+        case 2: hipLaunchKernelGGL((igemm_wgh_kernel<2>), grid, block, 0, st, p); break;
+        case 3: hipLaunchKernelGGL((igemm_wgh_kernel<3>), grid, block, 0, st, p); break;
+        case 4: hipLaunchKernelGGL((igemm_wgh_kernel<4>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((igemm_wgh_kernel<5>), grid, block, 0, st, p); break;
+    }
+    int rc = check_launch("igemm_wgh_kernel");
+    if (rc) return rc;
+    if (p.ksplit > 1 && sq) rc = sqnorm_rows_accumulate(gw, p.n_groups, (long long)c->K * c->R * c->S * c->C, sq, st);
+    return rc;
+}
+
+}  // namespace cslgan

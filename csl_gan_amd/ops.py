@@ -205,11 +205,23 @@ def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None, wkey=None):
     return gx
 
 
-def dense_wgrad_group(N, K, Cc, R, S, PQ, upsample=False):
+def dense_wgrad_group(N, K, Cc, R, S, PQ, upsample=False, stride=1, out_hw=None):
     """Samples per slab for a dense (summed) weight gradient.  The slab count sets the workgroup count, and the launch
     time follows how well that count fills 256 CUs x 3 resident workgroups (800 workgroups take two rounds, 3200 take
     4.2: measured 1.45 vs 1.16 ms on the same 55 GFLOP); more slabs cost their write + re-read by the column sum.
     Model: t(g) = FLOP / (100 TF x fill(g)) + 2 x slab bytes / 4 TB/s, minimised over g | N."""
+    if (out_hw is not None and not upsample and stride in (1, 2) and 2 <= S <= 5 and K % 128 == 0 and Cc % 64 == 0
+            and out_hw[0] % 8 == 0 and out_hw[1] % 8 == 0):
+        # igemm_wgh (LDS-resident operands): (K/128)(C/64)R tiles per slab; measured best at ~1280 workgroups
+        # (scripts/wgrad_group_sweep.py) -> the largest group that keeps >= 1024
+        tiles = (K // 128) * (Cc // 64) * R
+        best = 1
+        g = 1
+        while g <= N:
+            if N % g == 0 and (N // g) * tiles >= 1024:
+                best = g
+            g *= 2
+        return best
     phases = upsample and R == 5 and S == 5 and Cc % 128 == 0
     ndim = 4 * ((9 * Cc + 255) // 256 * 256) if phases else R * S * Cc
     bn = 256 if (32 < K <= 64 and ndim >= 1024) else 128
@@ -366,7 +378,7 @@ def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, upsample=False, alpha=1.0, 
         out = torch.empty(K * R * S * Cc, device=x.device, dtype=torch.float32)
         clip_accum_noise([partial], [out])
         return out.view(K, R, S, Cc)
-    group = dense_wgrad_group(N, K, Cc, R, S, P * Q, upsample=upsample)
+    group = dense_wgrad_group(N, K, Cc, R, S, P * Q, upsample=upsample, stride=stride, out_hw=None if row_scale is not None else (P, Q))
     slabs = conv2d_wgrad_grouped(gy, x, R, S, stride=stride, pad=pad, group=group, alpha=alpha, upsample=upsample, row_scale=row_scale)
     if slabs.shape[0] == 1:
         return slabs[0]

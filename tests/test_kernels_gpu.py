@@ -165,6 +165,12 @@ WGRAD_CASES = [
     (6, 1, 1, 128, 10, 1, 1, 0),
     (2, 64, 64, 3, 64, 5, 2, 2),
     (2, 8, 8, 256, 512, 5, 2, 2),
+    # 8x8-patchable outputs, K % 128 == 0, C % 64 == 0: LDS-resident weight-gradient kernel (igemm_wgh)
+    (4, 16, 16, 64, 128, 5, 2, 2),
+    (2, 32, 32, 64, 128, 5, 2, 2),
+    (4, 8, 8, 128, 256, 5, 1, 2),
+    (2, 16, 24, 64, 128, 3, 1, 1),
+    (6, 16, 16, 128, 128, 5, 2, 2),
 ]
 
 

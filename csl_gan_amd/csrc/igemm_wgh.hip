@@ -33,8 +33,10 @@ struct WghParams {
     int xw;                      // staged columns: 7*stride + S
 };
 
-template <int S>
+// TM = 32-row MFMA tiles per wavefront along m: 2 -> 128 output channels per workgroup, 1 -> 64 (K = 64 layers)
+template <int S, int TM>
 __global__ __launch_bounds__(256, 2) void igemm_wgh_kernel(const WghParams p) {
+    constexpr int BM = 64 * TM;
     __shared__ __attribute__((aligned(16))) float Gs[64 * WG_LDG];
     __shared__ __attribute__((aligned(16))) float Xs[8 * WG_MAXW * WG_LDX];
     __shared__ float s_red[4];
@@ -46,15 +48,15 @@ __global__ __launch_bounds__(256, 2) void igemm_wgh_kernel(const WghParams p) {
     const int tc = bid % p.tiles_c; bid /= p.tiles_c;
     const int tm = bid % p.tiles_m;
     const int g = bid / p.tiles_m;
-    const int m0 = tm * WG_BM, c0 = tc * WG_BC;
+    const int m0 = tm * BM, c0 = tc * WG_BC;
 
     const int lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
 
-    f32x16 acc[2][S];
+    f32x16 acc[TM][S];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
@@ -68,20 +70,22 @@ __global__ __launch_bounds__(256, 2) void igemm_wgh_kernel(const WghParams p) {
         const long long img = (long long)g * p.group + il;
         const int py0 = (pr / pq8) << 3, px0 = (pr - (pr / pq8) * pq8) << 3;
         __syncthreads();                        // every wavefront is done with the previous patch
-        // ---- gy patch: 64 pixels x 128 channels, 8 float4 per thread, staged four at a time --------------------
+        // ---- gy patch: 64 pixels x BM channels, 4*TM float4 per thread, staged four at a time ------------------
+        constexpr int M4 = BM / 4;             // float4 per pixel
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < TM; ++half) {
             float4 v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int idx = tid + 256 * (half * 4 + j);
-                const int pix = idx >> 5, m4 = idx & 31;
+                const int pix = idx / M4, m4 = idx - pix * M4;
                 v[j] = *reinterpret_cast<const float4*>(p.gy + ((img * p.P + py0 + (pix >> 3)) * p.Q + px0 + (pix & 7)) * p.K + m0 + m4 * 4);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int idx = tid + 256 * (half * 4 + j);
-                *reinterpret_cast<float4*>(&Gs[(idx >> 5) * WG_LDG + (idx & 31) * 4]) = v[j];
+                const int pix = idx / M4, m4 = idx - pix * M4;
+                *reinterpret_cast<float4*>(&Gs[pix * WG_LDG + m4 * 4]) = v[j];
             }
         }
         // ---- input slab of filter row r: 8 rows x xw columns x 64 channels ------------------------------------
@@ -109,14 +113,14 @@ __global__ __launch_bounds__(256, 2) void igemm_wgh_kernel(const WghParams p) {
         for (int ks = 0; ks < 32; ++ks) {
             const int q = 2 * ks + h;
             const int qy = q >> 3, qx = q & 7;
-            float a[2], b[S];
+            float a[TM], b[S];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = Gs[q * WG_LDG + wm * 64 + i * 32 + l31];
+            for (int i = 0; i < TM; ++i) a[i] = Gs[q * WG_LDG + wm * 32 * TM + i * 32 + l31];
             const float* xrow = &Xs[(qy * p.xw + qx * p.stride) * WG_LDX + wn * 32 + l31];
 #pragma unroll
             for (int s = 0; s < S; ++s) b[s] = xrow[s * WG_LDX];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int s = 0; s < S; ++s)
                     acc[i][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[s], acc[i][s], 0, 0, 0);
@@ -128,12 +132,12 @@ __global__ __launch_bounds__(256, 2) void igemm_wgh_kernel(const WghParams p) {
     float* __restrict__ outg = p.gw ? p.gw + (long long)g * p.K * p.R * S * p.C : nullptr;
     const int c = c0 + wn * 32 + l31;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                const int m = m0 + wm * 32 * TM + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
                 const float val = p.alpha * acc[i][s][v];
                 ss = fmaf(val, val, ss);
                 if (outg) {
@@ -152,7 +156,7 @@ int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, flo
 
 // Shapes this kernel takes (the rest stays on igemm_mc).
 bool wgh_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const void* x) {
-    return !out_bf16 && !c->upsample && (c->stride == 1 || c->stride == 2) && c->S >= 2 && c->S <= WG_MAXS && c->K % WG_BM == 0 &&
+    return !out_bf16 && !c->upsample && (c->stride == 1 || c->stride == 2) && c->S >= 2 && c->S <= WG_MAXS && c->K % 64 == 0 &&
            c->C % WG_BC == 0 && (c->P & 7) == 0 && (c->Q & 7) == 0 && aligned16(gy) && aligned16(x);
 }
 
@@ -161,13 +165,14 @@ int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int grou
     p.gy = gy; p.x = x; p.gw = gw; p.sq = sq;
     p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->P; p.Q = c->Q; p.K = c->K; p.R = c->R; p.S = c->S;
     p.stride = c->stride; p.pad = c->pad; p.group = group; p.n_groups = c->N / group; p.alpha = alpha;
-    p.tiles_m = c->K / WG_BM; p.tiles_c = c->C / WG_BC; p.ppi = (c->P >> 3) * (c->Q >> 3);
+    const bool half_m = c->K % WG_BM != 0;       // K = 64, 192, ...: 64-channel m tiles
+    p.tiles_m = half_m ? c->K / 64 : c->K / WG_BM; p.tiles_c = c->C / WG_BC; p.ppi = (c->P >> 3) * (c->Q >> 3);
     p.xw = 7 * c->stride + c->S;
     const long long base = (long long)p.n_groups * p.tiles_m * p.tiles_c * c->R;
     const int n_patch = group * p.ppi;
     p.ksplit = 1;
-    if (gw && base < 384 && n_patch >= 8) {      // few tiles, long patch loops: split the patches, add atomically
-        long long want = (768 + base - 1) / base;
+    if (gw && base < 768 && n_patch >= 8) {      // few tiles, long patch loops: split the patches, add atomically
+        long long want = (1280 + base - 1) / base;
         const long long cap = n_patch / 4;
         p.ksplit = (int)(want < cap ? want : cap);
         if (p.ksplit < 1) p.ksplit = 1;
@@ -179,11 +184,20 @@ int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int grou
     const long long nb = base * p.ksplit;
     if (nb > 0x7fffffffll) { set_error("wgrad: grid too large"); return CSLGAN_ERR_INVALID_ARG; }
     const dim3 grid((unsigned)nb), block(256);
-    switch (c->S) {
-        case 2: hipLaunchKernelGGL((igemm_wgh_kernel<2>), grid, block, 0, st, p); break;
-        case 3: hipLaunchKernelGGL((igemm_wgh_kernel<3>), grid, block, 0, st, p); break;
-        case 4: hipLaunchKernelGGL((igemm_wgh_kernel<4>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((igemm_wgh_kernel<5>), grid, block, 0, st, p); break;
+    if (half_m) {
+        switch (c->S) {
+            case 2: hipLaunchKernelGGL((igemm_wgh_kernel<2, 1>), grid, block, 0, st, p); break;
+            case 3: hipLaunchKernelGGL((igemm_wgh_kernel<3, 1>), grid, block, 0, st, p); break;
+            case 4: hipLaunchKernelGGL((igemm_wgh_kernel<4, 1>), grid, block, 0, st, p); break;
+            default: hipLaunchKernelGGL((igemm_wgh_kernel<5, 1>), grid, block, 0, st, p); break;
+        }
+    } else {
+        switch (c->S) {
+            case 2: hipLaunchKernelGGL((igemm_wgh_kernel<2, 2>), grid, block, 0, st, p); break;
+            case 3: hipLaunchKernelGGL((igemm_wgh_kernel<3, 2>), grid, block, 0, st, p); break;
+            case 4: hipLaunchKernelGGL((igemm_wgh_kernel<4, 2>), grid, block, 0, st, p); break;
+            default: hipLaunchKernelGGL((igemm_wgh_kernel<5, 2>), grid, block, 0, st, p); break;
+        }
     }
     int rc = check_launch("igemm_wgh_kernel");
     if (rc) return rc;

@@ -210,11 +210,14 @@ def dense_wgrad_group(N, K, Cc, R, S, PQ, upsample=False, stride=1, out_hw=None)
     time follows how well that count fills 256 CUs x 3 resident workgroups (800 workgroups take two rounds, 3200 take
     4.2: measured 1.45 vs 1.16 ms on the same 55 GFLOP); more slabs cost their write + re-read by the column sum.
     Model: t(g) = FLOP / (100 TF x fill(g)) + 2 x slab bytes / 4 TB/s, minimised over g | N."""
-    if (out_hw is not None and not upsample and stride in (1, 2) and 2 <= S <= 5 and K % 128 == 0 and Cc % 64 == 0
+    if (out_hw is not None and not upsample and stride in (1, 2) and 2 <= S <= 5 and K % 64 == 0 and Cc % 64 == 0
             and out_hw[0] % 8 == 0 and out_hw[1] % 8 == 0):
-        # igemm_wgh (LDS-resident operands): (K/128)(C/64)R tiles per slab; measured best at ~1280 workgroups
-        # (scripts/wgrad_group_sweep.py) -> the largest group that keeps >= 1024
-        tiles = (K // 128) * (Cc // 64) * R
+        # igemm_wgh (LDS-resident operands): (K/128)(C/64)R tiles per slab.  Big launches (the generator's convs, >= 40 GFLOP):
+        # ONE slab — the kernel splits the patch loop over workgroups itself (atomic adds), no slab traffic.  Small ones:
+        # the largest group that keeps >= 1024 workgroups (scripts/wgrad_group_sweep.py).
+        if 2.0 * N * PQ * K * R * S * Cc >= 40e9:
+            return N
+        tiles = (K // 128 if K % 128 == 0 else K // 64) * (Cc // 64) * R
         best = 1
         g = 1
         while g <= N:

@@ -171,6 +171,8 @@ WGRAD_CASES = [
     (4, 8, 8, 128, 256, 5, 1, 2),
     (2, 16, 24, 64, 128, 3, 1, 1),
     (6, 16, 16, 128, 128, 5, 2, 2),
+    (4, 16, 16, 64, 64, 5, 1, 2),       # 64-channel m tiles
+    (2, 16, 16, 128, 192, 3, 2, 1),
 ]
 
 

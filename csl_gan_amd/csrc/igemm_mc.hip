@@ -298,7 +298,8 @@ __global__ __launch_bounds__(256) void bias_grad_grouped_vec_kernel(const float*
 int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, float* sq_accum, hipStream_t st);   // clip_kernels.hip
 
 bool wgh_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const void* x);      // igemm_wgh.hip
-int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st);
+int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st,
+               int phase_stride = 0);
 
 template <int BM, int BN, int WM, int WN>
 static int launch_mc_tile(McParams& p, bool vecA, bool vecB, hipStream_t st) {
@@ -398,6 +399,13 @@ int cslgan_conv2d_up_wgrad_phases_f32(const cslgan_conv_t* c, const float* gy, c
     CSLGAN_REQUIRE(c->C % 128 == 0 && c->K % 4 == 0, "conv2d_up_wgrad_phases: needs C %% 128 == 0 and K %% 4 == 0");
     CSLGAN_REQUIRE(group >= 1 && c->N % group == 0, "conv2d_up_wgrad_phases: N=%d not divisible by group=%d", c->N, group);
     CSLGAN_REQUIRE(aligned16(gy) && aligned16(x), "conv2d_up_wgrad_phases: operands must be 16-byte aligned");
+    {   // low-res grids of 8x8 patches: the LDS-resident kernel on the equivalent 3x3 stride-1 conv
+        static const int wgh_env = [] { const char* e = getenv("CSLGAN_WGH"); return e ? atoi(e) : 1; }();
+        cslgan_conv_t lo = *c;
+        lo.R = lo.S = 3; lo.pad = 1; lo.stride = 1; lo.upsample = 0; lo.P = c->H; lo.Q = c->W;
+        if (wgh_env && wgh_eligible(&lo, 0, gy, x))
+            return launch_wgh(&lo, gy, x, group, alpha, gwp, nullptr, (hipStream_t)stream, (9 * c->C + 255) / 256 * 256);
+    }
     McParams p{};
     p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->H; p.Q = c->W; p.Kc = c->K;
     p.phase_stride = (9 * c->C + 255) / 256 * 256;

@@ -226,6 +226,9 @@ def dense_wgrad_group(N, K, Cc, R, S, PQ, upsample=False, stride=1, out_hw=None)
             g *= 2
         return best
     phases = upsample and R == 5 and S == 5 and Cc % 128 == 0
+    if (phases and out_hw is not None and K % 64 == 0 and out_hw[0] % 16 == 0 and out_hw[1] % 16 == 0
+            and 2.0 * N * (PQ // 4) * K * 36 * Cc >= 40e9):
+        return N            # sub-pixel form on igemm_wgh (low-res grid of 8x8 patches): one slab, the kernel splits the patch loop
     ndim = 4 * ((9 * Cc + 255) // 256 * 256) if phases else R * S * Cc
     bn = 256 if (32 < K <= 64 and ndim >= 1024) else 128
     tiles = ((K + 127) // 128 if K > 64 else 1) * ((ndim + bn - 1) // bn)

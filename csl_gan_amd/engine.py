@@ -13,6 +13,7 @@ Data layout in HBM (288 GB per GPU — per-sample gradients are materialised, no
 """
 from __future__ import annotations
 
+import os
 import types
 from typing import List, Optional, Sequence
 
@@ -141,6 +142,9 @@ class _LayerCollector:
 
     def __init__(self, engine, layer):
         self.e, self.layer = engine, layer
+
+    def side_stream(self):
+        return self.e._side_stream()
 
     def collect(self, pass_idx, gz, x, R, S, stride, pad, has_bias):
         e, layer = self.e, self.layer
@@ -322,6 +326,8 @@ class PrivacyEngine(PerSampleSink):
         self.row_roles = None                   # set by Trainer.train_D_fused for one fused forward/backward
         self._dense = {}
         self._ghost = {}                        # id(weight) -> {pass: (gz, x, R, S, stride, pad, scale)} awaiting clip()
+        self.use_side_stream = os.environ.get("CSLGAN_SIDE_STREAM", "0") == "1"
+        self._side, self._side_dirty = None, False
         self.module = module
         self.batch_size, self.sample_size = batch_size, sample_size
         self.alphas = list(alphas)
@@ -369,6 +375,21 @@ class PrivacyEngine(PerSampleSink):
     def lean(self):
         return self.materialize in ("private", "ghost")
 
+    def _side_stream(self):
+        """Stream for the weight-gradient side work of the backward hooks (None = same stream)."""
+        if not self.use_side_stream:
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.params[0].device)
+        self._side_dirty = True
+        return self._side
+
+    def join_side_stream(self):
+        """Make the current stream wait for the side work: call before anything reads norms / per-sample buffers."""
+        if self._side is not None and self._side_dirty:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_dirty = False
+
     def _ghost_layer(self, gz, x, stride):
         return self.materialize == "ghost" and not self.accum_passes and ops.gram_norms_preferred(gz.shape, x.shape, stride)
 
@@ -381,6 +402,7 @@ class PrivacyEngine(PerSampleSink):
 
     def norms_rows_sqnorms(self) -> torch.Tensor:
         """[n_params, n] squared norms of the "norms" row block of a fused pass."""
+        self.join_side_stream()
         return torch.stack([self._bufs[("norms", id(p))][1].reshape(-1) for p in self.params])
 
     def _buffers(self, p, n_pass, B, numel, dtype=torch.float32):
@@ -454,6 +476,7 @@ class PrivacyEngine(PerSampleSink):
         """[n_params, n_passes*B] squared per-sample norms.  Default: the values the wgrad epilogue
         accumulated; recompute=True re-reads the materialised grad_sample (cslgan_sample_sqnorm_f32),
         which is what must be used after a caller edited p.grad_sample in place (train.py:447)."""
+        self.join_side_stream()
         stored = [self._bufs[id(p)][1].reshape(-1) for p in self.params]
         if recompute:
             mat = [i for i, p in enumerate(self.params) if id(p) not in self._ghost]
@@ -465,6 +488,7 @@ class PrivacyEngine(PerSampleSink):
     # -- train.py:399-402, 417 -----------------------------------------------------------------
     def clip(self, recompute_norms=False):
         """Per-sample clip factors + clipped sum into p.summed_grad (a SUM over samples)."""
+        self.join_side_stream()
         ps = self.params
         mat_idx = [i for i, p in enumerate(ps) if id(p) not in self._ghost]
         mats = [_rows(ps[i].grad_sample) for i in mat_idx]

@@ -246,7 +246,18 @@ class ConvPerSample(Function):
                 gz = ops.act_bwd(gz, y, _SLOPE[act])
             elif act == ops.ACT_TANH:
                 gz = gz * (1 - y * y)
-            ctx.sink.collect(ctx.pass_idx, gz, x, w.shape[1], w.shape[2], stride, pad, ctx.has_bias)
+            side = ctx.sink.side_stream()
+            if side is None:
+                ctx.sink.collect(ctx.pass_idx, gz, x, w.shape[1], w.shape[2], stride, pad, ctx.has_bias)
+            else:
+                # the per-sample / norm / dense weight-gradient launches do not feed the backward chain: they go to a side
+                # stream and fill the CUs the (small) data-gradient launches leave idle; the engine joins before clip()
+                cur = torch.cuda.current_stream()
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    ctx.sink.collect(ctx.pass_idx, gz, x, w.shape[1], w.shape[2], stride, pad, ctx.has_bias)
+                gz.record_stream(side)
+                x.record_stream(side)
             gx = None
             if ctx.needs_input_grad[0]:
                 gx = ops.conv2d_dgrad(gz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad, wkey=ctx.wkey)

@@ -78,7 +78,7 @@ def main(argv=None):
             privacy_log.flush()
 
     print("\nStarting training...\n")
-    tr.logger.reset_stats()
+    tr.reset_stats()
     for it in range(opt.warmup_iter):                      # train.py:567-569: public / mean samples, no DP
         img, labels = next(iter(public_dataloader)) if opt.public_set_size > 0 else mean_sampler.sample(opt.batch_size)
         tr.train(-1, it, img, labels if labels is not None else torch.zeros(len(img), dtype=torch.long), use_dp=False)
@@ -92,7 +92,7 @@ def main(argv=None):
 
     iters, epoch, eps = 0, start_epoch, 0.0
     for epoch in range(opt.resume_epochs, opt.n_epochs):
-        tr.logger.reset_stats()
+        tr.reset_stats()
         batch_i = 0
         for batch_i, (img, labels) in enumerate(dataloader):
             tr.train(epoch, batch_i, img, labels, use_dp=opt.use_dp)

@@ -454,6 +454,14 @@ class Trainer:
         cur = self.dev_stats.get(name)
         self.dev_stats[name] = value.clone() if cur is None else cur + value
 
+    def reset_stats(self):
+        """logger.reset_stats() of the reference (train.py:566, 576): the statistics live partly on the device here, so the
+        pending device-side sums (everything accumulated since the last log line) must be dropped with them — otherwise the
+        tail of one epoch leaks into the first log line of the next."""
+        self.logger.reset_stats()
+        for k in [k for k in self.dev_stats if not k.startswith("_")]:
+            del self.dev_stats[k]
+
     def flush_stats(self):
         """Fold device-side sums into the Logger (this is where the host synchronises)."""
         for k, v in list(self.dev_stats.items()):

@@ -219,3 +219,23 @@ def test_dense_wgrad_group_and_gram_policy():
     assert not ops.gram_norms_preferred((128, 8, 8, 256), (128, 16, 16, 128), 2)      # 64 output pixels: product kernel
     assert not ops.gram_norms_preferred((128, 4, 4, 512), (128, 8, 8, 256), 2, upsample=True)
     assert not ops.gram_norms_preferred((128, 4, 4, 100), (128, 8, 8, 256), 2)        # K % 64 != 0
+
+
+def test_trainer_reset_stats_drops_pending_device_sums(tmp_path):
+    """train.py:566,576 reset the logger at every epoch start; the build keeps running sums on the device between log lines,
+    so the reset must drop those too (they used to leak into the next epoch's first log line: 160 % accuracies)."""
+    import torch
+    from csl_gan_amd import init_util, options
+    from csl_gan_amd.trainer import Trainer
+    opt = options.parse(["MNIST", "--model", "Vanilla", "-bs", "4", "-gd", "cpu", "-dd", "cpu", "-o", str(tmp_path), "--g_latent_dim", "8"])
+    G, D = init_util.init_models(opt)
+    tr = Trainer(opt, G, D, log_to=str(tmp_path / "log.csv"))
+    tr._acc("D Real Acc", torch.tensor(50.0))
+    tr._acc("_d_adv_gate", torch.tensor(1.0))
+    tr.reset_stats()
+    tr.flush_stats()
+    assert tr.logger.stats["D Real Acc"] == 0
+    assert "_d_adv_gate" in tr.dev_stats            # the G-step gate is not a logged statistic
+    tr._acc("D Real Acc", torch.tensor(50.0))
+    tr.flush_stats()
+    assert tr.logger.stats["D Real Acc"] == 50.0

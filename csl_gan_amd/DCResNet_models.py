@@ -5,11 +5,13 @@ order (weights_seed parity) as the reference; device tensors run NHWC through
 csl_gan_amd.nn.HipConv2d / HipLinear / HipGroupNormAct.
 
 MI355X-first differences, all exact re-associations of the reference arithmetic:
-  * UpsampleConv never materialises the cat+pixel_shuffle tensor (DCResNet_models.py:14-15): the
-    conv kernel reads x[h>>1][w>>1] directly.
-  * the 1x1 shortcut conv runs at the LOW resolution (a 1x1 conv commutes with nearest upsampling)
-    and is added in the epilogue of the block's last conv;
-  * bias, LeakyReLU(0.2) / tanh are conv-kernel epilogues; GroupNorm+ReLU is one op.
+  * UpsampleConv (DCResNet_models.py:8-17) is cat([x]*4, 1) + pixel_shuffle(2) + conv.  pixel_shuffle is channel-major, so the
+    shuffled tensor is up[c,2h+i,2w+j] = x[(4c+2i+j) mod C,h,w]: its C channels are the C/4 channels of the plain depth-to-space
+    tensor ps[c',2h+i,2w+j] = x[4c'+2i+j,h,w] repeated four times.  The device path therefore never builds `up`: the
+    normalisation kernel writes ps directly and the conv runs on ps with its filter summed over the four channel groups
+    (ops.fold_channels4) — a quarter of the reference's multiply-adds for these layers;
+  * the 1x1 shortcut's result is added in the epilogue of the block's last conv;
+  * bias, LeakyReLU(0.2) / tanh are conv-kernel epilogues; GroupNorm/BatchNorm+ReLU is one op.
 """
 import torch
 import torch.nn.functional as F
@@ -22,30 +24,49 @@ from .nn import HipConv2d, HipGroupNormAct, HipLinear
 
 
 class UpsampleConv(nn.Module):
-    """Nearest 2x upsample followed by a 'same' conv (DCResNet_models.py:8-17)."""
+    """cat([x]*4, dim=1) -> pixel_shuffle(2) -> 'same' conv (DCResNet_models.py:8-17)."""
 
     def __init__(self, in_ch, out_ch, filter_size, bias=True):
         super().__init__()
-        self.conv = HipConv2d(in_ch, out_ch, filter_size, padding="same", bias=bias, upsample=True)
+        self.conv = HipConv2d(in_ch, out_ch, filter_size, padding="same", bias=bias)
+
+    def forward_shuffled(self, x_ps):
+        """x_ps: the depth-to-space tensor [N,2H,2W,C/4] (NHWC) of this layer's input."""
+        return self.conv.forward_shuffled(x_ps)
 
     def forward(self, x):
-        return self.conv(x)
+        if x.is_cuda:
+            if x.shape[1] % 4:
+                raise NotImplementedError("UpsampleConv on HIP needs in_ch %% 4 == 0 (got %d)" % x.shape[1])
+            return HF.nchw_view(self.forward_shuffled(HF.DepthToSpace.apply(HF.nhwc(x))))
+        return self.conv(F.pixel_shuffle(torch.cat([x, x, x, x], 1), 2))
 
 
 class _BatchNormAct(nn.BatchNorm2d):
-    """BatchNorm2d + ReLU for the bn=True generator of the non-per-sample modes (init_util.py:46): batch
-    statistics and the running-stat update run on cslgan_batchnorm_act_f32, the backward on
-    cslgan_norm_act_bwd_f32; eval-mode (running statistics) inference is the image-sampling path, out of scope."""
+    """BatchNorm2d + ReLU for the bn=True generator of the non-per-sample modes (init_util.py:46): batch statistics and the
+    running-stat update run on cslgan_batchnorm_act_f32, the backward on cslgan_norm_act_bwd_f32; eval mode (running
+    statistics: the sampling path train.py:298-308, gensamples.py:26-41) on cslgan_batchnorm_eval_act_f32."""
 
-    def forward_nhwc(self, x):
-        if not self.training:
-            raise NotImplementedError("eval-mode BatchNorm on HIP (image sampling) is out of scope")
+    def _train_stats(self):
+        return self.training or self.running_mean is None
+
+    def forward_nhwc(self, x, d2s=False):
+        g, b = self.weight, self.bias
+        if not self._train_stats():
+            if torch.is_grad_enabled() and (x.requires_grad or g.requires_grad):
+                raise NotImplementedError("eval-mode BatchNorm on HIP is inference-only (no backward)")
+            return ops.batchnorm_eval_act(x, g.detach(), b.detach(), self.running_mean, self.running_var, eps=self.eps, relu=True,
+                                          d2s=d2s, want_raw=d2s)
         if self.num_batches_tracked is not None:
             self.num_batches_tracked += 1
-        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            return HF.NormAct.apply(x, self.weight, self.bias, 0, self.eps, True, self.running_mean, self.running_var, self.momentum)
-        return ops.batchnorm_act(x, self.weight.detach(), self.bias.detach(), self.running_mean, self.running_var,
-                                 momentum=self.momentum, eps=self.eps, relu=True)
+        if torch.is_grad_enabled() and (x.requires_grad or g.requires_grad):
+            y = HF.NormAct.apply(x, g, b, 0, self.eps, True, self.running_mean, self.running_var, self.momentum)
+            return (HF.DepthToSpace.apply(y), HF.DepthToSpace.apply(x)) if d2s else y
+        return ops.batchnorm_act(x, g.detach(), b.detach(), self.running_mean, self.running_var, momentum=self.momentum,
+                                 eps=self.eps, relu=True, d2s=d2s, want_raw=d2s)
+
+    def forward_shuffled(self, x):
+        return self.forward_nhwc(x, d2s=True)
 
     def forward(self, x):
         if x.is_cuda:
@@ -69,12 +90,12 @@ class ResBlockUp(nn.Module):
         self.conv = HipConv2d(out_ch, out_ch, filter_size, padding="same")
 
     def forward_nhwc(self, x):
-        sc = self.shortcut.conv
-        # 1x1 conv at low resolution; upsampled on the fly by the last conv's residual read
-        w_sc = sc.weight.permute(0, 2, 3, 1).contiguous()
-        s_low = HF.Conv.apply(x, w_sc, sc.bias, 1, 0, ops.ACT_NONE, False, None, 0, sc._wkey(w_sc))
-        o = self.convUp.conv.forward_nhwc(self.bn1.forward_nhwc(x))
-        return self.conv.forward_nhwc(self.bn2.forward_nhwc(o), residual=s_low, res_shift=1)
+        if x.shape[-1] % 4:
+            raise NotImplementedError("ResBlockUp on HIP needs in_ch %% 4 == 0 (got %d)" % x.shape[-1])
+        a_ps, x_ps = self.bn1.forward_shuffled(x)       # one read of x: depth_to_space(relu(norm(x))) and depth_to_space(x)
+        s = self.shortcut.forward_shuffled(x_ps)        # 1x1 conv over the C/4 shuffled channels, full resolution
+        o = self.convUp.forward_shuffled(a_ps)
+        return self.conv.forward_nhwc(self.bn2.forward_nhwc(o), residual=s)
 
     def forward(self, x):
         if x.is_cuda:

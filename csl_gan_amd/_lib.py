@@ -11,15 +11,18 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcslgan_hip.so")
 MAX_SEGS = 16
+ABI_VERSION = 2          # include/cslgan.h CSLGAN_ABI_VERSION
 
 EXPORTS = [
     "cslgan_version", "cslgan_last_error", "cslgan_device_count",
     "cslgan_sample_sqnorm_f32", "cslgan_sample_sqnorm_bf16", "cslgan_clip_factors_f32", "cslgan_clip_accum_noise_f32",
     "cslgan_clip_accum_noise_bf16", "cslgan_conv2d_wgrad_grouped_bf16out_f32",
     "cslgan_l2_clip_rows_f32", "cslgan_row_l2norm_f32", "cslgan_row_l2norm_bwd_f32",
-    "cslgan_conv2d_fwd_f32", "cslgan_conv2d_up_fwd_f32", "cslgan_conv2d_up_ws_floats", "cslgan_conv2d_up_dgrad_f32", "cslgan_conv2d_dgrad_f32", "cslgan_conv2d_wgrad_grouped_f32",
-    "cslgan_conv2d_wgrad_scaled_f32", "cslgan_conv2d_wgrad_sqnorm_gram_f32", "cslgan_conv2d_up_wgrad_phases_f32", "cslgan_fold_up_wgrad_f32", "cslgan_conv2d_up_wgrad_phase_stride", "cslgan_conv2d_wgrad_skinny_f32", "cslgan_conv2d_s2_fwd_f32",
-    "cslgan_bias_grad_grouped_f32", "cslgan_act_bwd_f32", "cslgan_groupnorm_act_f32", "cslgan_batchnorm_act_f32", "cslgan_norm_act_bwd_f32", "cslgan_norm_bwd_ws_floats", "cslgan_sum2x2_f32",
+    "cslgan_conv2d_fwd_f32", "cslgan_conv2d_dgrad_f32", "cslgan_conv2d_wgrad_grouped_f32",
+    "cslgan_conv2d_wgrad_scaled_f32", "cslgan_conv2d_wgrad_sqnorm_gram_f32", "cslgan_conv2d_wgrad_skinny_f32", "cslgan_conv2d_s2_fwd_f32",
+    "cslgan_depth_to_space_f32", "cslgan_fold_channels4_f32",
+    "cslgan_bias_grad_grouped_f32", "cslgan_act_bwd_f32", "cslgan_groupnorm_act_f32", "cslgan_batchnorm_act_f32", "cslgan_batchnorm_eval_act_f32",
+    "cslgan_norm_act_bwd_f32", "cslgan_norm_bwd_ws_floats",
     "cslgan_adam_step_f32",
 ]
 
@@ -34,7 +37,7 @@ class SegsT(C.Structure):
 
 class ConvT(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "upsample", "P", "Q")]
+                ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "reserved", "P", "Q")]
 
 
 _lib = None
@@ -71,36 +74,30 @@ def lib():
         "cslgan_l2_clip_rows_f32": [vp, vp, i64, i64, f32, vp, vp],
         "cslgan_row_l2norm_f32": [vp, i64, i64, vp, vp],
         "cslgan_row_l2norm_bwd_f32": [vp, vp, vp, i64, i64, vp, vp],
-        "cslgan_conv2d_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, vp, i32, i32, vp, vp],
-        "cslgan_conv2d_up_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, i32, vp, vp, i32, i32, vp, vp],
+        "cslgan_conv2d_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, vp, i32, vp, vp],
         "cslgan_conv2d_dgrad_f32": [C.POINTER(ConvT), vp, vp, vp, i32, vp, vp, vp],
-        "cslgan_conv2d_up_dgrad_f32": [C.POINTER(ConvT), vp, vp, vp, i32, vp, vp],
         "cslgan_norm_act_bwd_f32": [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, i32, vp, vp, vp, vp, vp],
-        "cslgan_sum2x2_f32": [vp, i32, i32, i32, i32, vp, vp],
+        "cslgan_depth_to_space_f32": [vp, i32, i32, i32, i32, i32, vp, vp],
+        "cslgan_fold_channels4_f32": [vp, i64, i32, i32, vp, vp],
         "cslgan_conv2d_wgrad_grouped_f32": [C.POINTER(ConvT), vp, vp, i32, f32, vp, vp, vp],
         "cslgan_conv2d_wgrad_scaled_f32": [C.POINTER(ConvT), vp, vp, vp, i32, f32, vp, vp],
         "cslgan_conv2d_wgrad_sqnorm_gram_f32": [C.POINTER(ConvT), vp, vp, f32, vp, vp],
-        "cslgan_conv2d_up_wgrad_phases_f32": [C.POINTER(ConvT), vp, vp, i32, f32, vp, vp],
-        "cslgan_fold_up_wgrad_f32": [vp, i64, i32, vp, vp],
         "cslgan_conv2d_wgrad_skinny_f32": [C.POINTER(ConvT), vp, vp, f32, vp, i32, vp],
         "cslgan_conv2d_s2_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, i32, vp, i32, vp, vp],
         "cslgan_bias_grad_grouped_f32": [vp, i32, i32, i32, i32, f32, vp, vp, vp],
         "cslgan_act_bwd_f32": [vp, vp, i64, f32, vp, vp],
-        "cslgan_groupnorm_act_f32": [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, vp],
-        "cslgan_batchnorm_act_f32": [vp, vp, vp, i64, i32, f32, i32, f32, vp, vp, vp, vp, vp],
+        "cslgan_groupnorm_act_f32": [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, i32, vp, vp],
+        "cslgan_batchnorm_act_f32": [vp, vp, vp, i64, i32, f32, i32, f32, vp, vp, vp, vp, i64, i32, vp, vp],
+        "cslgan_batchnorm_eval_act_f32": [vp, vp, vp, vp, vp, i64, i32, f32, i32, vp, vp, i64, i32, vp, vp],
         "cslgan_adam_step_f32": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = C.c_int
-    L.cslgan_conv2d_up_ws_floats.argtypes = [i32, i32, i32]
-    L.cslgan_conv2d_up_ws_floats.restype = C.c_int64
-    L.cslgan_conv2d_up_wgrad_phase_stride.argtypes = [i32]
-    L.cslgan_conv2d_up_wgrad_phase_stride.restype = C.c_int64
     L.cslgan_norm_bwd_ws_floats.argtypes = [i64, i64, i32, i32]
     L.cslgan_norm_bwd_ws_floats.restype = C.c_int64
-    if L.cslgan_version() != 1:
+    if L.cslgan_version() != ABI_VERSION:
         raise HipLibraryMissing("libcslgan_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -17,13 +17,12 @@ constexpr int IG_MAX_TAPS = 40;
 // "K-contiguous" implicit GEMM:  Out[m][n] = sum_k A(m,k) * Wm[n][k]
 //   m -> (img, oy, ox) over a per-image grid OHc x OWc
 //   k -> (tap t, channel c), k = t*AC + c
-//   A(m,k) = a[img][(oy*sy+ty[t]) >> ups][(ox*sx+tx[t]) >> ups][c]   (zero outside the virtual VH x VW image)
+//   A(m,k) = a[img][oy*sy+ty[t]][ox*sx+tx[t]][c]   (zero outside the VH x VW image)
 // One launch covers up to 4 "classes" that share a, out and the channel counts but have their own
 // row grid, tap table, filter matrix and output phase:
 //   forward conv            : 1 class, sy=stride, ty[t]=kh-pad
 //   data gradient, stride s : s*s output-parity classes, sy=1, ty[t]=(py+pad-kh)/s over kh == (py+pad) mod s
-//   nearest-2x upsample+conv: 4 output-phase classes, each a (R/2+1)^2-tap conv of the LOW-res input with
-//                             summed filter taps (sub-pixel decomposition: 25 -> 9 MACs per output for 5x5)
+//   stride-2 forward (halo) : 4 input-parity classes accumulated into one output (acc_classes)
 constexpr int IG_MAX_CLS = 4;
 struct KcClass {
     int M, OHc, OWc;     // rows and per-image grid of this class
@@ -43,8 +42,7 @@ struct KcParams {
     unsigned a_bytes, w_bytes;   // byte sizes of a and w (buffer-descriptor range checks)
     unsigned ac_recip;           // ceil(2^32 / AC)
     int AH, AW, AC;      // stored dims of a
-    int VH, VW;          // virtual dims used for the bounds test (2*AH,2*AW when ups==1)
-    int ups;
+    int VH, VW;          // dims used for the bounds test (== AH, AW)
     int sy, sx;
     const float* w;
     int Nn;
@@ -52,8 +50,7 @@ struct KcParams {
     int OHf, OWf, osy, osx, ldo;
     int dense_out;       // 1: out offset == m*ldo (single-class forward conv)
     const float* bias;
-    const float* res;    // res[img][oyf>>rs][oxf>>rs][n]
-    int res_shift;
+    const float* res;    // same indexing as out (the ResBlockUp shortcut added before the activation)
     const float* mask;   // same indexing as out
     int act;
     int n_cls;
@@ -99,9 +96,7 @@ CSL_HD int kc_out_offset(const KcParams& p, const KcClass& k, const RowCoord& rc
 }
 
 CSL_HD int kc_res_offset(const KcParams& p, const KcClass& k, const RowCoord& rc) {
-    const int oyf = rc.oy * p.osy + k.oy0, oxf = rc.ox * p.osx + k.ox0;
-    const int RH = p.OHf >> p.res_shift, RW = p.OWf >> p.res_shift;
-    return ((rc.img * RH + (oyf >> p.res_shift)) * RW + (oxf >> p.res_shift)) * p.ldo;
+    return kc_out_offset(p, k, rc);
 }
 
 // Bijective XCD-aware remap of a linear workgroup id: blocks b and b+8 share an XCD, so give each
@@ -122,7 +117,6 @@ struct McParams {
     int T;               // taps R*S
     int Ndim;            // T*C
     int stride;
-    int ups;             // 1: x is read through a nearest-2x upsample (H, W are the stored low-res dims)
     int group;           // samples per group
     int n_groups;
     float alpha;
@@ -132,10 +126,6 @@ struct McParams {
     int tiles_m, tiles_n;
     int ksplit;          // >1: the group's pixels are divided over ksplit workgroups that atomically add into zeroed gw
     const float* row_scale;   // nullable [N]: gy of sample n is multiplied by row_scale[n] on load (clip-weighted sums)
-    int gy_phase;        // 1: sub-pixel form of an upsample+conv weight gradient.  P,Q are the LOW-res grid, gy is the full
-                         // [N][2P][2Q][Kc] tensor read at (2*oy+a, 2*ox+b); n -> (phase a*2+b, tap, c) with Ndim = 4*T*C, and
-                         // every BN-wide n-tile lies inside one phase: phases are phase_stride (a multiple of 256) columns apart
-    int phase_stride;
     signed char ty[IG_MAX_TAPS], tx[IG_MAX_TAPS];   // kh-pad, kw-pad
 };
 

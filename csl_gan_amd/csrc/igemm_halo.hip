@@ -1,5 +1,5 @@
 // fp32 MFMA convolution with an LDS-resident input halo, for the stride-1 tap classes (5x5 "same" convs,
-// the 3x3 phases of the upsample convs, the parity classes of the strided data gradient).  gfx950 only.
+// the parity classes of the strided data gradient).  gfx950 only.
 //
 // igemm_kc_kernel re-gathers the A operand from global memory once per filter tap: 25 (or 9) passes over the
 // same input window, each with its own address arithmetic, 16-byte loads and ds_write_b128.  rocprofv3 showed
@@ -255,10 +255,10 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(const KcParams p) {
     }   // sub
 }
 
-// Eligibility: every class stride 1, no upsample-on-read, 8x8-patchable grid, channel count a multiple of 32,
+// Eligibility: every class stride 1, 8x8-patchable grid, channel count a multiple of 32,
 // 2..25 taps within a 12x12 halo, enough output channels to fill the 64-wide N tile.
 bool halo_eligible(const KcParams& p) {
-    if (p.sy != 1 || p.sx != 1 || p.ups != 0 || (p.AC & 31) || p.Nn < 64 || p.ksplit > 1) return false;
+    if (p.sy != 1 || p.sx != 1 || (p.AC & 31) || p.Nn < 64 || p.ksplit > 1) return false;
     for (int c = 0; c < p.n_cls; ++c) {
         const KcClass& k = p.cls[c];
         const bool quad = k.OHc == 4 && k.OWc == 4;
@@ -294,7 +294,7 @@ int launch_halo(KcParams& p, hipStream_t st) {
     }
     p.tiles_m = tm;
     p.ksplit = 1;
-    // Equal classes (forward convs, upsample phases): 128-wide N tiles.  Unequal classes (9/6/6/4 taps of a 5x5 stride-2 data
+    // Equal classes (forward convs): 128-wide N tiles.  Unequal classes (9/6/6/4 taps of a 5x5 stride-2 data
     // gradient): 64-wide tiles, and the heaviest class is paired with the lightest in ONE workgroup so every workgroup
     // carries the same number of K steps — when the halved grid still fills the chip.  Measured on the critic's data
     // gradients at 128 / 384 rows (scripts/dgrad_sweep.py): 63 -> 81, 68 -> 75, 76 -> 96, 83 -> 98, 65 -> 79 TF.

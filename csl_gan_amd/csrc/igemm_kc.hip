@@ -1,5 +1,5 @@
-// fp32 MFMA implicit-GEMM convolution, "K-contiguous" form: forward conv / linear, nearest-2x
-// upsample + conv (sub-pixel decomposed) and the data gradient (transposed conv).  gfx950 only.
+// fp32 MFMA implicit-GEMM convolution, "K-contiguous" form: forward conv / linear and the data
+// gradient (transposed conv).  gfx950 only.
 //
 //   Out[m][n] = epilogue( sum_k A(m,k) * Wm[n][k] )      (index maps and classes: igemm.h)
 //
@@ -12,12 +12,12 @@
 // so the sum is unchanged.  Global loads for tile t+1 are issued before the MFMAs of tile t and
 // written to the other LDS buffer after them (one barrier per K tile).
 //
-// One launch covers every output class of an op (the 4 parity classes of a stride-2 data gradient,
-// the 4 output phases of an upsample+conv), so small layers still put >= 256 workgroups on the chip;
+// One launch covers every output class of an op (the 4 parity classes of a stride-2 data gradient),
+// so small layers still put >= 256 workgroups on the chip;
 // layers with few tiles and a long K (the [B,8192]x[8192,1] critic head) split K over workgroups.
 //
 // Replaces (reference file:line): torch.nn.Conv2d / nn.Linear forward DCResNet_models.py:131-132,
-// 145, 13-17, 60-70, 95-104; MNIST_models.py:17-23, 41-46; and the autograd data-gradient of those.
+// 145, 16 (the conv of UpsampleConv, on the depth-to-space tensor), 60-70, 95-104; MNIST_models.py:17-23, 41-46; and the autograd data-gradient of those.
 #include <stdlib.h>
 #include "common.h"
 #include "igemm.h"
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void igemm_kc_kernel(cons
     auto a_offset = [&](int i, int ty, int tx, int c, bool kin) -> unsigned {
         const int iy = a_iy[i] + ty, ix = a_ix[i] + tx;
         const bool ok = kin && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
-        const unsigned e = (unsigned)(a_img[i] + ((iy >> p.ups) * p.AW + (ix >> p.ups)) * p.AC + c);
+        const unsigned e = (unsigned)(a_img[i] + (iy * p.AW + ix) * p.AC + c);
         return ok ? 4u * e : OOB;
     };
 
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void igemm_kc_kernel(cons
 
 // Repack KRSC filters into per-class [Nout][taps][Cred] matrices.
 //   transposed == 1 (data gradient): wt[off + (c*Tc + t)*K + k]      = w[((k*R + kh_t)*S + kw_t)*C + c]
-//   transposed == 0 (upsample phases): wt[off + (k*Tc + t)*C + c]    = sum over the (kh,kw) that fold onto tap t
+//   transposed == 0 (stride-2 forward parity classes): wt[off + (k*Tc + t)*C + c] = the (kh,kw) of tap t
 struct RepackArgs {
     int K, R, S, C;
     int n_class;
@@ -442,7 +442,8 @@ static int check_conv(const cslgan_conv_t* c, const char* who) {
     CSLGAN_REQUIRE(c->N > 0 && c->H > 0 && c->W > 0 && c->C > 0 && c->K > 0 && c->R > 0 && c->S > 0 && c->stride > 0 && c->pad >= 0,
                    "%s: non-positive dimension", who);
     CSLGAN_REQUIRE(c->R * c->S <= IG_MAX_TAPS, "%s: %dx%d filter has more than %d taps", who, c->R, c->S, IG_MAX_TAPS);
-    const int VH = c->upsample ? 2 * c->H : c->H, VW = c->upsample ? 2 * c->W : c->W;
+    CSLGAN_REQUIRE(c->reserved == 0, "%s: cslgan_conv_t.reserved must be 0", who);
+    const int VH = c->H, VW = c->W;
     const int P = (VH + 2 * c->pad - c->R) / c->stride + 1, Q = (VW + 2 * c->pad - c->S) / c->stride + 1;
     CSLGAN_REQUIRE(P == c->P && Q == c->Q, "%s: output %dx%d does not match P,Q=%d,%d", who, P, Q, c->P, c->Q);
     CSLGAN_REQUIRE((long long)c->N * c->P * c->Q * c->K < (1ll << 31) && (long long)c->N * VH * VW * c->C < (1ll << 31) &&
@@ -461,19 +462,17 @@ using namespace cslgan;
 extern "C" {
 
 int cslgan_conv2d_fwd_f32(const cslgan_conv_t* c, const float* x, const float* w, const float* bias,
-                          const float* residual, int res_shift, int act, float* y, void* stream) {
+                          const float* residual, int act, float* y, void* stream) {
     CSLGAN_REQUIRE(c && x && w && y, "conv2d_fwd: null argument");
     int rc = check_conv(c, "conv2d_fwd");
     if (rc) return rc;
-    CSLGAN_REQUIRE(res_shift == 0 || res_shift == 1, "conv2d_fwd: res_shift must be 0 or 1");
     CSLGAN_REQUIRE(act >= 0 && act <= 3, "conv2d_fwd: unknown activation %d", act);
-    CSLGAN_REQUIRE(!residual || res_shift == 0 || (c->P % 2 == 0 && c->Q % 2 == 0), "conv2d_fwd: shifted residual needs even output dims");
     KcParams p{};
     p.a = x; p.AH = c->H; p.AW = c->W; p.AC = c->C;
-    p.VH = c->upsample ? 2 * c->H : c->H; p.VW = c->upsample ? 2 * c->W : c->W; p.ups = c->upsample ? 1 : 0;
+    p.VH = c->H; p.VW = c->W;
     p.sy = p.sx = c->stride;
     p.w = w; p.Nn = c->K; p.out = y; p.OHf = c->P; p.OWf = c->Q; p.osy = p.osx = 1; p.ldo = c->K; p.dense_out = 1;
-    p.bias = bias; p.res = residual; p.res_shift = res_shift; p.mask = nullptr; p.act = act;
+    p.bias = bias; p.res = residual; p.mask = nullptr; p.act = act;
     p.n_cls = 1;
     KcClass& k = p.cls[0];
     k.M = c->N * c->P * c->Q; k.OHc = c->P; k.OWc = c->Q; k.T = c->R * c->S; k.Kdim = k.T * c->C; k.w_off = 0; k.oy0 = k.ox0 = 0;
@@ -481,66 +480,6 @@ int cslgan_conv2d_fwd_f32(const cslgan_conv_t* c, const float* x, const float* w
     for (int kh = 0; kh < c->R; ++kh)
         for (int kw = 0; kw < c->S; ++kw) { k.ty[kh * c->S + kw] = (signed char)(kh - c->pad); k.tx[kh * c->S + kw] = (signed char)(kw - c->pad); }
     return launch_kc(p, (hipStream_t)stream, (long long)c->N * c->P * c->Q * c->K);
-}
-
-int cslgan_conv2d_up_fwd_f32(const cslgan_conv_t* c, const float* x, const float* w, float* wphase_ws, int repack,
-                             const float* bias, const float* residual, int res_shift, int act, float* y, void* stream) {
-    CSLGAN_REQUIRE(c && x && w && wphase_ws && y, "conv2d_up_fwd: null argument");
-    int rc = check_conv(c, "conv2d_up_fwd");
-    if (rc) return rc;
-    CSLGAN_REQUIRE(c->upsample == 1 && c->stride == 1, "conv2d_up_fwd: needs upsample=1, stride=1");
-    CSLGAN_REQUIRE(c->R == c->S && (c->R % 2 == 1) && c->pad == c->R / 2, "conv2d_up_fwd: needs an odd square 'same' filter");
-    CSLGAN_REQUIRE(res_shift == 0 || res_shift == 1, "conv2d_up_fwd: res_shift must be 0 or 1");
-    CSLGAN_REQUIRE(act >= 0 && act <= 3, "conv2d_up_fwd: unknown activation %d", act);
-    hipStream_t st = (hipStream_t)stream;
-    // fold the R taps of each axis onto the low-res offsets d = floor((a + kh - pad) / 2)
-    const int R = c->R, pad = c->pad;
-    int d_lo[2], nd[2], first[2][8], last[2][8];   // per phase a: offsets d_lo .. d_lo+nd-1 and their kh ranges
-    for (int a = 0; a < 2; ++a) {
-        auto fl = [](int v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); };
-        d_lo[a] = fl(a - pad);
-        const int d_hi = fl(a + R - 1 - pad);
-        nd[a] = d_hi - d_lo[a] + 1;
-        CSLGAN_REQUIRE(nd[a] <= 8, "conv2d_up_fwd: filter too large");
-        for (int u = 0; u < nd[a]; ++u) { first[a][u] = R; last[a][u] = -1; }
-        for (int kh = 0; kh < R; ++kh) {
-            const int u = fl(a + kh - pad) - d_lo[a];
-            if (kh < first[a][u]) first[a][u] = kh;
-            if (kh > last[a][u]) last[a][u] = kh;
-        }
-    }
-    RepackArgs ra{};
-    ra.K = c->K; ra.R = R; ra.S = R; ra.C = c->C; ra.n_class = 4; ra.transposed = 0;
-    KcParams p{};
-    p.a = x; p.AH = c->H; p.AW = c->W; p.AC = c->C; p.VH = c->H; p.VW = c->W; p.ups = 0; p.sy = p.sx = 1;
-    p.w = wphase_ws; p.Nn = c->K; p.out = y; p.OHf = c->P; p.OWf = c->Q; p.osy = p.osx = 2; p.ldo = c->K; p.dense_out = 0;
-    p.bias = bias; p.res = residual; p.res_shift = res_shift; p.mask = nullptr; p.act = act; p.n_cls = 4;
-    int off = 0;
-    for (int a = 0; a < 2; ++a)
-        for (int b = 0; b < 2; ++b) {
-            const int cls = a * 2 + b;
-            const int T = nd[a] * nd[b];
-            CSLGAN_REQUIRE(T <= IG_MAX_TAPS, "conv2d_up_fwd: too many folded taps");
-            KcClass& k = p.cls[cls];
-            k.M = c->N * c->H * c->W; k.OHc = c->H; k.OWc = c->W; k.T = T; k.Kdim = T * c->C; k.w_off = off; k.oy0 = a; k.ox0 = b;
-            clear_taps(k);
-            for (int u = 0; u < nd[a]; ++u)
-                for (int v = 0; v < nd[b]; ++v) {
-                    const int t = u * nd[b] + v;
-                    k.ty[t] = (signed char)(d_lo[a] + u); k.tx[t] = (signed char)(d_lo[b] + v);
-                    ra.kh_lo[cls][t] = (signed char)first[a][u]; ra.kh_hi[cls][t] = (signed char)(last[a][u] + 1);
-                    ra.kw_lo[cls][t] = (signed char)first[b][v]; ra.kw_hi[cls][t] = (signed char)(last[b][v] + 1);
-                }
-            ra.cls_T[cls] = T; ra.cls_off[cls] = off; off += T * c->K * c->C;
-        }
-    if (repack) {
-        unsigned gxn = (unsigned)(((long long)c->K * c->C * 9 + 255) / 256);
-        gxn = gxn > 1024 ? 1024 : (gxn < 1 ? 1 : gxn);
-        hipLaunchKernelGGL(repack_filters_kernel, dim3(gxn, 4), dim3(256), 0, st, w, wphase_ws, ra);
-        rc = check_launch("repack_filters_kernel");
-        if (rc) return rc;
-    }
-    return launch_kc(p, st, 0);
 }
 
 // Stride-2 forward conv as four stride-1 convs over the parity sub-images of x (class (a,b) = input pixels (2i+a, 2j+b)),
@@ -552,7 +491,7 @@ int cslgan_conv2d_s2_fwd_f32(const cslgan_conv_t* c, const float* x, const float
     CSLGAN_REQUIRE(c && x && w && wcls_ws && y, "conv2d_s2_fwd: null argument");
     int rc = check_conv(c, "conv2d_s2_fwd");
     if (rc) return rc;
-    CSLGAN_REQUIRE(c->stride == 2 && !c->upsample && c->R == c->S, "conv2d_s2_fwd: needs stride 2, a square filter, no upsample");
+    CSLGAN_REQUIRE(c->stride == 2 && c->R == c->S, "conv2d_s2_fwd: needs stride 2 and a square filter");
     CSLGAN_REQUIRE(act >= 0 && act <= 3, "conv2d_s2_fwd: unknown activation %d", act);
     hipStream_t st = (hipStream_t)stream;
     const int R = c->R, pad = c->pad;
@@ -560,9 +499,9 @@ int cslgan_conv2d_s2_fwd_f32(const cslgan_conv_t* c, const float* x, const float
     RepackArgs ra{};
     ra.K = c->K; ra.R = R; ra.S = R; ra.C = c->C; ra.transposed = 0;
     KcParams p{};
-    p.a = x; p.AH = c->H; p.AW = c->W; p.AC = c->C; p.VH = c->H; p.VW = c->W; p.ups = 0; p.sy = p.sx = 1;
+    p.a = x; p.AH = c->H; p.AW = c->W; p.AC = c->C; p.VH = c->H; p.VW = c->W; p.sy = p.sx = 1;
     p.w = wcls_ws; p.Nn = c->K; p.out = y; p.OHf = c->P; p.OWf = c->Q; p.osy = p.osx = 1; p.ldo = c->K; p.dense_out = 0;
-    p.bias = bias; p.res = nullptr; p.res_shift = 0; p.mask = nullptr; p.act = act; p.acc_classes = 1;
+    p.bias = bias; p.res = nullptr; p.mask = nullptr; p.act = act; p.acc_classes = 1;
     int n = 0, off = 0;
     bool ok = R * R <= IG_MAX_TAPS;
     for (int a = 0; ok && a < 2; ++a)
@@ -593,7 +532,7 @@ int cslgan_conv2d_s2_fwd_f32(const cslgan_conv_t* c, const float* x, const float
     static const int s2_min_tiles = [] { const char* e = getenv("CSLGAN_S2_MIN_TILES"); return e ? atoi(e) : 512; }();
     const long long wide_tiles = ((long long)c->N * c->P * c->Q + 127) / 128 * ((c->K + 127) / 128);
     if (!ok || n == 0 || !halo_env || !s2_env || wide_tiles < s2_min_tiles || !halo_eligible(p))
-        return cslgan_conv2d_fwd_f32(c, x, w, bias, nullptr, 0, act, y, stream);
+        return cslgan_conv2d_fwd_f32(c, x, w, bias, nullptr, act, y, stream);
     if (repack) {
         const long long per = (long long)c->C * 9 * c->K;
         unsigned gxn = (unsigned)((per + 255) / 256);
@@ -605,71 +544,21 @@ int cslgan_conv2d_s2_fwd_f32(const cslgan_conv_t* c, const float* x, const float
     return launch_kc(p, st, 0);
 }
 
-// floats of workspace cslgan_conv2d_up_fwd_f32 needs for a K x R x R x C filter
-int64_t cslgan_conv2d_up_ws_floats(int K, int R, int C) {
-    const int n = R / 2 + 1;   // folded taps per axis (upper bound over both phases)
-    return (int64_t)4 * n * n * K * C;
-}
-
-// Data gradient of (nearest-2x upsample -> RxR 'same' conv) with respect to the LOW-res input:
-//   gx[i] = sum_o w'(o) gy[2i + o],  o in [pad-R+1, pad+1] per axis, w'(o) = sum of the filter taps kh with
-//   kh in {pad-o, pad-o+1}: the 2x2 sum-pool of the dense data gradient folded into (R+1)^2 strided taps
-//   (36 instead of 4*25 MACs per low-res pixel for 5x5).
-int cslgan_conv2d_up_dgrad_f32(const cslgan_conv_t* c, const float* gy, const float* w, float* wt_ws, int repack, float* gx,
-                               void* stream) {
-    CSLGAN_REQUIRE(c && gy && w && wt_ws && gx, "conv2d_up_dgrad: null argument");
-    int rc = check_conv(c, "conv2d_up_dgrad");
-    if (rc) return rc;
-    CSLGAN_REQUIRE(c->upsample == 1 && c->stride == 1, "conv2d_up_dgrad: needs upsample=1, stride=1");
-    CSLGAN_REQUIRE(c->R == c->S && (c->R % 2 == 1) && c->pad == c->R / 2, "conv2d_up_dgrad: needs an odd square 'same' filter");
-    const int R = c->R, pad = c->pad, no = R + 1;
-    CSLGAN_REQUIRE(no * no <= IG_MAX_TAPS, "conv2d_up_dgrad: filter too large (%d folded taps)", no * no);
-    hipStream_t st = (hipStream_t)stream;
-    RepackArgs ra{};
-    ra.K = c->K; ra.R = R; ra.S = R; ra.C = c->C; ra.n_class = 1; ra.transposed = 1;
-    KcParams p{};
-    p.a = gy; p.AH = c->P; p.AW = c->Q; p.AC = c->K; p.VH = c->P; p.VW = c->Q; p.ups = 0; p.sy = p.sx = 2;
-    p.w = wt_ws; p.Nn = c->C; p.out = gx; p.OHf = c->H; p.OWf = c->W; p.osy = p.osx = 1; p.ldo = c->C; p.dense_out = 1;
-    p.bias = nullptr; p.res = nullptr; p.res_shift = 0; p.mask = nullptr; p.act = CSLGAN_ACT_NONE; p.n_cls = 1;
-    KcClass& k = p.cls[0];
-    clear_taps(k);
-    k.M = c->N * c->H * c->W; k.OHc = c->H; k.OWc = c->W; k.T = no * no; k.Kdim = k.T * c->K; k.w_off = 0; k.oy0 = k.ox0 = 0;
-    for (int u = 0; u < no; ++u)
-        for (int v = 0; v < no; ++v) {
-            const int t = u * no + v;
-            const int oy = pad - R + 1 + u, ox = pad - R + 1 + v;
-            k.ty[t] = (signed char)oy; k.tx[t] = (signed char)ox;
-            const int ylo = pad - oy, xlo = pad - ox;
-            ra.kh_lo[0][t] = (signed char)(ylo < 0 ? 0 : ylo); ra.kh_hi[0][t] = (signed char)(ylo + 2 > R ? R : ylo + 2);
-            ra.kw_lo[0][t] = (signed char)(xlo < 0 ? 0 : xlo); ra.kw_hi[0][t] = (signed char)(xlo + 2 > R ? R : xlo + 2);
-        }
-    ra.cls_T[0] = k.T; ra.cls_off[0] = 0;
-    if (repack) {
-        unsigned gxn = (unsigned)(((long long)c->K * c->C * k.T + 255) / 256);
-        gxn = gxn > 1024 ? 1024 : (gxn < 1 ? 1 : gxn);
-        hipLaunchKernelGGL(repack_filters_kernel, dim3(gxn, 1), dim3(256), 0, st, w, wt_ws, ra);
-        rc = check_launch("repack_filters_kernel");
-        if (rc) return rc;
-    }
-    return launch_kc(p, st, (long long)c->N * c->H * c->W * c->C);
-}
-
 int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* c, const float* gy, const float* w, float* wt_ws, int repack,
                             const float* mask, float* gx, void* stream) {
     CSLGAN_REQUIRE(c && gy && w && wt_ws && gx, "conv2d_dgrad: null argument");
     int rc = check_conv(c, "conv2d_dgrad");
     if (rc) return rc;
-    CSLGAN_REQUIRE(!c->upsample, "conv2d_dgrad: upsample-on-read convs have no data-gradient path yet");
     CSLGAN_REQUIRE(c->stride >= 1 && c->stride <= 2, "conv2d_dgrad: stride %d unsupported", c->stride);
     const int s = c->stride;
     hipStream_t st = (hipStream_t)stream;
     RepackArgs ra{};
     ra.K = c->K; ra.R = c->R; ra.S = c->S; ra.C = c->C; ra.n_class = s * s; ra.transposed = 1;
     KcParams p{};
-    p.a = gy; p.AH = c->P; p.AW = c->Q; p.AC = c->K; p.VH = c->P; p.VW = c->Q; p.ups = 0; p.sy = p.sx = 1;
+    p.a = gy; p.AH = c->P; p.AW = c->Q; p.AC = c->K; p.VH = c->P; p.VW = c->Q; p.sy = p.sx = 1;
     p.w = wt_ws; p.Nn = c->C; p.out = gx; p.OHf = c->H; p.OWf = c->W; p.osy = p.osx = s; p.ldo = c->C;
     p.dense_out = (s == 1) ? 1 : 0;
-    p.bias = nullptr; p.res = nullptr; p.res_shift = 0; p.mask = mask; p.act = CSLGAN_ACT_NONE;
+    p.bias = nullptr; p.res = nullptr; p.mask = mask; p.act = CSLGAN_ACT_NONE;
     int off = 0, ncls = 0;
     for (int py = 0; py < s; ++py)
         for (int px = 0; px < s; ++px) {

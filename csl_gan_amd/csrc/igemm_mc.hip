@@ -48,16 +48,12 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
     // B columns are fixed per thread: decode (tap, c) once
     int b_ty[4], b_tx[4], b_c[4];
     bool b_nok[4];
-    const int per_phase = p.gy_phase ? p.phase_stride : p.T * p.C;
-    const int phase = p.gy_phase ? n0 / per_phase : 0;          // uniform: an n-tile never straddles phases
-    const int ph_a = phase >> 1, ph_b = phase & 1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int n = n0 + b_nc + e;
-        const int nl = n - phase * per_phase;
-        b_nok[e] = n < p.Ndim && nl < p.T * p.C;
-        const int t = b_nok[e] ? nl / p.C : 0;
-        b_c[e] = nl - t * p.C;
+        b_nok[e] = n < p.Ndim;
+        const int t = b_nok[e] ? n / p.C : 0;
+        b_c[e] = n - t * p.C;
         b_ty[e] = p.ty[t];
         b_tx[e] = p.tx[t];
     }
@@ -72,11 +68,6 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (kk < Ktot) {
                 const float* src = p.gy + (pix_base + kk) * p.Kc + m0 + a_mc;
-                if (p.gy_phase) {
-                    const int il = kk / PQ, pix = kk - il * PQ;
-                    const int oy = pix / p.Q, ox = pix - oy * p.Q;
-                    src = p.gy + ((((long long)g * p.group + il) * (2 * p.P) + 2 * oy + ph_a) * (2 * p.Q) + 2 * ox + ph_b) * p.Kc + m0 + a_mc;
-                }
                 if (VEC_A) {
                     if (m0 + a_mc < p.Kc) v = *reinterpret_cast<const float4*>(src);
                 } else {
@@ -102,18 +93,18 @@ __global__ __launch_bounds__(256) void igemm_mc_kernel(const McParams p) {
                 const int oy = pix / p.Q, ox = pix - oy * p.Q;
                 const long long img = (long long)g * p.group + il;
                 const int by = oy * p.stride, bx = ox * p.stride;
-                const int VH = p.H << p.ups, VW = p.W << p.ups;
+                const int VH = p.H, VW = p.W;
                 if (VEC_B) {
                     const int iy = by + b_ty[0], ix = bx + b_tx[0];
                     if (b_nok[0] && iy >= 0 && iy < VH && ix >= 0 && ix < VW)
-                        v = *reinterpret_cast<const float4*>(p.x + ((img * p.H + (iy >> p.ups)) * p.W + (ix >> p.ups)) * p.C + b_c[0]);
+                        v = *reinterpret_cast<const float4*>(p.x + ((img * p.H + iy) * p.W + ix) * p.C + b_c[0]);
                 } else {
                     float t4[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int iy = by + b_ty[e], ix = bx + b_tx[e];
                         t4[e] = (b_nok[e] && iy >= 0 && iy < VH && ix >= 0 && ix < VW)
-                                    ? p.x[((img * p.H + (iy >> p.ups)) * p.W + (ix >> p.ups)) * p.C + b_c[e]] : 0.f;
+                                    ? p.x[((img * p.H + iy) * p.W + ix) * p.C + b_c[e]] : 0.f;
                     }
                     v = make_float4(t4[0], t4[1], t4[2], t4[3]);
                 }
@@ -298,8 +289,7 @@ __global__ __launch_bounds__(256) void bias_grad_grouped_vec_kernel(const float*
 int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, float* sq_accum, hipStream_t st);   // clip_kernels.hip
 
 bool wgh_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const void* x);      // igemm_wgh.hip
-int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st,
-               int phase_stride = 0);
+int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st);
 
 template <int BM, int BN, int WM, int WN>
 static int launch_mc_tile(McParams& p, bool vecA, bool vecB, hipStream_t st) {
@@ -352,15 +342,15 @@ static int wgrad_grouped_impl(const cslgan_conv_t* c, const float* gy, const flo
     CSLGAN_REQUIRE(gw || sq, "conv2d_wgrad: neither gw nor sq requested");
     CSLGAN_REQUIRE(group >= 1 && c->N % group == 0, "conv2d_wgrad: N=%d not divisible by group=%d", c->N, group);
     CSLGAN_REQUIRE(c->R * c->S <= IG_MAX_TAPS, "conv2d_wgrad: too many taps");
-    const int VH = c->upsample ? 2 * c->H : c->H, VW = c->upsample ? 2 * c->W : c->W;
-    const int P = (VH + 2 * c->pad - c->R) / c->stride + 1, Q = (VW + 2 * c->pad - c->S) / c->stride + 1;
+    CSLGAN_REQUIRE(c->reserved == 0, "conv2d_wgrad: cslgan_conv_t.reserved must be 0");
+    const int P = (c->H + 2 * c->pad - c->R) / c->stride + 1, Q = (c->W + 2 * c->pad - c->S) / c->stride + 1;
     CSLGAN_REQUIRE(P == c->P && Q == c->Q, "conv2d_wgrad: output %dx%d does not match P,Q=%d,%d", P, Q, c->P, c->Q);
     static const int wgh_env = [] { const char* e = getenv("CSLGAN_WGH"); return e ? atoi(e) : 1; }();
     if (wgh_env && !row_scale && wgh_eligible(c, out_bf16, gy, x))
         return launch_wgh(c, gy, x, group, alpha, gw, sq, (hipStream_t)stream);
     McParams p{};
     p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->P; p.Q = c->Q; p.Kc = c->K;
-    p.T = c->R * c->S; p.Ndim = p.T * c->C; p.stride = c->stride; p.ups = c->upsample ? 1 : 0; p.group = group; p.n_groups = c->N / group;
+    p.T = c->R * c->S; p.Ndim = p.T * c->C; p.stride = c->stride; p.group = group; p.n_groups = c->N / group;
     p.alpha = alpha; p.gw = gw; p.sq = sq; p.out_bf16 = out_bf16; p.row_scale = row_scale;
     for (int t = 0; t < IG_MAX_TAPS; ++t) { p.ty[t] = 0; p.tx[t] = 0; }
     for (int kh = 0; kh < c->R; ++kh)
@@ -389,35 +379,6 @@ int cslgan_conv2d_wgrad_scaled_f32(const cslgan_conv_t* c, const float* gy, cons
                                    float alpha, float* gw, void* stream) {
     CSLGAN_REQUIRE(row_scale && gw, "conv2d_wgrad_scaled: null argument");
     return wgrad_grouped_impl(c, gy, x, group, alpha, gw, nullptr, stream, 0, row_scale);
-}
-
-int cslgan_conv2d_up_wgrad_phases_f32(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha,
-                                      float* gwp, void* stream) {
-    CSLGAN_REQUIRE(c && gy && x && gwp, "conv2d_up_wgrad_phases: null argument");
-    CSLGAN_REQUIRE(c->upsample == 1 && c->stride == 1 && c->R == 5 && c->S == 5 && c->pad == 2, "conv2d_up_wgrad_phases: needs a 5x5 'same' upsample conv");
-    CSLGAN_REQUIRE(c->P == 2 * c->H && c->Q == 2 * c->W, "conv2d_up_wgrad_phases: output must be 2H x 2W");
-    CSLGAN_REQUIRE(c->C % 128 == 0 && c->K % 4 == 0, "conv2d_up_wgrad_phases: needs C %% 128 == 0 and K %% 4 == 0");
-    CSLGAN_REQUIRE(group >= 1 && c->N % group == 0, "conv2d_up_wgrad_phases: N=%d not divisible by group=%d", c->N, group);
-    CSLGAN_REQUIRE(aligned16(gy) && aligned16(x), "conv2d_up_wgrad_phases: operands must be 16-byte aligned");
-    {   // low-res grids of 8x8 patches: the LDS-resident kernel on the equivalent 3x3 stride-1 conv
-        static const int wgh_env = [] { const char* e = getenv("CSLGAN_WGH"); return e ? atoi(e) : 1; }();
-        cslgan_conv_t lo = *c;
-        lo.R = lo.S = 3; lo.pad = 1; lo.stride = 1; lo.upsample = 0; lo.P = c->H; lo.Q = c->W;
-        if (wgh_env && wgh_eligible(&lo, 0, gy, x))
-            return launch_wgh(&lo, gy, x, group, alpha, gwp, nullptr, (hipStream_t)stream, (9 * c->C + 255) / 256 * 256);
-    }
-    McParams p{};
-    p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->H; p.Q = c->W; p.Kc = c->K;
-    p.phase_stride = (9 * c->C + 255) / 256 * 256;
-    p.T = 9; p.Ndim = 4 * p.phase_stride; p.stride = 1; p.ups = 0; p.group = group; p.n_groups = c->N / group;
-    p.alpha = alpha; p.gw = gwp; p.sq = nullptr; p.out_bf16 = 0; p.row_scale = nullptr; p.gy_phase = 1;
-    for (int t = 0; t < IG_MAX_TAPS; ++t) { p.ty[t] = 0; p.tx[t] = 0; }
-    for (int u = 0; u < 3; ++u)
-        for (int v = 0; v < 3; ++v) { p.ty[u * 3 + v] = (signed char)(u - 1); p.tx[u * 3 + v] = (signed char)(v - 1); }
-    if (c->K > 64) return launch_mc_tile<128, 128, 2, 2>(p, true, true, (hipStream_t)stream);
-    if (c->K > 32 && (long long)p.n_groups * ((p.Ndim + 255) / 256) >= 256)
-        return launch_mc_tile<64, 256, 1, 4>(p, true, true, (hipStream_t)stream);
-    return launch_mc_tile<64, 128, 1, 4>(p, true, true, (hipStream_t)stream);
 }
 
 int cslgan_bias_grad_grouped_f32(const float* gy, int N, int PQ, int K, int group, float alpha, float* gb, float* sq,

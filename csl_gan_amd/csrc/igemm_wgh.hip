@@ -31,8 +31,6 @@ struct WghParams {
     int tiles_m, tiles_c, ppi;   // K/128, C/64, patches per image
     int ksplit;                  // workgroups per (group, tile, filter row): they take every ksplit-th patch and add atomically
     int xw;                      // staged columns: 7*stride + S
-    int gy_phase;                // 1: sub-pixel form of an upsample-conv gradient (igemm.h McParams::gy_phase): P,Q are the LOW-res grid,
-    int phase_stride;            // gy is [N][2P][2Q][K] read at (2y+a, 2x+b); output [g][m][phase][u*3+v][c], phases phase_stride apart
 };
 
 // TM = 32-row MFMA tiles per wavefront along m: 2 -> 128 output channels per workgroup, 1 -> 64 (K = 64 layers)
@@ -46,9 +44,6 @@ __global__ __launch_bounds__(256, 2) void igemm_wgh_kernel(const WghParams p) {
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
     const int split = bid % p.ksplit; bid /= p.ksplit;
-    int phase = 0;
-    if (p.gy_phase) { phase = bid & 3; bid >>= 2; }
-    const int ph_a = phase >> 1, ph_b = phase & 1;
     const int r = bid % p.R; bid /= p.R;
     const int tc = bid % p.tiles_c; bid /= p.tiles_c;
     const int tm = bid % p.tiles_m;
@@ -84,9 +79,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgh_kernel(const WghParams p) {
             for (int j = 0; j < 4; ++j) {
                 const int idx = tid + 256 * (half * 4 + j);
                 const int pix = idx / M4, m4 = idx - pix * M4;
-                const long long gpix = p.gy_phase
-                    ? (img * (2 * p.P) + 2 * (py0 + (pix >> 3)) + ph_a) * (2 * p.Q) + 2 * (px0 + (pix & 7)) + ph_b
-                    : (img * p.P + py0 + (pix >> 3)) * p.Q + px0 + (pix & 7);
+                const long long gpix = (img * p.P + py0 + (pix >> 3)) * p.Q + px0 + (pix & 7);
                 v[j] = *reinterpret_cast<const float4*>(p.gy + gpix * p.K + m0 + m4 * 4);
             }
 #pragma unroll
@@ -137,9 +130,9 @@ __global__ __launch_bounds__(256, 2) void igemm_wgh_kernel(const WghParams p) {
 
     // ---- epilogue ---------------------------------------------------------------------------------------------
     float ss = 0.f;
-    const long long row_len = p.gy_phase ? 4ll * p.phase_stride : (long long)p.R * S * p.C;      // floats per output channel m
+    const long long row_len = (long long)p.R * S * p.C;      // floats per output channel m
     float* __restrict__ outg = p.gw ? p.gw + (long long)g * p.K * row_len : nullptr;
-    const long long col0 = p.gy_phase ? (long long)phase * p.phase_stride + (long long)r * S * p.C : (long long)r * S * p.C;
+    const long long col0 = (long long)r * S * p.C;
     const int c = c0 + wn * 32 + l31;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -166,24 +159,19 @@ int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, flo
 
 // Shapes this kernel takes (the rest stays on igemm_mc).
 bool wgh_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const void* x) {
-    return !out_bf16 && !c->upsample && (c->stride == 1 || c->stride == 2) && c->S >= 2 && c->S <= WG_MAXS && c->K % 64 == 0 &&
+    return !out_bf16 && (c->stride == 1 || c->stride == 2) && c->S >= 2 && c->S <= WG_MAXS && c->K % 64 == 0 &&
            c->C % WG_BC == 0 && (c->P & 7) == 0 && (c->Q & 7) == 0 && aligned16(gy) && aligned16(x);
 }
 
-// phase_stride > 0: the sub-pixel form of a 5x5 upsample-conv gradient — c describes the equivalent 3x3 stride-1 conv over the
-// low-res input (P = H, Q = W), gy is the full-resolution gradient, gw the [g][K][4*phase_stride] phase tensor (zero-filled
-// padding columns are the caller's: they are never written here, cslgan_fold_up_wgrad_f32 never reads them).
-int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st,
-               int phase_stride = 0) {
+int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st) {
     WghParams p{};
     p.gy = gy; p.x = x; p.gw = gw; p.sq = sq;
     p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->P; p.Q = c->Q; p.K = c->K; p.R = c->R; p.S = c->S;
     p.stride = c->stride; p.pad = c->pad; p.group = group; p.n_groups = c->N / group; p.alpha = alpha;
-    p.gy_phase = phase_stride > 0 ? 1 : 0; p.phase_stride = phase_stride;
     const bool half_m = c->K % WG_BM != 0;       // K = 64, 192, ...: 64-channel m tiles
     p.tiles_m = half_m ? c->K / 64 : c->K / WG_BM; p.tiles_c = c->C / WG_BC; p.ppi = (c->P >> 3) * (c->Q >> 3);
     p.xw = 7 * c->stride + c->S;
-    const long long base = (long long)p.n_groups * p.tiles_m * p.tiles_c * c->R * (p.gy_phase ? 4 : 1);
+    const long long base = (long long)p.n_groups * p.tiles_m * p.tiles_c * c->R;
     const int n_patch = group * p.ppi;
     p.ksplit = 1;
     if (gw && base < 768 && n_patch >= 8) {      // few tiles, long patch loops: split the patches, add atomically
@@ -192,7 +180,7 @@ int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int grou
         p.ksplit = (int)(want < cap ? want : cap);
         if (p.ksplit < 1) p.ksplit = 1;
     }
-    const size_t out_floats = (size_t)p.n_groups * c->K * (p.gy_phase ? (size_t)4 * phase_stride : (size_t)c->R * c->S * c->C);
+    const size_t out_floats = (size_t)p.n_groups * c->K * c->R * c->S * c->C;
     if (p.ksplit > 1 && hipMemsetAsync(gw, 0, sizeof(float) * out_floats, st) != hipSuccess) {
         set_error("wgrad: hipMemsetAsync failed");
         return CSLGAN_ERR_LAUNCH;

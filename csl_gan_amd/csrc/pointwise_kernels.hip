@@ -120,11 +120,25 @@ __global__ void norm_stats_finalize_kernel(const float* __restrict__ x, long lon
     stats[2 * s + 1] = css;
 }
 
+// Depth-to-space addressing of UpsampleConv (DCResNet_models.py:13-15): cat([x]*4, dim=1) + pixel_shuffle(2) gives
+// up[c][2h+i][2w+j] = x[(4c+2i+j) mod C][h][w], i.e. for C % 4 == 0 the C output channels are the C/4 channels of the
+// plain depth-to-space tensor  ps[n][2h+i][2w+j][c'] = x[n][h][w][4c'+2i+j]  repeated four times (the conv that follows
+// runs on ps with its filter summed over the four channel groups, cslgan_fold_channels4_f32).  Element (row r, channel
+// 4c'+p) of x[N*H*W][C] lands at ps offset d2s_offset(r, p) + c'.
+__device__ __forceinline__ long long d2s_offset(long long r, int p, int H, int W, int Cq) {
+    const int w = (int)(r % W);
+    const long long t = r / W;
+    const int h = (int)(t % H);
+    const long long n = t / H;
+    return ((n * 2 * H + 2 * h + (p >> 1)) * 2 * W + 2 * w + (p & 1)) * Cq;
+}
+
 // y = act((x - mean_s) * rstd_s * gamma[c] + beta[c])
-template <bool VEC>
+// D2S: y (and xs, the raw input, when given) are written in the depth-to-space layout [N][2H][2W][C/4].
+template <bool VEC, bool D2S>
 __global__ void norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                   const float* __restrict__ stats, long long total, long long rows_per_stat, int C, int cpg,
-                                  int n_groups, float eps, int relu, float* __restrict__ y) {
+                                  int n_groups, float eps, int relu, float* __restrict__ y, int H, int W, float* __restrict__ xs) {
     const float inv_cnt = 1.f / ((float)rows_per_stat * (float)cpg);
     const long long per_stat_elems = rows_per_stat * C;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -144,7 +158,18 @@ __global__ void norm_apply_kernel(const float* __restrict__ x, const float* __re
                 float t = (in[e] - mean) * rstd * gamma[c + e] + beta[c + e];
                 o[e] = (relu && t < 0.f) ? 0.f : t;
             }
-            reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+            if (D2S) {
+                const long long r = e0 / C;
+                const int Cq = C >> 2, cq = c >> 2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {          // lanes hold consecutive c': each of the four stores is coalesced
+                    const long long off = d2s_offset(r, e, H, W, Cq) + cq;
+                    y[off] = o[e];
+                    if (xs) xs[off] = in[e];
+                }
+            } else {
+                reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+            }
         }
     } else {
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -153,9 +178,68 @@ __global__ void norm_apply_kernel(const float* __restrict__ x, const float* __re
             const float mean = stats[2 * s] * inv_cnt;
             const float rstd = rsqrtf(stats[2 * s + 1] * inv_cnt + eps);
             float t = (x[i] - mean) * rstd * gamma[c] + beta[c];
-            y[i] = (relu && t < 0.f) ? 0.f : t;
+            t = (relu && t < 0.f) ? 0.f : t;
+            if (D2S) {
+                const long long off = d2s_offset(i / C, c & 3, H, W, C >> 2) + (c >> 2);
+                y[off] = t;
+                if (xs) xs[off] = x[i];
+            } else {
+                y[i] = t;
+            }
         }
     }
+}
+
+// ps[n][2h+i][2w+j][c'] = x[n][h][w][4c'+2i+j]  (INVERSE: x from ps — the backward of the forward and vice versa)
+template <bool INVERSE>
+__global__ void depth_to_space_kernel(const float* __restrict__ in, long long rows, int H, int W, int C, float* __restrict__ out) {
+    const int Cq = C >> 2;
+    const long long n4 = rows * Cq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / Cq;
+        const int cq = (int)(i - r * Cq);
+        if (INVERSE) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = in[d2s_offset(r, e, H, W, Cq) + cq];
+            reinterpret_cast<float4*>(out)[i] = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            const float4 v = reinterpret_cast<const float4*>(in)[i];
+            const float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[d2s_offset(r, e, H, W, Cq) + cq] = a[e];
+        }
+    }
+}
+
+// The conv after the depth-to-space sees four identical channel groups, so it equals a conv over C/4 channels with
+//   wf[row][c'] = sum_q w[row][c' + q*C/4]      (row = (k, r, s) of a KRSC filter)
+// UNFOLD is its transpose (the gradient of w from the gradient of wf): gw[row][c' + q*C/4] = gwf[row][c'].
+template <bool UNFOLD>
+__global__ void fold_channels4_kernel(const float* __restrict__ in, long long rows, int C, float* __restrict__ out) {
+    const int Cq = C >> 2;
+    const long long n = rows * Cq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / Cq;
+        const int cq = (int)(i - r * Cq);
+        if (UNFOLD) {
+            const float v = in[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[r * C + q * Cq + cq] = v;
+        } else {
+            const float* b = in + r * C + cq;
+            out[i] = (b[0] + b[Cq]) + (b[2 * Cq] + b[3 * Cq]);
+        }
+    }
+}
+
+// eval-mode BatchNorm: the (sum, centred sum of squares) pair norm_apply_kernel consumes, from the running statistics
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, int C, float cnt,
+                                     float* __restrict__ stats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    stats[2 * c] = rm[c] * cnt;
+    stats[2 * c + 1] = rv[c] * cnt;
 }
 
 // ---- normalisation backward (GroupNorm / BatchNorm + optional ReLU) -------------------------------
@@ -267,43 +351,6 @@ __global__ void norm_bwd_apply_kernel(const float* __restrict__ x, const float* 
     }
 }
 
-// out[n][i][j][c] = sum of the 2x2 block in[n][2i+a][2j+b][c]  (gradient of a nearest-2x upsampled read)
-__global__ void sum2x2_kernel(const float* __restrict__ in, int N, int H, int W, int C, float* __restrict__ out) {
-    const long long total = (long long)N * H * W * C;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        long long r = i / C;
-        const int j = (int)(r % W); r /= W;
-        const int ii = (int)(r % H);
-        const long long n = r / H;
-        const float* b = in + (((n * 2 * H + 2 * ii) * 2 * W) + 2 * j) * C + c;
-        out[i] = b[0] + b[C] + b[(long long)2 * W * C] + b[(long long)2 * W * C + C];
-    }
-}
-
-// Fold the four sub-pixel phase gradients of a 5x5 upsample conv back onto its 25 taps:
-//   gw[gk][r][s][c] = sum_{a,b in {0,1}} gwp[gk][a*2+b][u(a,r)][v(b,s)][c],   u(a,r) = floor((a + r - 2) / 2) + 1 in {0,1,2}
-__global__ void fold_up_wgrad_kernel(const float* __restrict__ gwp, long long GK, int C, int phase_stride, float* __restrict__ gw) {
-    const long long total = GK * 25 * C;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        long long q = i / C;
-        const int rs = (int)(q % 25);
-        const long long gk = q / 25;
-        const int r = rs / 5, s = rs - r * 5;
-        const float* base = gwp + gk * 4 * phase_stride + c;
-        float acc = 0.f;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int u = ((a + r) >> 1), v = ((b + s) >> 1);          // floor((a+r-2)/2)+1 == (a+r)>>1
-                acc += base[(a * 2 + b) * phase_stride + (u * 3 + v) * C];
-            }
-        gw[i] = acc;
-    }
-}
-
 // BatchNorm running statistics (torch semantics: running_var uses the unbiased batch variance)
 __global__ void bn_running_kernel(const float* __restrict__ stats, int C, float cnt, float momentum, float* __restrict__ rm,
                                   float* __restrict__ rv) {
@@ -315,15 +362,37 @@ __global__ void bn_running_kernel(const float* __restrict__ stats, int C, float 
     rv[c] = (1.f - momentum) * rv[c] + momentum * var_unb;
 }
 
+static int launch_norm_apply(const float* x, const float* gamma, const float* beta, long long R, long long rows_per_stat, int C,
+                             int cpg, int n_groups, float eps, int relu, const float* stats, float* y, int d2s_H, int d2s_W,
+                             float* xs, bool vec, hipStream_t st) {
+    const long long total = R * C;
+    long long nb = (total / 4 + 255) / 256;
+    nb = nb > 4096 ? 4096 : (nb < 1 ? 1 : nb);
+    const dim3 g((unsigned)nb), b(256);
+    if (d2s_W > 0) {
+        if (vec) hipLaunchKernelGGL((norm_apply_kernel<true, true>), g, b, 0, st, x, gamma, beta, stats, total, rows_per_stat, C, cpg, n_groups, eps, relu, y, d2s_H, d2s_W, xs);
+        else hipLaunchKernelGGL((norm_apply_kernel<false, true>), g, b, 0, st, x, gamma, beta, stats, total, rows_per_stat, C, cpg, n_groups, eps, relu, y, d2s_H, d2s_W, xs);
+    } else {
+        if (vec) hipLaunchKernelGGL((norm_apply_kernel<true, false>), g, b, 0, st, x, gamma, beta, stats, total, rows_per_stat, C, cpg, n_groups, eps, relu, y, 0, 0, (float*)nullptr);
+        else hipLaunchKernelGGL((norm_apply_kernel<false, false>), g, b, 0, st, x, gamma, beta, stats, total, rows_per_stat, C, cpg, n_groups, eps, relu, y, 0, 0, (float*)nullptr);
+    }
+    return check_launch("norm_apply_kernel");
+}
+
+static bool norm_vec_ok(const float* x, const float* y, const float* xs, int C, int cpg) {
+    return (C % 4 == 0) && ((C / 4) <= 256) && (256 % (C / 4) == 0) && (cpg % 4 == 0 || 4 % cpg == 0) && aligned16(x) && aligned16(y) &&
+           (!xs || aligned16(xs));
+}
+
 static int launch_norm(const float* x, const float* gamma, const float* beta, long long R, long long rows_per_stat, int C, int cpg,
-                       int n_groups, float eps, int relu, float* stats, float* y, hipStream_t st) {
+                       int n_groups, float eps, int relu, float* stats, float* y, int d2s_H, int d2s_W, float* xs, hipStream_t st) {
     const long long n_row_groups = R / rows_per_stat;
     const long long n_stats = n_row_groups * n_groups;
     if (hipMemsetAsync(stats, 0, sizeof(float) * 2 * n_stats, st) != hipSuccess) {
         set_error("norm: hipMemsetAsync failed");
         return CSLGAN_ERR_LAUNCH;
     }
-    const bool vec = (C % 4 == 0) && ((C / 4) <= 256) && (256 % (C / 4) == 0) && (cpg % 4 == 0 || 4 % cpg == 0) && aligned16(x) && aligned16(y);
+    const bool vec = norm_vec_ok(x, y, xs, C, cpg);
     // about 1024 workgroups in all, each with at least NS_ROWS_MIN rows: fewer, longer blocks mean fewer global atomics
     long long rpb = (rows_per_stat * n_row_groups / 1024 + NS_ROWS_MIN - 1) / NS_ROWS_MIN * NS_ROWS_MIN;
     rpb = rpb < NS_ROWS_MIN ? NS_ROWS_MIN : (rpb > 4096 ? 4096 : rpb);
@@ -337,12 +406,20 @@ static int launch_norm(const float* x, const float* gamma, const float* beta, lo
                        n_groups, n_stats, stats);
     rc = check_launch("norm_stats_finalize_kernel");
     if (rc) return rc;
-    const long long total = R * C;
-    long long nb = (total / 4 + 255) / 256;
-    nb = nb > 4096 ? 4096 : (nb < 1 ? 1 : nb);
-    if (vec) hipLaunchKernelGGL((norm_apply_kernel<true>), dim3((unsigned)nb), dim3(256), 0, st, x, gamma, beta, stats, total, rows_per_stat, C, cpg, n_groups, eps, relu, y);
-    else hipLaunchKernelGGL((norm_apply_kernel<false>), dim3((unsigned)nb), dim3(256), 0, st, x, gamma, beta, stats, total, rows_per_stat, C, cpg, n_groups, eps, relu, y);
-    return check_launch("norm_apply_kernel");
+    return launch_norm_apply(x, gamma, beta, R, rows_per_stat, C, cpg, n_groups, eps, relu, stats, y, d2s_H, d2s_W, xs, vec, st);
+}
+
+// d2s_W > 0 asks for the depth-to-space output layout: rows are (n, h, w) with w fastest, H = rows_per_image / d2s_W
+static int check_d2s(long long rows_per_image, int C, int d2s_W, const float* xs, int* H_out) {
+    *H_out = 0;
+    if (d2s_W <= 0) {
+        CSLGAN_REQUIRE(d2s_W == 0 && !xs, "norm: x_shuffled needs d2s_W > 0");
+        return CSLGAN_OK;
+    }
+    CSLGAN_REQUIRE(C % 4 == 0, "norm: depth-to-space output needs C %% 4 == 0 (C=%d)", C);
+    CSLGAN_REQUIRE(rows_per_image % d2s_W == 0, "norm: d2s_W=%d does not divide the %lld pixels of an image", d2s_W, rows_per_image);
+    *H_out = (int)(rows_per_image / d2s_W);
+    return CSLGAN_OK;
 }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
@@ -373,16 +450,6 @@ using namespace cslgan;
 
 extern "C" {
 
-int64_t cslgan_conv2d_up_wgrad_phase_stride(int C) { return ((int64_t)9 * C + 255) / 256 * 256; }
-
-int cslgan_fold_up_wgrad_f32(const float* gwp, int64_t GK, int C, float* gw, void* stream) {
-    CSLGAN_REQUIRE(gwp && gw, "fold_up_wgrad: null argument");
-    CSLGAN_REQUIRE(GK > 0 && C > 0, "fold_up_wgrad: bad sizes");
-    hipLaunchKernelGGL(fold_up_wgrad_kernel, dim3(grid_for(GK * 25 * C)), dim3(256), 0, (hipStream_t)stream, gwp, (long long)GK, C,
-                       (int)cslgan_conv2d_up_wgrad_phase_stride(C), gw);
-    return check_launch("fold_up_wgrad_kernel");
-}
-
 int cslgan_act_bwd_f32(const float* g, const float* y, int64_t n, float slope, float* out, void* stream) {
     CSLGAN_REQUIRE(g && y && out, "act_bwd: null argument");
     CSLGAN_REQUIRE(n >= 0, "act_bwd: n < 0");
@@ -393,19 +460,28 @@ int cslgan_act_bwd_f32(const float* g, const float* y, int64_t n, float slope, f
 }
 
 int cslgan_groupnorm_act_f32(const float* x, const float* gamma, const float* beta, int N, int HW, int C, int groups,
-                             float eps, int relu, float* stats_ws, float* y, void* stream) {
+                             float eps, int relu, float* stats_ws, float* y, int d2s_W, float* x_shuffled, void* stream) {
     CSLGAN_REQUIRE(x && gamma && beta && stats_ws && y, "groupnorm: null argument");
     CSLGAN_REQUIRE(N > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, "groupnorm: C=%d not divisible by groups=%d", C, groups);
     CSLGAN_REQUIRE(N <= 65535 && C <= 8192, "groupnorm: N or C too large");
-    return launch_norm(x, gamma, beta, (long long)N * HW, HW, C, C / groups, groups, eps, relu, stats_ws, y, (hipStream_t)stream);
+    int H = 0;
+    int rc = check_d2s(HW, C, d2s_W, x_shuffled, &H);
+    if (rc) return rc;
+    return launch_norm(x, gamma, beta, (long long)N * HW, HW, C, C / groups, groups, eps, relu, stats_ws, y, H, d2s_W, x_shuffled,
+                       (hipStream_t)stream);
 }
 
 int cslgan_batchnorm_act_f32(const float* x, const float* gamma, const float* beta, int64_t rows, int C, float eps, int relu,
-                             float momentum, float* running_mean, float* running_var, float* stats_ws, float* y, void* stream) {
+                             float momentum, float* running_mean, float* running_var, float* stats_ws, float* y,
+                             int64_t rows_per_image, int d2s_W, float* x_shuffled, void* stream) {
     CSLGAN_REQUIRE(x && gamma && beta && stats_ws && y, "batchnorm: null argument");
     CSLGAN_REQUIRE(rows > 0 && C > 0 && C <= 8192, "batchnorm: bad sizes");
     CSLGAN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "batchnorm: running_mean/var must both be given or both null");
-    int rc = launch_norm(x, gamma, beta, rows, rows, C, 1, C, eps, relu, stats_ws, y, (hipStream_t)stream);
+    int H = 0;
+    CSLGAN_REQUIRE(d2s_W == 0 || (rows_per_image > 0 && rows % rows_per_image == 0), "batchnorm: rows_per_image must divide rows");
+    int rc = check_d2s(rows_per_image, C, d2s_W, x_shuffled, &H);
+    if (rc) return rc;
+    rc = launch_norm(x, gamma, beta, rows, rows, C, 1, C, eps, relu, stats_ws, y, H, d2s_W, x_shuffled, (hipStream_t)stream);
     if (rc) return rc;
     if (running_mean) {
         hipLaunchKernelGGL(bn_running_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, (hipStream_t)stream, stats_ws, C,
@@ -413,6 +489,44 @@ int cslgan_batchnorm_act_f32(const float* x, const float* gamma, const float* be
         return check_launch("bn_running_kernel");
     }
     return CSLGAN_OK;
+}
+
+int cslgan_batchnorm_eval_act_f32(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, int64_t rows, int C, float eps, int relu, float* stats_ws, float* y,
+                                  int64_t rows_per_image, int d2s_W, float* x_shuffled, void* stream) {
+    CSLGAN_REQUIRE(x && gamma && beta && running_mean && running_var && stats_ws && y, "batchnorm_eval: null argument");
+    CSLGAN_REQUIRE(rows > 0 && C > 0 && C <= 8192, "batchnorm_eval: bad sizes");
+    CSLGAN_REQUIRE(d2s_W == 0 || (rows_per_image > 0 && rows % rows_per_image == 0), "batchnorm_eval: rows_per_image must divide rows");
+    int H = 0;
+    int rc = check_d2s(rows_per_image, C, d2s_W, x_shuffled, &H);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, st, running_mean, running_var, C,
+                       (float)rows, stats_ws);
+    rc = check_launch("bn_eval_stats_kernel");
+    if (rc) return rc;
+    return launch_norm_apply(x, gamma, beta, rows, rows, C, 1, C, eps, relu, stats_ws, y, H, d2s_W, x_shuffled,
+                             norm_vec_ok(x, y, x_shuffled, C, 1), st);
+}
+
+int cslgan_depth_to_space_f32(const float* x, int N, int H, int W, int C, int inverse, float* y, void* stream) {
+    CSLGAN_REQUIRE(x && y, "depth_to_space: null argument");
+    CSLGAN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "depth_to_space: needs C %% 4 == 0 (C=%d)", C);
+    CSLGAN_REQUIRE(aligned16(inverse ? y : x), "depth_to_space: the [N,H,W,C] tensor must be 16-byte aligned");
+    const long long rows = (long long)N * H * W;
+    const dim3 g(grid_for(rows * (C / 4))), b(256);
+    if (inverse) hipLaunchKernelGGL((depth_to_space_kernel<true>), g, b, 0, (hipStream_t)stream, x, rows, H, W, C, y);
+    else hipLaunchKernelGGL((depth_to_space_kernel<false>), g, b, 0, (hipStream_t)stream, x, rows, H, W, C, y);
+    return check_launch("depth_to_space_kernel");
+}
+
+int cslgan_fold_channels4_f32(const float* in, int64_t rows, int C, int unfold, float* out, void* stream) {
+    CSLGAN_REQUIRE(in && out, "fold_channels4: null argument");
+    CSLGAN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "fold_channels4: needs C %% 4 == 0 (C=%d)", C);
+    const dim3 g(grid_for((long long)rows * (C / 4))), b(256);
+    if (unfold) hipLaunchKernelGGL((fold_channels4_kernel<true>), g, b, 0, (hipStream_t)stream, in, (long long)rows, C, out);
+    else hipLaunchKernelGGL((fold_channels4_kernel<false>), g, b, 0, (hipStream_t)stream, in, (long long)rows, C, out);
+    return check_launch("fold_channels4_kernel");
 }
 
 int cslgan_norm_act_bwd_f32(const float* x, const float* dy, const float* y, const float* gamma, const float* stats,
@@ -450,13 +564,6 @@ int cslgan_norm_act_bwd_f32(const float* x, const float* dy, const float* y, con
 int64_t cslgan_norm_bwd_ws_floats(int64_t rows, int64_t rows_per_stat, int C, int groups) {
     const int64_t nrg = rows_per_stat > 0 ? rows / rows_per_stat : 0;
     return nrg * C * 2 + nrg * groups * 2;
-}
-
-int cslgan_sum2x2_f32(const float* in, int N, int H, int W, int C, float* out, void* stream) {
-    CSLGAN_REQUIRE(in && out, "sum2x2: null argument");
-    CSLGAN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "sum2x2: bad sizes");
-    hipLaunchKernelGGL(sum2x2_kernel, dim3(grid_for((long long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, in, N, H, W, C, out);
-    return check_launch("sum2x2_kernel");
 }
 
 int cslgan_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,

@@ -93,11 +93,10 @@ def _dense_group(N: int, tiles: int = 1) -> int:
 
 class Conv(Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, upsample, residual, res_shift, wkey=None):
-        y = ops.conv2d_fwd(x, w, b, stride=stride, pad=pad, upsample=upsample, residual=residual,
-                           res_shift=res_shift, act=act, wkey=wkey)
+    def forward(ctx, x, w, b, stride, pad, act, residual, wkey=None, alg_scale=1.0):
+        y = ops.conv2d_fwd(x, w, b, stride=stride, pad=pad, residual=residual, act=act, wkey=wkey, alg_scale=alg_scale)
         ctx.wkey = wkey            # the owning layer's cache token: lets ops reuse repacked filters while the parameter is unchanged
-        ctx.cfg = (stride, pad, act, upsample, res_shift)
+        ctx.cfg = (stride, pad, act)
         ctx.has_res = residual is not None
         ctx.input_only = _INPUT_GRADS_ONLY
         ctx.save_for_backward(x, w, y if act != ops.ACT_NONE else None)
@@ -106,9 +105,7 @@ class Conv(Function):
     @staticmethod
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
-        stride, pad, act, upsample, res_shift = ctx.cfg
-        if upsample or ctx.has_res:
-            return Conv._backward_generator(ctx, gy, x, w, y)
+        stride, pad, act = ctx.cfg
         gz = gy
         if act in _SLOPE:
             gz = ActBwd.apply(gy, y, _SLOPE[act])
@@ -122,36 +119,55 @@ class Conv(Function):
             gw = Wgrad.apply(gz, x, w.shape[1], w.shape[2], stride, pad)
         if ctx.needs_input_grad[2] and not ctx.input_only:
             gb = BiasGrad.apply(gz)
-        return gx, gw, gb, None, None, None, None, None, None, None
+        # the residual is added before the activation (ResBlockUp's "o + s", DCResNet_models.py:38): its gradient is gz
+        gres = gz if (ctx.has_res and ctx.needs_input_grad[6]) else None
+        return gx, gw, gb, None, None, None, gres, None, None
 
 
-def _conv_backward_generator(ctx, gy, x, w, y):
-    """First-order backward of the generator-only conv forms (upsample-on-read, residual epilogue): train_G
-    (train.py:502-511).  Not differentiable again — nothing in the reference differentiates G twice."""
-    stride, pad, act, upsample, res_shift = ctx.cfg
-    with torch.no_grad():
-        gz = gy.contiguous()
-        if act in _SLOPE:
-            gz = ops.act_bwd(gz, y, _SLOPE[act])
-        elif act == ops.ACT_TANH:
-            gz = gz * (1 - y * y)
-        gx = gw = gb = gres = None
-        R, S = w.shape[1], w.shape[2]
-        if ctx.needs_input_grad[0]:
-            gx = (ops.conv2d_up_dgrad(gz, w, pad, wkey=ctx.wkey) if upsample
-                  else ops.conv2d_dgrad(gz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad, wkey=ctx.wkey))
-        if ctx.needs_input_grad[1]:
-            gw = ops.conv2d_wgrad_dense(gz, x, R, S, stride=stride, pad=pad, upsample=upsample)
-        if ctx.needs_input_grad[2]:
-            part = ops.bias_grad_grouped(gz, group=1)
-            gb = torch.empty(part.shape[1], device=x.device, dtype=torch.float32)
-            ops.clip_accum_noise([part], [gb])
-        if ctx.has_res and ctx.needs_input_grad[7]:
-            gres = ops.sum2x2(gz) if res_shift else gz
-    return gx, gw, gb, None, None, None, None, gres, None, None
+class DepthToSpace(Function):
+    """UpsampleConv's cat([x]*4, 1) + pixel_shuffle(2) (DCResNet_models.py:13-15) reduced to its C/4 distinct channels:
+    [N,H,W,C] -> [N,2H,2W,C/4] (ops.depth_to_space).  A permutation: the backward is the inverse map."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.depth_to_space(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return SpaceToDepth.apply(g)
 
 
-Conv._backward_generator = staticmethod(_conv_backward_generator)
+class SpaceToDepth(Function):
+    @staticmethod
+    def forward(ctx, g):
+        return ops.depth_to_space(g.contiguous(), inverse=True)
+
+    @staticmethod
+    def backward(ctx, gg):
+        return DepthToSpace.apply(gg)
+
+
+class FoldChannels4(Function):
+    """wf[k,r,s,c'] = sum_q w[k,r,s,c'+q*C/4]: the filter of UpsampleConv's conv as seen by the depth-to-space tensor,
+    whose four channel groups are identical.  Linear; the backward copies the folded gradient to the four groups."""
+
+    @staticmethod
+    def forward(ctx, w):
+        return ops.fold_channels4(w.contiguous())      # never the cached tensor: autograd owns this output
+
+    @staticmethod
+    def backward(ctx, gwf):
+        return UnfoldChannels4.apply(gwf)
+
+
+class UnfoldChannels4(Function):
+    @staticmethod
+    def forward(ctx, gwf):
+        return ops.unfold_channels4(gwf.contiguous())
+
+    @staticmethod
+    def backward(ctx, ggw):
+        return FoldChannels4.apply(ggw)
 
 
 class NormAct(Function):
@@ -194,7 +210,7 @@ class Dgrad(Function):
         ggx = ggx.contiguous()
         g_gy = g_w = None
         if ctx.needs_input_grad[0]:
-            g_gy = Conv.apply(ggx, w, None, stride, pad, ops.ACT_NONE, False, None, 0, ctx.wkey)
+            g_gy = Conv.apply(ggx, w, None, stride, pad, ops.ACT_NONE, None, ctx.wkey)
         if ctx.needs_input_grad[1]:
             g_w = Wgrad.apply(gy, ggx, w.shape[1], w.shape[2], stride, pad)
         return g_gy, g_w, None, None, None, None, None
@@ -216,7 +232,7 @@ class Wgrad(Function):
         ggw = ggw.contiguous()
         g_gy = g_x = None
         if ctx.needs_input_grad[0]:
-            g_gy = Conv.apply(x, ggw, None, stride, pad, ops.ACT_NONE, False, None, 0)
+            g_gy = Conv.apply(x, ggw, None, stride, pad, ops.ACT_NONE, None)
         if ctx.needs_input_grad[1]:
             g_x = Dgrad.apply(gy, ggw, x.shape[1], x.shape[2], stride, pad)
         return g_gy, g_x, None, None, None, None

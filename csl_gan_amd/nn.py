@@ -48,25 +48,34 @@ class HipConv2d(nn.Conv2d, _PerSampleMixin):
     """nn.Conv2d (DCResNet_models.py:118, :11, :26, :85) with a fused activation epilogue.
 
     act: ops.ACT_* applied in the conv kernel's epilogue (D: LeakyReLU 0.2, DCResNet_models.py:132).
-    upsample: nearest-2x applied on read (UpsampleConv, DCResNet_models.py:13-16).
     """
 
-    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True, act=ops.ACT_NONE, upsample=False):
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True, act=ops.ACT_NONE):
         if padding == "same":
             padding = k // 2
         super().__init__(cin, cout, k, stride=stride, padding=padding, bias=bias)
-        self.act, self.upsample = act, upsample
+        self.act = act
         self._wtoken = next(_tokens)
 
-    def forward_nhwc(self, x, residual=None, res_shift=0):
-        """x: NHWC-contiguous device tensor -> NHWC output."""
+    def forward_nhwc(self, x, residual=None):
+        """x: NHWC-contiguous device tensor -> NHWC output (+ residual before the activation)."""
         w = self.weight.permute(0, 2, 3, 1).contiguous()
-        if self._per_sample_active() and residual is None and not self.upsample:
+        if self._per_sample_active() and residual is None:
             sink = self._sink
             return HF.ConvPerSample.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act,
                                           sink.collector(self), sink.next_pass(self), self._wkey(w))
-        return HF.Conv.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act, self.upsample,
-                             residual, res_shift, self._wkey(w))
+        return HF.Conv.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act, residual, self._wkey(w))
+
+    def forward_shuffled(self, x_ps):
+        """UpsampleConv's conv (DCResNet_models.py:16) on the depth-to-space tensor x_ps[N,2H,2W,C/4]: the reference convolves
+        four identical channel groups, i.e. x_ps with the filter summed over the groups (a quarter of the MACs)."""
+        w = self.weight.permute(0, 2, 3, 1).contiguous()
+        if torch.is_grad_enabled() and w.requires_grad:
+            wf = HF.FoldChannels4.apply(w)
+        else:
+            wf = ops.fold_channels4(w.detach(), wkey=self._wkey(w))
+        # wf is a temporary as far as ops.repack_cache is concerned (wkey=None): its address can be reused by a later fold
+        return HF.Conv.apply(x_ps, wf, self.bias, 1, self.padding[0], self.act, None, None, 4.0)
 
     def _wkey(self, w):
         # only a zero-copy view of the parameter shares its version counter; a re-laid-out copy must not be cached
@@ -74,9 +83,7 @@ class HipConv2d(nn.Conv2d, _PerSampleMixin):
 
     def forward(self, x):
         if not x.is_cuda:
-            xin = x.repeat_interleave(2, 2).repeat_interleave(2, 3) if self.upsample else x
-            y = super().forward(xin)
-            return _act_cpu(y, self.act)
+            return _act_cpu(super().forward(x), self.act)
         return HF.nchw_view(self.forward_nhwc(HF.nhwc(x)))
 
 
@@ -100,7 +107,7 @@ class HipLinear(nn.Linear, _PerSampleMixin):
             sink = self._sink
             y = HF.ConvPerSample.apply(x4, w4, self.bias, 1, 0, self.act, sink.collector(self), sink.next_pass(self), wkey)
         else:
-            y = HF.Conv.apply(x4, w4, self.bias, 1, 0, self.act, False, None, 0, wkey)
+            y = HF.Conv.apply(x4, w4, self.bias, 1, 0, self.act, None, wkey)
         return y.reshape(B, self.out_features)
 
 
@@ -116,6 +123,13 @@ class HipGroupNormAct(nn.GroupNorm):
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
             return HF.NormAct.apply(x, self.weight, self.bias, self.num_groups, self.eps, self.relu, None, None, 0.0)
         return ops.groupnorm_act(x, self.weight.detach(), self.bias.detach(), self.num_groups, eps=self.eps, relu=self.relu)
+
+    def forward_shuffled(self, x):
+        """(depth_to_space(act(norm(x))), depth_to_space(x)) — the inputs of ResBlockUp's convUp and shortcut."""
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            return HF.DepthToSpace.apply(self.forward_nhwc(x)), HF.DepthToSpace.apply(x)
+        return ops.groupnorm_act(x, self.weight.detach(), self.bias.detach(), self.num_groups, eps=self.eps, relu=self.relu,
+                                 d2s=True, want_raw=True)
 
     def forward(self, x):
         if not x.is_cuda:

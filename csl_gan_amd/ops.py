@@ -22,10 +22,11 @@ def _stream():
 
 
 class _RepackCache:
-    """Repacked filter matrices (data-gradient classes, upsample phases) keyed by the filter tensor's storage and
-    autograd version counter: any in-place torch op bumps the counter, and HipAdam — which writes the weights
-    through raw pointers — bumps it explicitly (torch.autograd.graph.increment_version).  A D-step reuses each
-    critic layer's repack four times and the generator's phase filters until the next generator step."""
+    """Repacked filter matrices (data-gradient classes, stride-2 parity classes, the channel-folded filters of the
+    generator's UpsampleConv layers) keyed by the filter tensor's storage and autograd version counter: any in-place
+    torch op bumps the counter, and HipAdam — which writes the weights through raw pointers — bumps it explicitly
+    (torch.autograd.graph.increment_version).  A D-step reuses each critic layer's repack four times and the
+    generator's folded filters until the next generator step."""
 
     def __init__(self, max_entries=64):
         self.d, self.max = {}, max_entries      # callers pass wkey (a never-reused per-module token, csl_gan_amd.nn) only for module-owned filters
@@ -93,7 +94,7 @@ def set_launch_timer(t):
 
 def _timed(name, flop, nbytes, fn, exec_flop=None, tag=None):
     """flop = algorithmic FLOP of the op as the reference executes it; exec_flop = FLOP the kernel really issues
-    (differs for the sub-pixel upsample convs)."""
+    (differs for the UpsampleConv layers, which run on C/4 folded channels, and for the zero-padded RGB input)."""
     if _timer is None:
         return fn()
     s = _timer.begin()
@@ -116,22 +117,20 @@ def _chk(t: torch.Tensor, name: str, allow_bf16=False):
     return t
 
 
-def conv_out_size(H, R, stride, pad, upsample=False):
-    VH = 2 * H if upsample else H
-    return (VH + 2 * pad - R) // stride + 1
+def conv_out_size(H, R, stride, pad):
+    return (H + 2 * pad - R) // stride + 1
 
 
-def _conv_desc(N, H, W, Cc, K, R, S, stride, pad, upsample):
-    P, Q = conv_out_size(H, R, stride, pad, upsample), conv_out_size(W, S, stride, pad, upsample)
-    return ConvT(N, H, W, Cc, K, R, S, stride, pad, 1 if upsample else 0, P, Q), P, Q
+def _conv_desc(N, H, W, Cc, K, R, S, stride, pad):
+    P, Q = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
+    return ConvT(N, H, W, Cc, K, R, S, stride, pad, 0, P, Q), P, Q
 
 
-def conv2d_fwd(x, w, bias=None, stride=1, pad=0, upsample=False, residual=None, res_shift=0, act=ACT_NONE, out=None,
-               direct_upsample=False, wkey=None):
-    """y[N,P,Q,K] = act(conv(x[N,H,W,C], w[K,R,S,C]) + bias [+ residual]).
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, out=None, wkey=None, alg_scale=1.0):
+    """y[N,P,Q,K] = act(conv(x[N,H,W,C], w[K,R,S,C]) + bias [+ residual[N,P,Q,K]]).
 
-    upsample=True: nearest-2x upsample of x first; computed by sub-pixel decomposition
-    (cslgan_conv2d_up_fwd_f32) unless direct_upsample=True (address shift on read, full RxS taps)."""
+    alg_scale: FLOP the reference spends on this layer / FLOP of this call (4 for an UpsampleConv's conv, which the
+    reference runs over four identical channel groups) — bench accounting only."""
     _chk(x, "x"); _chk(w, "w")
     N, H, W, Cc = x.shape
     K, R, S, C2 = w.shape
@@ -142,37 +141,69 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, upsample=False, residual=None, 
         # (scalar gathers ran at 22-32 TF); the zero channel adds nothing to the sums
         x, w, Cc, wkey = _pad_c4(x), _pad_c4(w), 4, None
     c_alg = C2                    # channels the reference convolves (FLOP accounting)
-    d, P, Q = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, upsample)
+    d, P, Q = _conv_desc(N, H, W, Cc, K, R, S, stride, pad)
     y = out if out is not None else torch.empty((N, P, Q, K), device=x.device, dtype=torch.float32)
     if bias is not None:
         _chk(bias, "bias")
     if residual is not None:
         _chk(residual, "residual")
-        exp = (N, P >> res_shift, Q >> res_shift, K)
-        if tuple(residual.shape) != exp:
-            raise RuntimeError("conv2d_fwd: residual shape %s, expected %s" % (tuple(residual.shape), exp))
-    VH, VW = (2 * H, 2 * W) if upsample else (H, W)
-    flop = 2.0 * N * P * Q * K * R * S * c_alg    # the dense conv the reference executes on the (up-sampled) input
-    nbytes = 4.0 * (N * VH * VW * c_alg + K * R * S * c_alg + N * P * Q * K)
-    if upsample and not direct_upsample and stride == 1 and R == S and R % 2 == 1 and pad == R // 2 and R > 1:
-        L = _lib.lib()
-        ws, repack = repack_cache.get("up_fwd", w, L.cslgan_conv2d_up_ws_floats(K, R, Cc), wkey)
-        _timed("conv2d_fwd", flop, nbytes, lambda: check(
-            L.cslgan_conv2d_up_fwd_f32(C.byref(d), _p(x), _p(w), _p(ws), repack, _p(bias), _p(residual), res_shift, act, _p(y), _stream()),
-            "conv2d_up_fwd"), exec_flop=flop * (R // 2 + 1) ** 2 / float(R * S),
-            tag=lambda: "up N%d %dx%d C%d K%d R%d" % (N, H, W, Cc, K, R))
-        return y
-    if stride == 2 and not upsample and R == S and R % 2 == 1 and R > 1 and Cc % 32 == 0 and K >= 64 and residual is None:
+        if tuple(residual.shape) != (N, P, Q, K):
+            raise RuntimeError("conv2d_fwd: residual shape %s, expected %s" % (tuple(residual.shape), (N, P, Q, K)))
+    flop = 2.0 * N * P * Q * K * R * S * c_alg * alg_scale    # the dense conv the reference executes
+    nbytes = 4.0 * (N * H * W * c_alg + K * R * S * c_alg + N * P * Q * K)
+    xflop = 2.0 * N * P * Q * K * R * S * Cc
+    if stride == 2 and R == S and R % 2 == 1 and R > 1 and Cc % 32 == 0 and K >= 64 and residual is None:
         # parity sub-images through the LDS-halo kernel (the C entry falls back to the generic kernel for other grids)
         ws, repack = repack_cache.get("s2_fwd", w, w.numel(), wkey)
         _timed("conv2d_fwd", flop, nbytes, lambda: check(
             _lib.lib().cslgan_conv2d_s2_fwd_f32(C.byref(d), _p(x), _p(w), _p(ws), repack, _p(bias), act, _p(y), _stream()),
-            "conv2d_s2_fwd"), tag=lambda: "N%d %dx%d C%d K%d R%d s2 halo" % (N, H, W, Cc, K, R))
+            "conv2d_s2_fwd"), exec_flop=xflop, tag=lambda: "N%d %dx%d C%d K%d R%d s2 halo" % (N, H, W, Cc, K, R))
         return y
     _timed("conv2d_fwd", flop, nbytes, lambda: check(
-        _lib.lib().cslgan_conv2d_fwd_f32(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), res_shift, act, _p(y), _stream()),
-        "conv2d_fwd"), exec_flop=flop * Cc / float(c_alg), tag=lambda: "N%d %dx%d C%d K%d R%d s%d" % (N, H, W, Cc, K, R, stride))
+        _lib.lib().cslgan_conv2d_fwd_f32(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), act, _p(y), _stream()),
+        "conv2d_fwd"), exec_flop=xflop, tag=lambda: "N%d %dx%d C%d K%d R%d s%d" % (N, H, W, Cc, K, R, stride))
     return y
+
+
+def depth_to_space(x, inverse=False):
+    """UpsampleConv's data movement (DCResNet_models.py:13-15) on NHWC data: [N,H,W,C] -> [N,2H,2W,C/4] with
+    out[n,2h+i,2w+j,c'] = x[n,h,w,4c'+2i+j]; inverse=True maps [N,2H,2W,C/4] back to [N,H,W,C] (its gradient)."""
+    _chk(x, "x")
+    if inverse:
+        N, H2, W2, Cq = x.shape
+        if H2 % 2 or W2 % 2:
+            raise RuntimeError("depth_to_space(inverse): spatial dims must be even, got %dx%d" % (H2, W2))
+        H, W, Cc = H2 // 2, W2 // 2, Cq * 4
+        out = torch.empty((N, H, W, Cc), device=x.device, dtype=torch.float32)
+    else:
+        N, H, W, Cc = x.shape
+        if Cc % 4:
+            raise RuntimeError("depth_to_space: C=%d is not a multiple of 4 (the HIP UpsampleConv path needs C %% 4 == 0)" % Cc)
+        out = torch.empty((N, 2 * H, 2 * W, Cc // 4), device=x.device, dtype=torch.float32)
+    check(_lib.lib().cslgan_depth_to_space_f32(_p(x), N, H, W, Cc, 1 if inverse else 0, _p(out), _stream()), "depth_to_space")
+    return out
+
+
+def fold_channels4(w, wkey=None):
+    """[K,R,S,C] -> [K,R,S,C/4]: wf[...,c'] = sum_q w[...,c'+q*C/4] — the filter UpsampleConv's conv applies to the
+    depth-to-space tensor (whose four channel groups are identical).  Cached per parameter version when wkey is given."""
+    _chk(w, "w")
+    K, R, S, Cc = w.shape
+    if Cc % 4:
+        raise RuntimeError("fold_channels4: C=%d is not a multiple of 4" % Cc)
+    wf, fresh = repack_cache.get("fold4", w, w.numel() // 4, wkey)
+    if fresh:
+        check(_lib.lib().cslgan_fold_channels4_f32(_p(w), K * R * S, Cc, 0, _p(wf), _stream()), "fold_channels4")
+    return wf.view(K, R, S, Cc // 4)
+
+
+def unfold_channels4(gwf):
+    """Gradient of fold_channels4: [K,R,S,C/4] -> [K,R,S,C] with gw[...,c'+q*C/4] = gwf[...,c']."""
+    _chk(gwf, "gwf")
+    K, R, S, Cq = gwf.shape
+    gw = torch.empty((K, R, S, 4 * Cq), device=gwf.device, dtype=torch.float32)
+    check(_lib.lib().cslgan_fold_channels4_f32(_p(gwf), K * R * S, 4 * Cq, 1, _p(gw), _stream()), "unfold_channels4")
+    return gw
 
 
 def _pad_c4(t):
@@ -188,7 +219,7 @@ def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None, wkey=None):
     N, P, Q, K = gy.shape
     K2, R, S, Cc = w.shape
     H, W = in_hw
-    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, False)
+    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad)
     if K2 != K or (P2, Q2) != (P, Q):
         raise RuntimeError("conv2d_dgrad: gy shape %s inconsistent with input %dx%d" % (tuple(gy.shape), H, W))
     gx = torch.empty((N, H, W, Cc), device=gy.device, dtype=torch.float32)
@@ -205,12 +236,12 @@ def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None, wkey=None):
     return gx
 
 
-def dense_wgrad_group(N, K, Cc, R, S, PQ, upsample=False, stride=1, out_hw=None):
+def dense_wgrad_group(N, K, Cc, R, S, PQ, stride=1, out_hw=None):
     """Samples per slab for a dense (summed) weight gradient.  The slab count sets the workgroup count, and the launch
     time follows how well that count fills 256 CUs x 3 resident workgroups (800 workgroups take two rounds, 3200 take
     4.2: measured 1.45 vs 1.16 ms on the same 55 GFLOP); more slabs cost their write + re-read by the column sum.
     Model: t(g) = FLOP / (100 TF x fill(g)) + 2 x slab bytes / 4 TB/s, minimised over g | N."""
-    if (out_hw is not None and not upsample and stride in (1, 2) and 2 <= S <= 5 and K % 64 == 0 and Cc % 64 == 0
+    if (out_hw is not None and stride in (1, 2) and 2 <= S <= 5 and K % 64 == 0 and Cc % 64 == 0
             and out_hw[0] % 8 == 0 and out_hw[1] % 8 == 0):
         # igemm_wgh (LDS-resident operands): (K/128)(C/64)R tiles per slab.  Big launches (the generator's convs, >= 40 GFLOP):
         # ONE slab — the kernel splits the patch loop over workgroups itself (atomic adds), no slab traffic.  Small ones:
@@ -225,11 +256,7 @@ def dense_wgrad_group(N, K, Cc, R, S, PQ, upsample=False, stride=1, out_hw=None)
                 best = g
             g *= 2
         return best
-    phases = upsample and R == 5 and S == 5 and Cc % 128 == 0
-    if (phases and out_hw is not None and K % 64 == 0 and out_hw[0] % 16 == 0 and out_hw[1] % 16 == 0
-            and 2.0 * N * (PQ // 4) * K * 36 * Cc >= 40e9):
-        return N            # sub-pixel form on igemm_wgh (low-res grid of 8x8 patches): one slab, the kernel splits the patch loop
-    ndim = 4 * ((9 * Cc + 255) // 256 * 256) if phases else R * S * Cc
+    ndim = R * S * Cc
     bn = 256 if (32 < K <= 64 and ndim >= 1024) else 128
     tiles = ((K + 127) // 128 if K > 64 else 1) * ((ndim + bn - 1) // bn)
     flop = 2.0 * N * PQ * K * ndim
@@ -248,20 +275,20 @@ def dense_wgrad_group(N, K, Cc, R, S, PQ, upsample=False, stride=1, out_hw=None)
     return best
 
 
-def gram_norms_eligible(gy_shape, x_shape, upsample=False):
+def gram_norms_eligible(gy_shape, x_shape):
     """Shapes cslgan_conv2d_wgrad_sqnorm_gram_f32 accepts (and where the Gram form is cheaper than the product)."""
     _, P, Q, K = gy_shape
-    return (not upsample) and P * Q <= 64 and K % 32 == 0 and x_shape[-1] % 32 == 0
+    return P * Q <= 64 and K % 32 == 0 and x_shape[-1] % 32 == 0
 
 
-def gram_norms_preferred(gy_shape, x_shape, stride, upsample=False):
+def gram_norms_preferred(gy_shape, x_shape, stride):
     """Shapes where the Gram form runs on the pixel-pair kernel (<= 16 output pixels and <= 16 input pixels per
     stride-parity class): there it is far cheaper than the product, so the engine uses it for norms and ghost clipping."""
     _, P, Q, K = gy_shape
     _, H, W, Cc = x_shape
-    if not upsample and P * Q == 1 and H * W == 1:
+    if P * Q == 1 and H * W == 1:
         return True              # a linear layer: ||gy_b x_b^T||^2 = ||gy_b||^2 ||x_b||^2
-    if upsample or stride not in (1, 2) or P * Q > 16 or K % 64 or Cc % 32:
+    if stride not in (1, 2) or P * Q > 16 or K % 64 or Cc % 32:
         return False
     return ((H + stride - 1) // stride) * ((W + stride - 1) // stride) <= 16
 
@@ -271,7 +298,7 @@ def conv2d_wgrad_sqnorm_gram(gy, x, R, S, stride=1, pad=0, alpha=1.0, sq=None):
     _chk(gy, "gy"); _chk(x, "x")
     N, H, W, Cc = x.shape
     N2, P, Q, K = gy.shape
-    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, False)
+    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad)
     if N2 != N or (P2, Q2) != (P, Q):
         raise RuntimeError("conv2d_wgrad_sqnorm_gram: gy %s inconsistent with x %s" % (tuple(gy.shape), tuple(x.shape)))
     if sq is None:
@@ -291,45 +318,27 @@ def conv2d_wgrad_sqnorm_gram(gy, x, R, S, stride=1, pad=0, alpha=1.0, sq=None):
     return sq
 
 
-def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_gw=True, sq=None, out=None, upsample=False,
-                         row_scale=None):
+def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_gw=True, sq=None, out=None, row_scale=None):
     """gw[N/group,K,R,S,C] (per-group weight gradients) and/or sq[N/group] += ||alpha*gw_g||^2.
-    upsample=True: x is the LOW-res input of an upsample+conv (read through the nearest-2x map).
     row_scale [N]: gy of sample n is weighted by row_scale[n] (clip-weighted sums; fp32 output, no sq)."""
     _chk(gy, "gy"); _chk(x, "x")
     N, H, W, Cc = x.shape
     N2, P, Q, K = gy.shape
     if Cc == 3 and R * S > 1 and row_scale is None and (out is None or out.dtype == torch.float32):
         # RGB input: run on a zero-padded 4th channel (aligned 16-byte gathers), then drop that channel's (zero) gradients
-        g4 = conv2d_wgrad_grouped(gy, _pad_c4(x), R, S, stride=stride, pad=pad, group=group, alpha=alpha, want_gw=want_gw, sq=sq,
-                                  upsample=upsample)
+        g4 = conv2d_wgrad_grouped(gy, _pad_c4(x), R, S, stride=stride, pad=pad, group=group, alpha=alpha, want_gw=want_gw, sq=sq)
         if g4 is None:
             return None
         if out is not None:
             out.view(g4.shape[:-1] + (3,)).copy_(g4[..., :3])
             return out
         return g4[..., :3].contiguous()
-    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, upsample)
+    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad)
     if N2 != N or (P2, Q2) != (P, Q):
         raise RuntimeError("conv2d_wgrad: gy %s inconsistent with x %s" % (tuple(gy.shape), tuple(x.shape)))
     if N % group:
         raise RuntimeError("conv2d_wgrad: N=%d not divisible by group=%d" % (N, group))
     G = N // group
-    if (upsample and R == 5 and S == 5 and stride == 1 and pad == 2 and Cc % 128 == 0 and K % 4 == 0 and want_gw and sq is None
-            and row_scale is None and (out is None or out.dtype == torch.float32)):
-        # sub-pixel form: 36 MACs per low-res pixel instead of 100, then fold the four phases onto the 25 taps
-        L = _lib.lib()
-        gwp = torch.empty((G, K, 4 * L.cslgan_conv2d_up_wgrad_phase_stride(Cc)), device=x.device, dtype=torch.float32)
-        gw = out if out is not None else torch.empty((G, K, R, S, Cc), device=x.device, dtype=torch.float32)
-        _chk(gw, "gw")
-        flop = 2.0 * N * P * Q * K * R * S * Cc
-
-        def run():
-            check(L.cslgan_conv2d_up_wgrad_phases_f32(C.byref(d), _p(gy), _p(x), group, float(alpha), _p(gwp), _stream()), "conv2d_up_wgrad_phases")
-            check(L.cslgan_fold_up_wgrad_f32(_p(gwp), G * K, Cc, _p(gw), _stream()), "fold_up_wgrad")
-        _timed("conv2d_wgrad_grouped", flop, 4.0 * (N * H * W * Cc + N * P * Q * K + G * K * R * S * Cc), run, exec_flop=flop * 9.0 / 25.0,
-               tag=lambda: "N%d %dx%d C%d K%d R%d g%d up-phases" % (N, H, W, Cc, K, R, group))
-        return gw
     if row_scale is not None:
         _chk(row_scale, "row_scale")
         if row_scale.numel() != N or sq is not None or not want_gw:
@@ -361,18 +370,18 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
     fn = L.cslgan_conv2d_wgrad_grouped_bf16out_f32 if (want_gw and gw.dtype == torch.bfloat16) else L.cslgan_conv2d_wgrad_grouped_f32
     _timed("conv2d_wgrad_grouped" + ("" if (want_gw and not scratch) else "_normonly"), flop, nbytes, lambda: check(
         fn(C.byref(d), _p(gy), _p(x), group, float(alpha), _p(gw), _p(sq), _stream()), "conv2d_wgrad_grouped"),
-        tag=lambda: "N%d %dx%d C%d K%d R%d s%d g%d%s" % (N, H, W, Cc, K, R, stride, group, " up" if upsample else ""))
+        tag=lambda: "N%d %dx%d C%d K%d R%d s%d g%d" % (N, H, W, Cc, K, R, stride, group))
     return None if scratch else gw
 
 
-def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, upsample=False, alpha=1.0, row_scale=None):
+def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, alpha=1.0, row_scale=None):
     """The summed weight gradient [K,R,S,C] of a batch: slabs of the grouped MFMA kernel + a column sum, or the
     vector-ALU kernel for 1..4 output channels."""
     N, H, W, Cc = x.shape
     _, P, Q, K = gy.shape
-    if (K <= 4 and Cc == 64 and stride == 1 and not upsample and R * S <= 9 and P % 8 == 0 and Q % 8 == 0 and row_scale is None):
+    if (K <= 4 and Cc == 64 and stride == 1 and R * S <= 9 and P % 8 == 0 and Q % 8 == 0 and row_scale is None):
         _chk(gy, "gy"); _chk(x, "x")
-        d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, False)
+        d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad)
         if (P2, Q2) != (P, Q):
             raise RuntimeError("conv2d_wgrad_dense: gy %s inconsistent with x %s" % (tuple(gy.shape), tuple(x.shape)))
         nb = min(512, N * (P // 8) * (Q // 8))
@@ -384,39 +393,12 @@ def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, upsample=False, alpha=1.0, 
         out = torch.empty(K * R * S * Cc, device=x.device, dtype=torch.float32)
         clip_accum_noise([partial], [out])
         return out.view(K, R, S, Cc)
-    group = dense_wgrad_group(N, K, Cc, R, S, P * Q, upsample=upsample, stride=stride, out_hw=None if row_scale is not None else (P, Q))
-    slabs = conv2d_wgrad_grouped(gy, x, R, S, stride=stride, pad=pad, group=group, alpha=alpha, upsample=upsample, row_scale=row_scale)
+    group = dense_wgrad_group(N, K, Cc, R, S, P * Q, stride=stride, out_hw=None if row_scale is not None else (P, Q))
+    slabs = conv2d_wgrad_grouped(gy, x, R, S, stride=stride, pad=pad, group=group, alpha=alpha, row_scale=row_scale)
     if slabs.shape[0] == 1:
         return slabs[0]
     out = torch.empty(slabs.shape[1:], device=x.device, dtype=torch.float32)
     clip_accum_noise([slabs.reshape(slabs.shape[0], -1)], [out.view(-1)])
-    return out
-
-
-def conv2d_up_dgrad(gy, w, pad, wkey=None):
-    """gx[N,H,W,C] for y = conv(nearest_up2(x), w[K,R,R,C]) ('same', stride 1) from gy[N,2H,2W,K]."""
-    _chk(gy, "gy"); _chk(w, "w")
-    N, P, Q, K = gy.shape
-    K2, R, S, Cc = w.shape
-    H, W = P // 2, Q // 2
-    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, 1, pad, True)
-    if K2 != K or (P2, Q2) != (P, Q):
-        raise RuntimeError("conv2d_up_dgrad: gy shape %s inconsistent" % (tuple(gy.shape),))
-    gx = torch.empty((N, H, W, Cc), device=gy.device, dtype=torch.float32)
-    ws, repack = repack_cache.get("up_dgrad", w, (R + 1) * (R + 1) * K * Cc, wkey)
-    flop = 2.0 * N * P * Q * K * R * S * Cc
-    _timed("conv2d_dgrad", flop, 4.0 * (gy.numel() + gx.numel() + w.numel()), lambda: check(
-        _lib.lib().cslgan_conv2d_up_dgrad_f32(C.byref(d), _p(gy), _p(w), _p(ws), repack, _p(gx), _stream()), "conv2d_up_dgrad"),
-        tag=lambda: "up N%d %dx%d C%d K%d R%d" % (N, H, W, Cc, K, R))
-    return gx
-
-
-def sum2x2(t):
-    """[N,2H,2W,C] -> [N,H,W,C] summing each 2x2 block."""
-    _chk(t, "t")
-    N, H2, W2, Cc = t.shape
-    out = torch.empty((N, H2 // 2, W2 // 2, Cc), device=t.device, dtype=torch.float32)
-    check(_lib.lib().cslgan_sum2x2_f32(_p(t), N, H2 // 2, W2 // 2, Cc, _p(out), _stream()), "sum2x2")
     return out
 
 
@@ -581,26 +563,66 @@ def act_bwd(g, y, slope):
     return out
 
 
-def groupnorm_act(x, gamma, beta, groups, eps=1e-5, relu=True, return_stats=False):
+def _d2s_out(x, d2s, want_raw):
+    N, H, W, Cc = x.shape
+    if not d2s:
+        if want_raw:
+            raise RuntimeError("want_raw needs d2s=True")
+        return torch.empty_like(x), None, 0
+    if Cc % 4:
+        raise RuntimeError("depth-to-space output needs C %% 4 == 0 (C=%d)" % Cc)
+    shp = (N, 2 * H, 2 * W, Cc // 4)
+    y = torch.empty(shp, device=x.device, dtype=torch.float32)
+    return y, (torch.empty(shp, device=x.device, dtype=torch.float32) if want_raw else None), W
+
+
+def groupnorm_act(x, gamma, beta, groups, eps=1e-5, relu=True, return_stats=False, d2s=False, want_raw=False):
+    """GroupNorm(+ReLU).  d2s=True: the output is written depth-to-space shuffled ([N,2H,2W,C/4], see depth_to_space);
+    want_raw=True additionally returns the raw x in that layout (one read of x feeds ResBlockUp's convUp and shortcut)."""
     _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
     N, H, W, Cc = x.shape
-    y = torch.empty_like(x)
+    y, xs, dW = _d2s_out(x, d2s, want_raw)
     ws = torch.empty(2 * N * groups, device=x.device, dtype=torch.float32)
     check(_lib.lib().cslgan_groupnorm_act_f32(_p(x), _p(gamma), _p(beta), N, H * W, Cc, groups, float(eps), 1 if relu else 0,
-                                              _p(ws), _p(y), _stream()), "groupnorm_act")
-    return (y, ws) if return_stats else y
+                                              _p(ws), _p(y), dW, _p(xs), _stream()), "groupnorm_act")
+    out = (y, xs) if want_raw else y
+    return (out, ws) if return_stats else out
 
 
-def batchnorm_act(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, relu=True, return_stats=False):
-    """Training-mode BatchNorm (+ReLU) over all leading dims of NHWC x; updates the running stats in place."""
+def batchnorm_act(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, relu=True, return_stats=False,
+                  d2s=False, want_raw=False):
+    """Training-mode BatchNorm (+ReLU) over all leading dims of NHWC x; updates the running stats in place.
+    d2s / want_raw as for groupnorm_act (x must then be 4-D)."""
     _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
     Cc = x.shape[-1]
     rows = x.numel() // Cc
-    y = torch.empty_like(x)
+    if d2s:
+        y, xs, dW = _d2s_out(x, d2s, want_raw)
+        rpi = x.shape[1] * x.shape[2]
+    else:
+        y, xs, dW, rpi = torch.empty_like(x), None, 0, 0
     ws = torch.empty(2 * Cc, device=x.device, dtype=torch.float32)
     check(_lib.lib().cslgan_batchnorm_act_f32(_p(x), _p(gamma), _p(beta), rows, Cc, float(eps), 1 if relu else 0, float(momentum),
-                                              _p(running_mean), _p(running_var), _p(ws), _p(y), _stream()), "batchnorm_act")
-    return (y, ws) if return_stats else y
+                                              _p(running_mean), _p(running_var), _p(ws), _p(y), rpi, dW, _p(xs), _stream()), "batchnorm_act")
+    out = (y, xs) if want_raw else y
+    return (out, ws) if return_stats else out
+
+
+def batchnorm_eval_act(x, gamma, beta, running_mean, running_var, eps=1e-5, relu=True, d2s=False, want_raw=False):
+    """Eval-mode BatchNorm (+ReLU) from the running statistics (the generator in eval(), train.py:298-308)."""
+    for t, n in ((x, "x"), (gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
+        _chk(t, n)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    if d2s:
+        y, xs, dW = _d2s_out(x, d2s, want_raw)
+        rpi = x.shape[1] * x.shape[2]
+    else:
+        y, xs, dW, rpi = torch.empty_like(x), None, 0, 0
+    ws = torch.empty(2 * Cc, device=x.device, dtype=torch.float32)
+    check(_lib.lib().cslgan_batchnorm_eval_act_f32(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var), rows, Cc, float(eps),
+                                                   1 if relu else 0, _p(ws), _p(y), rpi, dW, _p(xs), _stream()), "batchnorm_eval_act")
+    return (y, xs) if want_raw else y
 
 
 def adam_step(p, g, m, v, lr, b1, b2, eps, weight_decay, step):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CSLGAN_ABI_VERSION 1
+#define CSLGAN_ABI_VERSION 2
 
 typedef enum {
     CSLGAN_OK = 0,
@@ -106,38 +106,21 @@ int cslgan_row_l2norm_bwd_f32(const float* in, const float* norm, const float* g
 /* ---- convolution family: fp32 MFMA implicit GEMM ------------------------------------------ */
 
 typedef struct {
-    int32_t N, H, W, C;          /* input  x[N][H][W][C]  (for upsample: the LOW-res input) */
+    int32_t N, H, W, C;          /* input  x[N][H][W][C]                                     */
     int32_t K, R, S;             /* filter w[K][R][S][C]                                     */
     int32_t stride, pad;
-    int32_t upsample;            /* 1: nearest-2x upsample of x is applied on read (DCResNet_models.py:13-16) */
+    int32_t reserved;            /* must be 0                                                */
     int32_t P, Q;                /* output y[N][P][Q][K]                                     */
 } cslgan_conv_t;
 
-/* y = act(conv(x, w) + bias) [+ residual].  Replaces torch.nn.Conv2d / nn.Linear forward at
- * DCResNet_models.py:131-132,145 (D), :13-17,:60-70,:95-104 (G), MNIST_models.py:41-46.
+/* y = act(conv(x, w) + bias [+ residual]).  Replaces torch.nn.Conv2d / nn.Linear forward at
+ * DCResNet_models.py:131-132,145 (D), :16 (the conv inside UpsampleConv, run on the depth-to-space tensor with
+ * channel-folded filters, see cslgan_depth_to_space_f32), :26,:36,:85,:95-104 (G), MNIST_models.py:17-23,41-46.
  *   bias      : [K] or NULL
- *   residual  : NULL or r[N][P>>res_shift][Q>>res_shift][K], added before act (res_shift 0/1)
+ *   residual  : NULL or r[N][P][Q][K], added before act (ResBlockUp's "o + s", DCResNet_models.py:38)
  * A Linear layer is the 1x1 case H=W=P=Q=R=S=1. */
 int cslgan_conv2d_fwd_f32(const cslgan_conv_t* p, const float* x, const float* w, const float* bias,
-                          const float* residual, int res_shift, int act, float* y, void* stream);
-
-/* Same result as cslgan_conv2d_fwd_f32 with p->upsample == 1 (nearest-2x upsample then an odd "same"
- * RxR stride-1 conv, DCResNet_models.py:13-17) computed by sub-pixel decomposition: each of the four
- * output phases is an (R/2+1)^2-tap conv of the LOW-resolution input with summed filter taps — 9
- * instead of 25 MACs per output for 5x5; the sums only re-associate the reference arithmetic.
- * wphase_ws: caller workspace of cslgan_conv2d_up_ws_floats(K,R,C) floats holding the folded filters; they are
- * (re)built from w when repack != 0 — a caller that knows w is unchanged since its last call with the same
- * workspace passes 0 and skips that launch.  All four phases run in ONE launch. */
-int cslgan_conv2d_up_fwd_f32(const cslgan_conv_t* p, const float* x, const float* w, float* wphase_ws, int repack,
-                             const float* bias, const float* residual, int res_shift, int act, float* y,
-                             void* stream);
-int64_t cslgan_conv2d_up_ws_floats(int K, int R, int C);
-
-/* Data gradient of the upsample+conv above with respect to its LOW-res input x[N][H][W][C], from
- * gy[N][2H][2W][K]: the 2x2 sum-pool of the dense data gradient folded into (R+1)^2 stride-2 taps.
- * wt_ws: caller workspace of (R+1)*(R+1)*K*C floats.  (Generator backward, train.py:502-511.) */
-int cslgan_conv2d_up_dgrad_f32(const cslgan_conv_t* p, const float* gy, const float* w, float* wt_ws, int repack,
-                               float* gx, void* stream);
+                          const float* residual, int act, float* y, void* stream);
 
 /* gx = conv_transpose(gy, w) [* lrelu'(mask)]: the data gradient (autograd of the conv above;
  * "conv_transpose2d" in the north star).  wt_ws: caller workspace of K*R*S*C floats receiving
@@ -168,19 +151,6 @@ int cslgan_conv2d_s2_fwd_f32(const cslgan_conv_t* p, const float* x, const float
 int cslgan_conv2d_wgrad_scaled_f32(const cslgan_conv_t* p, const float* gy, const float* x, const float* row_scale,
                                    int group, float alpha, float* gw, void* stream);
 
-/* Weight gradient of y = conv5x5(nearest_up2(x)) ('same', stride 1; UpsampleConv, DCResNet_models.py:13-16) in
- * sub-pixel form: the four output phases (a,b) of gy each see a 3x3 window of the LOW-res x, so
- *   gwp[g][k][a*2+b][u][v][c] = alpha * sum_{n in group g} sum_{i,j} gy[n,2i+a,2j+b,k] x[n,i+u-1,j+v-1,c]
- * costs 36 MACs per low-res pixel where the direct form costs 100 (train_G backward, train.py:502-517).
- * cslgan_fold_up_wgrad_f32 adds the phases back onto the 25 filter taps: gw[gk][r][s][c], GK = groups*K.
- * Needs C % 128 == 0, K % 4 == 0. */
-int cslgan_conv2d_up_wgrad_phases_f32(const cslgan_conv_t* p, const float* gy, const float* x, int group, float alpha,
-                                      float* gwp, void* stream);
-int cslgan_fold_up_wgrad_f32(const float* gwp, int64_t GK, int C, float* gw, void* stream);
-/* Columns per phase in gwp: 9*C rounded up to a multiple of 256 (n-tiles never straddle a phase);
- * gwp holds groups * K * 4 * phase_stride floats, laid out [g][k][phase][u*3+v][c] with that stride. */
-int64_t cslgan_conv2d_up_wgrad_phase_stride(int C);
-
 /* Dense weight gradient of a stride-1 conv with 1..4 output channels and 64 input channels (G's output conv in
  * train_G, train.py:502-511), on the vector ALU.  Each of the n_blocks workgroups writes one partial [K][R*S][64]
  * row into partial[n_blocks][K*R*S*64]; the caller sums the rows (cslgan_clip_accum_noise_f32).  Needs P, Q
@@ -191,7 +161,7 @@ int cslgan_conv2d_wgrad_skinny_f32(const cslgan_conv_t* p, const float* gy, cons
 /* Per-sample squared norms of the weight gradient WITHOUT forming it:  sq[n] += alpha^2 * sum_{p,p'}
  * (GY_n GY_n^T)[p,p'] (XU_n XU_n^T)[p,p']  — the same value cslgan_conv2d_wgrad_grouped_f32(group=1, gw=NULL)
  * accumulates (opacus calc_sample_norms, train.py:311-314), 30x fewer FLOP for the critic's last conv.
- * Needs P*Q <= 64, K % 32 == 0, C % 32 == 0, no upsample.  sq: [N], caller zeroes. */
+ * Needs P*Q <= 64, K % 32 == 0, C % 32 == 0.  sq: [N], caller zeroes. */
 int cslgan_conv2d_wgrad_sqnorm_gram_f32(const cslgan_conv_t* p, const float* gy, const float* x, float alpha, float* sq,
                                         void* stream);
 
@@ -209,18 +179,43 @@ int cslgan_bias_grad_grouped_f32(const float* gy, int N, int PQ, int K, int grou
 /* out = g * (y > 0 ? 1 : slope)   (LeakyReLU / ReLU backward from the OUTPUT y) */
 int cslgan_act_bwd_f32(const float* g, const float* y, int64_t n, float slope, float* out, void* stream);
 
+/* UpsampleConv's data movement (DCResNet_models.py:13-15): torch.cat([x]*4, 1) followed by F.pixel_shuffle(., 2).
+ * pixel_shuffle is channel-major, so up[c][2h+i][2w+j] = x[(4c + 2i + j) mod C][h][w]: for C % 4 == 0 the C channels of
+ * `up` are the C/4 channels of the plain depth-to-space tensor
+ *       ps[n][2h+i][2w+j][c'] = x[n][h][w][4c' + 2i + j]                         (NHWC, [N][2H][2W][C/4])
+ * repeated four times, and the conv that follows (DCResNet_models.py:16) equals a conv of ps with the filter summed over
+ * the four channel groups — a quarter of the multiply-adds, the sums only re-associate the reference arithmetic.
+ *   cslgan_depth_to_space_f32 : inverse == 0: ps from x[N][H][W][C];  inverse != 0: x[N][H][W][C] from ps (its gradient)
+ *   cslgan_fold_channels4_f32 : unfold == 0: wf[row][c'] = sum_q w[row][c' + q*C/4], rows = K*R*S of a KRSC filter;
+ *                               unfold != 0: gw[row][c' + q*C/4] = gwf[row][c']  (the gradient of w from that of wf)
+ * The normalisation entries below can write their output (and the raw input) directly in the ps layout. */
+int cslgan_depth_to_space_f32(const float* in, int N, int H, int W, int C, int inverse, float* out, void* stream);
+int cslgan_fold_channels4_f32(const float* in, int64_t rows, int C, int unfold, float* out, void* stream);
+
 /* GroupNorm(groups) + optional ReLU on NHWC x[N][HW][C] (DCResNet_models.py:55-57,63-67,101-102).
- * stats_ws: caller workspace [2*N*groups] floats (mean, rstd). */
+ * stats_ws: caller workspace [2*N*groups] floats (sum, centred sum of squares per statistic).
+ * d2s_W > 0: the image is HW/d2s_W rows of d2s_W pixels and y is written depth-to-space shuffled,
+ * y[n][2h+i][2w+j][c'] = act(norm(x))[n][h][w][4c'+2i+j] (C % 4 == 0); x_shuffled (nullable) receives the raw x in the
+ * same layout — the inputs of ResBlockUp's convUp and shortcut (DCResNet_models.py:29-34) from one read of x.
+ * d2s_W == 0: y has x's layout and x_shuffled must be NULL. */
 int cslgan_groupnorm_act_f32(const float* x, const float* gamma, const float* beta, int N, int HW, int C,
-                             int groups, float eps, int relu, float* stats_ws, float* y, void* stream);
+                             int groups, float eps, int relu, float* stats_ws, float* y, int d2s_W, float* x_shuffled,
+                             void* stream);
 
 /* Training-mode BatchNorm2d (+ optional ReLU) on NHWC x[rows][C], rows = N*H*W: batch statistics per channel,
  * running_mean / running_var (nullable pair) updated with `momentum` and the unbiased variance — the bn=True
  * generator of the non-per-sample modes (init_util.py:46, DCResNet_models.py:23,25,84).
- * stats_ws: caller workspace [2*C] floats. */
+ * stats_ws: caller workspace [2*C] floats.  rows_per_image / d2s_W / x_shuffled: as for GroupNorm (rows_per_image
+ * = H*W is only read when d2s_W > 0). */
 int cslgan_batchnorm_act_f32(const float* x, const float* gamma, const float* beta, int64_t rows, int C, float eps,
                              int relu, float momentum, float* running_mean, float* running_var, float* stats_ws,
-                             float* y, void* stream);
+                             float* y, int64_t rows_per_image, int d2s_W, float* x_shuffled, void* stream);
+
+/* Eval-mode BatchNorm2d (+ optional ReLU): y = act((x - running_mean) / sqrt(running_var + eps) * gamma + beta) — the
+ * generator in eval() when images are sampled (train.py:298-308, gensamples.py:26-41). */
+int cslgan_batchnorm_eval_act_f32(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, int64_t rows, int C, float eps, int relu, float* stats_ws,
+                                  float* y, int64_t rows_per_image, int d2s_W, float* x_shuffled, void* stream);
 
 /* Backward of GroupNorm / BatchNorm (+ReLU): dx, dgamma, dbeta from the forward's x, y (ReLU mask) and the
  * stats workspace the forward filled.  rows_per_stat = H*W (GroupNorm) or rows (BatchNorm, groups = C).
@@ -229,9 +224,6 @@ int cslgan_norm_act_bwd_f32(const float* x, const float* dy, const float* y, con
                             int64_t rows, int64_t rows_per_stat, int C, int groups, float eps, int relu, float* ws,
                             float* dx, float* dgamma, float* dbeta, void* stream);
 int64_t cslgan_norm_bwd_ws_floats(int64_t rows, int64_t rows_per_stat, int C, int groups);
-
-/* out[n][i][j][c] = sum of in[n][2i..2i+1][2j..2j+1][c]: gradient of a nearest-2x upsampled (shifted) read. */
-int cslgan_sum2x2_f32(const float* in, int N, int H, int W, int C, float* out, void* stream);
 
 /* Adam (torch.optim.Adam semantics, train.py:76): in-place on p, m, v.  step is 1-based. */
 int cslgan_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,

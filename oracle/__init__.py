@@ -12,9 +12,10 @@ Pinning status (see DESIGN.md "Oracle"):
   * gradient penalty, ``Discriminator.aux_loss``, ``Logger`` — pinned against the
     reference's own importable modules (tests/golden/make_golden.py runs them in
     the build container and commits the vectors).
-  * model stacks (DCResNet / MNIST vanilla) — restated; the reference files that
-    define them import ``torchvision``/``opacus`` (absent here), so they are pinned
-    through the SURVEY.md §8c probe numbers and by construction on torch.nn layers.
+  * model stacks (DCResNet / MNIST vanilla; init order, G forward, D forward, G.loss,
+    train_G gradients) — pinned against the reference's own classes, executed from their
+    source in the build container (tests/golden/make_golden.py: reference_model_classes);
+    vectors in tests/golden/model_*.npz and upsample_conv.npz, checked by tests/test_oracle_golden.py.
   * per-sample gradients / clip / noise / immediate sensitivity — the arithmetic
     lives in the un-pinned third-party fork ``git+git://github.com/twosixlabs/opacus``
     which is not in the container: PARITY UNPINNED at that boundary.  The oracle

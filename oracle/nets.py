@@ -4,7 +4,8 @@ TEST INFRASTRUCTURE — see oracle/__init__.py.
 
 Follows (reference file:line):
   models.py:7-67            Generator / Discriminator bases, aux_loss
-  DCResNet_models.py:8-17   UpsampleConv  (cat x4 + pixel_shuffle(2) == nearest 2x, then "same" conv)
+  DCResNet_models.py:8-17   UpsampleConv  (cat x4 on channels + pixel_shuffle(2), then "same" conv).  NOT a nearest
+                            up-sample: pixel_shuffle is channel-major, so out[c,2h+i,2w+j] = x[(4c+2i+j) mod C,h,w]
   DCResNet_models.py:19-38  ResBlockUp
   DCResNet_models.py:72-107 DCResNetGenerator
   DCResNet_models.py:109-153 DCResNetDiscriminator
@@ -45,15 +46,15 @@ def one_hot(y, n):
 
 
 class _UpConv(nn.Module):
-    """nearest-2x upsample then 'same' conv (DCResNet_models.py:8-17)."""
+    """cat([x]*4, dim=1) -> pixel_shuffle(2) -> 'same' conv (DCResNet_models.py:8-17), literally."""
 
     def __init__(self, cin, cout, k, bias=True):
         super().__init__()
         self.conv = nn.Conv2d(cin, cout, k, padding="same", bias=bias)
 
     def forward(self, x):
-        # cat([x]*4, 1) + pixel_shuffle(2) places x[c] at all four sub-pixels -> nearest upsample
-        up = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+        # a channel-interleaving depth-to-space: up[c, 2h+i, 2w+j] = x[(4c + 2i + j) mod C, h, w]
+        up = F.pixel_shuffle(torch.cat([x, x, x, x], 1), 2)
         return self.conv(up)
 
 

@@ -29,7 +29,7 @@ def test_header_symbols_are_exported(built_lib):
 def test_library_loads_and_reports_version(built_lib):
     from csl_gan_amd import _lib
     L = _lib.lib()
-    assert L.cslgan_version() == 1
+    assert L.cslgan_version() == _lib.ABI_VERSION
     assert L.cslgan_device_count() >= 0
     assert isinstance(L.cslgan_last_error(), bytes)
 
@@ -41,7 +41,7 @@ def test_invalid_arguments_fail_loudly_without_gpu(built_lib):
     rc = L.cslgan_sample_sqnorm_f32(None, 4, None, None)
     assert rc == -1 and b"null" in L.cslgan_last_error()
     d = _lib.ConvT(1, 8, 8, 4, 4, 5, 5, 2, 2, 0, 99, 99)
-    rc = L.cslgan_conv2d_fwd_f32(ctypes.byref(d), 1, 1, None, None, 0, 0, 1, None)
+    rc = L.cslgan_conv2d_fwd_f32(ctypes.byref(d), 1, 1, None, None, 0, 1, None)
     assert rc == -1 and b"does not match" in L.cslgan_last_error()
 
 

@@ -228,9 +228,9 @@ def test_double_backward_wiring_without_activations():
         else:
             h = HF.nhwc(xx)
             for w_, b_ in zip(W[:2], Bi):
-                h = HF.Conv.apply(h, w_.permute(0, 2, 3, 1).contiguous(), b_, 2, 2, ops.ACT_NONE, False, None, 0)
+                h = HF.Conv.apply(h, w_.permute(0, 2, 3, 1).contiguous(), b_, 2, 2, ops.ACT_NONE, None)
             flat = HF.nchw_view(h).reshape(B, -1)
-            out = HF.Conv.apply(flat.reshape(B, 1, 1, -1), W[2].reshape(1, 1, 1, -1), None, 1, 0, ops.ACT_NONE, False, None, 0).reshape(B, 1)
+            out = HF.Conv.apply(flat.reshape(B, 1, 1, -1), W[2].reshape(1, 1, 1, -1), None, 1, 0, ops.ACT_NONE, None).reshape(B, 1)
             gr, = torch.autograd.grad(out, xx, torch.ones_like(out), create_graph=True)
             n = HF.RowL2Norm.apply(gr.reshape(B, -1))
         pen = 10 * ((n - 1) ** 2).mean()

@@ -208,8 +208,8 @@ def test_dense_wgrad_group_and_gram_policy():
     sample, and the Gram-norm path is chosen only for few-pixel layers."""
     from csl_gan_amd import ops
     for N in (1, 6, 128, 384):
-        for (K, C, R, PQ, up) in ((512, 256, 5, 16, False), (64, 3, 5, 1024, False), (1, 8192, 1, 1, False), (64, 128, 5, 4096, True)):
-            g = ops.dense_wgrad_group(N, K, C, R, R, PQ, upsample=up)
+        for (K, C, R, PQ) in ((512, 256, 5, 16), (64, 3, 5, 1024), (1, 8192, 1, 1), (64, 32, 5, 4096)):
+            g = ops.dense_wgrad_group(N, K, C, R, R, PQ)
             assert g >= 1 and N % g == 0
     assert ops.dense_wgrad_group(6, 128, 64, 5, 5, 256) == 1
     assert ops.dense_wgrad_group(128, 512, 256, 5, 5, 16) > 1
@@ -217,7 +217,6 @@ def test_dense_wgrad_group_and_gram_policy():
     assert ops.gram_norms_preferred((128, 4, 4, 512), (128, 8, 8, 256), 2)
     assert ops.gram_norms_preferred((128, 1, 1, 1), (128, 1, 1, 8192), 1)            # linear layer
     assert not ops.gram_norms_preferred((128, 8, 8, 256), (128, 16, 16, 128), 2)      # 64 output pixels: product kernel
-    assert not ops.gram_norms_preferred((128, 4, 4, 512), (128, 8, 8, 256), 2, upsample=True)
     assert not ops.gram_norms_preferred((128, 4, 4, 100), (128, 8, 8, 256), 2)        # K % 64 != 0
 
 

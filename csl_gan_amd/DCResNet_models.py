@@ -51,6 +51,13 @@ class _BatchNormAct(nn.BatchNorm2d):
         return self.training or self.running_mean is None
 
     def forward_nhwc(self, x, d2s=False):
+        from . import nn as hnn
+        if hnn._mask_recorder is not None:          # parity-test hook (csl_gan_amd.nn.ActivationMaskRecorder): two-launch form
+            y = hnn._record_mask(self, self._forward_nhwc(x, False))
+            return (HF.DepthToSpace.apply(y), HF.DepthToSpace.apply(x)) if d2s else y
+        return self._forward_nhwc(x, d2s)
+
+    def _forward_nhwc(self, x, d2s):
         g, b = self.weight, self.bias
         if not self._train_stats():
             if torch.is_grad_enabled() and (x.requires_grad or g.requires_grad):

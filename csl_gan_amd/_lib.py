@@ -14,7 +14,7 @@ MAX_SEGS = 16
 ABI_VERSION = 2          # include/cslgan.h CSLGAN_ABI_VERSION
 
 EXPORTS = [
-    "cslgan_version", "cslgan_last_error", "cslgan_device_count",
+    "cslgan_version", "cslgan_last_error", "cslgan_last_kernel", "cslgan_device_count",
     "cslgan_sample_sqnorm_f32", "cslgan_sample_sqnorm_bf16", "cslgan_clip_factors_f32", "cslgan_clip_accum_noise_f32",
     "cslgan_clip_accum_noise_bf16", "cslgan_conv2d_wgrad_grouped_bf16out_f32",
     "cslgan_l2_clip_rows_f32", "cslgan_row_l2norm_f32", "cslgan_row_l2norm_bwd_f32",
@@ -61,6 +61,7 @@ def lib():
     import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     L.cslgan_last_error.restype = C.c_char_p
+    L.cslgan_last_kernel.restype = C.c_char_p
     vp, i32, i64, f32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
     sig = {
         "cslgan_version": [],

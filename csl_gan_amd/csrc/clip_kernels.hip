@@ -23,6 +23,14 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static thread_local char g_kernel[128] = "";
+void note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+
 // 4 consecutive elements as floats: fp32 = one 16-byte load, bf16 = one 8-byte load widened by a 16-bit shift
 struct bf16x4 { unsigned short v[4]; };
 template <typename T> struct Elem;
@@ -270,6 +278,7 @@ static int launch_sqnorm(const float* const* in, const long long* len, const lon
         return CSLGAN_ERR_LAUNCH;
     }
     if (tot == 0 || n_rows == 0) return CSLGAN_OK;
+    note_kernel(bf16 ? "sample_sqnorm_kernel<bf16>" : "sample_sqnorm_kernel<float>");
     if (bf16) hipLaunchKernelGGL(sample_sqnorm_kernel<unsigned short>, dim3(tot, (unsigned)n_rows), dim3(SQ_THREADS), 0, st, a, n_rows, out_sq);
     else hipLaunchKernelGGL(sample_sqnorm_kernel<float>, dim3(tot, (unsigned)n_rows), dim3(SQ_THREADS), 0, st, a, n_rows, out_sq);
     return check_launch("sample_sqnorm_kernel");
@@ -298,6 +307,7 @@ extern "C" {
 
 int cslgan_version(void) { return CSLGAN_ABI_VERSION; }
 const char* cslgan_last_error(void) { return cslgan::g_err; }
+const char* cslgan_last_kernel(void) { return cslgan::g_kernel; }
 
 int cslgan_device_count(void) {
     int n = 0;
@@ -368,6 +378,7 @@ static int clip_accum_noise_impl(const cslgan_segs_t* segs, int64_t n_rows, cons
     a.tile_prefix[CSLGAN_MAX_SEGS] = tot;
     for (int s = segs->n_seg; s <= CSLGAN_MAX_SEGS; ++s) a.tile_prefix[s] = tot;
     if (tot == 0) return CSLGAN_OK;
+    note_kernel(bf16 ? "clip_accum_noise_kernel<bf16>" : "clip_accum_noise_kernel<float>");
     if (bf16) hipLaunchKernelGGL(clip_accum_noise_kernel<unsigned short>, dim3(tot), dim3(CA_THREADS), 0, (hipStream_t)stream, a, (long long)n_rows,
                                  factors, factors_per_seg, noise_std, (unsigned long long)seed, (unsigned long long)offset, scale, beta);
     else hipLaunchKernelGGL(clip_accum_noise_kernel<float>, dim3(tot), dim3(CA_THREADS), 0, (hipStream_t)stream, a, (long long)n_rows,

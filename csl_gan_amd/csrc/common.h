@@ -9,6 +9,10 @@
 namespace cslgan {
 
 void set_error(const char* fmt, ...);
+// Name of the device kernel most recently launched by the calling thread (printf-style; read back through
+// cslgan_last_kernel()): bench.py tags its HIP-event timings with it, so roofline figures name a KERNEL as
+// rocprofv3 --kernel-trace lists it, not a C-ABI entry that may dispatch to several.
+void note_kernel(const char* fmt, ...);
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

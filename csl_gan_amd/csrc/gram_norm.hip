@@ -300,6 +300,7 @@ int cslgan_conv2d_wgrad_sqnorm_gram_f32(const cslgan_conv_t* c, const float* gy,
                     sp.tdy[t] = (signed char)dy; sp.tdx[t] = (signed char)dx;
                     sp.tcls[t] = (signed char)((oy - dy * st) * st + (ox - dx * st));
                 }
+            note_kernel("gram_sqnorm_small_kernel");
             hipLaunchKernelGGL(gram_sqnorm_small_kernel, dim3((unsigned)c->N), dim3(256), 0, (hipStream_t)stream, sp);
             return check_launch("gram_sqnorm_small_kernel");
         }
@@ -311,6 +312,7 @@ int cslgan_conv2d_wgrad_sqnorm_gram_f32(const cslgan_conv_t* c, const float* gy,
     for (int kh = 0; kh < c->R; ++kh)
         for (int kw = 0; kw < c->S; ++kw) { p.ty[kh * c->S + kw] = (signed char)(kh - c->pad); p.tx[kh * c->S + kw] = (signed char)(kw - c->pad); }
     const dim3 grid((unsigned)c->N), block(256);
+    note_kernel("gram_sqnorm_kernel<%d>", p.PQ <= 32 ? 1 : 4);
     if (p.PQ <= 32) hipLaunchKernelGGL((gram_sqnorm_kernel<1>), grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gram_sqnorm_kernel<4>), grid, block, 0, (hipStream_t)stream, p);
     return check_launch("gram_sqnorm_kernel");

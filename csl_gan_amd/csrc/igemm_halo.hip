@@ -327,6 +327,7 @@ int launch_halo(KcParams& p, hipStream_t st) {
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);
     bool gen = p.pair_mode != 0 || p.acc_classes != 0;
     for (int c = 0; c < p.n_cls; ++c) gen = gen || p.cls[c].patch == 2 || p.cls[c].ay_mul > 1 || p.cls[c].ax_mul > 1;
+    note_kernel("igemm_halo_kernel<%d,%s>", wide ? 128 : 64, gen ? "true" : "false");
     if (wide && gen) hipLaunchKernelGGL((igemm_halo_kernel<128, true>), grid, block, 0, st, p);
     else if (wide) hipLaunchKernelGGL((igemm_halo_kernel<128, false>), grid, block, 0, st, p);
     else if (gen) hipLaunchKernelGGL((igemm_halo_kernel<64, true>), grid, block, 0, st, p);

@@ -363,6 +363,7 @@ static int launch_kc_tile(KcParams& p, bool vecA, bool vecB, hipStream_t st, lon
     const dim3 grid((unsigned)(tiles * p.ksplit)), block(256);
     // NBUF = 1 (single LDS buffer, 4 workgroups/CU) was measured slower on every shape of the D-step
     // (G b1: 59 vs 102 TF; G b4: 107 vs 105 TF), so only the double-buffered form is instantiated.
+    note_kernel("igemm_kc_kernel<%d,%d>", BM, BN);
     if (vecA && vecB) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, true, true, 2>), grid, block, 0, st, p);
     else if (vecA) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, true, false, 2>), grid, block, 0, st, p);
     else if (vecB) hipLaunchKernelGGL((igemm_kc_kernel<BM, BN, WM, WN, false, true, 2>), grid, block, 0, st, p);

@@ -317,6 +317,7 @@ static int launch_mc_tile(McParams& p, bool vecA, bool vecB, hipStream_t st) {
     const long long nb = (long long)p.n_groups * p.tiles_m * p.tiles_n * p.ksplit;
     if (nb > 0x7fffffffll) { set_error("wgrad: grid too large"); return CSLGAN_ERR_INVALID_ARG; }
     const dim3 grid((unsigned)nb), block(256);
+    note_kernel("igemm_mc_kernel<%d,%d>", BM, BN);
     if (vecA && vecB) hipLaunchKernelGGL((igemm_mc_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, p);
     else if (vecA) hipLaunchKernelGGL((igemm_mc_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, p);
     else if (vecB) hipLaunchKernelGGL((igemm_mc_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, p);

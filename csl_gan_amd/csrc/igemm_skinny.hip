@@ -156,6 +156,7 @@ int launch_skinny(KcParams& p, hipStream_t st) {
     p.tiles_n = 1;
     p.ksplit = 1;
     const dim3 grid((unsigned)tm), block(256);
+    note_kernel("igemm_skinny_kernel<%d>", p.Nn < 4 ? p.Nn : 4);
     switch (p.Nn) {
         case 1: hipLaunchKernelGGL((igemm_skinny_kernel<1>), grid, block, 0, st, p); break;
         case 2: hipLaunchKernelGGL((igemm_skinny_kernel<2>), grid, block, 0, st, p); break;
@@ -298,6 +299,7 @@ int cslgan_conv2d_wgrad_skinny_f32(const cslgan_conv_t* c, const float* gy, cons
         for (int kw = 0; kw < c->S; ++kw) { p.ty[kh * c->S + kw] = (signed char)(kh - c->pad); p.tx[kh * c->S + kw] = (signed char)(kw - c->pad); }
     p.ty_min = -c->pad; p.tx_min = -c->pad; p.halo_h = 8 + c->R - 1; p.halo_w = 8 + c->S - 1;
     const dim3 grid((unsigned)n_blocks), block(256);
+    note_kernel("skinny_wgrad_kernel<%d>", c->K);
     switch (c->K) {
         case 1: hipLaunchKernelGGL((skinny_wgrad_kernel<1>), grid, block, 0, (hipStream_t)stream, p); break;
         case 2: hipLaunchKernelGGL((skinny_wgrad_kernel<2>), grid, block, 0, (hipStream_t)stream, p); break;

@@ -188,6 +188,7 @@ int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int grou
     const long long nb = base * p.ksplit;
     if (nb > 0x7fffffffll) { set_error("wgrad: grid too large"); return CSLGAN_ERR_INVALID_ARG; }
     const dim3 grid((unsigned)nb), block(256);
+    note_kernel("igemm_wgh_kernel<%d,%d>", c->S < 2 ? 2 : c->S, half_m ? 1 : 2);
     if (half_m) {
         switch (c->S) {
             case 2: hipLaunchKernelGGL((igemm_wgh_kernel<2, 1>), grid, block, 0, st, p); break;

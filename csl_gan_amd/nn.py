@@ -24,6 +24,37 @@ from . import ops
 _tokens = itertools.count(1)
 
 
+class ActivationMaskRecorder:
+    """Parity-test hook: records the sign mask (output > 0) of every fused ReLU / LeakyReLU this package applies, per module
+    and in call order, as logical-NCHW bool tensors on the host.  The CPU oracle replays them (oracle.nets.MaskPlayer) so
+    gradient tensors can be compared entry by entry without the discontinuity of a unit that sits at zero.  Off (None) in
+    every product run; while installed, the fused depth-to-space normalisation takes its two-launch form."""
+
+    def __init__(self, **nets):
+        self.names = {id(m): "%s.%s" % (tag, n) for tag, net in nets.items() for n, m in net.named_modules()}
+        self.masks = {}
+
+    def record(self, module, y, nhwc=True):
+        m = y.detach() > 0
+        if nhwc and m.dim() == 4:
+            m = m.permute(0, 3, 1, 2)
+        self.masks.setdefault(self.names[id(module)], []).append(m.contiguous().cpu())
+
+
+_mask_recorder = None
+
+
+def set_mask_recorder(r):
+    global _mask_recorder
+    _mask_recorder = r
+
+
+def _record_mask(module, y, act=None, nhwc=True):
+    if _mask_recorder is not None and (act is None or act in (ops.ACT_LRELU02, ops.ACT_RELU)):
+        _mask_recorder.record(module, y, nhwc)
+    return y
+
+
 class PerSampleSink:
     """Interface the DP engine implements to receive per-sample gradients from a layer's backward."""
 
@@ -62,9 +93,10 @@ class HipConv2d(nn.Conv2d, _PerSampleMixin):
         w = self.weight.permute(0, 2, 3, 1).contiguous()
         if self._per_sample_active() and residual is None:
             sink = self._sink
-            return HF.ConvPerSample.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act,
-                                          sink.collector(self), sink.next_pass(self), self._wkey(w))
-        return HF.Conv.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act, residual, self._wkey(w))
+            return _record_mask(self, HF.ConvPerSample.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act,
+                                                            sink.collector(self), sink.next_pass(self), self._wkey(w)), self.act)
+        return _record_mask(self, HF.Conv.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act, residual, self._wkey(w)),
+                            self.act)
 
     def forward_shuffled(self, x_ps):
         """UpsampleConv's conv (DCResNet_models.py:16) on the depth-to-space tensor x_ps[N,2H,2W,C/4]: the reference convolves
@@ -108,7 +140,7 @@ class HipLinear(nn.Linear, _PerSampleMixin):
             y = HF.ConvPerSample.apply(x4, w4, self.bias, 1, 0, self.act, sink.collector(self), sink.next_pass(self), wkey)
         else:
             y = HF.Conv.apply(x4, w4, self.bias, 1, 0, self.act, None, wkey)
-        return y.reshape(B, self.out_features)
+        return _record_mask(self, y.reshape(B, self.out_features), self.act)
 
 
 class HipGroupNormAct(nn.GroupNorm):
@@ -121,12 +153,14 @@ class HipGroupNormAct(nn.GroupNorm):
 
     def forward_nhwc(self, x):
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            return HF.NormAct.apply(x, self.weight, self.bias, self.num_groups, self.eps, self.relu, None, None, 0.0)
-        return ops.groupnorm_act(x, self.weight.detach(), self.bias.detach(), self.num_groups, eps=self.eps, relu=self.relu)
+            y = HF.NormAct.apply(x, self.weight, self.bias, self.num_groups, self.eps, self.relu, None, None, 0.0)
+        else:
+            y = ops.groupnorm_act(x, self.weight.detach(), self.bias.detach(), self.num_groups, eps=self.eps, relu=self.relu)
+        return _record_mask(self, y) if self.relu else y
 
     def forward_shuffled(self, x):
         """(depth_to_space(act(norm(x))), depth_to_space(x)) — the inputs of ResBlockUp's convUp and shortcut."""
-        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+        if (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)) or _mask_recorder is not None:
             return HF.DepthToSpace.apply(self.forward_nhwc(x)), HF.DepthToSpace.apply(x)
         return ops.groupnorm_act(x, self.weight.detach(), self.bias.detach(), self.num_groups, eps=self.eps, relu=self.relu,
                                  d2s=True, want_raw=True)

@@ -55,7 +55,8 @@ repack_cache = _RepackCache()
 class LaunchTimer:
     """HIP-event timing of individual C-ABI launches on the stream they are enqueued on (torch's
     current stream), for bench.py's live roofline figures.  Events are resolved once, after the
-    caller has synchronised."""
+    caller has synchronised.  Each record carries the name of the device kernel the entry dispatched to
+    (cslgan_last_kernel), so figures can be grouped per KERNEL as rocprofv3 lists them."""
 
     def __init__(self):
         self.records = []
@@ -65,14 +66,16 @@ class LaunchTimer:
         e.record()
         return e
 
-    def end(self, name, flop, nbytes, start, exec_flop=None, tag=None):
+    def end(self, name, flop, nbytes, start, exec_flop=None, tag=None, kernel=None):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        self.records.append((name, flop, nbytes, start, e, flop if exec_flop is None else exec_flop, tag))
+        self.records.append((name, flop, nbytes, start, e, flop if exec_flop is None else exec_flop, tag, kernel or name))
 
-    def summary(self, by_shape=False):
+    def summary(self, by_shape=False, by_kernel=False):
         out = {}
-        for name, flop, nbytes, s, e, xf, tag in self.records:
+        for name, flop, nbytes, s, e, xf, tag, kernel in self.records:
+            if by_kernel:
+                name = kernel
             if by_shape and tag:
                 name = "%s %s" % (name, tag)
             d = out.setdefault(name, {"name": name, "ms": 0.0, "flop": 0.0, "exec_flop": 0.0, "bytes": 0.0, "n": 0})
@@ -99,7 +102,8 @@ def _timed(name, flop, nbytes, fn, exec_flop=None, tag=None):
         return fn()
     s = _timer.begin()
     r = fn()
-    _timer.end(name, flop, nbytes, s, exec_flop, tag() if callable(tag) else tag)
+    _timer.end(name, flop, nbytes, s, exec_flop, tag() if callable(tag) else tag,
+               _lib.lib().cslgan_last_kernel().decode(errors="replace"))
     return r
 
 

@@ -346,6 +346,8 @@ class Trainer:
                 if use_imm_sens:
                     pe.backward(d_loss, img)
                     self.update_is_logging()
+                    if self.explicit.get("keep"):
+                        self.last["is_param_grads"] = [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in D.parameters()]
                 else:
                     d_loss.backward()
         else:

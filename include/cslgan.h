@@ -54,6 +54,10 @@ typedef struct {
 
 int cslgan_version(void);
 const char* cslgan_last_error(void);
+/* Name of the device kernel most recently launched by the calling thread through a conv / clip / norm entry, as rocprofv3
+ * --kernel-trace lists it (e.g. "igemm_halo_kernel<128,false>"); "" before the first launch.  Measurement aid: bench.py
+ * tags its per-launch HIP-event timings with it. */
+const char* cslgan_last_kernel(void);
 /* number of visible HIP devices (>=0) or a negative status */
 int cslgan_device_count(void);
 

@@ -45,6 +45,50 @@ def one_hot(y, n):
     return F.one_hot(y, n)
 
 
+# ---------------------------------------------------------------------------
+# Activation-mask playback (parity tests only).  ReLU / LeakyReLU make gradient TENSORS discontinuous in the
+# pre-activations: a unit within fp32 rounding of zero may take the other slope on another device.  To compare
+# gradients entry by entry, a test records the sign masks the device path used (csl_gan_amd.nn.ActivationMaskRecorder)
+# and installs a MaskPlayer here: every piecewise-linear activation of the oracle then multiplies by the recorded
+# slope pattern instead of deciding from its own pre-activation.  With identical masks both sides are the same smooth
+# function, so any remaining difference is a wiring / arithmetic error, not a flipped unit.
+# ---------------------------------------------------------------------------
+class MaskPlayer:
+    def __init__(self, masks, **nets):
+        """masks: {"<tag>.<module name>": [bool tensors in call order]}; nets: tag -> oracle module (names as named_modules())."""
+        self.masks = {k: list(v) for k, v in masks.items()}
+        self.names = {id(m): "%s.%s" % (tag, n) for tag, net in nets.items() for n, m in net.named_modules()}
+
+    def act(self, module, pre, slope):
+        q = self.masks[self.names[id(module)]]
+        m, n = q[0], pre.size(0)
+        if m.size(0) == n:
+            q.pop(0)
+        else:                       # the device ran several logical passes as one concatenated batch: consume its rows in order
+            assert m.size(0) > n, "recorded mask has %d rows, forward has %d" % (m.size(0), n)
+            q[0], m = m[n:], m[:n]
+        assert m.shape == pre.shape, (self.names[id(module)], tuple(m.shape), tuple(pre.shape))
+        return pre * torch.where(m, 1.0, float(slope)).to(pre.dtype)
+
+    def exhausted(self):
+        return all(len(q) == 0 for q in self.masks.values())
+
+
+_player = None
+
+
+def set_mask_player(p):
+    global _player
+    _player = p
+
+
+def _act(module, pre, slope):
+    """LeakyReLU(slope) / ReLU (slope 0) of `pre`, the output of `module` — or the recorded mask when a player is installed."""
+    if _player is not None:
+        return _player.act(module, pre, slope)
+    return F.leaky_relu(pre, slope) if slope else F.relu(pre)
+
+
 class _UpConv(nn.Module):
     """cat([x]*4, dim=1) -> pixel_shuffle(2) -> 'same' conv (DCResNet_models.py:8-17), literally."""
 
@@ -71,8 +115,8 @@ class _ResUp(nn.Module):
 
     def forward(self, x):
         s = self.shortcut(x)
-        o = self.convUp(F.relu(self.bn1(x)))
-        o = self.conv(F.relu(self.bn2(o)))
+        o = self.convUp(_act(self.bn1, self.bn1(x), 0.0))
+        o = self.conv(_act(self.bn2, self.bn2(o), 0.0))
         return o + s
 
 
@@ -98,7 +142,7 @@ class OracleDCRNGenerator(nn.Module):
         x = self.linIn(x).reshape(z.size(0), -1, self.first, self.first)
         for blk in self.blocks:
             x = blk(x)
-        return torch.tanh(self.convOut(F.relu(self.bn(x))))
+        return torch.tanh(self.convOut(_act(self.bn, self.bn(x), 0.0)))
 
     def loss(self, d_out, device=None):  # DCResNet_models.py:106-107
         return -d_out.mean()
@@ -151,7 +195,7 @@ class OracleDCRNDiscriminator(_DiscBase):
             planes = one_hot(y, self.n_classes).view(x.size(0), -1, 1, 1).expand(-1, -1, x.size(2), x.size(3))
             o = torch.cat((x, planes.to(x.dtype)), dim=1)
         for conv in self.blocks:
-            o = F.leaky_relu(conv(o), 0.2)
+            o = _act(conv, conv(o), 0.2)
         o = o.reshape(x.size(0), -1)
         out_aux = self.linOutAux(o) if (aux and hasattr(self, "linOutAux")) else None
         if out_aux is not None and self.conditional_arch == "WCGAN":
@@ -178,7 +222,7 @@ class OracleVanillaG(nn.Module):
 
     def forward(self, z, y=None):
         x = z if y is None else torch.cat([z, one_hot(y, self.n_classes)], dim=1)
-        return torch.sigmoid(self.lin2(F.relu(self.lin1(x)))).reshape(z.size(0), 1, 28, 28)
+        return torch.sigmoid(self.lin2(_act(self.lin1, self.lin1(x), 0.0))).reshape(z.size(0), 1, 28, 28)
 
     def loss(self, d_out, device=None):
         return F.binary_cross_entropy_with_logits(d_out, torch.ones_like(d_out))
@@ -200,7 +244,7 @@ class OracleVanillaD(_DiscBase):
         o = x.reshape(x.size(0), -1)
         if y is not None:
             o = torch.cat([o, one_hot(y, self.n_classes).to(o.dtype)], dim=1)
-        h = F.relu(self.lin1(o))
+        h = _act(self.lin1, self.lin1(o), 0.0)
         use_aux = aux and self.conditional_arch == "ACGAN" and self.n_classes > 1
         return self.lin2(h), (self.linOutAux(h) if use_aux else None)
 

@@ -3,7 +3,7 @@
 # Outputs land in gpurun_out/prof_final/; copy the summaries into profiles/ afterwards.
 set -e
 ROOT=$(pwd)
-OUT=$ROOT/gpurun_out/prof_final
+OUT=$ROOT/gpurun_out/${PROF_TAG:-prof_r02}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --loop-steps 0 > $OUT/stats_bench.json 2> /dev/null

@@ -102,14 +102,14 @@ def gp_case(name, dataset, im_size, B, seed, one_sided=False, conditional=False,
         else:
             grads = torch.autograd.grad(pen, list(D.parameters()), allow_unused=True)
             out["penalty"] = np.float64(pen.item())
-            out["grad_norms"] = np.array([0.0 if gr is None else gr.norm().item() for gr in grads])
+            out["grad_norms"] = np.array([0.0 if gr is None else gr.double().norm().item() for gr in grads])
             out["grad_heads"] = np.stack([np.zeros(8, np.float32) if gr is None else
                                           gr.reshape(-1)[:8].numpy() for gr in grads])
         out["alpha"] = alpha.reshape(-1).numpy()
     with torch.no_grad():
         d_out, d_aux = D(real, labels)
     out.update(real=real.numpy(), fake=fake.numpy(), d_out_real=d_out.numpy(),
-               weight_norms=np.array([p.norm().item() for p in D.parameters()]),
+               weight_norms=np.array([p.detach().double().norm().item() for p in D.parameters()]),
                meta=np.array([B, im_size, seed, int(one_sided), int(conditional), int(aux_penalty)]))
     if labels is not None:
         out["labels"] = labels.numpy()
@@ -170,10 +170,10 @@ def model_case(name, dataset, model, im_size, B, seed, latent=128, **kw):
     out = dict(z=z.numpy(), real=real.numpy(), fake=fake.detach().numpy(), d_fake=d_fake.detach().numpy(),
                d_real=d_real.numpy(), g_loss=np.float64(g_loss.item()), g_total_loss=np.float64(total.item()),
                d_real_loss=np.float64(D.real_loss(d_real, "cpu").item()), d_fake_loss=np.float64(D.fake_loss(d_fake, "cpu").item()),
-               g_weight_norms=np.array([p.norm().item() for _, p in gparams]),
-               d_weight_norms=np.array([p.norm().item() for p in D.parameters()]),
+               g_weight_norms=np.array([p.detach().double().norm().item() for _, p in gparams]),
+               d_weight_norms=np.array([p.detach().double().norm().item() for p in D.parameters()]),
                g_param_names=np.array([n for n, _ in gparams]),
-               g_grad_norms=np.array([0.0 if gr is None else gr.norm().item() for gr in grads]),
+               g_grad_norms=np.array([0.0 if gr is None else gr.double().norm().item() for gr in grads]),      # float64 reductions
                g_grad_heads=np.stack([_head8(gr) for gr in grads]),
                meta=np.array([B, im_size, seed, latent, ncls, int(kw.get("per_sample_grad", True))]))
     if y is not None:

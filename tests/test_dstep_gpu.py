@@ -19,16 +19,15 @@ def _close(got, exp, what, rtol=RTOL):
     assert err <= rtol * scale, "%s: max abs err %.3e, scale %.3e, rel %.3e" % (what, err, scale, err / scale)
 
 
-def _close_grad(got, exp, what, l2_tol=2e-2, frac_tol=1.0, abs_floor=0.0):
-    """Gradient TENSORS of a LeakyReLU network are discontinuous in the activations: a unit whose
-    pre-activation is within fp32 rounding of zero takes a different slope on CPU and GPU and shifts the
-    gradient entries it feeds by a whole term (entries are sums of hundreds of cancelling terms, so that is
-    percent-level on a few rows).  Which units flip also varies from run to run (GroupNorm statistics and
-    norms are reduced with float atomics) and one flipped unit of one sample shifts EVERY entry of that sample's
-    upstream gradients slightly, so a per-entry count is not a stable criterion (observed: 0 or 12 of the 64
-    entries of the conv0 bias sum beyond 1e-3, run to run).  The bound is 2e-2 in relative L2; the activation-free
-    tests below check the same wiring to 1e-4 / 5e-4, and losses, penalty, per-sample norms and clip factors
-    are held to 1e-3."""
+def _close_grad(got, exp, what, l2_tol=5e-3, abs_floor=0.0):
+    """FREE-RUNNING comparison of a gradient tensor (each side decides its own ReLU / LeakyReLU masks).  Gradient tensors of
+    such a network are discontinuous in the pre-activations: a unit within fp32 rounding of zero may take the other slope on
+    the other device, and because every upstream gradient entry of that sample passes through the unit, ONE flip moves a large
+    share of the entries by a little (measured: 41 % of the entries of a 512x512 shortcut filter beyond 1e-3 of scale at a
+    relative L2 error below 1e-2, while the mask-shared run of the same step agrees to 1e-3 on every entry).  A per-entry
+    count is therefore not a property of the implementation and this SECONDARY check bounds the relative L2 error only
+    (5e-3 for the D-step, as observed).  The PRIMARY check is _close (per entry, 1e-3 of scale) on the mask-shared run —
+    see _masked_oracle."""
     got = torch.as_tensor(got).detach().cpu().double().reshape(-1)
     exp = torch.as_tensor(exp).detach().cpu().double().reshape(-1)
     assert got.shape == exp.shape, (what, got.shape, exp.shape)
@@ -36,10 +35,36 @@ def _close_grad(got, exp, what, l2_tol=2e-2, frac_tol=1.0, abs_floor=0.0):
         return          # both are rounding noise (e.g. a bias feeding a BatchNorm has an exactly-zero gradient)
     l2 = ((got - exp).norm() / (exp.norm() + 1e-30)).item()
     assert l2 <= l2_tol, "%s: relative L2 error %.3e" % (what, l2)
-    scale = exp.abs().max().item() + 1e-30
-    n_off = ((got - exp).abs() > RTOL * scale).double().sum().item()
-    allowed = max(frac_tol * got.numel(), 4)       # a single flipped unit touches a handful of entries even in a 64-entry bias
-    assert n_off <= allowed, "%s: %d of %d entries off by more than 1e-3 of scale" % (what, n_off, got.numel())
+
+
+class _masks:
+    """Context: record the activation sign masks the HIP path uses (csl_gan_amd.nn.ActivationMaskRecorder)."""
+
+    def __init__(self, **nets):
+        from csl_gan_amd import nn as hnn
+        self.hnn, self.rec = hnn, hnn.ActivationMaskRecorder(**nets)
+
+    def __enter__(self):
+        self.hnn.set_mask_recorder(self.rec)
+        return self.rec
+
+    def __exit__(self, *a):
+        self.hnn.set_mask_recorder(None)
+
+
+class _masked_oracle:
+    """Context: the oracle replays the recorded masks (oracle.nets.MaskPlayer), so both sides are the same smooth function."""
+
+    def __init__(self, rec, **nets):
+        from oracle import nets as onets
+        self.onets, self.player = onets, onets.MaskPlayer(rec.masks, **nets)
+
+    def __enter__(self):
+        self.onets.set_mask_player(self.player)
+        return self.player
+
+    def __exit__(self, *a):
+        self.onets.set_mask_player(None)
 
 
 def _setup(tmp_path, dataset, extra, B, latent):
@@ -105,7 +130,8 @@ def test_train_D_matches_oracle(tmp_path, dataset, extra, B, latent):
 
     tr.explicit = dict(ms_adapt=ms_a, pen_real=ms_p, alpha=alpha, z_adapt=z_ad.cuda(), keep=True)
     pe.host_noise = zs                   # unit normals applied in each parameter's MEMORY order
-    tr.train_D(img.cuda(), None, z.cuda(), None, use_dp=True)
+    with _masks(G=tr.G, D=tr.D) as rec:
+        tr.train_D(img.cuda(), None, z.cuda(), None, use_dp=True)
     torch.cuda.synchronize()
     last = tr.last
 
@@ -123,6 +149,25 @@ def test_train_D_matches_oracle(tmp_path, dataset, extra, B, latent):
         obs = oracle.step(img, None, z, None, ms_adapt=ms_a, z_adapt=z_ad, pen_real=ms_p if opt.penalty else None,
                           alpha=alpha, noise=None, noise_gen=None, apply_update=False)
     oracle.cfg.sigma = 0.0
+    C0 = oracle.max_grad_norm
+    # PRIMARY: the oracle replays the HIP run's activation masks -> gradient tensors must agree ENTRY BY ENTRY (1e-3 of scale)
+    with _masked_oracle(rec, G=oracle.G, D=Do) as player:
+        run_oracle()
+        assert player.exhausted(), "oracle and HIP path ran a different number of activation calls"
+    for i, (a, b) in enumerate(zip(last["summed_clipped"], obs["summed_clipped"])):
+        _close(a, b, "masked summed_clipped[%d]" % i)
+    if opt.penalty:
+        pscale = max(b.abs().max().item() for b in obs["penalty_grads"] if b is not None)
+        for i, (a, b) in enumerate(zip(last["penalty_grads"], obs["penalty_grads"])):
+            if b is None or b.abs().max() <= 1e-6 * pscale:
+                assert a is None or a.abs().max().item() <= 1e-5 * pscale       # bias gradients of the penalty are exactly zero
+            else:
+                _close(a, b, "masked penalty_grads[%d]" % i)
+    for i, (a, b) in enumerate(zip(last["summed_grad"], obs["summed_grad"])):
+        _close(a, b, "masked summed_grad[%d]" % i)
+    _close(last["fake_img"], obs["fake_img"], "masked fake_img")
+    # SECONDARY: free-running oracle (its own masks) — losses / norms / factors at 1e-3, gradient tensors in L2 + entry count
+    oracle.max_grad_norm = C0
     run_oracle()
     Cfin = oracle.max_grad_norm
     stds = [opt.sigma * c for c in Cfin] if isinstance(Cfin, list) else [opt.sigma * Cfin] * len(params_o)
@@ -155,7 +200,7 @@ def test_train_D_matches_oracle(tmp_path, dataset, extra, B, latent):
             if b is None or b.abs().max() == 0:
                 assert a is None or a.abs().max().item() < 1e-6
             else:
-                _close_grad(a, b, "penalty_grads[%d]" % i, l2_tol=2e-2)     # L2 only: the per-entry count is not run-to-run stable (see _close_grad)
+                _close_grad(a, b, "penalty_grads[%d]" % i)
     for i, (a, b) in enumerate(zip(last["summed_grad"], obs["summed_grad"])):
         _close_grad(a, b, "summed_grad[%d]" % i)
     for i, (p, b) in enumerate(zip(tr.D.parameters(), grads_o)):
@@ -277,16 +322,32 @@ def test_train_D_immediate_sensitivity_matches_oracle(tmp_path, per_param):
     zs = [torch.randn(p.numel(), generator=torch.Generator().manual_seed(50 + i)) for i, p in enumerate(params_o)]
     tr.explicit = dict(pen_real=ms_p, alpha=alpha, keep=True)
     pe.host_noise = zs
-    tr.train_D(img.cuda(), None, z.cuda(), None, use_dp=True)
+    with _masks(G=tr.G, D=tr.D) as rec:
+        tr.train_D(img.cuda(), None, z.cuda(), None, use_dp=True)
     torch.cuda.synchronize()
+    s_g = np.atleast_1d(np.asarray(pe.batch_sensitivity, dtype=np.float64))
+    # PRIMARY: shared activation masks -> sensitivities and parameter gradients at 1e-3
+    bn_state = {k: v.clone() for k, v in Go.state_dict().items()}
+    with _masked_oracle(rec, G=Go, D=Do) as player:
+        obs = oracle.step(img, None, z, None, pen_real=ms_p, alpha=alpha, apply_update=False)
+        assert player.exhausted()
+    s_o = np.atleast_1d(np.asarray(obs["batch_sensitivity"], dtype=np.float64))
+    assert s_g.shape == s_o.shape == ((len(params_o),) if per_param else (1,))
+    np.testing.assert_allclose(s_g, s_o, rtol=1e-3, atol=1e-6 * s_o.max())
+    gs_is = max(g.abs().max().item() for g in obs["is_param_grads"])
+    for i, (a, b) in enumerate(zip(tr.last["is_param_grads"], obs["is_param_grads"])):
+        if b.abs().max().item() <= 1e-6 * gs_is:
+            assert a.abs().max().item() <= 1e-5 * gs_is
+        else:
+            _close(a, b, "masked IS param grad[%d]" % i)
+    # SECONDARY: free-running oracle
+    Go.load_state_dict(bn_state)            # the BatchNorm generator updated its running statistics in the first oracle step
     obs = oracle.step(img, None, z, None, pen_real=ms_p, alpha=alpha, apply_update=False)
     _close(tr.last["fake_img"], obs["fake_img"], "fake_img (BatchNorm generator)")
     _close(tr.last["d_real_loss"], obs["d_real_loss"], "d_real_loss")
     _close(tr.last["penalty"], obs["penalty"], "penalty")
     s_o = np.atleast_1d(np.asarray(obs["batch_sensitivity"], dtype=np.float64))
-    s_g = np.atleast_1d(np.asarray(pe.batch_sensitivity, dtype=np.float64))
-    assert s_g.shape == s_o.shape == ((len(params_o),) if per_param else (1,))
-    np.testing.assert_allclose(s_g, s_o, rtol=2e-2, atol=1e-7)
+    np.testing.assert_allclose(s_g, s_o, rtol=5e-3, atol=1e-6 * s_o.max())
     sens = np.broadcast_to(s_o, (len(params_o),))
 
     def to_logical(zv, p):
@@ -296,7 +357,7 @@ def test_train_D_immediate_sensitivity_matches_oracle(tmp_path, per_param):
         return zv.view(p.shape)
     for i, (p, go, zv, po) in enumerate(zip(tr.D.parameters(), obs["is_param_grads"], zs, params_o)):
         exp = go + to_logical(zv, po) * (opt.sigma * float(sens[i]) / B)
-        _close_grad(p.grad, exp, "IS noised grad[%d]" % i, l2_tol=2e-2)
+        _close_grad(p.grad, exp, "IS noised grad[%d]" % i, abs_floor=1e-6 * gs_is)
     assert pe.steps == 1
     # running statistics of the BatchNorm generator were updated like torch's
     for (n1, b1), (n2, b2) in zip(G.named_buffers(), Go.named_buffers()):
@@ -306,8 +367,8 @@ def test_train_D_immediate_sensitivity_matches_oracle(tmp_path, per_param):
 
 @pytest.mark.parametrize("dataset,B,latent,mode", [("MNIST", 6, 16, "gc"), ("CelebA", 4, 128, "gc"), ("MNIST", 6, 16, "is")])
 def test_train_G_gradients_match_oracle(tmp_path, dataset, B, latent, mode):
-    """Generator step (train.py:502-517): backward through D's data gradients, the tanh / residual / sub-pixel
-    upsample conv epilogues and GroupNorm (gc) or BatchNorm (is) + ReLU, all on the HIP kernels."""
+    """Generator step (train.py:502-517): backward through D's data gradients, the tanh / residual epilogues, the
+    depth-to-space + folded-filter UpsampleConv and GroupNorm (gc) or BatchNorm (is) + ReLU, all on the HIP kernels."""
     from csl_gan_amd import init_util, options, util
     from csl_gan_amd.trainer import Trainer
     from oracle.nets import build_models
@@ -320,22 +381,34 @@ def test_train_G_gradients_match_oracle(tmp_path, dataset, B, latent, mode):
     Go, Do = build_models(dataset=dataset, model=opt.model, im_size=opt.im_size, weights_seed=opt.weights_seed, manual_seed=1,
                           per_sample_grad=(mode == "gc"), g_latent_dim=latent)
     z = torch.randn(B, latent, generator=torch.Generator().manual_seed(31))
-    lo = Go.loss(Do(Go(z))[0])
-    go = torch.autograd.grad(lo, list(Go.parameters()))
     util.zero_grad(G)
     util.freeze(D)
-    d_fake, _, img = tr.eval_G_D(z.cuda(), None)
+    with _masks(G=G, D=D) as rec:
+        d_fake, _, img = tr.eval_G_D(z.cuda(), None)
     loss = G.loss(d_fake, "cuda:0")
     loss.backward()
     util.unfreeze(D)
-    _close(loss, lo, "G loss")
+    # PRIMARY: the oracle replays the HIP run's ReLU / LeakyReLU masks -> every gradient entry at 1e-3 of the tensor's scale
+    g_state = {k: v.clone() for k, v in Go.state_dict().items()}
+    with _masked_oracle(rec, G=Go, D=Do) as player:
+        lo = Go.loss(Do(Go(z))[0])
+        assert player.exhausted()
+    go = torch.autograd.grad(lo, list(Go.parameters()))
+    _close(loss, lo, "masked G loss")
     gscale = max(g.abs().max().item() for g in go)
     for (n, p), g in zip(G.named_parameters(), go):
         assert p.grad is not None, n
-        # every ReLU of G and LeakyReLU of D sits between the loss and these gradients, so a handful of flipped
-        # units perturbs EVERY upstream entry at the 1e-3 level: only the L2 bound is meaningful here; the
-        # activation-free variant below checks the same wiring to 1e-4
-        _close_grad(p.grad, g, "dL/d " + n, l2_tol=1e-2, frac_tol=1.0, abs_floor=1e-6 * gscale)
+        if g.abs().max().item() <= 1e-6 * gscale:       # a bias feeding a BatchNorm: exactly zero, rounding noise on both sides
+            assert p.grad.abs().max().item() <= 1e-5 * gscale, n
+        else:
+            _close(p.grad, g, "masked dL/d " + n)
+    # SECONDARY: free-running oracle (its own masks): L2 and entry-count bounds
+    Go.load_state_dict(g_state)
+    lo = Go.loss(Do(Go(z))[0])
+    go = torch.autograd.grad(lo, list(Go.parameters()))
+    _close(loss, lo, "G loss")
+    for (n, p), g in zip(G.named_parameters(), go):
+        _close_grad(p.grad, g, "dL/d " + n, l2_tol=1e-2, abs_floor=1e-6 * gscale)
     # and the full train_G call updates the generator
     before = [p.detach().clone() for p in G.parameters()]
     tr.train_G(z.cuda(), None)
@@ -407,7 +480,7 @@ def test_train_D_bf16_grad_sample_storage(tmp_path):
     n_o = obs["norms"]
     _close(tr.last["norms"].reshape(9, -1), n_o.reshape(9, -1), "per-sample norms (bf16 storage)", rtol=5e-3)
     for i, (a, b) in enumerate(zip(tr.last["summed_clipped"], obs["summed_clipped"])):
-        _close_grad(a, b, "summed_clipped[%d] (bf16 storage)" % i, l2_tol=1e-2, frac_tol=1.0)
+        _close_grad(a, b, "summed_clipped[%d] (bf16 storage)" % i, l2_tol=1e-2)
 
 
 @pytest.mark.parametrize("dataset,extra,B,latent", [
@@ -451,11 +524,22 @@ def test_train_D_conditional_matches_oracle(tmp_path, dataset, extra, B, latent)
     ms_a, ms_p = torch.rand(B, ch, im, im, generator=g) - 0.5, torch.rand(B, ch, im, im, generator=g) - 0.5
     z, alpha = torch.randn(B, latent, generator=g), torch.rand(B, generator=g)
     tr.explicit = dict(ms_adapt=ms_a, ms_adapt_labels=labels, pen_real=ms_p, alpha=alpha, keep=True)
-    tr.train_D(img.cuda(), labels.cuda(), z.cuda(), labels.cuda(), use_dp=True)
+    with _masks(G=tr.G, D=tr.D) as rec:
+        tr.train_D(img.cuda(), labels.cuda(), z.cuda(), labels.cuda(), use_dp=True)
     torch.cuda.synchronize()
-    obs = oracle.step(img, labels, z, labels, ms_adapt=ms_a, ms_adapt_labels=labels, pen_real=ms_p if opt.penalty else None,
-                      pen_labels=labels, alpha=alpha, apply_update=False)
     last = tr.last
+    C0 = oracle.max_grad_norm
+
+    def run_oracle():
+        return oracle.step(img, labels, z, labels, ms_adapt=ms_a, ms_adapt_labels=labels, pen_real=ms_p if opt.penalty else None,
+                           pen_labels=labels, alpha=alpha, apply_update=False)
+    with _masked_oracle(rec, G=Go, D=Do) as player:          # PRIMARY: shared activation masks, per entry at 1e-3
+        obs = run_oracle()
+        assert player.exhausted()
+    for i, (a, b) in enumerate(zip(last["summed_grad"], obs["summed_grad"])):
+        _close(a, b, "masked summed_grad[%d]" % i)
+    oracle.max_grad_norm = C0
+    obs = run_oracle()                                        # SECONDARY: free-running
     _close(last["fake_img"], obs["fake_img"], "conditional generator forward")
     _close(last["d_real_loss"], obs["d_real_loss"], "d_real_loss")
     _close(last["d_fake_loss"], obs["d_fake_loss"], "d_fake_loss")

@@ -56,8 +56,8 @@ def _check_models(tmp_path, golden_dir, name, argv, latent, device, tol, grad_l2
     assert bool(z["meta"][5]) == bool(opt.per_sample_grad)
     # init_util.py:63-69: same parameter names, order and values as the reference classes under weights_seed
     assert [n for n, _ in G.named_parameters()] == list(z["g_param_names"])
-    np.testing.assert_allclose([p.detach().cpu().norm().item() for p in G.parameters()], z["g_weight_norms"], rtol=1e-5)
-    np.testing.assert_allclose([p.detach().cpu().norm().item() for p in D.parameters()], z["d_weight_norms"], rtol=1e-5)
+    np.testing.assert_allclose([p.detach().cpu().double().norm().item() for p in G.parameters()], z["g_weight_norms"], rtol=1e-5)
+    np.testing.assert_allclose([p.detach().cpu().double().norm().item() for p in D.parameters()], z["d_weight_norms"], rtol=1e-5)
     zz = torch.from_numpy(z["z"]).to(device)
     real = torch.from_numpy(z["real"]).to(device)
     y = torch.from_numpy(z["labels"]).to(device) if ncls else None
@@ -129,7 +129,7 @@ def test_hip_gradient_penalty_matches_reference_vectors(tmp_path, golden_dir, na
     from csl_gan_amd.gradient_penalty import calc_penalty
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     opt, _, D = _build(tmp_path, argv, 128, "cuda:0", init_G=False)      # the fixture's D was built alone (make_golden.gp_case)
-    np.testing.assert_allclose([p.detach().cpu().norm().item() for p in D.parameters()], z["weight_norms"], rtol=1e-5)
+    np.testing.assert_allclose([p.detach().cpu().double().norm().item() for p in D.parameters()], z["weight_norms"], rtol=1e-5)
     real, fake = torch.from_numpy(z["real"]).cuda(), torch.from_numpy(z["fake"]).cuda()
     labels = torch.from_numpy(z["labels"]).cuda() if "labels" in z.files else None
     alpha = torch.from_numpy(z["alpha"])

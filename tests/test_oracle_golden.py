@@ -30,7 +30,7 @@ def test_penalty_matches_reference(golden_dir, name, dataset, im, one_sided, con
     _, D = build_models(dataset=dataset, model="DeepConvResNet", im_size=im, weights_seed=42, manual_seed=1,
                         init_G=False, conditional=cond, n_classes=10 if dataset == "MNIST" else 2)
     # weight-init parity with the build that produced the fixture
-    np.testing.assert_allclose([p.norm().item() for p in D.parameters()], z["weight_norms"], rtol=1e-6)
+    np.testing.assert_allclose([p.detach().double().norm().item() for p in D.parameters()], z["weight_norms"], rtol=1e-6)
     real, fake = torch.from_numpy(z["real"]), torch.from_numpy(z["fake"])
     labels = torch.from_numpy(z["labels"]) if cond else None
     alpha = torch.from_numpy(z["alpha"])
@@ -41,7 +41,7 @@ def test_penalty_matches_reference(golden_dir, name, dataset, im, one_sided, con
     pen = OP.calc_penalty(D, ptype, real, labels, fake, alpha, aux_penalty=bool(z["meta"][5]))
     assert pen.item() == pytest.approx(float(z["penalty"]), rel=1e-5, abs=1e-7)
     grads = torch.autograd.grad(pen, list(D.parameters()), allow_unused=True)
-    norms = np.array([0.0 if g is None else g.norm().item() for g in grads])
+    norms = np.array([0.0 if g is None else g.double().norm().item() for g in grads])
     np.testing.assert_allclose(norms, z["grad_norms"], rtol=1e-4, atol=1e-7)
     heads = np.stack([np.zeros(8, np.float32) if g is None else g.reshape(-1)[:8].numpy() for g in grads])
     np.testing.assert_allclose(heads, z["grad_heads"], rtol=1e-3, atol=1e-6)
@@ -106,8 +106,8 @@ def test_model_stacks_match_reference_classes(golden_dir, name, dataset, model, 
     G, D = build_models(dataset=dataset, model=model, im_size=im, weights_seed=42, manual_seed=1, g_latent_dim=latent, **kw)
     # init order / seeding (init_util.py:63-69): every parameter tensor of G and D
     assert [n for n, _ in G.named_parameters()] == list(z["g_param_names"])
-    np.testing.assert_allclose([p.norm().item() for p in G.parameters()], z["g_weight_norms"], rtol=1e-6)
-    np.testing.assert_allclose([p.norm().item() for p in D.parameters()], z["d_weight_norms"], rtol=1e-6)
+    np.testing.assert_allclose([p.detach().double().norm().item() for p in G.parameters()], z["g_weight_norms"], rtol=1e-6)
+    np.testing.assert_allclose([p.detach().double().norm().item() for p in D.parameters()], z["d_weight_norms"], rtol=1e-6)
     zz, real = torch.from_numpy(z["z"]), torch.from_numpy(z["real"])
     y = torch.from_numpy(z["labels"]) if ncls else None
     fake = G(zz, y)
@@ -123,7 +123,7 @@ def test_model_stacks_match_reference_classes(golden_dir, name, dataset, model, 
         total = total + D.aux_loss(d_fake_aux, y)
     assert total.item() == pytest.approx(float(z["g_total_loss"]), abs=1e-6)
     grads = torch.autograd.grad(total, list(G.parameters()), allow_unused=True)
-    norms = np.array([0.0 if g is None else g.norm().item() for g in grads])
+    norms = np.array([0.0 if g is None else g.double().norm().item() for g in grads])
     np.testing.assert_allclose(norms, z["g_grad_norms"], rtol=1e-4, atol=1e-9)
     for g, head, nrm in zip(grads, z["g_grad_heads"], z["g_grad_norms"]):
         if g is not None:

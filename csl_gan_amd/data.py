@@ -10,6 +10,7 @@ import os
 
 import torch
 from torch.utils.data import DataLoader, TensorDataset
+from torch.utils.data.distributed import DistributedSampler
 
 
 class SyntheticImages(TensorDataset):
@@ -31,7 +32,21 @@ class SyntheticImages(TensorDataset):
         return x[i], int(y[i])
 
 
-def init_real_data(opt):
+def _private_loader(ds, opt, rank, world, **kw):
+    """The loader over the PRIVATE training set.  One process: the reference's DataLoader(shuffle=True).  --dist: every
+    rank draws from its own disjoint 1/world share of a shared per-epoch permutation (DistributedSampler seeded with the
+    same seed on every rank; call loader.sampler.set_epoch(epoch)), so a private sample is seen by exactly one rank per
+    epoch and the global batch of a step is world x batch_size DISTINCT samples — what the accountant's sample rate
+    q = world * batch_size / N (engine.PrivacyEngine.sample_rate) assumes."""
+    if world <= 1:
+        return DataLoader(ds, batch_size=opt.batch_size, shuffle=True, **kw)
+    sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=int(getattr(opt, "dist_data_seed", 0)),
+                                 drop_last=True)
+    kw.pop("drop_last", None)
+    return DataLoader(ds, batch_size=opt.batch_size, sampler=sampler, drop_last=True, **kw)
+
+
+def init_real_data(opt, rank=0, world=1):
     """init_util.init_data (init_util.py:13-42) on the real files: returns (dataset, loader, public set, loader)."""
     from . import datasets as ds
     pub = None
@@ -44,20 +59,20 @@ def init_real_data(opt):
         if opt.public_set_size > 0:
             pub = ds.CelebADataset(opt.data_path, im_size=opt.im_size, length=opt.public_set_size, offset=opt.train_set_size,
                                    attr_file=opt.label_path, attr=opt.label_attr)
-    dl = DataLoader(data, num_workers=opt.num_workers, pin_memory=torch.cuda.is_available(), batch_size=opt.batch_size, shuffle=True)
+    dl = _private_loader(data, opt, rank, world, num_workers=opt.num_workers, pin_memory=torch.cuda.is_available())
     pdl = DataLoader(pub, batch_size=opt.batch_size, num_workers=opt.num_workers, shuffle=True) if pub is not None else None
     return data, dl, pub, pdl
 
 
-def init_data(opt):
+def init_data(opt, rank=0, world=1):
     """Real files when --data_path exists and --synthetic is not given; otherwise the synthetic counterpart of
-    init_util.init_data: same return tuple, shuffle=True loaders."""
+    init_util.init_data: same return tuple, shuffle=True loaders (rank-partitioned under --dist, see _private_loader)."""
     if not getattr(opt, "synthetic", False) and opt.data_path and os.path.isdir(opt.data_path):
-        return init_real_data(opt)
+        return init_real_data(opt, rank, world)
     n = min(opt.train_set_size, getattr(opt, "synthetic_cap", 4096))
     ds = SyntheticImages(opt.dataset, n, opt.im_size, seed=opt.manual_seed)
     pub = SyntheticImages(opt.dataset, min(opt.public_set_size, 2048), opt.im_size, seed=opt.manual_seed, offset=1) \
         if opt.public_set_size > 0 else None
-    dl = DataLoader(ds, batch_size=opt.batch_size, shuffle=True, drop_last=True, num_workers=0)
+    dl = _private_loader(ds, opt, rank, world, drop_last=True, num_workers=0)
     pdl = DataLoader(pub, batch_size=opt.batch_size, shuffle=True, num_workers=0) if pub is not None else None
     return ds, dl, pub, pdl

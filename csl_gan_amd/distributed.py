@@ -65,6 +65,21 @@ def average_across_ranks(t: torch.Tensor, use_max=False, group=None):
     return t
 
 
+def broadcast_object(obj, src=0):
+    """A small picklable host object from rank `src` to every rank (seeds, the mean-sample tensor's shape)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        box = [obj]
+        dist.broadcast_object_list(box, src=src)
+        return box[0]
+    return obj
+
+
+def broadcast_tensor(t, src=0):
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(t, src=src)
+    return t
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         if dist.get_backend() == "nccl":      # name the device: RCCL otherwise guesses it from the rank

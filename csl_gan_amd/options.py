@@ -10,6 +10,8 @@ Additions of this build (all optional, none changes a reference default):
   --fuse_passes B      run the adaptive / generated / real discriminator passes as one forward+backward over the
                        concatenated batch (same numbers, fewer and fuller launches); needs --materialize private|ghost
   --grad_sample_dtype  storage type of the materialised per-sample weight gradients (fp32 | bf16; fp32 accumulate)
+  --moving_avg_beta B  the smoothing factor train.py:249 reads as opt.moving_avg_beta but options.py never defines
+                       (imm_sens_scaling_mode=moving-avg-pl raises AttributeError in the reference without it)
   --materialize M      per-sample gradients kept in HBM: "all" passes (the fork's p.grad_sample layout) or only
                        the "private" (clipped) passes; "ghost" additionally never materialises layers with few
                        output pixels (Gram norms + clip-weighted dense wgrad) — see csl_gan_amd.engine.PrivacyEngine
@@ -153,6 +155,7 @@ _ARGS = [
     (("--materialize",), dict(type=str, choices=["all", "private", "ghost"], default="ghost")),
     (("--fuse_passes",), dict(type=str2bool, default=True)),
     (("--grad_sample_dtype",), dict(type=str, choices=["fp32", "bf16"], default="fp32")),
+    (("--moving_avg_beta",), dict(type=float, default=None)),
 ]
 ALWAYS_KEEP = ["g_device", "d_device", "num_workers", "resume_path", "resume_epochs"]
 

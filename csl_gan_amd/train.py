@@ -17,10 +17,21 @@ from .mean_sampler import MeanSampler
 from .trainer import Trainer
 
 
-def build_mean_sampler(opt, dataset):
-    """train.py:53-73."""
+def build_mean_sampler(opt, dataset, rank=0, world=1):
+    """train.py:53-73.  --dist: the mean samples are a DP release of the private data, paid for once in the privacy cost —
+    so they are built ONCE (rank 0, over the whole private set) and broadcast; every rank then perturbs the same released
+    samples (post-processing)."""
     if opt.num_mean_samples <= 0:
         return None, 0.0
+    if world > 1 and rank != 0:
+        n_cls = opt.n_classes if opt.conditional else 1
+        ms = MeanSampler(noise_std=opt.mean_sample_noise_std, num_samples=opt.num_mean_samples, mean_size=opt.mean_sample_size,
+                         dataset_size=opt.train_set_size, default_batch_size=opt.batch_size, n_classes=n_cls, res=opt.im_size,
+                         ch=1 if opt.dataset == "MNIST" else 3, device=opt.d_device)
+        shape = dist_util.broadcast_object(None)
+        ms.mean_samples = dist_util.broadcast_tensor(torch.empty(shape, device=opt.d_device))
+        cost = dist_util.broadcast_object(None)
+        return ms, cost
     print("Generating mean samples...")
     keep = opt.batch_size
     n_cls = opt.n_classes if opt.conditional else 1
@@ -38,6 +49,11 @@ def build_mean_sampler(opt, dataset):
                      ch=1 if opt.dataset == "MNIST" else 3, device=opt.d_device)
     cost, _ = ms.get_privacy_cost(target_delta=opt.delta)
     print("Privacy Cost from Mean Samples:", cost)
+    if world > 1:
+        ms.mean_samples = ms.mean_samples.to(opt.d_device).contiguous()
+        dist_util.broadcast_object(tuple(ms.mean_samples.shape))
+        dist_util.broadcast_tensor(ms.mean_samples)
+        dist_util.broadcast_object(cost)
     return ms, cost
 
 
@@ -52,17 +68,26 @@ def main(argv=None):
     world, rank, local = dist_util.init() if getattr(opt, "dist", False) else (1, 0, 0)
     if world > 1:
         opt.g_device = opt.d_device = "cuda:%d" % local
-    with open(opt.output_dir + "opt.txt", "w") as f:
-        json.dump(opt.__dict__, f)
+        # one seed for the shared data permutation (--manual_seed -1 draws a different seed in every process)
+        opt.dist_data_seed = dist_util.broadcast_object(int(opt.manual_seed))
+    if rank == 0:
+        with open(opt.output_dir + "opt.txt", "w") as f:
+            json.dump(opt.__dict__, f)
 
     G, D = init_util.init_models(opt)
     if not getattr(opt, "synthetic", False) and not os.path.isdir(opt.data_path or ""):
         print("data_path %r not found: using the synthetic dataset (--synthetic)" % opt.data_path)
-    dataset, dataloader, public_dataset, public_dataloader = syn_data.init_data(opt)
-    mean_sampler, mean_cost = build_mean_sampler(opt, dataset)
+    dataset, dataloader, public_dataset, public_dataloader = syn_data.init_data(opt, rank, world)
+    mean_sampler, mean_cost = build_mean_sampler(opt, dataset, rank, world)
+    if world > 1:
+        # init_models left every rank on the same RNG state: z, penalty alpha and mean-sample jitter must differ per rank
+        # (the private batches already do, through the partitioned sampler)
+        torch.manual_seed(int(opt.dist_data_seed) + 7919 * rank)
+        torch.cuda.manual_seed(int(opt.dist_data_seed) + 7919 * rank)
     reducer = dist_util.FlatGradReducer() if world > 1 else None
     tr = Trainer(opt, G, D, dataset=dataset, public_dataloader=public_dataloader, public_dataset=public_dataset,
-                 mean_sampler=mean_sampler, world_size=world, rank=rank, grad_reducer=reducer)
+                 mean_sampler=mean_sampler, world_size=world, rank=rank, grad_reducer=reducer,
+                 log_to=None if rank == 0 else opt.output_dir + "log_rank%d.csv" % rank)
 
     start_epoch = 0
     if opt.resume_epochs > 0:
@@ -90,12 +115,28 @@ def main(argv=None):
             with open(pe_path) as f:
                 pe.load_state_dict(json.load(f))
 
+    # train.py:555-563, 538-539: -p wraps the training loop in torch.profiler (wait 1 / warm-up 1 / active 5 steps, one
+    # profiler.step() per batch) and prints the key-averages table sorted by self CPU time, row_limit = n_classes
+    profiler = None
+    if opt.profile_training:
+        from torch.profiler import ProfilerActivity, profile, schedule
+
+        def trace_handler(p):
+            print(p.key_averages().table(sort_by="self_cpu_time_total", row_limit=opt.n_classes))
+        acts = [ProfilerActivity.CPU] + ([ProfilerActivity.CUDA] if torch.cuda.is_available() else [])
+        profiler = profile(activities=acts, schedule=schedule(wait=1, warmup=1, active=5), on_trace_ready=trace_handler)
+        profiler.__enter__()
+
     iters, epoch, eps = 0, start_epoch, 0.0
     for epoch in range(opt.resume_epochs, opt.n_epochs):
         tr.reset_stats()
+        if hasattr(dataloader.sampler, "set_epoch"):
+            dataloader.sampler.set_epoch(epoch)        # --dist: a new shared permutation, still disjoint across ranks
         batch_i = 0
         for batch_i, (img, labels) in enumerate(dataloader):
             tr.train(epoch, batch_i, img, labels, use_dp=opt.use_dp)
+            if profiler is not None:
+                profiler.step()
             iters += 1
             if opt.max_iters and iters >= opt.max_iters:
                 break
@@ -115,6 +156,8 @@ def main(argv=None):
         if opt.max_iters and iters >= opt.max_iters:
             break
 
+    if profiler is not None:
+        profiler.__exit__(None, None, None)
     print("Finished training.")
     if rank == 0:
         util.save_model(opt.n_epochs, D, tr.d_optimizer, 0, opt.output_dir + "saves/D-" + str(epoch + 1))

@@ -191,6 +191,20 @@ class Trainer:
         self._acc("Grads Clipped", (fac < 0.999).float().mean(dim=1))
         self.last.update(norms=norms, clip_factors=f, clip_params=pe.max_grad_norm_device().clone())
 
+    # ---- train.py:247-249 ---------------------------------------------------------------------
+    def update_sens_moving_avg(self):
+        """--imm_sens_scaling_mode moving-avg-pl: scaling_vec <- beta * scaling_vec + (1 - beta) * ||p.grad||_2 per tensor.
+        The reference reads opt.moving_avg_beta, which options.py never defines (train.py:249 raises AttributeError), so the
+        mode cannot run there; here --moving_avg_beta (a build extension) supplies it and its absence is reported as such."""
+        o, pe = self.opt, self.privacy_engine
+        beta = getattr(o, "moving_avg_beta", None)
+        if beta is None:
+            raise AttributeError("imm_sens_scaling_mode=moving-avg-pl needs opt.moving_avg_beta, which the reference's options.py "
+                                 "never defines (train.py:249 fails the same way); pass --moving_avg_beta")
+        vec = pe.scaling_vec
+        norms = [0.0 if p.grad is None else float(p.grad.reshape(-1).norm(2)) for p in self.D.parameters()]
+        pe.set_scaling_vec([vec[i] * beta + n * (1 - beta) for i, n in enumerate(norms)])
+
     def update_is_logging(self):
         s = self.privacy_engine.batch_sensitivity
         lg = self.logger
@@ -345,6 +359,8 @@ class Trainer:
                 d_loss = d_loss + penalty
                 if use_imm_sens:
                     pe.backward(d_loss, img)
+                    if o.imm_sens_scaling_mode == "moving-avg-pl":
+                        self.update_sens_moving_avg()
                     self.update_is_logging()
                     if self.explicit.get("keep"):
                         self.last["is_param_grads"] = [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in D.parameters()]
@@ -355,7 +371,10 @@ class Trainer:
                 pe.accumulate_batch()
             elif use_imm_sens:
                 pe.backward(d_loss, img)
-                self.update_is_logging()
+                if o.imm_sens_scaling_mode == "moving-avg-pl":
+                    self.update_sens_moving_avg()
+                else:
+                    self.update_is_logging()
             else:
                 d_loss.backward()
 
@@ -445,6 +464,12 @@ class Trainer:
 
     def log(self, epoch, epoch_progress, print_dp=False):
         self.flush_stats()
+        if self.rank != 0:          # --dist: every rank keeps its own CSV (log_rank<r>.csv); only rank 0 prints
+            import contextlib
+            import os
+            with open(os.devnull, "w") as null, contextlib.redirect_stdout(null):
+                self.logger.log(epoch, epoch_progress)
+            return
         self.logger.log(epoch, epoch_progress)
         pe = self.privacy_engine
         if print_dp and pe is not None and pe.steps > 0:

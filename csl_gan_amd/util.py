@@ -20,7 +20,9 @@ def save_model(epoch, model, optimizer, loss, path):
 
 
 def load_model(path, model, device, optimizer=None):
-    ckpt = torch.load(path, map_location=device, weights_only=False)
+    """util.py:36-42.  The dict holds tensors, ints and the optimizer state_dict only, so the no-code loader suffices:
+    a reference-trained or third-party checkpoint is never unpickled with arbitrary-code execution."""
+    ckpt = torch.load(path, map_location=device, weights_only=True)
     model.load_state_dict(ckpt["model_state_dict"])
     if optimizer is not None:
         optimizer.load_state_dict(ckpt["optimizer_state_dict"])

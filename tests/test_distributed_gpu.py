@@ -1,0 +1,123 @@
+"""The N > 1 path through the REAL engine (-m gpu): two ranks (gloo, both on cuda:0 — the box has one GPU) drive
+Trainer.train_D -> PrivacyEngine._before_step -> FlatGradReducer with world_size=2 on their own shards; the reduced
+gradient must equal ONE process running the concatenated batch:
+
+    rank r:  (sum_b f_b g_b + B*pen_grad_r + (sigma*C/sqrt(R)) z_r) / (B*R)   --all-reduce(SUM)-->
+    single:  (sum over all 2B samples + 2B*pen_grad + sigma*C * (z_0 + z_1)/sqrt(2)) / (2B)
+
+with the adaptive clip statistics averaged across ranks (mean over the global batch), the accountant told the GLOBAL
+sample rate, rank-keyed Philox seeds, and — immediate-sensitivity mode — the batch maximum taken over all ranks' samples
+(all-reduce MAX) before the noise is scaled.  SURVEY.md §8(e); csl_gan_amd/distributed.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+BL, LATENT = 4, 16
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _inputs(world):
+    g = torch.Generator().manual_seed(123)
+    n = world * BL
+    return dict(img=torch.rand(n, 1, 28, 28, generator=g), ms_a=torch.rand(n, 1, 28, 28, generator=g) * 0.6,
+                ms_p=torch.rand(n, 1, 28, 28, generator=g) * 0.6, z=torch.randn(n, LATENT, generator=g), alpha=torch.rand(n, generator=g))
+
+
+def _trainer(out, mode, B, world, rank, reducer):
+    from csl_gan_amd import init_util, options
+    from csl_gan_amd.trainer import Trainer
+    extra = ["-gcm", "adaptive-pl", "--materialize", "all"] if mode == "gc" else ["-ispp", "True"]
+    opt = options.parse(["MNIST", "--model", "DeepConvResNet", "-dpm", mode, "-nms", "4", "-bs", str(B), "-gd", "cuda:0", "-dd", "cuda:0",
+                         "-o", out, "--manual_seed", "1", "--g_latent_dim", str(LATENT), "--sigma", "0.8", "--penalty", "WGAN-GP"] + extra)
+    G, D = init_util.init_models(opt)
+    tr = Trainer(opt, G, D, log_to=os.path.join(out, "log%d.csv" % rank), world_size=world, rank=rank, grad_reducer=reducer)
+    pe = tr.setup_privacy_engine()
+    return opt, tr, pe, D
+
+
+def _noise(D, rank):
+    return [torch.randn(p.numel(), generator=torch.Generator().manual_seed(1000 + 17 * rank + i)) for i, p in enumerate(D.parameters())]
+
+
+def _step(tr, pe, D, inp, sl, noise):
+    tr.explicit = dict(ms_adapt=inp["ms_a"][sl], pen_real=inp["ms_p"][sl], alpha=inp["alpha"][sl], keep=True)
+    pe.host_noise = noise
+    tr.train_D(inp["img"][sl].cuda(), None, inp["z"][sl].cuda(), None, use_dp=True)
+    torch.cuda.synchronize()
+    return torch.cat([p.grad.detach().reshape(-1).cpu() for p in D.parameters()])
+
+
+def _worker(rank, world, port, out, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    from csl_gan_amd import distributed as Dist
+    w, r, _ = Dist.init("gloo")
+    assert (w, r) == (world, rank)
+    red = Dist.FlatGradReducer()
+    opt, tr, pe, D = _trainer(os.path.join(out, "r%d" % rank), mode, BL, world, rank, red)
+    assert pe.world_size == world and pe.grad_reducer is red
+    assert pe.sample_rate == pytest.approx(world * BL / opt.train_set_size)         # the accountant sees the GLOBAL batch
+    inp = _inputs(world)
+    flat = _step(tr, pe, D, inp, slice(rank * BL, (rank + 1) * BL), _noise(D, rank))
+    assert red.bytes_reduced == flat.numel() * 4 and pe.steps == 1
+    res = {"grad": flat.numpy(), "seed": pe.seed}
+    if mode == "gc":
+        res["C"] = np.asarray(pe.max_grad_norm, dtype=np.float64)
+    else:
+        res["sens"] = np.asarray(pe.batch_sensitivity, dtype=np.float64)
+    np.savez(os.path.join(out, "rank%d.npz" % rank), **res)
+    Dist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64).reshape(-1), np.asarray(b, dtype=np.float64).reshape(-1)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def test_two_rank_gc_step_equals_one_process_on_the_concatenated_batch(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "gc"), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["grad"], r1["grad"]), "ranks hold different gradients after the all-reduce"
+    assert np.array_equal(r0["C"], r1["C"]), "ranks clipped with different adaptive norms"
+    assert int(r0["seed"]) != int(r1["seed"]), "Philox streams must be keyed by rank"
+    # one process, global batch; its unit normals are the ranks' normals summed / sqrt(R)
+    opt, tr, pe, D = _trainer(str(tmp_path / "single"), "gc", world * BL, 1, 0, None)
+    z = [(a + b) / world ** 0.5 for a, b in zip(_noise(D, 0), _noise(D, 1))]
+    ref = _step(tr, pe, D, _inputs(world), slice(0, world * BL), z).numpy()
+    assert _rel(r0["C"], np.asarray(pe.max_grad_norm)) <= 1e-4
+    off = 0
+    for n, p in D.named_parameters():              # per tensor, against its own scale
+        seg = slice(off, off + p.numel())
+        off += p.numel()
+        assert _rel(r0["grad"][seg], ref[seg]) <= 1e-3, "%s: %.3e" % (n, _rel(r0["grad"][seg], ref[seg]))
+
+
+def test_two_rank_immediate_sensitivity_takes_the_maximum_over_all_ranks(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "is"), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["grad"], r1["grad"]) and np.array_equal(r0["sens"], r1["sens"])
+    # each shard alone (world 1): its local sensitivities; the distributed value must be their element-wise maximum
+    local = []
+    inp = _inputs(world)
+    for r in range(world):
+        opt, tr, pe, D = _trainer(str(tmp_path / ("solo%d" % r)), "is", BL, 1, r, None)
+        _step(tr, pe, D, inp, slice(r * BL, (r + 1) * BL), _noise(D, r))
+        local.append(np.asarray(pe.batch_sensitivity, dtype=np.float64))
+    assert _rel(r0["sens"], np.maximum(local[0], local[1])) <= 1e-3
+    assert (np.abs(local[0] - local[1]) > 1e-3 * np.abs(local[0]).max()).any(), "shards should differ for the test to mean anything"

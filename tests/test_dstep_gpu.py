@@ -292,31 +292,34 @@ def test_double_backward_wiring_without_activations():
             _close(a, b, "d penalty / d param %d" % i, rtol=1e-4)
 
 
-@pytest.mark.parametrize("per_param", [True, False])
-def test_train_D_immediate_sensitivity_matches_oracle(tmp_path, per_param):
+@pytest.mark.parametrize("dataset,per_param,B,latent", [("MNIST", True, 6, 16), ("MNIST", False, 6, 16),
+                                                        # BASELINE configs[3]: CelebA DCResNet WGAN-GP dp_mode=is -ispp True
+                                                        ("CelebA", True, 4, 128)])
+def test_train_D_immediate_sensitivity_matches_oracle(tmp_path, dataset, per_param, B, latent):
     """dp_mode=is (train.py:375, 453-460): BatchNorm generator forward on HIP, parameter gradients with
     create_graph, one double-backward sweep per sensitivity, noise scaled by the batch sensitivity."""
     from csl_gan_amd import init_util, options
     from csl_gan_amd.trainer import Trainer
     from oracle.dstep import OracleDStep, StepConfig
     from oracle.nets import build_models
-    B, latent = 6, 16
-    argv = ["MNIST", "--model", "DeepConvResNet", "-dpm", "is", "-nms", "4", "-bs", str(B), "-gd", "cuda:0", "-dd", "cuda:0",
-            "-o", str(tmp_path), "--manual_seed", "1", "--g_latent_dim", str(latent), "--sigma", "0.5", "--penalty", "WGAN-GP",
-            "-ispp", "True" if per_param else "False"]
+    extra = ["--model", "DeepConvResNet", "--penalty", "WGAN-GP"] if dataset == "MNIST" else []
+    argv = [dataset, "-dpm", "is", "-nms", "4", "-bs", str(B), "-gd", "cuda:0", "-dd", "cuda:0",
+            "-o", str(tmp_path), "--manual_seed", "1", "--g_latent_dim", str(latent), "--sigma", "0.5",
+            "-ispp", "True" if per_param else "False"] + extra
     opt = options.parse(argv)
-    assert opt.imm_sens_per_param == per_param and not opt.per_sample_grad
+    assert opt.imm_sens_per_param == per_param and not opt.per_sample_grad and list(opt.penalty) == ["WGAN-GP"]
     G, D = init_util.init_models(opt)
     tr = Trainer(opt, G, D, log_to=str(tmp_path / "log.csv"))
     pe = tr.setup_privacy_engine()
-    Go, Do = build_models(dataset="MNIST", model="DeepConvResNet", im_size=28, weights_seed=42, manual_seed=1,
+    Go, Do = build_models(dataset=dataset, model="DeepConvResNet", im_size=opt.im_size, weights_seed=42, manual_seed=1,
                           per_sample_grad=False, g_latent_dim=latent)
     cfg = StepConfig(dp_mode="is", sigma=0.0, penalty=("WGAN-GP",), lr=opt.d_lr, adam_b1=opt.adam_b1, adam_b2=opt.adam_b2,
                      imm_sens_per_param=per_param, imm_sens_scaling_vec=None)
     oracle = OracleDStep(Go, Do, cfg)
     g = torch.Generator().manual_seed(21)
-    img = torch.rand(B, 1, 28, 28, generator=g)
-    ms_p = torch.rand(B, 1, 28, 28, generator=g)
+    ch, im = (1, 28) if dataset == "MNIST" else (3, 64)
+    img = torch.rand(B, ch, im, im, generator=g) * (1 if dataset == "MNIST" else 2) - (0 if dataset == "MNIST" else 1)
+    ms_p = torch.rand(B, ch, im, im, generator=g) * 0.6
     z, alpha = torch.randn(B, latent, generator=g), torch.rand(B, generator=g)
     params_o = list(Do.parameters())
     zs = [torch.randn(p.numel(), generator=torch.Generator().manual_seed(50 + i)) for i, p in enumerate(params_o)]

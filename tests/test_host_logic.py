@@ -134,8 +134,72 @@ def test_cli_config0_mnist_vanilla_cpu_no_dp(tmp_path):
     vals = [float(v) for v in rows[1].split(",")[2:]]
     assert all(np.isfinite(vals)) and 0 < vals[1] < 5
     assert os.path.exists(str(tmp_path / "saves" / "D-1")) and os.path.exists(str(tmp_path / "opt.txt"))
-    ck = torch.load(str(tmp_path / "saves" / "D-1"), weights_only=False)
+    ck = torch.load(str(tmp_path / "saves" / "D-1"), weights_only=True)       # the no-code loader reads our checkpoints
     assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss"}
+    # resume through util.load_model (weights_only=True inside): weights and Adam state come back
+    from csl_gan_amd import util
+    from csl_gan_amd.MNIST_models import MNISTVanillaD
+    from csl_gan_amd.engine import HipAdam
+    D2 = MNISTVanillaD()
+    opt2 = HipAdam(D2.parameters(), lr=1e-3)
+    assert util.load_model(str(tmp_path / "saves" / "D-1"), D2, "cpu", opt2) == ck["epoch"]
+    for a, b in zip(D2.parameters(), tr.D.parameters()):
+        assert torch.equal(a, b)
+    assert len(opt2.state_dict()["state"]) == len(list(D2.parameters()))
+
+
+def test_cli_profile_flag_runs_torch_profiler(tmp_path, capsys):
+    """-p (train.py:555-563): the loop runs under torch.profiler and the key-averages table is printed."""
+    from csl_gan_amd import train
+    train.main(["MNIST", "-bs", "16", "-gd", "cpu", "-dd", "cpu", "-o", str(tmp_path), "--max_iters", "9", "--synthetic",
+                "--log_every", "4096", "--manual_seed", "3", "-p"])
+    out = capsys.readouterr().out
+    assert "Self CPU" in out and "Finished training." in out
+
+
+def test_dist_sampler_partitions_the_private_set():
+    """--dist: every rank draws a disjoint share of one shared permutation per epoch (csl_gan_amd.data._private_loader); the
+    union of the ranks' batches of a step is world x batch_size DISTINCT private samples, the assumption behind q = R*B/N."""
+    from types import SimpleNamespace as NS
+    from csl_gan_amd import data
+    o = NS(dataset="MNIST", train_set_size=256, public_set_size=0, im_size=28, manual_seed=5, batch_size=16, synthetic=True,
+           data_path=None, synthetic_cap=256, dist_data_seed=5)
+    loaders = [data.init_data(o, rank=r, world=4)[1] for r in range(4)]
+    x_all = loaders[0].dataset.tensors[0]
+    key = {tuple(x_all[i].flatten()[:6].tolist()): i for i in range(len(x_all))}
+
+    def epoch_indices(dl, epoch):
+        dl.sampler.set_epoch(epoch)
+        return [[key[tuple(img.flatten()[:6].tolist())] for img in batch] for batch, _ in dl]
+    per_rank = [epoch_indices(dl, 0) for dl in loaders]
+    assert all(len(b) == 4 for b in per_rank)                                   # 256 / 4 ranks / 16 per batch
+    for step in range(4):
+        idx = [i for r in range(4) for i in per_rank[r][step]]
+        assert len(idx) == 64 and len(set(idx)) == 64                             # one global batch: all distinct
+    flat = [i for r in range(4) for b in per_rank[r] for i in b]
+    assert sorted(flat) == list(range(256))                                      # an epoch covers the set exactly once
+    again = [epoch_indices(dl, 1) for dl in loaders]
+    assert again != per_rank                                                      # set_epoch reshuffles
+    one = data.init_data(o)[1]
+    assert not hasattr(one.sampler, "set_epoch") or one.sampler.__class__.__name__ == "RandomSampler"
+
+
+def test_moving_avg_scaling_needs_the_beta_the_reference_never_defines(tmp_path):
+    from types import SimpleNamespace as NS
+    from csl_gan_amd.trainer import Trainer
+    t = Trainer.__new__(Trainer)
+    t.opt = NS(moving_avg_beta=None)
+    t.privacy_engine, t.D = NS(scaling_vec=[1.0, 2.0]), None
+    with pytest.raises(AttributeError, match="moving_avg_beta"):
+        t.update_sens_moving_avg()
+    p1, p2 = torch.nn.Parameter(torch.ones(4)), torch.nn.Parameter(torch.ones(9))
+    p1.grad, p2.grad = torch.full((4,), 3.0), None
+    t.D = NS(parameters=lambda: [p1, p2])
+    got = {}
+    t.privacy_engine = NS(scaling_vec=[1.0, 2.0], set_scaling_vec=lambda v: got.setdefault("v", v))
+    t.opt = NS(moving_avg_beta=0.9)
+    t.update_sens_moving_avg()
+    assert got["v"] == pytest.approx([0.9 * 1.0 + 0.1 * 6.0, 0.9 * 2.0])
 
 
 def test_dp_engine_refuses_cpu_modules():

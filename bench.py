@@ -30,6 +30,7 @@ import torch  # noqa: E402
 # layers are charged at the reference's C input channels although only C/4 are distinct
 FLOP_PER_IMG_STEP = 14.3e9
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA (never the 2:1-sparsity headline)
 B_PER_GPU = 128
 
 
@@ -44,17 +45,19 @@ def build_trainer(rank, world, local, batch=B_PER_GPU, outdir=None, extra=()):
     G, Dm = init_util.init_models(opt)
     g = torch.Generator().manual_seed(1234)
     # 32 mean samples: mean of 1000 synthetic images + N(0, 0.12^2)  (options.py:71-72)
-    acc = torch.zeros(32, 3, 64, 64)
+    S = opt.im_size
+    acc = torch.zeros(32, 3, S, S)
     for i in range(32):
-        acc[i] = (torch.randn(1000, 3, 64, 64, generator=g) * 0.5).clamp(-1, 1).mean(0)
-    ms = MeanSampler(noise_std=0.12, num_samples=32, mean_size=1000, dataset_size=opt.train_set_size, device=dev)
+        acc[i] = (torch.randn(250, 3, S, S, generator=g) * 0.5).clamp(-1, 1).mean(0) if S > 64 else \
+            (torch.randn(1000, 3, S, S, generator=g) * 0.5).clamp(-1, 1).mean(0)
+    ms = MeanSampler(noise_std=0.12, num_samples=32, mean_size=1000, dataset_size=opt.train_set_size, device=dev, res=S)
     ms.mean_samples = (acc + torch.randn(acc.shape, generator=g) * 0.12).unsqueeze(0).to(dev)
     reducer = D.FlatGradReducer() if world > 1 else None
     tr = Trainer(opt, G, Dm, mean_sampler=ms, log_to=os.path.join(outdir, "log_rank%d.csv" % rank), world_size=world,
                  rank=rank, grad_reducer=reducer)
     tr.setup_privacy_engine()
     gr = torch.Generator().manual_seed(1234 + rank)
-    img = (torch.randn(batch, 3, 64, 64, generator=gr) * 0.5).clamp(-1, 1).to(dev)
+    img = (torch.randn(batch, 3, S, S, generator=gr) * 0.5).clamp(-1, 1).to(dev)
     return opt, tr, img
 
 
@@ -91,6 +94,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--loop-steps", type=int, default=10, help="iterations of the full train() loop timed for the secondary metric (0 = skip)")
+    ap.add_argument("--dump-shapes", type=str, default="", help="write the per-kernel, per-shape launch table (HIP-event times) to this file")
     ap.add_argument("--opt", type=str, default="", help="extra train.py flags for experiments, e.g. '--grad_sample_dtype bf16' "
                     "(the headline line is the run WITHOUT this)")
     a = ap.parse_args()
@@ -170,9 +174,10 @@ def main():
         except Exception:
             traffic = None
         ach = dom["exec_flop"] / (dom["ms"] * 1e-3) / 1e12
+        peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom["name"] else PEAK_FP32_MFMA_TFLOPS
         worst = sorted((v for k, v in shapes.items() if k.startswith(dom["name"])), key=lambda v: -v["ms"])
-        roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+        roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]),
                 "flop_per_launch_executed": round(dom["exec_flop"] / dom["n"]),
                 "reference_algorithmic_tflops": round(dom["flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
@@ -184,12 +189,21 @@ def main():
                                                                      "tflops": round(v["exec_flop"] / (v["ms"] * 1e-3) / 1e12, 1)}
                                   for v in worst[:8]}}
     exec_flop_step = sum(v["exec_flop"] for v in kernels.values()) / a.steps
+    if a.dump_shapes:
+        with open(a.dump_shapes, "w") as f:
+            for k, v in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"]):
+                f.write("%-78s n/step %5.1f  avg_ms %8.4f  ms/step %7.3f  %s\n" % (
+                    k, v["n"] / a.steps, v["ms"] / v["n"], v["ms"] / a.steps,
+                    ("%6.1f TF" % (v["exec_flop"] / (v["ms"] * 1e-3) / 1e12)) if v["exec_flop"] else ("%7.1f GB/s" % (v["bytes"] / (v["ms"] * 1e-3) / 1e9))))
+    bf16 = getattr(opt, "compute_dtype", "fp32") == "bf16"
+    step_peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
     line = {
         "metric": "images/sec/GPU CelebA DCResNet dp_mode=gc bs=128 at 1/2/4/8 MI355X",
         "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "CelebA DCResNet D-step: dp_mode=gc -gcm adaptive-pl -nms 32, WGAN-GP on mean samples, 3x64x64",
+        "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+        "config": {"workload": "CelebA DCResNet D-step: dp_mode=gc -gcm adaptive-pl -nms 32, WGAN-GP on mean samples, 3x%dx%d" % (opt.im_size, opt.im_size),
+                   "compute_dtype": getattr(opt, "compute_dtype", "fp32"),
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                    "materialize": getattr(opt, "materialize", "all"), "grad_sample_dtype": getattr(opt, "grad_sample_dtype", "fp32"),
                    "fuse_passes": bool(getattr(opt, "fuse_passes", False)),
@@ -197,8 +211,8 @@ def main():
         "per_gpu": round(ips / world, 2),
         "step_gflop_executed_per_image": round(exec_flop_step / B / 1e9, 3),
         "step_tflops_executed": round(exec_flop_step / (dt / a.steps) / 1e12, 2),
-        "step_frac_of_fp32_mfma_peak": round(exec_flop_step / (dt / a.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-        "step_tflops_reference_algorithmic": round(FLOP_PER_IMG_STEP * ips / world / 1e12, 2),
+        ("step_frac_of_bf16_mfma_peak" if bf16 else "step_frac_of_fp32_mfma_peak"): round(exec_flop_step / (dt / a.steps) / 1e12 / step_peak, 4),
+        "step_tflops_reference_algorithmic": None if a.opt else round(FLOP_PER_IMG_STEP * ips / world / 1e12, 2),
         "roofline": roof,
         "secondary": loop,
         "entries_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in sorted(entries.items(), key=lambda kv: -kv[1]["ms"])},

@@ -37,7 +37,7 @@ class SegsT(C.Structure):
 
 class ConvT(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "reserved", "P", "Q")]
+                ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "compute", "P", "Q")]
 
 
 _lib = None

@@ -272,7 +272,7 @@ int cslgan_conv2d_wgrad_sqnorm_gram_f32(const cslgan_conv_t* c, const float* gy,
                                         void* stream) {
     CSLGAN_REQUIRE(c && gy && x && sq, "wgrad_sqnorm_gram: null argument");
     CSLGAN_REQUIRE(c->N > 0 && c->H > 0 && c->W > 0 && c->R > 0 && c->S > 0 && c->stride > 0 && c->pad >= 0, "wgrad_sqnorm_gram: non-positive dimension");
-    CSLGAN_REQUIRE(c->reserved == 0, "wgrad_sqnorm_gram: cslgan_conv_t.reserved must be 0");
+    
     CSLGAN_REQUIRE(c->R * c->S <= IG_MAX_TAPS, "wgrad_sqnorm_gram: too many taps");
     const int P = (c->H + 2 * c->pad - c->R) / c->stride + 1, Q = (c->W + 2 * c->pad - c->S) / c->stride + 1;
     CSLGAN_REQUIRE(P == c->P && Q == c->Q, "wgrad_sqnorm_gram: output %dx%d does not match P,Q=%d,%d", P, Q, c->P, c->Q);

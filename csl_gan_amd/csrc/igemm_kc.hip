@@ -377,6 +377,7 @@ static long long tiles_for(const KcParams& p, int BM, int BN) {
     return tm * ((p.Nn + BN - 1) / BN);
 }
 
+int launch_kc_bf16(KcParams& p, hipStream_t st, long long out_elems);     // igemm_bf16.hip
 bool halo_eligible(const KcParams& p);          // igemm_halo.hip
 int launch_halo(KcParams& p, hipStream_t st);
 bool skinny_eligible(const KcParams& p);        // igemm_skinny.hip
@@ -411,6 +412,10 @@ int launch_kc(KcParams& p, hipStream_t st, long long out_elems) {
             p.ac_recip = (unsigned)(((1ull << 32) + (unsigned long long)p.AC - 1) / (unsigned long long)p.AC);
         }
     }
+    if (p.bf16) {
+        if (p.acc_classes) { set_error("igemm_kc: accumulated classes have no bf16 form"); return CSLGAN_ERR_INVALID_ARG; }
+        return launch_kc_bf16(p, st, out_elems);
+    }
     static const int skinny_env = [] { const char* e = getenv("CSLGAN_KC_SKINNY"); return e ? atoi(e) : 1; }();
     if (skinny_env && skinny_eligible(p)) return launch_skinny(p, st);
     static const int halo_env = [] { const char* e = getenv("CSLGAN_KC_HALO"); return e ? atoi(e) : 1; }();
@@ -443,7 +448,7 @@ static int check_conv(const cslgan_conv_t* c, const char* who) {
     CSLGAN_REQUIRE(c->N > 0 && c->H > 0 && c->W > 0 && c->C > 0 && c->K > 0 && c->R > 0 && c->S > 0 && c->stride > 0 && c->pad >= 0,
                    "%s: non-positive dimension", who);
     CSLGAN_REQUIRE(c->R * c->S <= IG_MAX_TAPS, "%s: %dx%d filter has more than %d taps", who, c->R, c->S, IG_MAX_TAPS);
-    CSLGAN_REQUIRE(c->reserved == 0, "%s: cslgan_conv_t.reserved must be 0", who);
+    CSLGAN_REQUIRE(c->compute == CSLGAN_COMPUTE_F32 || c->compute == CSLGAN_COMPUTE_BF16, "%s: unknown cslgan_conv_t.compute %d", who, c->compute);
     const int VH = c->H, VW = c->W;
     const int P = (VH + 2 * c->pad - c->R) / c->stride + 1, Q = (VW + 2 * c->pad - c->S) / c->stride + 1;
     CSLGAN_REQUIRE(P == c->P && Q == c->Q, "%s: output %dx%d does not match P,Q=%d,%d", who, P, Q, c->P, c->Q);
@@ -473,7 +478,7 @@ int cslgan_conv2d_fwd_f32(const cslgan_conv_t* c, const float* x, const float* w
     p.VH = c->H; p.VW = c->W;
     p.sy = p.sx = c->stride;
     p.w = w; p.Nn = c->K; p.out = y; p.OHf = c->P; p.OWf = c->Q; p.osy = p.osx = 1; p.ldo = c->K; p.dense_out = 1;
-    p.bias = bias; p.res = residual; p.mask = nullptr; p.act = act;
+    p.bias = bias; p.res = residual; p.mask = nullptr; p.act = act; p.bf16 = c->compute == CSLGAN_COMPUTE_BF16;
     p.n_cls = 1;
     KcClass& k = p.cls[0];
     k.M = c->N * c->P * c->Q; k.OHc = c->P; k.OWc = c->Q; k.T = c->R * c->S; k.Kdim = k.T * c->C; k.w_off = 0; k.oy0 = k.ox0 = 0;
@@ -532,7 +537,7 @@ int cslgan_conv2d_s2_fwd_f32(const cslgan_conv_t* c, const float* x, const float
     // launch, no gain or a loss below ~500 tiles (four halo stagings per chunk for 2-9 taps each) -> igemm_kc keeps those.
     static const int s2_min_tiles = [] { const char* e = getenv("CSLGAN_S2_MIN_TILES"); return e ? atoi(e) : 512; }();
     const long long wide_tiles = ((long long)c->N * c->P * c->Q + 127) / 128 * ((c->K + 127) / 128);
-    if (!ok || n == 0 || !halo_env || !s2_env || wide_tiles < s2_min_tiles || !halo_eligible(p))
+    if (!ok || n == 0 || !halo_env || !s2_env || wide_tiles < s2_min_tiles || c->compute != CSLGAN_COMPUTE_F32 || !halo_eligible(p))
         return cslgan_conv2d_fwd_f32(c, x, w, bias, nullptr, act, y, stream);
     if (repack) {
         const long long per = (long long)c->C * 9 * c->K;
@@ -559,7 +564,7 @@ int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* c, const float* gy, const float
     p.a = gy; p.AH = c->P; p.AW = c->Q; p.AC = c->K; p.VH = c->P; p.VW = c->Q; p.sy = p.sx = 1;
     p.w = wt_ws; p.Nn = c->C; p.out = gx; p.OHf = c->H; p.OWf = c->W; p.osy = p.osx = s; p.ldo = c->C;
     p.dense_out = (s == 1) ? 1 : 0;
-    p.bias = nullptr; p.res = nullptr; p.mask = mask; p.act = CSLGAN_ACT_NONE;
+    p.bias = nullptr; p.res = nullptr; p.mask = mask; p.act = CSLGAN_ACT_NONE; p.bf16 = c->compute == CSLGAN_COMPUTE_BF16;
     int off = 0, ncls = 0;
     for (int py = 0; py < s; ++py)
         for (int px = 0; px < s; ++px) {

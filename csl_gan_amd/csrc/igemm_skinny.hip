@@ -285,7 +285,7 @@ int cslgan_conv2d_wgrad_skinny_f32(const cslgan_conv_t* c, const float* gy, cons
                                    int n_blocks, void* stream) {
     CSLGAN_REQUIRE(c && gy && x && partial, "conv2d_wgrad_skinny: null argument");
     CSLGAN_REQUIRE(c->K >= 1 && c->K <= 4 && c->C == SK_C, "conv2d_wgrad_skinny: needs 1..4 output and 64 input channels");
-    CSLGAN_REQUIRE(c->stride == 1 && c->reserved == 0 && c->R * c->S <= SK_MAXT && c->R <= 5 && c->S <= 5, "conv2d_wgrad_skinny: needs stride 1 and at most 9 taps");
+    CSLGAN_REQUIRE(c->stride == 1 && c->R * c->S <= SK_MAXT && c->R <= 5 && c->S <= 5, "conv2d_wgrad_skinny: needs stride 1 and at most 9 taps");
     CSLGAN_REQUIRE(c->N > 0 && c->P == c->H + 2 * c->pad - c->R + 1 && c->Q == c->W + 2 * c->pad - c->S + 1, "conv2d_wgrad_skinny: inconsistent output size");
     CSLGAN_REQUIRE((c->P & 7) == 0 && (c->Q & 7) == 0, "conv2d_wgrad_skinny: output grid must be a multiple of 8x8");
     CSLGAN_REQUIRE(n_blocks >= 1 && aligned16(x), "conv2d_wgrad_skinny: bad workspace / alignment");

@@ -15,6 +15,37 @@ from . import _lib
 from ._lib import ConvT, SegsT, check
 
 ACT_NONE, ACT_LRELU02, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+COMPUTE_F32, COMPUTE_BF16 = 0, 1          # cslgan_conv_t.compute (include/cslgan.h)
+
+_compute = COMPUTE_F32
+
+
+def set_compute_dtype(name):
+    """Arithmetic of every MFMA conv / linear / weight-gradient launch of this process: "fp32" (exact fp32 MFMA, the default)
+    or "bf16" (operands rounded to bfloat16 in the kernels, fp32 accumulate; tensors stay fp32 in HBM).  One process drives
+    one GPU and one training run, so this is process-wide state set once from --compute_dtype."""
+    global _compute
+    if name not in ("fp32", "bf16"):
+        raise ValueError("compute dtype must be 'fp32' or 'bf16', got %r" % (name,))
+    _compute = COMPUTE_BF16 if name == "bf16" else COMPUTE_F32
+
+
+def get_compute_dtype():
+    return "bf16" if _compute == COMPUTE_BF16 else "fp32"
+
+
+class compute_dtype:
+    """Context manager form of set_compute_dtype (tests)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = get_compute_dtype()
+        set_compute_dtype(self.name)
+
+    def __exit__(self, *a):
+        set_compute_dtype(self.prev)
 
 
 def _stream():
@@ -127,7 +158,7 @@ def conv_out_size(H, R, stride, pad):
 
 def _conv_desc(N, H, W, Cc, K, R, S, stride, pad):
     P, Q = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
-    return ConvT(N, H, W, Cc, K, R, S, stride, pad, 0, P, Q), P, Q
+    return ConvT(N, H, W, Cc, K, R, S, stride, pad, _compute, P, Q), P, Q
 
 
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, out=None, wkey=None, alg_scale=1.0):
@@ -245,7 +276,7 @@ def dense_wgrad_group(N, K, Cc, R, S, PQ, stride=1, out_hw=None):
     time follows how well that count fills 256 CUs x 3 resident workgroups (800 workgroups take two rounds, 3200 take
     4.2: measured 1.45 vs 1.16 ms on the same 55 GFLOP); more slabs cost their write + re-read by the column sum.
     Model: t(g) = FLOP / (100 TF x fill(g)) + 2 x slab bytes / 4 TB/s, minimised over g | N."""
-    if (out_hw is not None and stride in (1, 2) and 2 <= S <= 5 and K % 64 == 0 and Cc % 64 == 0
+    if (_compute == COMPUTE_F32 and out_hw is not None and stride in (1, 2) and 2 <= S <= 5 and K % 64 == 0 and Cc % 64 == 0
             and out_hw[0] % 8 == 0 and out_hw[1] % 8 == 0):
         # igemm_wgh (LDS-resident operands): (K/128)(C/64)R tiles per slab.  Big launches (the generator's convs, >= 40 GFLOP):
         # ONE slab — the kernel splits the patch loop over workgroups itself (atomic adds), no slab traffic.  Small ones:

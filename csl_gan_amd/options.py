@@ -10,6 +10,10 @@ Additions of this build (all optional, none changes a reference default):
   --fuse_passes B      run the adaptive / generated / real discriminator passes as one forward+backward over the
                        concatenated batch (same numbers, fewer and fuller launches); needs --materialize private|ghost
   --grad_sample_dtype  storage type of the materialised per-sample weight gradients (fp32 | bf16; fp32 accumulate)
+  --compute_dtype T    arithmetic of the conv / linear / weight-gradient kernels: fp32 (exact fp32 MFMA, default) or bf16
+                       (operands rounded to bfloat16 inside the kernels, fp32 accumulate; BASELINE.json configs[4]).  With bf16
+                       the per-sample norms must be norms of the gradients that are actually summed, so ghost clipping (whose
+                       Gram norms are computed in fp32) is replaced by --materialize private
   --moving_avg_beta B  the smoothing factor train.py:249 reads as opt.moving_avg_beta but options.py never defines
                        (imm_sens_scaling_mode=moving-avg-pl raises AttributeError in the reference without it)
   --materialize M      per-sample gradients kept in HBM: "all" passes (the fork's p.grad_sample layout) or only
@@ -156,6 +160,7 @@ _ARGS = [
     (("--fuse_passes",), dict(type=str2bool, default=True)),
     (("--grad_sample_dtype",), dict(type=str, choices=["fp32", "bf16"], default="fp32")),
     (("--moving_avg_beta",), dict(type=float, default=None)),
+    (("--compute_dtype",), dict(type=str, choices=["fp32", "bf16"], default="fp32")),
 ]
 ALWAYS_KEEP = ["g_device", "d_device", "num_workers", "resume_path", "resume_epochs"]
 
@@ -216,6 +221,10 @@ def finalize(opt, make_dirs=True):
         print("Currently configured to calculate penalty per-sample. It is strongly recommended that you use public data or mean samples for gradient penalties when using grad clipping.")
     if opt.model == "Vanilla" and (opt.g_label_emb_mode, opt.d_label_emb_mode) != ("concat", "concat"):
         raise Exception("Vanilla model with embedded labels not implemented")
+
+    if getattr(opt, "compute_dtype", "fp32") == "bf16" and opt.materialize == "ghost":
+        print("compute_dtype=bf16: using --materialize private (ghost clipping's Gram norms are fp32 norms of unrounded products)")
+        opt.materialize = "private"
 
     if not opt.output_dir:
         stamp = datetime.now().strftime("output/%m-%d-%H:%M-")

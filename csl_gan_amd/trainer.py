@@ -30,6 +30,9 @@ class Trainer:
     def __init__(self, opt, G, D, dataset=None, public_dataloader=None, public_dataset=None, mean_sampler=None,
                  log_to=None, world_size=1, rank=0, grad_reducer=None):
         self.opt, self.G, self.D = opt, G, D
+        if any(p.is_cuda for p in D.parameters()):
+            from . import ops
+            ops.set_compute_dtype(getattr(opt, "compute_dtype", "fp32"))     # process-wide: one process drives one run
         self.dataset, self.public_dataloader, self.public_dataset = dataset, public_dataloader, public_dataset
         self.mean_sampler = mean_sampler
         self.world_size, self.rank, self.grad_reducer = world_size, rank, grad_reducer

@@ -109,11 +109,19 @@ int cslgan_row_l2norm_bwd_f32(const float* in, const float* norm, const float* g
 
 /* ---- convolution family: fp32 MFMA implicit GEMM ------------------------------------------ */
 
+/* cslgan_conv_t.compute.  All tensors are fp32 in HBM either way.
+ *   CSLGAN_COMPUTE_F32 : v_mfma_f32_32x32x2_f32 — bit-for-bit an fp32 fmaf chain; the default and the headline path.
+ *   CSLGAN_COMPUTE_BF16: operands rounded to bfloat16 (round-to-nearest-even) on their way into LDS, v_mfma_f32_32x32x16_bf16
+ *                        with fp32 accumulate (BASELINE.json configs[4]; `--compute_dtype bf16`).  Honoured by conv2d_fwd,
+ *                        conv2d_s2_fwd, conv2d_dgrad, conv2d_wgrad_grouped(_bf16out), conv2d_wgrad_scaled; the vector-ALU
+ *                        (1..4 channel) and Gram-norm entries compute in fp32 regardless. */
+enum { CSLGAN_COMPUTE_F32 = 0, CSLGAN_COMPUTE_BF16 = 1 };
+
 typedef struct {
     int32_t N, H, W, C;          /* input  x[N][H][W][C]                                     */
     int32_t K, R, S;             /* filter w[K][R][S][C]                                     */
     int32_t stride, pad;
-    int32_t reserved;            /* must be 0                                                */
+    int32_t compute;             /* CSLGAN_COMPUTE_F32 (exact fp32 MFMA) or CSLGAN_COMPUTE_BF16 (see below) */
     int32_t P, Q;                /* output y[N][P][Q][K]                                     */
 } cslgan_conv_t;
 

@@ -594,3 +594,100 @@ def test_wgrad_dense_skinny(case):
     ref, = torch.autograd.grad(y, w, gy)
     got = ops.conv2d_wgrad_dense(_nhwc(gy), _nhwc(x), R, R, stride=1, pad=R // 2, alpha=1.5)
     _close(got.permute(0, 3, 1, 2), ref * 1.5, what="skinny dense wgrad %s" % (case,))
+
+
+# ---- bf16 MFMA compute path (cslgan_conv_t.compute = BF16; BASELINE.json configs[4]) ------------------------------------
+def _bf(t):
+    """Round-to-nearest-even to bfloat16 and back: what the kernels do to every MFMA operand."""
+    return t.to(torch.bfloat16).float()
+
+
+BF16_FWD = [c for c in FWD_CASES if not c[10]][:24] + [(4, 16, 16, 64, 128, 5, 1, 2, True, 1, False, 0), (130, 4, 4, 48, 72, 3, 1, 1, True, 2, False, None)]
+
+
+@pytest.mark.parametrize("case", BF16_FWD)
+def test_conv2d_fwd_bf16(case):
+    """Forward conv on v_mfma_f32_32x32x16_bf16 against torch fp32 math on bf16-ROUNDED operands (so only the fp32 summation
+    order differs: 1e-4 of scale), and against the unrounded fp32 conv at the bf16 tolerance 2e-2 of scale."""
+    ops = _ops()
+    N, H, W, C, K, R, s, p, has_b, act, ups, res = case
+    g = torch.Generator().manual_seed(hash(case) % 10000)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
+    b = torch.randn(K, generator=g) if has_b else None
+
+    def ref(xx, ww):
+        y = F.conv2d(xx, ww, b, stride=s, padding=p)
+        if res is not None:
+            y = y + rs
+        return F.leaky_relu(y, 0.2) if act == 1 else (F.relu(y) if act == 2 else (torch.tanh(y) if act == 3 else y))
+    rs = torch.randn(F.conv2d(x, w, None, stride=s, padding=p).shape, generator=g) if res is not None else None
+    with ops.compute_dtype("bf16"):
+        y = ops.conv2d_fwd(_nhwc(x), _krsc(w), None if b is None else b.cuda(), stride=s, pad=p,
+                           residual=None if rs is None else _nhwc(rs), act=act)
+    assert ops.get_compute_dtype() == "fp32"
+    _close(y.permute(0, 3, 1, 2), ref(_bf(x), _bf(w)), rtol=1e-4, what="bf16 fwd vs rounded-operand reference %s" % (case,))
+    _close(y.permute(0, 3, 1, 2), ref(x, w), rtol=2e-2, what="bf16 fwd vs fp32 %s" % (case,))
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES)
+def test_conv2d_dgrad_bf16(case):
+    ops = _ops()
+    N, H, W, C, K, R, s, p, use_mask = case
+    g = torch.Generator().manual_seed(sum(case) + 3)
+    w = torch.randn(K, C, R, R, generator=g) / (K * R * R) ** 0.5
+    P, Q = (H + 2 * p - R) // s + 1, (W + 2 * p - R) // s + 1
+    gy = torch.randn(N, K, P, Q, generator=g)
+    ref = F.conv_transpose2d(_bf(gy), _bf(w), None, stride=s, padding=p, output_padding=(H + 2 * p - R - (P - 1) * s, W + 2 * p - R - (Q - 1) * s))
+    mask = None
+    if use_mask:
+        mask = torch.randn(N, C, H, W, generator=g)
+        ref = ref * torch.where(mask > 0, 1.0, 0.2)
+    with ops.compute_dtype("bf16"):
+        gx = ops.conv2d_dgrad(_nhwc(gy), _krsc(w), (H, W), stride=s, pad=p, mask=None if mask is None else _nhwc(mask))
+    _close(gx.permute(0, 3, 1, 2), ref, rtol=1e-4, what="bf16 dgrad %s" % (case,))
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 8, 16, 5, 2, 2), (3, 16, 16, 3, 64, 5, 2, 2), (4, 8, 8, 64, 128, 5, 2, 2), (2, 7, 9, 12, 20, 3, 1, 1),
+                                  (6, 1, 1, 794, 128, 1, 1, 0), (4, 32, 32, 64, 128, 5, 2, 2), (8, 8, 8, 256, 512, 5, 2, 2), (3, 64, 64, 4, 64, 5, 2, 2),
+                                  (2, 16, 16, 128, 256, 5, 2, 2)])
+@pytest.mark.parametrize("group", [1, 2, 0])
+def test_conv2d_wgrad_grouped_bf16(case, group):
+    """Grouped weight gradient (group=1: per-sample gradients) on the bf16 MFMA: gradients, the fused per-group squared norms,
+    bf16 storage and the clip-weighted (row_scale) form, against fp32 math on bf16-rounded operands."""
+    ops = _ops()
+    N, H, W, C, K, R, s, p = case
+    grp = N if group == 0 else group
+    if N % grp:
+        pytest.skip("N not divisible by group")
+    g = torch.Generator().manual_seed(sum(case) + 11 * grp)
+    x = torch.randn(N, C, H, W, generator=g)
+    P, Q = (H + 2 * p - R) // s + 1, (W + 2 * p - R) // s + 1
+    gy = torch.randn(N, K, P, Q, generator=g)
+    alpha = 1.75
+    xr, gr = _bf(x), _bf(gy)
+    wz = torch.zeros(K, C, R, R, requires_grad=True)
+    refs = []
+    for b0 in range(0, N, grp):
+        y = F.conv2d(xr[b0:b0 + grp], wz, None, stride=s, padding=p)
+        refs.append(torch.autograd.grad(y, wz, gr[b0:b0 + grp])[0] * alpha)
+    ref = torch.stack(refs)
+    sq = torch.zeros(N // grp, device="cuda")
+    with ops.compute_dtype("bf16"):
+        gw = ops.conv2d_wgrad_grouped(_nhwc(gy), _nhwc(x), R, R, stride=s, pad=p, group=grp, alpha=alpha, sq=sq)
+        sq2 = torch.zeros(N // grp, device="cuda")
+        none = ops.conv2d_wgrad_grouped(_nhwc(gy), _nhwc(x), R, R, stride=s, pad=p, group=grp, alpha=alpha, want_gw=False, sq=sq2)
+        f = torch.rand(N, generator=g) + 0.1
+        gws = ops.conv2d_wgrad_grouped(_nhwc(gy), _nhwc(x), R, R, stride=s, pad=p, group=grp, alpha=alpha, row_scale=f.cuda())
+    assert none is None
+    _close(gw.permute(0, 1, 4, 2, 3), ref, rtol=1e-4, what="bf16 wgrad %s g%d" % (case, grp))
+    exp_sq = ref.reshape(N // grp, -1).double().pow(2).sum(1).float()
+    _close(sq, exp_sq, rtol=2e-4, what="bf16 wgrad sq")
+    _close(sq2, exp_sq, rtol=2e-4, what="bf16 wgrad sq (norms only)")
+    # clip-weighted form: gy rows scaled BEFORE the bf16 rounding (the kernel multiplies on load)
+    refs = []
+    grs = _bf(gy * f.view(-1, 1, 1, 1))
+    for b0 in range(0, N, grp):
+        y = F.conv2d(xr[b0:b0 + grp], wz, None, stride=s, padding=p)
+        refs.append(torch.autograd.grad(y, wz, grs[b0:b0 + grp])[0] * alpha)
+    _close(gws.permute(0, 1, 4, 2, 3), torch.stack(refs), rtol=1e-4, what="bf16 wgrad scaled")

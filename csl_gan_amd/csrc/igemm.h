@@ -59,7 +59,8 @@ struct KcParams {
     int pair_mode;          // igemm_halo: 1 = a workgroup runs TWO classes back to back on the same m-tile index (heaviest with
     int pair_cls[2][2];     // lightest: the 9+4 / 6+6 tap classes of a 5x5 stride-2 data gradient), tiles_m = 2 * tiles_per_cls
     int tiles_per_cls;
-    int bf16;               // 1: operands rounded to bfloat16, v_mfma_f32_32x32x16_bf16 (igemm_bf16.hip); 0: exact fp32 MFMA
+    int bf16;               // 0: exact fp32 MFMA; 1: operands rounded to bfloat16, v_mfma_f32_32x32x16_bf16 (igemm_bf16.hip);
+                            // 3: fp32 emulated from three bfloat16 pieces per operand, six bf16 MFMAs per step
     int acc_classes;        // igemm_halo: 1 = every workgroup runs ALL classes on its m-tile into ONE accumulator (the classes are
                             // partial sums of the same output: a stride-2 conv as four stride-1 convs over parity sub-images)
     KcClass cls[IG_MAX_CLS];

@@ -49,16 +49,38 @@ __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned byte_
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
 }
 
+// ---- fp32 from three bfloat16 pieces ---------------------------------------------------------------------------------------
+// x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): three 8-bit mantissas cover fp32's 24 bits
+// (|x - hi - mid - lo| <= 2^-24 |x|).  A product a*b is then the sum of 9 piece products, each EXACT in fp32 (8 x 8 bits);
+// dropping the three smallest (mid*lo, lo*mid, lo*lo: <= 2^-23 |a||b| together) leaves SIX bf16 MFMAs per fp32 MFMA step:
+//     a*b ~= hi*hi + (hi*mid + mid*hi) + (hi*lo + lo*hi + mid*mid)
+// at 16x the fp32 MFMA rate each — 2.67x the fp32 matrix rate for a per-product error of about one fp32 ulp
+// (CSLGAN_COMPUTE_BF16X3; the same construction vendor BLAS libraries ship as "fp32 emulation").  Small terms are added first.
+struct bf16x3_t { uint2 hi, mid, lo; };
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ bf16x3_t split4_bf16(const float4& v) {
+    bf16x3_t r;
+    r.hi = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+    const float r0 = v.x - bf_lo(r.hi.x), r1 = v.y - bf_hi(r.hi.x), r2 = v.z - bf_lo(r.hi.y), r3 = v.w - bf_hi(r.hi.y);   // exact
+    r.mid = make_uint2(pack_bf16(r0, r1), pack_bf16(r2, r3));
+    r.lo = make_uint2(pack_bf16(r0 - bf_lo(r.mid.x), r1 - bf_hi(r.mid.x)), pack_bf16(r2 - bf_lo(r.mid.y), r3 - bf_hi(r.mid.y)));
+    return r;
+}
+
 // ---- K-contiguous: Out[m][n] = epilogue( sum_k A(m,k) * Wm[n][k] ) ------------------------------------------------------
 // K tile = 32 (two 16-k MFMA steps); LDS entry e = k/8 in the tile (4 entries), each [rows][8 bf16] + 16 B pad.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC_A, bool VEC_B>
+// NSPLIT = 1: plain bf16 operands, two LDS buffers.  NSPLIT = 3: three bf16 pieces per operand (fp32 emulation), one LDS
+// buffer (3 x the image; 64 KB per workgroup is the limit) with the next tile held in registers across the MFMAs.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC_A, bool VEC_B, int NSPLIT>
 __global__ __launch_bounds__(256, 2) void igemm_kc_bf16_kernel(const KcParams p) {
     constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
     static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "bad tile");
     constexpr int A_ES = BM * 2 + 2, B_ES = BN * 2 + 2;      // uint2 (8-byte) units per LDS entry, padded by 16 B
     constexpr int A_PASS = BM / 32, B_PASS = BN / 32;
-    __shared__ __attribute__((aligned(16))) uint2 As[2][4 * A_ES];
-    __shared__ __attribute__((aligned(16))) uint2 Bs[2][4 * B_ES];
+    constexpr int NBUF = NSPLIT == 1 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) uint2 As[NBUF][NSPLIT][4 * A_ES];
+    __shared__ __attribute__((aligned(16))) uint2 Bs[NBUF][NSPLIT][4 * B_ES];
     __shared__ int s_tap[IG_MAX_TAPS];
     __shared__ int s_off[BM];
     __shared__ int s_roff[BM];
@@ -149,9 +171,25 @@ __global__ __launch_bounds__(256, 2) void igemm_kc_bf16_kernel(const KcParams p)
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_PASS; ++i) As[buf][(q >> 1) * A_ES + (lrow + 32 * i) * 2 + (q & 1)] = pack4_bf16(ra[i]);
+        for (int i = 0; i < A_PASS; ++i) {
+            const int at = (q >> 1) * A_ES + (lrow + 32 * i) * 2 + (q & 1);
+            if (NSPLIT == 1) {
+                As[buf][0][at] = pack4_bf16(ra[i]);
+            } else {
+                const bf16x3_t t = split4_bf16(ra[i]);
+                As[buf][0][at] = t.hi; As[buf][NSPLIT > 1 ? 1 : 0][at] = t.mid; As[buf][NSPLIT > 2 ? 2 : 0][at] = t.lo;
+            }
+        }
 #pragma unroll
-        for (int i = 0; i < B_PASS; ++i) Bs[buf][(q >> 1) * B_ES + (lrow + 32 * i) * 2 + (q & 1)] = pack4_bf16(rb[i]);
+        for (int i = 0; i < B_PASS; ++i) {
+            const int at = (q >> 1) * B_ES + (lrow + 32 * i) * 2 + (q & 1);
+            if (NSPLIT == 1) {
+                Bs[buf][0][at] = pack4_bf16(rb[i]);
+            } else {
+                const bf16x3_t t = split4_bf16(rb[i]);
+                Bs[buf][0][at] = t.hi; Bs[buf][NSPLIT > 1 ? 1 : 0][at] = t.mid; Bs[buf][NSPLIT > 2 ? 2 : 0][at] = t.lo;
+            }
+        }
     };
 
     const int lane = tid & 63, wid = tid >> 6;
@@ -181,22 +219,53 @@ __global__ __launch_bounds__(256, 2) void igemm_kc_bf16_kernel(const KcParams p)
     __syncthreads();
 
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (kt - kt0) & 1;
+        const int buf = NBUF == 2 ? ((kt - kt0) & 1) : 0;
         load_tile(kt + 1);       // past the last tile every offset is out of range -> zeros, never read
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 af[TM], bf[TN];
+            const int ea = (2 * s + h) * A_ES, eb = (2 * s + h) * B_ES;
+            if (NSPLIT == 1) {
+                bf16x8 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&As[buf][(2 * s + h) * A_ES + (arow0 + i * 32) * 2]);
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&As[buf][0][ea + (arow0 + i * 32) * 2]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][(2 * s + h) * B_ES + (brow0 + j * 32) * 2]);
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][0][eb + (brow0 + j * 32) * 2]);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            } else {
+                bf16x8 af[3][TM], bf[3][TN];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[c][i] = *reinterpret_cast<const bf16x8*>(&As[buf][NSPLIT > c ? c : 0][ea + (arow0 + i * 32) * 2]);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[c][j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][NSPLIT > c ? c : 0][eb + (brow0 + j * 32) * 2]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {      // smallest terms first: hi*lo, lo*hi, mid*mid, then hi*mid, mid*hi, then hi*hi
+                        f32x16 a = acc[i][j];
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], a, 0, 0, 0);
+                        acc[i][j] = a;
+                    }
+            }
         }
-        store_tile(buf ^ 1);
-        __syncthreads();
+        if (NBUF == 2) {
+            store_tile(buf ^ 1);
+            __syncthreads();
+        } else {
+            __syncthreads();             // every wavefront has read the tile
+            store_tile(0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue (as igemm_kc) ---------------------------------------------------------------
@@ -245,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kc_bf16_kernel(const KcParams p)
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NSPLIT>
 static int launch_kc_bf16_tile(KcParams& p, bool vecA, bool vecB, hipStream_t st, long long out_elems) {
     int tm = 0;
     for (int c = 0; c < p.n_cls; ++c) {
@@ -271,11 +340,11 @@ static int launch_kc_bf16_tile(KcParams& p, bool vecA, bool vecB, hipStream_t st
         return CSLGAN_ERR_LAUNCH;
     }
     const dim3 grid((unsigned)(tiles * p.ksplit)), block(256);
-    note_kernel("igemm_kc_bf16_kernel<%d,%d>", BM, BN);
-    if (vecA && vecB) hipLaunchKernelGGL((igemm_kc_bf16_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, p);
-    else if (vecA) hipLaunchKernelGGL((igemm_kc_bf16_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, p);
-    else if (vecB) hipLaunchKernelGGL((igemm_kc_bf16_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((igemm_kc_bf16_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, p);
+    note_kernel(NSPLIT == 1 ? "igemm_kc_bf16_kernel<%d,%d>" : "igemm_kc_bf16x3_kernel<%d,%d>", BM, BN);
+    if (vecA && vecB) hipLaunchKernelGGL((igemm_kc_bf16_kernel<BM, BN, WM, WN, true, true, NSPLIT>), grid, block, 0, st, p);
+    else if (vecA) hipLaunchKernelGGL((igemm_kc_bf16_kernel<BM, BN, WM, WN, true, false, NSPLIT>), grid, block, 0, st, p);
+    else if (vecB) hipLaunchKernelGGL((igemm_kc_bf16_kernel<BM, BN, WM, WN, false, true, NSPLIT>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_kc_bf16_kernel<BM, BN, WM, WN, false, false, NSPLIT>), grid, block, 0, st, p);
     return check_launch("igemm_kc_bf16_kernel");
 }
 
@@ -291,9 +360,14 @@ int launch_kc_bf16(KcParams& p, hipStream_t st, long long out_elems) {
     const bool vecB = kd4 && aligned16(p.w);
     long long rows = 0;
     for (int c = 0; c < p.n_cls; ++c) rows += (p.cls[c].M + 127) / 128;
-    if (p.Nn <= 64) return launch_kc_bf16_tile<128, 64, 2, 2>(p, vecA, vecB, st, out_elems);
-    if (rows * ((p.Nn + 127) / 128) >= 256) return launch_kc_bf16_tile<128, 128, 2, 2>(p, vecA, vecB, st, out_elems);
-    return launch_kc_bf16_tile<64, 128, 1, 4>(p, vecA, vecB, st, out_elems);
+    if (p.bf16 == 3) {
+        if (p.Nn <= 64) return launch_kc_bf16_tile<128, 64, 2, 2, 3>(p, vecA, vecB, st, out_elems);
+        if (rows * ((p.Nn + 127) / 128) >= 256) return launch_kc_bf16_tile<128, 128, 2, 2, 3>(p, vecA, vecB, st, out_elems);
+        return launch_kc_bf16_tile<64, 128, 1, 4, 3>(p, vecA, vecB, st, out_elems);
+    }
+    if (p.Nn <= 64) return launch_kc_bf16_tile<128, 64, 2, 2, 1>(p, vecA, vecB, st, out_elems);
+    if (rows * ((p.Nn + 127) / 128) >= 256) return launch_kc_bf16_tile<128, 128, 2, 2, 1>(p, vecA, vecB, st, out_elems);
+    return launch_kc_bf16_tile<64, 128, 1, 4, 1>(p, vecA, vecB, st, out_elems);
 }
 
 // ---- M-contiguous: gw[g][m][n] = alpha * sum_{k in group g} GY[k][m] * X(k, n) ----------------------------------------
@@ -301,13 +375,14 @@ int launch_kc_bf16(KcParams& p, hipStream_t st, long long out_elems) {
 // 8 consecutive pixels) = 8 x 16-byte loads, transposed in registers into 4 LDS entries [k/8][m][8 bf16].
 constexpr int MCB_BK = 32;
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC_A, bool VEC_B>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC_A, bool VEC_B, int NSPLIT>
 __global__ __launch_bounds__(256, 2) void igemm_mc_bf16_kernel(const McParams p) {
     constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
     static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1 && BM == 128 && BN == 128, "128x128 tile only");
     constexpr int ES = 128 * 2 + 2;                          // uint2 units per LDS entry (128 rows x 16 B + 16 B pad)
-    __shared__ __attribute__((aligned(16))) uint2 As[2][4 * ES];
-    __shared__ __attribute__((aligned(16))) uint2 Bs[2][4 * ES];
+    constexpr int NBUF = NSPLIT == 1 ? 2 : 1;                // three pieces per operand: one buffer (64 KB per workgroup)
+    __shared__ __attribute__((aligned(16))) uint2 As[NBUF][NSPLIT][4 * ES];
+    __shared__ __attribute__((aligned(16))) uint2 Bs[NBUF][NSPLIT][4 * ES];
     __shared__ float s_red[4];
 
     const int tid = threadIdx.x;
@@ -387,17 +462,31 @@ __global__ __launch_bounds__(256, 2) void igemm_mc_bf16_kernel(const McParams p)
     };
     // rv[j] = (row c4+0..3) at pixel j of the group  ->  entry kg, row c4+e: the 8 pixels of row e, 16 bytes
     auto store_tile = [&](int buf) {
-        uint2* dst = (is_a ? As[buf] : Bs[buf]) + kg * ES;
-        const uint4 w0 = make_uint4(pack_bf16(rv[0].x, rv[1].x), pack_bf16(rv[2].x, rv[3].x), pack_bf16(rv[4].x, rv[5].x), pack_bf16(rv[6].x, rv[7].x));
-        const uint4 w1 = make_uint4(pack_bf16(rv[0].y, rv[1].y), pack_bf16(rv[2].y, rv[3].y), pack_bf16(rv[4].y, rv[5].y), pack_bf16(rv[6].y, rv[7].y));
-        const uint4 w2 = make_uint4(pack_bf16(rv[0].z, rv[1].z), pack_bf16(rv[2].z, rv[3].z), pack_bf16(rv[4].z, rv[5].z), pack_bf16(rv[6].z, rv[7].z));
-        const uint4 w3 = make_uint4(pack_bf16(rv[0].w, rv[1].w), pack_bf16(rv[2].w, rv[3].w), pack_bf16(rv[4].w, rv[5].w), pack_bf16(rv[6].w, rv[7].w));
         const int rot = lt & 3;             // lanes start on different rows: fewer LDS bank conflicts on the 64-byte row stride
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int er = (e + rot) & 3;
-            const uint4 w = er == 0 ? w0 : (er == 1 ? w1 : (er == 2 ? w2 : w3));
-            *reinterpret_cast<uint4*>(&dst[(c4 + er) * 2]) = w;
+        for (int c = 0; c < NSPLIT; ++c) {
+            uint2* dst = (is_a ? As[buf][c] : Bs[buf][c]) + kg * ES;
+            const uint4 w0 = make_uint4(pack_bf16(rv[0].x, rv[1].x), pack_bf16(rv[2].x, rv[3].x), pack_bf16(rv[4].x, rv[5].x), pack_bf16(rv[6].x, rv[7].x));
+            const uint4 w1 = make_uint4(pack_bf16(rv[0].y, rv[1].y), pack_bf16(rv[2].y, rv[3].y), pack_bf16(rv[4].y, rv[5].y), pack_bf16(rv[6].y, rv[7].y));
+            const uint4 w2 = make_uint4(pack_bf16(rv[0].z, rv[1].z), pack_bf16(rv[2].z, rv[3].z), pack_bf16(rv[4].z, rv[5].z), pack_bf16(rv[6].z, rv[7].z));
+            const uint4 w3 = make_uint4(pack_bf16(rv[0].w, rv[1].w), pack_bf16(rv[2].w, rv[3].w), pack_bf16(rv[4].w, rv[5].w), pack_bf16(rv[6].w, rv[7].w));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int er = (e + rot) & 3;
+                const uint4 w = er == 0 ? w0 : (er == 1 ? w1 : (er == 2 ? w2 : w3));
+                *reinterpret_cast<uint4*>(&dst[(c4 + er) * 2]) = w;
+            }
+            if (c + 1 < NSPLIT) {           // next piece: what the pieces so far leave of each value (exact subtractions)
+                const unsigned* u0 = &w0.x; const unsigned* u1 = &w1.x; const unsigned* u2 = &w2.x; const unsigned* u3 = &w3.x;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int wd = j >> 1;
+                    rv[j].x -= (j & 1) ? bf_hi(u0[wd]) : bf_lo(u0[wd]);
+                    rv[j].y -= (j & 1) ? bf_hi(u1[wd]) : bf_lo(u1[wd]);
+                    rv[j].z -= (j & 1) ? bf_hi(u2[wd]) : bf_lo(u2[wd]);
+                    rv[j].w -= (j & 1) ? bf_hi(u3[wd]) : bf_lo(u3[wd]);
+                }
+            }
         }
     };
 
@@ -426,22 +515,53 @@ __global__ __launch_bounds__(256, 2) void igemm_mc_bf16_kernel(const McParams p)
     store_tile(0);
     __syncthreads();
     for (int kt = kt0; kt < nk; ++kt) {
-        const int buf = (kt - kt0) & 1;
+        const int buf = NBUF == 2 ? ((kt - kt0) & 1) : 0;
         if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 af[TM], bf[TN];
+            const int eo = (2 * s + h) * ES;
+            if (NSPLIT == 1) {
+                bf16x8 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&As[buf][(2 * s + h) * ES + (arow0 + i * 32) * 2]);
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&As[buf][0][eo + (arow0 + i * 32) * 2]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][(2 * s + h) * ES + (brow0 + j * 32) * 2]);
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][0][eo + (brow0 + j * 32) * 2]);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            } else {
+                bf16x8 af[3][TM], bf[3][TN];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[c][i] = *reinterpret_cast<const bf16x8*>(&As[buf][NSPLIT > c ? c : 0][eo + (arow0 + i * 32) * 2]);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[c][j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][NSPLIT > c ? c : 0][eo + (brow0 + j * 32) * 2]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        f32x16 a = acc[i][j];
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], a, 0, 0, 0);
+                        acc[i][j] = a;
+                    }
+            }
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
+        if (NBUF == 2) {
+            if (kt + 1 < nk) store_tile(buf ^ 1);
+            __syncthreads();
+        } else {
+            __syncthreads();
+            if (kt + 1 < nk) store_tile(0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: scale, store, per-group sum of squares (as igemm_mc) ------------------------
@@ -482,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void igemm_mc_bf16_kernel(const McParams p)
 int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, float* sq_accum, hipStream_t st);   // clip_kernels.hip
 
 // Called by the wgrad entries (igemm_mc.hip) when cslgan_conv_t.compute == CSLGAN_COMPUTE_BF16.
-int launch_mc_bf16(McParams& p, bool vecA, bool vecB, hipStream_t st) {
+int launch_mc_bf16(McParams& p, bool vecA, bool vecB, hipStream_t st, int nsplit) {
     p.tiles_m = (p.Kc + 127) / 128;
     p.tiles_n = (p.Ndim + 127) / 128;
     p.ksplit = 1;
@@ -502,11 +622,19 @@ int launch_mc_bf16(McParams& p, bool vecA, bool vecB, hipStream_t st) {
     const long long nb = (long long)p.n_groups * p.tiles_m * p.tiles_n * p.ksplit;
     if (nb > 0x7fffffffll) { set_error("wgrad_bf16: grid too large"); return CSLGAN_ERR_INVALID_ARG; }
     const dim3 grid((unsigned)nb), block(256);
-    note_kernel("igemm_mc_bf16_kernel<128,128>");
-    if (vecA && vecB) hipLaunchKernelGGL((igemm_mc_bf16_kernel<128, 128, 2, 2, true, true>), grid, block, 0, st, p);
-    else if (vecA) hipLaunchKernelGGL((igemm_mc_bf16_kernel<128, 128, 2, 2, true, false>), grid, block, 0, st, p);
-    else if (vecB) hipLaunchKernelGGL((igemm_mc_bf16_kernel<128, 128, 2, 2, false, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((igemm_mc_bf16_kernel<128, 128, 2, 2, false, false>), grid, block, 0, st, p);
+    if (nsplit == 3) {
+        note_kernel("igemm_mc_bf16x3_kernel<128,128>");
+        if (vecA && vecB) hipLaunchKernelGGL((igemm_mc_bf16_kernel<128, 128, 2, 2, true, true, 3>), grid, block, 0, st, p);
+        else if (vecA) hipLaunchKernelGGL((igemm_mc_bf16_kernel<128, 128, 2, 2, true, false, 3>), grid, block, 0, st, p);
+        else if (vecB) hipLaunchKernelGGL((igemm_mc_bf16_kernel<128, 128, 2, 2, false, true, 3>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((igemm_mc_bf16_kernel<128, 128, 2, 2, false, false, 3>), grid, block, 0, st, p);
+    } else {
+        note_kernel("igemm_mc_bf16_kernel<128,128>");
+        if (vecA && vecB) hipLaunchKernelGGL((igemm_mc_bf16_kernel<128, 128, 2, 2, true, true, 1>), grid, block, 0, st, p);
+        else if (vecA) hipLaunchKernelGGL((igemm_mc_bf16_kernel<128, 128, 2, 2, true, false, 1>), grid, block, 0, st, p);
+        else if (vecB) hipLaunchKernelGGL((igemm_mc_bf16_kernel<128, 128, 2, 2, false, true, 1>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((igemm_mc_bf16_kernel<128, 128, 2, 2, false, false, 1>), grid, block, 0, st, p);
+    }
     int rc = check_launch("igemm_mc_bf16_kernel");
     if (rc) return rc;
     if (p.ksplit > 1 && p.sq) rc = sqnorm_rows_accumulate(p.gw, p.n_groups, (long long)p.Kc * p.Ndim, p.sq, st);

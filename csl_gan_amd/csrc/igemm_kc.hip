@@ -448,7 +448,7 @@ static int check_conv(const cslgan_conv_t* c, const char* who) {
     CSLGAN_REQUIRE(c->N > 0 && c->H > 0 && c->W > 0 && c->C > 0 && c->K > 0 && c->R > 0 && c->S > 0 && c->stride > 0 && c->pad >= 0,
                    "%s: non-positive dimension", who);
     CSLGAN_REQUIRE(c->R * c->S <= IG_MAX_TAPS, "%s: %dx%d filter has more than %d taps", who, c->R, c->S, IG_MAX_TAPS);
-    CSLGAN_REQUIRE(c->compute == CSLGAN_COMPUTE_F32 || c->compute == CSLGAN_COMPUTE_BF16, "%s: unknown cslgan_conv_t.compute %d", who, c->compute);
+    CSLGAN_REQUIRE(c->compute >= CSLGAN_COMPUTE_F32 && c->compute <= CSLGAN_COMPUTE_BF16X3, "%s: unknown cslgan_conv_t.compute %d", who, c->compute);
     const int VH = c->H, VW = c->W;
     const int P = (VH + 2 * c->pad - c->R) / c->stride + 1, Q = (VW + 2 * c->pad - c->S) / c->stride + 1;
     CSLGAN_REQUIRE(P == c->P && Q == c->Q, "%s: output %dx%d does not match P,Q=%d,%d", who, P, Q, c->P, c->Q);
@@ -478,7 +478,7 @@ int cslgan_conv2d_fwd_f32(const cslgan_conv_t* c, const float* x, const float* w
     p.VH = c->H; p.VW = c->W;
     p.sy = p.sx = c->stride;
     p.w = w; p.Nn = c->K; p.out = y; p.OHf = c->P; p.OWf = c->Q; p.osy = p.osx = 1; p.ldo = c->K; p.dense_out = 1;
-    p.bias = bias; p.res = residual; p.mask = nullptr; p.act = act; p.bf16 = c->compute == CSLGAN_COMPUTE_BF16;
+    p.bias = bias; p.res = residual; p.mask = nullptr; p.act = act; p.bf16 = c->compute == CSLGAN_COMPUTE_BF16 ? 1 : (c->compute == CSLGAN_COMPUTE_BF16X3 ? 3 : 0);
     p.n_cls = 1;
     KcClass& k = p.cls[0];
     k.M = c->N * c->P * c->Q; k.OHc = c->P; k.OWc = c->Q; k.T = c->R * c->S; k.Kdim = k.T * c->C; k.w_off = 0; k.oy0 = k.ox0 = 0;
@@ -564,7 +564,7 @@ int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* c, const float* gy, const float
     p.a = gy; p.AH = c->P; p.AW = c->Q; p.AC = c->K; p.VH = c->P; p.VW = c->Q; p.sy = p.sx = 1;
     p.w = wt_ws; p.Nn = c->C; p.out = gx; p.OHf = c->H; p.OWf = c->W; p.osy = p.osx = s; p.ldo = c->C;
     p.dense_out = (s == 1) ? 1 : 0;
-    p.bias = nullptr; p.res = nullptr; p.mask = mask; p.act = CSLGAN_ACT_NONE; p.bf16 = c->compute == CSLGAN_COMPUTE_BF16;
+    p.bias = nullptr; p.res = nullptr; p.mask = mask; p.act = CSLGAN_ACT_NONE; p.bf16 = c->compute == CSLGAN_COMPUTE_BF16 ? 1 : (c->compute == CSLGAN_COMPUTE_BF16X3 ? 3 : 0);
     int off = 0, ncls = 0;
     for (int py = 0; py < s; ++py)
         for (int px = 0; px < s; ++px) {

@@ -291,7 +291,7 @@ int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, flo
 bool wgh_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const void* x);      // igemm_wgh.hip
 int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st);
 
-int launch_mc_bf16(McParams& p, bool vecA, bool vecB, hipStream_t st);        // igemm_bf16.hip
+int launch_mc_bf16(McParams& p, bool vecA, bool vecB, hipStream_t st, int nsplit);        // igemm_bf16.hip
 
 template <int BM, int BN, int WM, int WN>
 static int launch_mc_tile(McParams& p, bool vecA, bool vecB, hipStream_t st) {
@@ -345,7 +345,7 @@ static int wgrad_grouped_impl(const cslgan_conv_t* c, const float* gy, const flo
     CSLGAN_REQUIRE(gw || sq, "conv2d_wgrad: neither gw nor sq requested");
     CSLGAN_REQUIRE(group >= 1 && c->N % group == 0, "conv2d_wgrad: N=%d not divisible by group=%d", c->N, group);
     CSLGAN_REQUIRE(c->R * c->S <= IG_MAX_TAPS, "conv2d_wgrad: too many taps");
-    CSLGAN_REQUIRE(c->compute == CSLGAN_COMPUTE_F32 || c->compute == CSLGAN_COMPUTE_BF16, "conv2d_wgrad: unknown cslgan_conv_t.compute %d", c->compute);
+    CSLGAN_REQUIRE(c->compute >= CSLGAN_COMPUTE_F32 && c->compute <= CSLGAN_COMPUTE_BF16X3, "conv2d_wgrad: unknown cslgan_conv_t.compute %d", c->compute);
     const int P = (c->H + 2 * c->pad - c->R) / c->stride + 1, Q = (c->W + 2 * c->pad - c->S) / c->stride + 1;
     CSLGAN_REQUIRE(P == c->P && Q == c->Q, "conv2d_wgrad: output %dx%d does not match P,Q=%d,%d", P, Q, c->P, c->Q);
     static const int wgh_env = [] { const char* e = getenv("CSLGAN_WGH"); return e ? atoi(e) : 1; }();
@@ -360,7 +360,7 @@ static int wgrad_grouped_impl(const cslgan_conv_t* c, const float* gy, const flo
         for (int kw = 0; kw < c->S; ++kw) { p.ty[kh * c->S + kw] = (signed char)(kh - c->pad); p.tx[kh * c->S + kw] = (signed char)(kw - c->pad); }
     const bool vecA = (c->K % 4 == 0) && aligned16(gy);
     const bool vecB = (c->C % 4 == 0) && aligned16(x);
-    if (c->compute == CSLGAN_COMPUTE_BF16) return launch_mc_bf16(p, vecA, vecB, (hipStream_t)stream);
+    if (c->compute != CSLGAN_COMPUTE_F32) return launch_mc_bf16(p, vecA, vecB, (hipStream_t)stream, c->compute == CSLGAN_COMPUTE_BF16X3 ? 3 : 1);
     if (c->K > 64) return launch_mc_tile<128, 128, 2, 2>(p, vecA, vecB, (hipStream_t)stream);
     // 64 output channels: a 64x256 tile reads 20 KB per K tile for the MACs a 64x128 tile does with 12 KB twice
     static const int wide64 = [] { const char* e = getenv("CSLGAN_MC_WIDE64"); return e ? atoi(e) : 1; }();

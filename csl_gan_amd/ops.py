@@ -15,23 +15,41 @@ from . import _lib
 from ._lib import ConvT, SegsT, check
 
 ACT_NONE, ACT_LRELU02, ACT_RELU, ACT_TANH = 0, 1, 2, 3
-COMPUTE_F32, COMPUTE_BF16 = 0, 1          # cslgan_conv_t.compute (include/cslgan.h)
+COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X3 = 0, 1, 2          # cslgan_conv_t.compute (include/cslgan.h)
 
 _compute = COMPUTE_F32
+_auto = False
 
 
 def set_compute_dtype(name):
-    """Arithmetic of every MFMA conv / linear / weight-gradient launch of this process: "fp32" (exact fp32 MFMA, the default)
-    or "bf16" (operands rounded to bfloat16 in the kernels, fp32 accumulate; tensors stay fp32 in HBM).  One process drives
-    one GPU and one training run, so this is process-wide state set once from --compute_dtype."""
-    global _compute
-    if name not in ("fp32", "bf16"):
-        raise ValueError("compute dtype must be 'fp32' or 'bf16', got %r" % (name,))
-    _compute = COMPUTE_BF16 if name == "bf16" else COMPUTE_F32
+    """Arithmetic of every MFMA conv / linear / weight-gradient launch of this process (tensors are fp32 in HBM either way):
+      "fp32"    exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the default;
+      "bf16"    operands rounded to bfloat16 in the kernels, fp32 accumulate (BASELINE configs[4]);
+      "bf16x3"  fp32 emulated from three bfloat16 pieces per operand on the bf16 matrix cores (fp32-accurate, see
+                csrc/igemm_bf16.hip) for every launch;
+      "fp32_auto"  fp32 accuracy on whichever of the two fp32-accurate paths is faster for the launch: bf16x3 for forward /
+                data-gradient launches that fill the chip (the generator's 5x5 convs, the critic's fused 384-row passes),
+                exact fp32 MFMA for weight gradients and small launches.
+    One process drives one GPU and one training run, so this is process-wide state set once from --compute_dtype."""
+    global _compute, _auto
+    if name not in ("fp32", "bf16", "bf16x3", "fp32_auto"):
+        raise ValueError("compute dtype must be 'fp32', 'bf16', 'bf16x3' or 'fp32_auto', got %r" % (name,))
+    _auto = name == "fp32_auto"
+    _compute = {"fp32": COMPUTE_F32, "bf16": COMPUTE_BF16, "bf16x3": COMPUTE_BF16X3, "fp32_auto": COMPUTE_F32}[name]
 
 
 def get_compute_dtype():
-    return "bf16" if _compute == COMPUTE_BF16 else "fp32"
+    return "fp32_auto" if _auto else {COMPUTE_F32: "fp32", COMPUTE_BF16: "bf16", COMPUTE_BF16X3: "bf16x3"}[_compute]
+
+
+def _kc_compute(rows, n_out, kdim):
+    """compute field for a forward / data-gradient launch of `rows` output rows x n_out output channels with reduction
+    length kdim.  fp32_auto: measured same-box (scripts/compute_modes.py) the three-piece path wins once the launch has
+    >= 128 tiles of 128x128 and a long reduction (150-185 vs 110-135 TF on the generator's convs, 100-155 vs 81-112 TF on
+    the critic's 384-row passes) and loses on the 128-row launches of the small layers."""
+    if _auto and n_out >= 64 and kdim >= 512 and ((rows + 127) // 128) * ((n_out + 127) // 128) >= 128:
+        return COMPUTE_BF16X3
+    return _compute
 
 
 class compute_dtype:
@@ -156,9 +174,15 @@ def conv_out_size(H, R, stride, pad):
     return (H + 2 * pad - R) // stride + 1
 
 
-def _conv_desc(N, H, W, Cc, K, R, S, stride, pad):
+def _conv_desc(N, H, W, Cc, K, R, S, stride, pad, kind="wgrad"):
+    """kind: "fwd" / "dgrad" may take the bf16x3 path under fp32_auto; weight gradients never do."""
     P, Q = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
-    return ConvT(N, H, W, Cc, K, R, S, stride, pad, _compute, P, Q), P, Q
+    comp = _compute
+    if kind == "fwd":
+        comp = _kc_compute(N * P * Q, K, R * S * Cc)
+    elif kind == "dgrad":
+        comp = _kc_compute(N * H * W, Cc, (R * S * K) // (stride * stride))
+    return ConvT(N, H, W, Cc, K, R, S, stride, pad, comp, P, Q), P, Q
 
 
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, out=None, wkey=None, alg_scale=1.0):
@@ -176,7 +200,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, ou
         # (scalar gathers ran at 22-32 TF); the zero channel adds nothing to the sums
         x, w, Cc, wkey = _pad_c4(x), _pad_c4(w), 4, None
     c_alg = C2                    # channels the reference convolves (FLOP accounting)
-    d, P, Q = _conv_desc(N, H, W, Cc, K, R, S, stride, pad)
+    d, P, Q = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, kind="fwd")
     y = out if out is not None else torch.empty((N, P, Q, K), device=x.device, dtype=torch.float32)
     if bias is not None:
         _chk(bias, "bias")
@@ -254,7 +278,7 @@ def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None, wkey=None):
     N, P, Q, K = gy.shape
     K2, R, S, Cc = w.shape
     H, W = in_hw
-    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad)
+    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, kind="dgrad")
     if K2 != K or (P2, Q2) != (P, Q):
         raise RuntimeError("conv2d_dgrad: gy shape %s inconsistent with input %dx%d" % (tuple(gy.shape), H, W))
     gx = torch.empty((N, H, W, Cc), device=gy.device, dtype=torch.float32)

@@ -10,8 +10,10 @@ Additions of this build (all optional, none changes a reference default):
   --fuse_passes B      run the adaptive / generated / real discriminator passes as one forward+backward over the
                        concatenated batch (same numbers, fewer and fuller launches); needs --materialize private|ghost
   --grad_sample_dtype  storage type of the materialised per-sample weight gradients (fp32 | bf16; fp32 accumulate)
-  --compute_dtype T    arithmetic of the conv / linear / weight-gradient kernels: fp32 (exact fp32 MFMA, default) or bf16
-                       (operands rounded to bfloat16 inside the kernels, fp32 accumulate; BASELINE.json configs[4]).  With bf16
+  --compute_dtype T    arithmetic of the conv / linear / weight-gradient kernels: fp32 (exact fp32 MFMA, default), bf16x3 (fp32
+                       emulated from three bfloat16 pieces on the bf16 matrix cores: fp32-accurate, faster on large launches),
+                       fp32_auto (per launch the faster of those two) or bf16 (operands rounded to bfloat16 inside the
+                       kernels, fp32 accumulate; BASELINE.json configs[4]).  With bf16
                        the per-sample norms must be norms of the gradients that are actually summed, so ghost clipping (whose
                        Gram norms are computed in fp32) is replaced by --materialize private
   --moving_avg_beta B  the smoothing factor train.py:249 reads as opt.moving_avg_beta but options.py never defines
@@ -160,7 +162,7 @@ _ARGS = [
     (("--fuse_passes",), dict(type=str2bool, default=True)),
     (("--grad_sample_dtype",), dict(type=str, choices=["fp32", "bf16"], default="fp32")),
     (("--moving_avg_beta",), dict(type=float, default=None)),
-    (("--compute_dtype",), dict(type=str, choices=["fp32", "bf16"], default="fp32")),
+    (("--compute_dtype",), dict(type=str, choices=["fp32", "bf16", "bf16x3", "fp32_auto"], default="fp32")),
 ]
 ALWAYS_KEEP = ["g_device", "d_device", "num_workers", "resume_path", "resume_epochs"]
 

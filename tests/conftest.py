@@ -26,3 +26,14 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _reset_compute_dtype():
+    """csl_gan_amd.ops.set_compute_dtype is process-wide state (a Trainer sets it from --compute_dtype): every test starts
+    and ends on the default exact-fp32 kernels."""
+    yield
+    import sys
+    ops = sys.modules.get("csl_gan_amd.ops")
+    if ops is not None:
+        ops.set_compute_dtype("fp32")

@@ -691,3 +691,65 @@ def test_conv2d_wgrad_grouped_bf16(case, group):
         y = F.conv2d(xr[b0:b0 + grp], wz, None, stride=s, padding=p)
         refs.append(torch.autograd.grad(y, wz, grs[b0:b0 + grp])[0] * alpha)
     _close(gws.permute(0, 1, 4, 2, 3), torch.stack(refs), rtol=1e-4, what="bf16 wgrad scaled")
+
+
+# ---- bf16x3: fp32 emulated from three bfloat16 pieces per operand (cslgan_conv_t.compute = BF16X3) ----------------------
+def _err64(got, ref64):
+    got = got.detach().cpu().double()
+    return ((got - ref64).abs().max() / (ref64.abs().max() + 1e-300)).item()
+
+
+@pytest.mark.parametrize("case", [(4, 16, 16, 64, 96, 5, 1, 2), (3, 16, 16, 32, 64, 5, 2, 2), (6, 1, 1, 794, 128, 1, 1, 0), (2, 9, 7, 12, 20, 3, 1, 1),
+                                  (2, 8, 8, 512, 512, 5, 1, 2), (16, 8, 8, 256, 512, 5, 2, 2), (3, 64, 64, 3, 64, 5, 2, 2)])
+def test_bf16x3_is_fp32_accurate(case):
+    """x = hi + mid + lo in bfloat16 covers fp32's 24 mantissa bits, and the six kept piece products are exact in fp32: the
+    emulated path must be AT LEAST as close to an fp64 reference as the exact-fp32 MFMA kernels (whose k-ordered fmaf chain
+    carries ~sqrt(K) roundings), for forward, data gradient and (per-sample) weight gradient — plus an absolute fp32-level
+    bound of 2e-6 of scale."""
+    ops = _ops()
+    N, H, W, C, K, R, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
+    P, Q = (H + 2 * p - R) // s + 1, (W + 2 * p - R) // s + 1
+    gy = torch.randn(N, K, P, Q, generator=g)
+    x64, w64, gy64 = x.double().requires_grad_(True), w.double().requires_grad_(True), gy.double()
+    y64 = F.conv2d(x64, w64, None, stride=s, padding=p)
+    gx64, gw64 = torch.autograd.grad(y64, (x64, w64), gy64)
+    gws64 = []                                                     # per-sample weight gradients
+    for b in range(N):
+        wz = w.double().requires_grad_(True)
+        gws64.append(torch.autograd.grad(F.conv2d(x[b:b + 1].double(), wz, None, stride=s, padding=p), wz, gy64[b:b + 1])[0])
+    gws64 = torch.stack(gws64)
+    errs = {}
+    for mode in ("fp32", "bf16x3"):
+        with ops.compute_dtype(mode):
+            y = ops.conv2d_fwd(_nhwc(x), _krsc(w), None, stride=s, pad=p).permute(0, 3, 1, 2)
+            gx = ops.conv2d_dgrad(_nhwc(gy), _krsc(w), (H, W), stride=s, pad=p).permute(0, 3, 1, 2)
+            sq = torch.zeros(N, device="cuda")
+            gw = ops.conv2d_wgrad_grouped(_nhwc(gy), _nhwc(x), R, R, stride=s, pad=p, group=1, sq=sq).permute(0, 1, 4, 2, 3)
+        errs[mode] = (_err64(y, y64.detach()), _err64(gx, gx64), _err64(gw, gws64),
+                      _err64(sq, gws64.reshape(N, -1).pow(2).sum(1)))
+    print("bf16x3 vs fp32 kernels, max error / scale against fp64, case %s:" % (case,))
+    ratios = []
+    for i, what in enumerate(("forward", "data gradient", "per-sample weight gradient", "per-sample squared norm")):
+        e32, e3 = errs["fp32"][i], errs["bf16x3"][i]
+        print("   %-28s fp32 kernels %.2e   bf16x3 %.2e" % (what, e32, e3))
+        # fp32-level for reductions of up to 6400 terms (the exact-fp32 MFMA chain itself reaches 2.6e-6 there)
+        assert e3 <= 4e-6, "%s: bf16x3 error %.3e vs fp64 (exact-fp32 kernels: %.3e)" % (what, e3, e32)
+        assert e3 <= 3 * e32 + 1e-6, "%s: bf16x3 error %.3e is far above the exact-fp32 kernels' %.3e" % (what, e3, e32)
+        ratios.append(e3 / max(e32, 1e-12))
+    _X3_RATIOS.extend(ratios)
+
+
+_X3_RATIOS = []
+
+
+def test_bf16x3_is_on_average_no_worse_than_fp32_kernels():
+    """Over all shapes and ops of the test above (which must have run): the geometric mean of error(bf16x3) / error(fp32
+    kernels) against fp64 is <= 1 — the emulated products are as good as the exact-fp32 MFMA's, not merely 'close'."""
+    if not _X3_RATIOS:
+        pytest.skip("run together with test_bf16x3_is_fp32_accurate")
+    gm = float(np.exp(np.mean(np.log(np.maximum(_X3_RATIOS, 1e-6)))))
+    print("geometric mean of error ratios bf16x3 / fp32 kernels over %d measurements: %.3f" % (len(_X3_RATIOS), gm))
+    assert gm <= 1.0, gm

@@ -23,7 +23,7 @@ EXPORTS = [
     "cslgan_depth_to_space_f32", "cslgan_fold_channels4_f32",
     "cslgan_bias_grad_grouped_f32", "cslgan_act_bwd_f32", "cslgan_groupnorm_act_f32", "cslgan_batchnorm_act_f32", "cslgan_batchnorm_eval_act_f32",
     "cslgan_norm_act_bwd_f32", "cslgan_norm_bwd_ws_floats",
-    "cslgan_adam_step_f32",
+    "cslgan_adam_step_f32", "cslgan_adam_step_dev_f32",
 ]
 
 
@@ -31,7 +31,7 @@ class SegsT(C.Structure):
     _fields_ = [
         ("n_seg", C.c_int32), ("_pad", C.c_int32),
         ("inp", C.c_void_p * MAX_SEGS), ("out", C.c_void_p * MAX_SEGS), ("noise", C.c_void_p * MAX_SEGS),
-        ("len", C.c_int64 * MAX_SEGS), ("row_stride", C.c_int64 * MAX_SEGS),
+        ("len", C.c_int64 * MAX_SEGS), ("row_stride", C.c_int64 * MAX_SEGS), ("call_counter", C.c_void_p),
     ]
 
 
@@ -91,6 +91,7 @@ def lib():
         "cslgan_batchnorm_act_f32": [vp, vp, vp, i64, i32, f32, i32, f32, vp, vp, vp, vp, i64, i32, vp, vp],
         "cslgan_batchnorm_eval_act_f32": [vp, vp, vp, vp, vp, i64, i32, f32, i32, vp, vp, i64, i32, vp, vp],
         "cslgan_adam_step_f32": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp],
+        "cslgan_adam_step_dev_f32": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

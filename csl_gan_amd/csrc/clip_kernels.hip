@@ -157,6 +157,7 @@ struct CaArgs {
     long long row_stride[CSLGAN_MAX_SEGS];
     int tile_prefix[CSLGAN_MAX_SEGS + 1];
     int vec_ok[CSLGAN_MAX_SEGS];
+    const unsigned long long* call_counter;   // nullable: the Philox offset advances by 64 x *call_counter (graph replays)
 };
 
 template <typename T>
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(CA_THREADS) void clip_accum_noise_kernel(CaArgs a, 
                                                                       unsigned long long offset, float scale,
                                                                       float beta) {
     const int bx = blockIdx.x;
+    if (a.call_counter) offset += 64ull * (*a.call_counter);
     int s = 0;
 #pragma unroll 1
     while (s + 1 < a.n_seg && bx >= a.tile_prefix[s + 1]) ++s;
@@ -359,6 +361,7 @@ static int clip_accum_noise_impl(const cslgan_segs_t* segs, int64_t n_rows, cons
     CSLGAN_REQUIRE(n_rows >= 0, "clip_accum_noise: n_rows < 0");
     CaArgs a;
     a.n_seg = segs->n_seg;
+    a.call_counter = reinterpret_cast<const unsigned long long*>(segs->call_counter);
     int tot = 0;
     for (int s = 0; s < CSLGAN_MAX_SEGS; ++s) {
         if (s < segs->n_seg) {

@@ -437,6 +437,23 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                long long n, float lr, float b1, float b2, float eps, float wd, const int* __restrict__ step_dev) {
+    const float st = (float)(*step_dev);
+    const float bc1 = 1.f - powf(b1, st), bc2_sqrt = sqrtf(1.f - powf(b2, st));
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
 static unsigned grid_for(long long n, int per_thread = 1) {
     long long b = (n / per_thread + 255) / 256;
     if (b > 2048) b = 2048;
@@ -576,6 +593,16 @@ int cslgan_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, lr, b1, b2,
                        eps, weight_decay, (float)bc1, (float)sqrt(bc2));
     return check_launch("adam_kernel");
+}
+
+int cslgan_adam_step_dev_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                             float weight_decay, const int32_t* step_dev, void* stream) {
+    CSLGAN_REQUIRE(p && g && m && v && step_dev, "adam_dev: null argument");
+    CSLGAN_REQUIRE(n >= 0, "adam_dev: bad n");
+    if (n == 0) return CSLGAN_OK;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, lr, b1, b2,
+                       eps, weight_decay, step_dev);
+    return check_launch("adam_dev_kernel");
 }
 
 }  // extern "C"

@@ -33,6 +33,9 @@ class HipAdam(torch.optim.Optimizer):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        # capturable: the step count the bias corrections need lives in HBM (one int32 per parameter, advanced by a device op)
+        # instead of in the launch arguments, so a step recorded in a HIP graph stays correct on replay
+        self.capturable = False
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -51,8 +54,14 @@ class HipAdam(torch.optim.Optimizer):
                 if p.is_cuda:
                     if g.stride() != p.stride() or not _dense(p):
                         g = _like_layout(g, p)
+                    step = st["step"]
+                    if self.capturable:
+                        if "step_dev" not in st:
+                            st["step_dev"] = torch.full((1,), st["step"] - 1, device=p.device, dtype=torch.int32)
+                        st["step_dev"].add_(1)
+                        step = st["step_dev"]
                     ops.adam_step(_flat(p), _flat(g), _flat(st["exp_avg"]), _flat(st["exp_avg_sq"]), grp["lr"], b1, b2,
-                                  grp["eps"], grp["weight_decay"], st["step"])
+                                  grp["eps"], grp["weight_decay"], step)
                     # the kernel wrote p through its raw pointer: tell autograd (and ops.repack_cache) it changed
                     torch.autograd.graph.increment_version(p)
                 else:
@@ -356,6 +365,8 @@ class PrivacyEngine(PerSampleSink):
         self.clipper = _Clipper(self)
         self.set_max_grad_norm(max_grad_norm)
         self.seed, self._noise_calls = 0, 0
+        self._noise_ctr = None                  # device mirror of _noise_calls: the Philox offset is read from HBM (graph replays)
+        self._idx_cache = {}
         self.host_noise_generator: Optional[torch.Generator] = None   # parity mode: noise drawn on the host
         self.host_noise = None                  # parity tests: explicit unit normals, one flat tensor per parameter
         self.optimizer = None
@@ -513,7 +524,7 @@ class PrivacyEngine(PerSampleSink):
         if len(mat_idx) == len(ps):
             ops.clip_accum_noise(mats, outs, factors=f)
         else:
-            f_mat = f[torch.tensor(mat_idx, device=f.device)].contiguous() if per_layer else f
+            f_mat = f[self._index_tensor(mat_idx, f.device)].contiguous() if per_layer else f
             ops.clip_accum_noise(mats, [outs[i] for i in mat_idx], factors=f_mat)
             for i, p in enumerate(ps):       # ghost layers: sum_b f_b g_b as one clip-weighted dense wgrad per pass
                 stash = self._ghost.get(id(p))
@@ -535,6 +546,14 @@ class PrivacyEngine(PerSampleSink):
             ops.clip_accum_noise([self._dense[id(ps[i])].view(1, -1) for i in idx], [outs[i] for i in idx], beta=1.0)
         self._accumulated = False
 
+    def _index_tensor(self, idx, device):
+        """Device copy of a small index list, uploaded once (a host->device copy per step is also not graph-capturable)."""
+        key = (tuple(idx), str(device))
+        t = self._idx_cache.get(key)
+        if t is None:
+            t = self._idx_cache[key] = torch.tensor(list(idx), device=device)
+        return t
+
     def accum_grads_across_passes(self):
         """The cross-pass sum (train.py:402) already happened inside clip(): rows = passes x samples."""
         return None
@@ -546,7 +565,12 @@ class PrivacyEngine(PerSampleSink):
     # -- train.py:135-136, 484 ------------------------------------------------------------------
     def _set_seed(self, seed):
         self.seed = int(seed)
-        self._noise_calls = 0
+        self._set_noise_calls(0)
+
+    def _set_noise_calls(self, n):
+        self._noise_calls = int(n)
+        if self._noise_ctr is not None:
+            self._noise_ctr.fill_(int(n))
 
     def attach(self, optimizer):
         self.optimizer = optimizer
@@ -608,8 +632,12 @@ class PrivacyEngine(PerSampleSink):
         std_dev = None
         if self.noise_multiplier > 0:
             std_dev = (self._C_device(dev) * (self.noise_multiplier / (R ** 0.5))).expand(len(ps)).contiguous()
-        ops.clip_accum_noise(ins, grads, noise_std=std_dev, noises=noises, seed=self.seed,
-                             offset=self._noise_calls, scale=1.0 / denom)
+        if self._noise_ctr is None:
+            self._noise_ctr = torch.full((1,), self._noise_calls, device=dev, dtype=torch.int64)
+        # Philox stream (seed, call, tensor, column): the call index is read from HBM, so a graph replay advances it too
+        ops.clip_accum_noise(ins, grads, noise_std=std_dev, noises=noises, seed=self.seed, offset=0, call_counter=self._noise_ctr,
+                             scale=1.0 / denom)
+        self._noise_ctr.add_(1)
         if self.grad_reducer is not None:
             self.grad_reducer(flat)
         self._noise_calls += 1
@@ -644,5 +672,6 @@ class PrivacyEngine(PerSampleSink):
                 "noise_multiplier": self.noise_multiplier, "sample_rate": self.sample_rate}
 
     def load_state_dict(self, st):
-        self.steps, self.seed, self._noise_calls = st["steps"], int(st["seed"]), int(st["noise_calls"])
+        self.steps, self.seed = st["steps"], int(st["seed"])
+        self._set_noise_calls(st["noise_calls"])
         self.set_max_grad_norm(st["max_grad_norm"])

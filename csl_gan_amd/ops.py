@@ -558,9 +558,10 @@ def clip_factors(sq, max_norm, flat, eps=1e-6, first_private_row=0, want_norms=F
     return (f, nrm) if want_norms else f
 
 
-def clip_accum_noise(mats, outs, factors=None, noise_std=None, noises=None, seed=0, offset=0, scale=1.0, beta=0.0):
+def clip_accum_noise(mats, outs, factors=None, noise_std=None, noises=None, seed=0, offset=0, scale=1.0, beta=0.0, call_counter=None):
     """outs[i] = beta*outs[i] + scale*(sum_r f_r * mats[i][r] + noise_std[i]*z_i).  mats may mix fp32 and bf16
-    segments (one launch per element type, fp32 accumulation either way)."""
+    segments (one launch per element type, fp32 accumulation either way).  call_counter: device int64 [1] whose value is
+    added to `offset` inside the kernel (graph-captured steps: the counter lives in HBM, not in the launch arguments)."""
     L = _lib.lib()
     if factors is not None:
         _chk(factors, "factors")
@@ -572,6 +573,10 @@ def clip_accum_noise(mats, outs, factors=None, noise_std=None, noises=None, seed
             sub = idx[i:i + _lib.MAX_SEGS]
             whole = len(sub) == len(mats)
             s, n_rows = _segs([mats[j] for j in sub], [outs[j] for j in sub], None if noises is None else [noises[j] for j in sub])
+            if call_counter is not None:
+                if call_counter.dtype != torch.int64 or not call_counter.is_cuda:
+                    raise RuntimeError("call_counter must be a device int64 tensor")
+                s.call_counter = call_counter.data_ptr()
             per_seg, f = 0, None
             if factors is not None:
                 if factors.dim() == 2:
@@ -685,7 +690,14 @@ def batchnorm_eval_act(x, gamma, beta, running_mean, running_var, eps=1e-5, relu
 
 
 def adam_step(p, g, m, v, lr, b1, b2, eps, weight_decay, step):
+    """step: int (1-based, passed by value) or a device int32 tensor [1] read by the kernel (graph-captured steps)."""
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t, n)
+    if isinstance(step, torch.Tensor):
+        if step.dtype != torch.int32 or not step.is_cuda:
+            raise RuntimeError("adam_step: a tensor step must be a device int32 tensor")
+        check(_lib.lib().cslgan_adam_step_dev_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(b1), float(b2), float(eps),
+                                                  float(weight_decay), _p(step), _stream()), "adam_step_dev")
+        return
     check(_lib.lib().cslgan_adam_step_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(b1), float(b2), float(eps),
                                           float(weight_decay), int(step), _stream()), "adam_step")

@@ -41,6 +41,7 @@ class Trainer:
         self.logger = self._make_logger(log_to)
         self.dev_stats = {}
         self.batches_per_epoch = opt.train_set_size / opt.batch_size
+        self.graphed = None                # GraphedDStep, created by setup_privacy_engine when --hip_graph is set
         self.last = {}                     # observables of the most recent D-step (device tensors), for tests
         self.explicit = {}                 # optional explicit random inputs (alpha / noise / mean-sample batches) for parity tests
 
@@ -77,6 +78,8 @@ class Trainer:
         pe.attach(self.d_optimizer)
         pe._set_seed(o.manual_seed + 7919 * self.rank)
         self.privacy_engine = pe
+        if getattr(o, "hip_graph", False) and o.dp_mode == "gc" and self.world_size == 1:
+            self.graphed = GraphedDStep(self)
         return pe
 
     # ---- train.py:150-161 ---------------------------------------------------------------------
@@ -448,12 +451,18 @@ class Trainer:
         img = real_images_batch.to(o.d_device)
         labels = real_labels_batch.to(o.d_device) if o.conditional else None
         n = img.size(0)
-        self.train_D(img, labels, self.gen_z(n), labels, use_dp=use_dp)
+        if self.graphed is not None and use_dp and n == o.batch_size:
+            self.graphed(img, labels)          # recorded once, replayed afterwards (z and the mean-sample draws happen inside)
+        else:
+            self.train_D(img, labels, self.gen_z(n), labels, use_dp=use_dp)
         if batch_i % o.n_d_steps == 0:
-            gate = self.dev_stats.pop("_d_adv_gate", None)
+            acc = self.dev_stats.get("_d_adv_gate")
+            gate = None if acc is None else acc.detach().reshape(1).clone()
+            if acc is not None:
+                acc.zero_()
             if gate is not None and self.world_size > 1:           # every rank must take the same branch
                 from .distributed import average_across_ranks
-                gate = average_across_ranks(gate.detach().reshape(1).clone())
+                gate = average_across_ranks(gate)
             d_adv = 0.0 if gate is None else float(gate)           # the one host sync, every n_d_steps iterations
             if d_adv / o.n_d_steps < o.train_d_until_threshold:
                 lg.log_g_iter += 1
@@ -481,16 +490,22 @@ class Trainer:
 
     # ---- device-side statistics ----------------------------------------------------------------
     def _acc(self, name, value):
+        """Running sums live in persistent device tensors updated IN PLACE (a step recorded in a HIP graph keeps accumulating
+        into the same memory on replay)."""
         cur = self.dev_stats.get(name)
-        self.dev_stats[name] = value.clone() if cur is None else cur + value
+        if cur is None or cur.shape != value.shape:
+            self.dev_stats[name] = value.detach().clone()
+        else:
+            cur.add_(value.detach())
 
     def reset_stats(self):
         """logger.reset_stats() of the reference (train.py:566, 576): the statistics live partly on the device here, so the
         pending device-side sums (everything accumulated since the last log line) must be dropped with them — otherwise the
         tail of one epoch leaks into the first log line of the next."""
         self.logger.reset_stats()
-        for k in [k for k in self.dev_stats if not k.startswith("_")]:
-            del self.dev_stats[k]
+        for k, v in self.dev_stats.items():
+            if not k.startswith("_"):
+                v.zero_()
 
     def flush_stats(self):
         """Fold device-side sums into the Logger (this is where the host synchronises)."""
@@ -501,7 +516,7 @@ class Trainer:
             val = float(val) if val.dim() == 0 else val.numpy().astype(np.float64)
             if k in self.logger.stats:
                 self.logger.stats[k] = self.logger.stats[k] + val
-            del self.dev_stats[k]
+            v.zero_()
 
     # ---- train.py:263-278 ---------------------------------------------------------------------
     def _make_logger(self, log_to):
@@ -526,3 +541,89 @@ class Trainer:
         lg = Logger(fmt, names, max(every // o.batch_size, 1), path)
         lg.log_g_iter = 0
         return lg
+
+
+class GraphedDStep:
+    """One `Trainer.train_D` recorded in a HIP graph and replayed (fixed batch size and configuration).
+
+    The D-step of the small models is bound by the host: BASELINE configs[1] (MNIST conditional vanilla GAN, bs=600) issues
+    ~100 launches for 0.6 ms of kernel work.  Every C-ABI entry enqueues on the caller's stream, never allocates or
+    synchronises, and takes its per-step scalars either from device memory (the Philox call counter, Adam's step count, the
+    adaptive clip norms) or as constants of the configuration — so the whole step, torch's autograd bookkeeping included,
+    can be captured once (torch.cuda.CUDAGraph on the same stream) and replayed with one host call.
+
+    Per step, OUTSIDE the graph: the batch is copied into static buffers, z / penalty alpha / mean-sample batches are drawn
+    into static buffers (torch's device generator), the graph is replayed, and the host-side counters the accountant and
+    checkpoints read (engine.steps, the noise-call mirror, Adam's step) are advanced.  use_graph=False runs the identical
+    sequence eagerly (the parity reference in tests/test_graph_gpu.py)."""
+
+    def __init__(self, trainer, use_graph=True, warmup=2):
+        self.tr, self.use_graph, self.warmup = trainer, use_graph, warmup
+        o = trainer.opt
+        if not (o.use_dp and o.dp_mode == "gc"):
+            raise NotImplementedError("GraphedDStep covers the gradient-clipping D-step (dp_mode=gc)")
+        self.graph, self.bufs = None, None
+        trainer.d_optimizer.capturable = True
+
+    def _alloc(self, img, labels):
+        o, dev, B = self.tr.opt, self.tr.opt.d_device, img.shape[0]
+        b = dict(img=torch.empty_like(img, device=dev), z=torch.empty((B, o.g_latent_dim), device=o.g_device),
+                 labels=None if labels is None else torch.empty_like(labels, device=dev))
+        need_ms = self.tr.mean_sampler is not None
+        if need_ms and (len(o.penalty) > 0 or o.grad_clip_mode.startswith("adaptive")):
+            b["ms_adapt"], b["pen_real"] = torch.empty_like(b["img"]), torch.empty_like(b["img"])
+            if labels is not None:
+                b["ms_labels"] = torch.empty_like(b["labels"])
+        if len(o.penalty) > 0:
+            b["alpha"] = torch.empty(B, device=dev)
+        self.bufs = b
+
+    def _fill(self, img, labels):
+        b = self.bufs
+        b["img"].copy_(img, non_blocking=True)
+        if labels is not None:
+            b["labels"].copy_(labels, non_blocking=True)
+        b["z"].normal_(0.0, 1.0)
+        if "ms_adapt" in b:
+            ms = self.tr.mean_sampler
+            xa, ya = ms.sample(img.shape[0], requested_labels=b.get("labels") if labels is not None else None)
+            b["ms_adapt"].copy_(xa)
+            xp, _ = ms.sample(img.shape[0], requested_labels=b.get("labels") if labels is not None else None)
+            b["pen_real"].copy_(xp)
+            if "ms_labels" in b:
+                b["ms_labels"].copy_(ya)
+        if "alpha" in b:
+            b["alpha"].uniform_(0.0, 1.0)
+
+    def _eager(self):
+        b = self.bufs
+        self.tr.train_D(b["img"], b["labels"], b["z"], b["labels"], use_dp=True)
+
+    def __call__(self, img, labels=None):
+        tr = self.tr
+        if self.bufs is None:
+            self._alloc(img, labels)
+            b = self.bufs
+            tr.explicit = {k: b[s] for k, s in (("ms_adapt", "ms_adapt"), ("pen_real", "pen_real"), ("alpha", "alpha"),
+                                                ("ms_adapt_labels", "ms_labels")) if s in b}
+        elif img.shape != self.bufs["img"].shape:
+            raise RuntimeError("GraphedDStep was recorded for batch shape %s, got %s" % (tuple(self.bufs["img"].shape), tuple(img.shape)))
+        self._fill(img, labels)
+        if not self.use_graph:
+            return self._eager()
+        if self.graph is None:
+            if self.warmup > 0:
+                self.warmup -= 1
+                return self._eager()             # first steps run eagerly: allocator pools, caches and accumulators settle
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._eager()                    # RECORDED, not executed; its host-side bookkeeping ran once
+            self.graph.replay()                  # the step itself
+            return
+        self.graph.replay()
+        pe = tr.privacy_engine                   # what the recorded python would have done on the host
+        pe.steps += 1
+        pe._noise_calls += 1
+        for st in tr.d_optimizer.state.values():
+            st["step"] += 1

@@ -50,6 +50,9 @@ typedef struct {
     const float* noise[CSLGAN_MAX_SEGS];   /* device, [len] pre-drawn N(0,1) or NULL -> Philox  */
     int64_t len[CSLGAN_MAX_SEGS];
     int64_t row_stride[CSLGAN_MAX_SEGS];   /* in elements */
+    const uint64_t* call_counter;          /* device, nullable (clip_accum only): the Philox offset used is
+                                            * offset + 64 * *call_counter — a step captured in a HIP graph passes its
+                                            * noise-call counter here instead of by value, so every replay draws new noise */
 } cslgan_segs_t;
 
 int cslgan_version(void);
@@ -244,6 +247,9 @@ int64_t cslgan_norm_bwd_ws_floats(int64_t rows, int64_t rows_per_stat, int C, in
 /* Adam (torch.optim.Adam semantics, train.py:76): in-place on p, m, v.  step is 1-based. */
 int cslgan_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
                          float b2, float eps, float weight_decay, int step, void* stream);
+/* Same with the (1-based) step count read from device memory: a step captured in a HIP graph must not bake it in. */
+int cslgan_adam_step_dev_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                             float b2, float eps, float weight_decay, const int32_t* step_dev, void* stream);
 
 #ifdef __cplusplus
 }

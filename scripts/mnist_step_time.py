@@ -19,7 +19,16 @@ img = torch.rand(B, 1, 28, 28, generator=g).cuda()
 lab = torch.randint(0, 10, (B,), generator=g).cuda()
 
 
+GRAPH = "--graph" in sys.argv
+if GRAPH:
+    from csl_gan_amd.trainer import GraphedDStep
+    gstep = GraphedDStep(tr)
+
+
 def step():
+    if GRAPH:
+        gstep(img, lab)
+        return
     tr.train_D(img, lab, tr.gen_z(B), lab, use_dp=True)
     tr.dev_stats.clear()
 
@@ -27,7 +36,9 @@ def step():
 for _ in range(5):
     step()
 torch.cuda.synchronize()
-timer = ops.LaunchTimer(); ops.set_launch_timer(timer)
+timer = ops.LaunchTimer()
+if not GRAPH:
+    ops.set_launch_timer(timer)
 t0 = time.perf_counter()
 N = 30
 for _ in range(N):
@@ -35,6 +46,6 @@ for _ in range(N):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / N
 ops.set_launch_timer(None)
-print("MNIST vanilla conditional gc bs=%d materialize=%s: %.3f ms/step, %.0f images/s" % (B, opt.materialize, dt * 1e3, B / dt))
+print("MNIST vanilla conditional gc bs=%d materialize=%s%s: %.3f ms/step, %.0f images/s" % (B, opt.materialize, " HIP-graph replay" if GRAPH else "", dt * 1e3, B / dt))
 for k, v in sorted(timer.summary(by_shape=True).items(), key=lambda kv: -kv[1]["ms"])[:10]:
     print("  %-66s %7.3f ms/step %5.1f x" % (k, v["ms"] / N, v["n"] / N))

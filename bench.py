@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--loop-steps", type=int, default=10, help="iterations of the full train() loop timed for the secondary metric (0 = skip)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the hip_graph / fp32_auto variant passes (profiling runs)")
     ap.add_argument("--dump-shapes", type=str, default="", help="write the per-kernel, per-shape launch table (HIP-event times) to this file")
     ap.add_argument("--opt", type=str, default="", help="extra train.py flags for experiments, e.g. '--grad_sample_dtype bf16' "
                     "(the headline line is the run WITHOUT this)")
@@ -116,11 +117,23 @@ def main():
         tr.train_D(img, None, tr.gen_z(B), None, use_dp=True)
         tr.dev_stats.clear()
 
-    for _ in range(a.warmup):
+    # Warm-up.  Its last steps are instrumented launch by launch (HIP events on the launch stream): they name the dominant
+    # device kernel and give the per-kernel tables.  Inside the TIMED region only that kernel's launches carry events — two
+    # event records per launch cost the host ~5 us, i.e. ~1 ms per step if every one of the ~170 launches were watched.
+    n_probe = min(3, a.warmup)
+    for _ in range(a.warmup - n_probe):
         step()
     torch.cuda.synchronize()
+    probe = ops.LaunchTimer()
+    ops.set_launch_timer(probe)
+    for _ in range(n_probe):
+        step()
+    torch.cuda.synchronize()
+    ops.set_launch_timer(None)
+    pk = {k: v for k, v in probe.summary(by_kernel=True).items() if v["exec_flop"] > 0}
+    dom_name = max(pk.values(), key=lambda k: k["ms"])["name"] if pk else None
     D.barrier()
-    timer = ops.LaunchTimer()
+    timer = ops.LaunchTimer(only=probe.keys_of_kernel(dom_name) if dom_name else set())
     ops.set_launch_timer(timer)
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -136,7 +149,7 @@ def main():
     # the same step on the other fp32-accurate arithmetic (fp32_auto: three-bfloat16-piece products on the bf16 matrix cores
     # for the launches where they are faster, csl_gan_amd/ops.py:_kc_compute) — reported beside the headline, never as it
     variant = None
-    if not a.opt and world == 1:
+    if not a.opt and world == 1 and not a.no_variants:
         variant = {}
         try:        # the same step replayed from a HIP graph (no per-launch host work; trainer.GraphedDStep)
             from csl_gan_amd.trainer import GraphedDStep
@@ -193,12 +206,14 @@ def main():
     if rank != 0:
         return
     ips = world * B * a.steps / dt
-    entries = timer.summary()
-    kernels = timer.summary(by_kernel=True)
-    shapes = timer.summary(by_kernel=True, by_shape=True)
-    # roofline: the dominant device KERNEL by summed HIP-event time inside the timed region (names as rocprofv3 lists them)
-    mfma = {k: v for k, v in kernels.items() if v["exec_flop"] > 0}
-    dom = max(mfma.values(), key=lambda k: k["ms"]) if mfma else None
+    n_pr = max(n_probe, 1)
+    entries = probe.summary()                                   # per-kernel tables: the instrumented warm-up steps
+    kernels = probe.summary(by_kernel=True)
+    shapes = probe.summary(by_kernel=True, by_shape=True)
+    timed = timer.summary(by_kernel=True)                       # the dominant kernel, inside the timed region
+    timed_shapes = timer.summary(by_kernel=True, by_shape=True)
+    # roofline: the dominant device KERNEL by summed HIP-event time (names as rocprofv3 lists them)
+    dom = timed.get(dom_name) if dom_name else None
     roof = None
     if dom:
         traffic = None
@@ -213,7 +228,7 @@ def main():
         mfma_mult = 6.0 if "bf16x3" in dom["name"] else 1.0
         ach = mfma_mult * dom["exec_flop"] / (dom["ms"] * 1e-3) / 1e12
         peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom["name"] else PEAK_FP32_MFMA_TFLOPS
-        worst = sorted((v for k, v in shapes.items() if k.startswith(dom["name"])), key=lambda v: -v["ms"])
+        worst = sorted((v for k, v in timed_shapes.items() if k.startswith(dom["name"])), key=lambda v: -v["ms"])
         roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]),
@@ -227,12 +242,12 @@ def main():
                 "launch_shapes": {v["name"][len(dom["name"]) + 1:]: {"n_per_step": v["n"] / a.steps, "avg_ms": round(v["ms"] / v["n"], 4),
                                                                      "tflops": round(v["exec_flop"] / (v["ms"] * 1e-3) / 1e12, 1)}
                                   for v in worst[:8]}}
-    exec_flop_step = sum(v["exec_flop"] for v in kernels.values()) / a.steps
+    exec_flop_step = sum(v["exec_flop"] for v in kernels.values()) / n_pr
     if a.dump_shapes:
         with open(a.dump_shapes, "w") as f:
             for k, v in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"]):
                 f.write("%-78s n/step %5.1f  avg_ms %8.4f  ms/step %7.3f  %s\n" % (
-                    k, v["n"] / a.steps, v["ms"] / v["n"], v["ms"] / a.steps,
+                    k, v["n"] / n_pr, v["ms"] / v["n"], v["ms"] / n_pr,
                     ("%6.1f TF" % (v["exec_flop"] / (v["ms"] * 1e-3) / 1e12)) if v["exec_flop"] else ("%7.1f GB/s" % (v["bytes"] / (v["ms"] * 1e-3) / 1e9))))
     bf16 = getattr(opt, "compute_dtype", "fp32") == "bf16"
     step_peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
@@ -255,8 +270,9 @@ def main():
         "roofline": roof,
         "secondary": loop,
         "variants": variant,
-        "entries_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in sorted(entries.items(), key=lambda kv: -kv[1]["ms"])},
-        "kernels_ms_per_step": {k: {"ms": round(v["ms"] / a.steps, 3), "n": v["n"] / a.steps,
+        "tables_from": "%d launch-by-launch instrumented warm-up step(s); roofline from the timed region" % n_pr,
+        "entries_ms_per_step": {k: round(v["ms"] / n_pr, 3) for k, v in sorted(entries.items(), key=lambda kv: -kv[1]["ms"])},
+        "kernels_ms_per_step": {k: {"ms": round(v["ms"] / n_pr, 3), "n": v["n"] / n_pr,
                                     "tflops": round(v["exec_flop"] / (v["ms"] * 1e-3) / 1e12, 1) if v["exec_flop"] else None,
                                     "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if not v["exec_flop"] else None}
                                 for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},

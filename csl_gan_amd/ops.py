@@ -107,8 +107,11 @@ class LaunchTimer:
     caller has synchronised.  Each record carries the name of the device kernel the entry dispatched to
     (cslgan_last_kernel), so figures can be grouped per KERNEL as rocprofv3 lists them."""
 
-    def __init__(self):
+    def __init__(self, only=None):
+        """only: optional set of (entry name, shape tag) pairs — launches outside it are not instrumented (two event records
+        per launch cost the host ~5 us; bench.py watches just the dominant kernel's launches inside its timed region)."""
         self.records = []
+        self.only = only
 
     def begin(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -119,6 +122,10 @@ class LaunchTimer:
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         self.records.append((name, flop, nbytes, start, e, flop if exec_flop is None else exec_flop, tag, kernel or name))
+
+    def keys_of_kernel(self, kernel_name):
+        """(entry name, shape tag) pairs whose launches dispatched to `kernel_name`."""
+        return {(name, tag) for name, _, _, _, _, _, tag, kernel in self.records if kernel == kernel_name}
 
     def summary(self, by_shape=False, by_kernel=False):
         out = {}
@@ -149,10 +156,12 @@ def _timed(name, flop, nbytes, fn, exec_flop=None, tag=None):
     (differs for the UpsampleConv layers, which run on C/4 folded channels, and for the zero-padded RGB input)."""
     if _timer is None:
         return fn()
+    tg = tag() if callable(tag) else tag
+    if _timer.only is not None and (name, tg) not in _timer.only:
+        return fn()
     s = _timer.begin()
     r = fn()
-    _timer.end(name, flop, nbytes, s, exec_flop, tag() if callable(tag) else tag,
-               _lib.lib().cslgan_last_kernel().decode(errors="replace"))
+    _timer.end(name, flop, nbytes, s, exec_flop, tg, _lib.lib().cslgan_last_kernel().decode(errors="replace"))
     return r
 
 

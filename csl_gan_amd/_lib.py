@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcslgan_hip.so")
+LIB_PATH = os.environ.get("CSLGAN_LIB_PATH") or os.path.join(_HERE, "libcslgan_hip.so")      # override: kernel experiments
 MAX_SEGS = 16
 ABI_VERSION = 2          # include/cslgan.h CSLGAN_ABI_VERSION
 
@@ -18,7 +18,7 @@ EXPORTS = [
     "cslgan_sample_sqnorm_f32", "cslgan_sample_sqnorm_bf16", "cslgan_clip_factors_f32", "cslgan_clip_accum_noise_f32",
     "cslgan_clip_accum_noise_bf16", "cslgan_conv2d_wgrad_grouped_bf16out_f32",
     "cslgan_l2_clip_rows_f32", "cslgan_row_l2norm_f32", "cslgan_row_l2norm_bwd_f32",
-    "cslgan_conv2d_fwd_f32", "cslgan_conv2d_dgrad_f32", "cslgan_conv2d_wgrad_grouped_f32",
+    "cslgan_conv2d_fwd_f32", "cslgan_conv2d_fwd_x3_f32", "cslgan_conv2d_dgrad_f32", "cslgan_conv2d_wgrad_grouped_f32",
     "cslgan_conv2d_wgrad_scaled_f32", "cslgan_conv2d_wgrad_sqnorm_gram_f32", "cslgan_conv2d_wgrad_skinny_f32", "cslgan_conv2d_s2_fwd_f32",
     "cslgan_depth_to_space_f32", "cslgan_fold_channels4_f32",
     "cslgan_bias_grad_grouped_f32", "cslgan_act_bwd_f32", "cslgan_groupnorm_act_f32", "cslgan_batchnorm_act_f32", "cslgan_batchnorm_eval_act_f32",
@@ -76,6 +76,7 @@ def lib():
         "cslgan_row_l2norm_f32": [vp, i64, i64, vp, vp],
         "cslgan_row_l2norm_bwd_f32": [vp, vp, vp, i64, i64, vp, vp],
         "cslgan_conv2d_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, vp, i32, vp, vp],
+        "cslgan_conv2d_fwd_x3_f32": [C.POINTER(ConvT), vp, vp, vp, i32, vp, vp, i32, vp, vp],
         "cslgan_conv2d_dgrad_f32": [C.POINTER(ConvT), vp, vp, vp, i32, vp, vp, vp],
         "cslgan_norm_act_bwd_f32": [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, i32, vp, vp, vp, vp, vp],
         "cslgan_depth_to_space_f32": [vp, i32, i32, i32, i32, i32, vp, vp],

@@ -378,6 +378,7 @@ static long long tiles_for(const KcParams& p, int BM, int BN) {
 }
 
 int launch_kc_bf16(KcParams& p, hipStream_t st, long long out_elems);     // igemm_bf16.hip
+int split_filter_x3(const float* w, int Nn, int T, int C, void* w3, hipStream_t st);
 bool halo_eligible(const KcParams& p);          // igemm_halo.hip
 int launch_halo(KcParams& p, hipStream_t st);
 bool skinny_eligible(const KcParams& p);        // igemm_skinny.hip
@@ -467,8 +468,28 @@ using namespace cslgan;
 
 extern "C" {
 
+static int conv2d_fwd_impl(const cslgan_conv_t* c, const float* x, const float* w, const void* w3, const float* bias,
+                           const float* residual, int act, float* y, void* stream);
+
 int cslgan_conv2d_fwd_f32(const cslgan_conv_t* c, const float* x, const float* w, const float* bias,
                           const float* residual, int act, float* y, void* stream) {
+    return conv2d_fwd_impl(c, x, w, nullptr, bias, residual, act, y, stream);
+}
+
+int cslgan_conv2d_fwd_x3_f32(const cslgan_conv_t* c, const float* x, const float* w, void* w3_ws, int repack, const float* bias,
+                             const float* residual, int act, float* y, void* stream) {
+    CSLGAN_REQUIRE(c && w && w3_ws, "conv2d_fwd_x3: null argument");
+    CSLGAN_REQUIRE(c->compute == CSLGAN_COMPUTE_BF16X3, "conv2d_fwd_x3: cslgan_conv_t.compute must be CSLGAN_COMPUTE_BF16X3");
+    CSLGAN_REQUIRE(aligned16(w) && aligned16(w3_ws) && ((long long)c->K * c->R * c->S * c->C) % 4 == 0, "conv2d_fwd_x3: filter must be 16-byte aligned with a multiple of 4 elements");
+    if (repack) {
+        int rc = split_filter_x3(w, c->K, c->R * c->S, c->C, w3_ws, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return conv2d_fwd_impl(c, x, w, w3_ws, bias, residual, act, y, stream);
+}
+
+static int conv2d_fwd_impl(const cslgan_conv_t* c, const float* x, const float* w, const void* w3, const float* bias,
+                           const float* residual, int act, float* y, void* stream) {
     CSLGAN_REQUIRE(c && x && w && y, "conv2d_fwd: null argument");
     int rc = check_conv(c, "conv2d_fwd");
     if (rc) return rc;
@@ -477,7 +498,7 @@ int cslgan_conv2d_fwd_f32(const cslgan_conv_t* c, const float* x, const float* w
     p.a = x; p.AH = c->H; p.AW = c->W; p.AC = c->C;
     p.VH = c->H; p.VW = c->W;
     p.sy = p.sx = c->stride;
-    p.w = w; p.Nn = c->K; p.out = y; p.OHf = c->P; p.OWf = c->Q; p.osy = p.osx = 1; p.ldo = c->K; p.dense_out = 1;
+    p.w = w; p.w3 = w3; p.Nn = c->K; p.out = y; p.OHf = c->P; p.OWf = c->Q; p.osy = p.osx = 1; p.ldo = c->K; p.dense_out = 1;
     p.bias = bias; p.res = residual; p.mask = nullptr; p.act = act; p.bf16 = c->compute == CSLGAN_COMPUTE_BF16 ? 1 : (c->compute == CSLGAN_COMPUTE_BF16X3 ? 3 : 0);
     p.n_cls = 1;
     KcClass& k = p.cls[0];

@@ -93,9 +93,11 @@ def _dense_group(N: int, tiles: int = 1) -> int:
 
 class Conv(Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, residual, wkey=None, alg_scale=1.0):
-        y = ops.conv2d_fwd(x, w, b, stride=stride, pad=pad, residual=residual, act=act, wkey=wkey, alg_scale=alg_scale)
-        ctx.wkey = wkey            # the owning layer's cache token: lets ops reuse repacked filters while the parameter is unchanged
+    def forward(ctx, x, w, b, stride, pad, act, residual, wkey=None, alg_scale=1.0, wversion=None):
+        y = ops.conv2d_fwd(x, w, b, stride=stride, pad=pad, residual=residual, act=act, wkey=wkey, alg_scale=alg_scale, wversion=wversion)
+        # the owning layer's cache token lets ops reuse repacked filters while the parameter is unchanged; a derived filter
+        # (wversion given) must not be cached by the backward, whose caches key on w's own version counter
+        ctx.wkey = wkey if wversion is None else None
         ctx.cfg = (stride, pad, act)
         ctx.has_res = residual is not None
         ctx.input_only = _INPUT_GRADS_ONLY
@@ -121,7 +123,7 @@ class Conv(Function):
             gb = BiasGrad.apply(gz)
         # the residual is added before the activation (ResBlockUp's "o + s", DCResNet_models.py:38): its gradient is gz
         gres = gz if (ctx.has_res and ctx.needs_input_grad[6]) else None
-        return gx, gw, gb, None, None, None, gres, None, None
+        return gx, gw, gb, None, None, None, gres, None, None, None
 
 
 class DepthToSpace(Function):

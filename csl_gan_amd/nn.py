@@ -104,10 +104,13 @@ class HipConv2d(nn.Conv2d, _PerSampleMixin):
         w = self.weight.permute(0, 2, 3, 1).contiguous()
         if torch.is_grad_enabled() and w.requires_grad:
             wf = HF.FoldChannels4.apply(w)
-        else:
-            wf = ops.fold_channels4(w.detach(), wkey=self._wkey(w))
-        # wf is a temporary as far as ops.repack_cache is concerned (wkey=None): its address can be reused by a later fold
-        return HF.Conv.apply(x_ps, wf, self.bias, 1, self.padding[0], self.act, None, None, 4.0)
+            return HF.Conv.apply(x_ps, wf, self.bias, 1, self.padding[0], self.act, None, None, 4.0)
+        wk = self._wkey(w)
+        wf = ops.fold_channels4(w.detach(), wkey=wk)
+        # wf is derived from the parameter (its own version counter is always 0, and a later fold may reuse its address): caches
+        # downstream of it are keyed on the PARAMETER's version under a token of their own
+        return HF.Conv.apply(x_ps, wf, self.bias, 1, self.padding[0], self.act, None, None if wk is None else (wk, "fold4"), 4.0,
+                             self.weight._version)
 
     def _wkey(self, w):
         # only a zero-copy view of the parameter shares its version counter; a re-laid-out copy must not be cached

@@ -80,11 +80,12 @@ class _RepackCache:
     def __init__(self, max_entries=64):
         self.d, self.max = {}, max_entries      # callers pass wkey (a never-reused per-module token, csl_gan_amd.nn) only for module-owned filters
 
-    def get(self, kind, w, numel, wkey=None):
+    def get(self, kind, w, numel, wkey=None, version=None):
+        """version: the autograd version to key on when `w` is itself derived from a parameter (its own counter is always 0)."""
         if wkey is None:          # not known to be a live parameter (a temporary may reuse an address): never cache
             return torch.empty(numel, device=w.device, dtype=torch.float32), 1
         key = (kind, wkey, w.data_ptr(), tuple(w.shape))
-        ver = w._version
+        ver = w._version if version is None else version
         hit = self.d.get(key)
         if hit is not None and hit[0] == ver and hit[1].numel() == numel and hit[1].device == w.device:
             return hit[1], 0
@@ -194,7 +195,7 @@ def _conv_desc(N, H, W, Cc, K, R, S, stride, pad, kind="wgrad"):
     return ConvT(N, H, W, Cc, K, R, S, stride, pad, comp, P, Q), P, Q
 
 
-def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, out=None, wkey=None, alg_scale=1.0):
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, out=None, wkey=None, alg_scale=1.0, wversion=None):
     """y[N,P,Q,K] = act(conv(x[N,H,W,C], w[K,R,S,C]) + bias [+ residual[N,P,Q,K]]).
 
     alg_scale: FLOP the reference spends on this layer / FLOP of this call (4 for an UpsampleConv's conv, which the
@@ -226,6 +227,13 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, ou
         _timed("conv2d_fwd", flop, nbytes, lambda: check(
             _lib.lib().cslgan_conv2d_s2_fwd_f32(C.byref(d), _p(x), _p(w), _p(ws), repack, _p(bias), act, _p(y), _stream()),
             "conv2d_s2_fwd"), exec_flop=xflop, tag=lambda: "N%d %dx%d C%d K%d R%d s2 halo" % (N, H, W, Cc, K, R))
+        return y
+    if d.compute == COMPUTE_BF16X3 and stride == 1 and R * S > 1 and Cc % 16 == 0 and K >= 64 and P % 8 == 0 and Q % 8 == 0:
+        # the LDS-halo form of the three-piece path reads the filter pre-split into bfloat16 pieces (cached per parameter version)
+        ws, repack = repack_cache.get("x3w", w, (3 * w.numel() + 1) // 2, wkey, version=wversion)
+        _timed("conv2d_fwd", flop, nbytes, lambda: check(
+            _lib.lib().cslgan_conv2d_fwd_x3_f32(C.byref(d), _p(x), _p(w), _p(ws), repack, _p(bias), _p(residual), act, _p(y), _stream()),
+            "conv2d_fwd_x3"), exec_flop=xflop, tag=lambda: "N%d %dx%d C%d K%d R%d s%d" % (N, H, W, Cc, K, R, stride))
         return y
     _timed("conv2d_fwd", flop, nbytes, lambda: check(
         _lib.lib().cslgan_conv2d_fwd_f32(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), act, _p(y), _stream()),

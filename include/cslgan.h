@@ -141,6 +141,13 @@ typedef struct {
 int cslgan_conv2d_fwd_f32(const cslgan_conv_t* p, const float* x, const float* w, const float* bias,
                           const float* residual, int act, float* y, void* stream);
 
+/* cslgan_conv2d_fwd_f32 with compute == CSLGAN_COMPUTE_BF16X3 and the filter pre-split into its three bfloat16 pieces:
+ * w3_ws is a caller workspace of 3 * K*R*S*C bfloat16 (= 1.5 * K*R*S*C floats), rebuilt from w when repack != 0 and reused
+ * otherwise (the caller knows when w changed).  Stride-1 convs on 8x8-patchable grids with C % 16 == 0 and K >= 64 then run on
+ * the LDS-halo kernel whose filter operand goes straight from that workspace to registers; other shapes ignore it. */
+int cslgan_conv2d_fwd_x3_f32(const cslgan_conv_t* p, const float* x, const float* w, void* w3_ws, int repack,
+                             const float* bias, const float* residual, int act, float* y, void* stream);
+
 /* gx = conv_transpose(gy, w) [* lrelu'(mask)]: the data gradient (autograd of the conv above;
  * "conv_transpose2d" in the north star).  wt_ws: caller workspace of K*R*S*C floats receiving
  * the repacked filters (rebuilt when repack != 0, reused otherwise).  mask (nullable) has gx's shape:

@@ -753,3 +753,43 @@ def test_bf16x3_is_on_average_no_worse_than_fp32_kernels():
     gm = float(np.exp(np.mean(np.log(np.maximum(_X3_RATIOS, 1e-6)))))
     print("geometric mean of error ratios bf16x3 / fp32 kernels over %d measurements: %.3f" % (len(_X3_RATIOS), gm))
     assert gm <= 1.0, gm
+
+
+@pytest.mark.parametrize("case", [c for c in FWD_CASES if not c[10]])
+def test_conv2d_fwd_bf16x3(case):
+    """Every forward shape / epilogue of test_conv2d_fwd on the three-piece path (gather kernel and LDS-halo kernel), against
+    the same fp32 torch reference at the same tolerance as the exact-fp32 kernels."""
+    ops = _ops()
+    N, H, W, C, K, R, s, p, has_b, act, ups, res = case
+    g = torch.Generator().manual_seed(hash(case) % 10000)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
+    b = torch.randn(K, generator=g) if has_b else None
+    ref = F.conv2d(x, w, b, stride=s, padding=p)
+    resid = None
+    if res is not None:
+        rs = torch.randn(ref.shape, generator=g)
+        ref = ref + rs
+        resid = _nhwc(rs)
+    ref = F.leaky_relu(ref, 0.2) if act == 1 else (F.relu(ref) if act == 2 else (torch.tanh(ref) if act == 3 else ref))
+    with ops.compute_dtype("bf16x3"):
+        y = ops.conv2d_fwd(_nhwc(x), _krsc(w), None if b is None else b.cuda(), stride=s, pad=p, residual=resid, act=act)
+    _close(y.permute(0, 3, 1, 2), ref, what="bf16x3 fwd %s" % (case,))
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES + [(4, 32, 32, 64, 128, 5, 2, 2, True), (2, 16, 16, 128, 256, 5, 2, 2, False), (3, 16, 16, 64, 64, 5, 1, 2, False)])
+def test_conv2d_dgrad_bf16x3(case):
+    ops = _ops()
+    N, H, W, C, K, R, s, p, use_mask = case
+    g = torch.Generator().manual_seed(sum(case) + 5)
+    w = torch.randn(K, C, R, R, generator=g) / (K * R * R) ** 0.5
+    P, Q = (H + 2 * p - R) // s + 1, (W + 2 * p - R) // s + 1
+    gy = torch.randn(N, K, P, Q, generator=g)
+    ref = F.conv_transpose2d(gy, w, None, stride=s, padding=p, output_padding=(H + 2 * p - R - (P - 1) * s, W + 2 * p - R - (Q - 1) * s))
+    mask = None
+    if use_mask:
+        mask = torch.randn(N, C, H, W, generator=g)
+        ref = ref * torch.where(mask > 0, 1.0, 0.2)
+    with ops.compute_dtype("bf16x3"):
+        gx = ops.conv2d_dgrad(_nhwc(gy), _krsc(w), (H, W), stride=s, pad=p, mask=None if mask is None else _nhwc(mask))
+    _close(gx.permute(0, 3, 1, 2), ref, what="bf16x3 dgrad %s" % (case,))

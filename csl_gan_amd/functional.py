@@ -93,8 +93,9 @@ def _dense_group(N: int, tiles: int = 1) -> int:
 
 class Conv(Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, residual, wkey=None, alg_scale=1.0, wversion=None):
+    def forward(ctx, x, w, b, stride, pad, act, residual, wkey=None, alg_scale=1.0, wversion=None, bpc=None):
         y = ops.conv2d_fwd(x, w, b, stride=stride, pad=pad, residual=residual, act=act, wkey=wkey, alg_scale=alg_scale, wversion=wversion)
+        ctx.bpc = bpc              # backprop clipping (csl_gan_amd.backprop_clip): per-sample clip of the pre-activation gradient
         # the owning layer's cache token lets ops reuse repacked filters while the parameter is unchanged; a derived filter
         # (wversion given) must not be cached by the backward, whose caches key on w's own version counter
         ctx.wkey = wkey if wversion is None else None
@@ -114,6 +115,8 @@ class Conv(Function):
         elif act == ops.ACT_TANH:
             gz = gy * (1 - y * y)
         gz = gz.contiguous()
+        if ctx.bpc is not None:
+            gz = ctx.bpc.clip_grad(gz)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = Dgrad.apply(gz, w, x.shape[1], x.shape[2], stride, pad, ctx.wkey)
@@ -123,7 +126,7 @@ class Conv(Function):
             gb = BiasGrad.apply(gz)
         # the residual is added before the activation (ResBlockUp's "o + s", DCResNet_models.py:38): its gradient is gz
         gres = gz if (ctx.has_res and ctx.needs_input_grad[6]) else None
-        return gx, gw, gb, None, None, None, gres, None, None, None
+        return gx, gw, gb, None, None, None, gres, None, None, None, None
 
 
 class DepthToSpace(Function):
@@ -245,9 +248,9 @@ class ConvPerSample(Function):
     store (the Opacus-hook replacement, train.py:373,387) and returns only the data gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, sink, pass_idx, wkey=None):
+    def forward(ctx, x, w, b, stride, pad, act, sink, pass_idx, wkey=None, bpc=None):
         y = ops.conv2d_fwd(x, w, b, stride=stride, pad=pad, act=act)
-        ctx.wkey = wkey
+        ctx.wkey, ctx.bpc = wkey, bpc
         ctx.cfg = (stride, pad, act)
         ctx.sink, ctx.pass_idx = sink, pass_idx
         ctx.has_bias = b is not None
@@ -264,6 +267,8 @@ class ConvPerSample(Function):
                 gz = ops.act_bwd(gz, y, _SLOPE[act])
             elif act == ops.ACT_TANH:
                 gz = gz * (1 - y * y)
+            if ctx.bpc is not None:
+                gz = ctx.bpc.clip_grad(gz)
             side = ctx.sink.side_stream()
             if side is None:
                 ctx.sink.collect(ctx.pass_idx, gz, x, w.shape[1], w.shape[2], stride, pad, ctx.has_bias)
@@ -279,7 +284,7 @@ class ConvPerSample(Function):
             gx = None
             if ctx.needs_input_grad[0]:
                 gx = ops.conv2d_dgrad(gz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad, wkey=ctx.wkey)
-        return gx, None, None, None, None, None, None, None, None
+        return gx, None, None, None, None, None, None, None, None, None
 
 
 class RowL2Norm(Function):

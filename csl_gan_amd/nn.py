@@ -69,6 +69,7 @@ class PerSampleSink:
 
 class _PerSampleMixin:
     _sink = None  # set by the engine (csl_gan_amd.engine.PrivacyEngine)
+    _bpc = None   # set by csl_gan_amd.backprop_clip.BackpropClipper: per-sample input / output-gradient clip of this layer
 
     def _per_sample_active(self):
         s = self._sink
@@ -91,12 +92,15 @@ class HipConv2d(nn.Conv2d, _PerSampleMixin):
     def forward_nhwc(self, x, residual=None):
         """x: NHWC-contiguous device tensor -> NHWC output (+ residual before the activation)."""
         w = self.weight.permute(0, 2, 3, 1).contiguous()
+        bpc = self._bpc
+        if bpc is not None:
+            x = bpc.clip_input(x)              # backprop_clip.py:103 (PGCWrapper.forward)
         if self._per_sample_active() and residual is None:
             sink = self._sink
             return _record_mask(self, HF.ConvPerSample.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act,
-                                                            sink.collector(self), sink.next_pass(self), self._wkey(w)), self.act)
-        return _record_mask(self, HF.Conv.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act, residual, self._wkey(w)),
-                            self.act)
+                                                            sink.collector(self), sink.next_pass(self), self._wkey(w), bpc), self.act)
+        return _record_mask(self, HF.Conv.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act, residual, self._wkey(w),
+                                                1.0, None, bpc), self.act)
 
     def forward_shuffled(self, x_ps):
         """UpsampleConv's conv (DCResNet_models.py:16) on the depth-to-space tensor x_ps[N,2H,2W,C/4]: the reference convolves
@@ -118,8 +122,17 @@ class HipConv2d(nn.Conv2d, _PerSampleMixin):
 
     def forward(self, x):
         if not x.is_cuda:
-            return _act_cpu(super().forward(x), self.act)
+            return _forward_cpu(self, super().forward, x)
         return HF.nchw_view(self.forward_nhwc(HF.nhwc(x)))
+
+
+def _forward_cpu(layer, plain_forward, x):
+    """CPU plumbing path of a layer: optional backprop-clip of the input and of the pre-activation gradient around the stock op."""
+    bpc = layer._bpc
+    if bpc is None:
+        return _act_cpu(plain_forward(x), layer.act)
+    from .backprop_clip import ClipGrad
+    return _act_cpu(ClipGrad.apply(plain_forward(bpc.clip_input(x)), bpc), layer.act)
 
 
 class HipLinear(nn.Linear, _PerSampleMixin):
@@ -133,16 +146,19 @@ class HipLinear(nn.Linear, _PerSampleMixin):
 
     def forward(self, x):
         if not x.is_cuda:
-            return _act_cpu(super().forward(x), self.act)
+            return _forward_cpu(self, super().forward, x)
         B = x.shape[0]
+        bpc = self._bpc
+        if bpc is not None:
+            x = bpc.clip_input(x)
         x4 = x.contiguous().reshape(B, 1, 1, self.in_features)
         w4 = self.weight.reshape(self.out_features, 1, 1, self.in_features)
         wkey = self._wtoken if w4.data_ptr() == self.weight.data_ptr() else None
         if self._per_sample_active():
             sink = self._sink
-            y = HF.ConvPerSample.apply(x4, w4, self.bias, 1, 0, self.act, sink.collector(self), sink.next_pass(self), wkey)
+            y = HF.ConvPerSample.apply(x4, w4, self.bias, 1, 0, self.act, sink.collector(self), sink.next_pass(self), wkey, bpc)
         else:
-            y = HF.Conv.apply(x4, w4, self.bias, 1, 0, self.act, None, wkey)
+            y = HF.Conv.apply(x4, w4, self.bias, 1, 0, self.act, None, wkey, 1.0, None, bpc)
         return _record_mask(self, y.reshape(B, self.out_features), self.act)
 
 

@@ -37,6 +37,7 @@ class Trainer:
         self.mean_sampler = mean_sampler
         self.world_size, self.rank, self.grad_reducer = world_size, rank, grad_reducer
         self.privacy_engine = None
+        self.prop_grad_clipper = None      # BackpropClipper, created by setup_backprop_clip when --backprop_clip is set
         self.g_optimizer, self.d_optimizer = self.init_optimizers()
         self.logger = self._make_logger(log_to)
         self.dev_stats = {}
@@ -51,9 +52,28 @@ class Trainer:
         return (E.HipAdam(self.G.parameters(), lr=o.g_lr, betas=(o.adam_b1, o.adam_b2)),
                 E.HipAdam(self.D.parameters(), lr=o.d_lr, betas=(o.adam_b1, o.adam_b2), weight_decay=o.weight_decay))
 
+    # ---- train.py:84-92 -----------------------------------------------------------------------
+    def setup_backprop_clip(self):
+        """Experimental in the reference (options.py:243-244).  Hangs the per-layer input / output-gradient clips on D and turns the
+        analytic per-sample gradient bounds into the engine's per-layer clip norms (x batch_size: the losses are batch means)."""
+        o = self.opt
+        if not o.backprop_clip:
+            return None
+        from .backprop_clip import BackpropClipper
+        with torch.no_grad():
+            p = ((o.bpc_back_clip_param_pl, o.bpc_forward_clip_param_pl) if o.grad_clip_mode[-3:] == "-pl"
+                 else (o.bpc_back_clip_param, o.bpc_forward_clip_param))
+            self.prop_grad_clipper = BackpropClipper(self.D, *p, o.bpc_auto_activation_scale, o.bpc_auto_weight_grad_scale, device=o.d_device)
+            clip_params = [c * o.batch_size for c in self.prop_grad_clipper.grad_l2_bounds]
+            o.clipping_param_per_layer = clip_params
+            o.clipping_param = np.linalg.norm(clip_params, ord=2)
+        return self.prop_grad_clipper
+
     # ---- train.py:95-138 ----------------------------------------------------------------------
     def setup_privacy_engine(self):
         o = self.opt
+        if o.backprop_clip and self.prop_grad_clipper is None:
+            self.setup_backprop_clip()
         params = dict(batch_size=o.batch_size, sample_size=o.train_set_size,
                       alphas=[1 + x / 10.0 for x in range(1, 100)] + list(range(12, 400)), noise_multiplier=o.sigma,
                       world_size=self.world_size)
@@ -78,7 +98,7 @@ class Trainer:
         pe.attach(self.d_optimizer)
         pe._set_seed(o.manual_seed + 7919 * self.rank)
         self.privacy_engine = pe
-        if getattr(o, "hip_graph", False) and o.dp_mode == "gc" and self.world_size == 1:
+        if getattr(o, "hip_graph", False) and o.dp_mode == "gc" and self.world_size == 1 and not o.backprop_clip:
             self.graphed = GraphedDStep(self)
         return pe
 
@@ -311,7 +331,7 @@ class Trainer:
         use_grad_clip = o.dp_mode == "gc" and use_dp
         use_imm_sens = o.dp_mode == "is" and use_dp
         if o.backprop_clip and use_dp:
-            raise NotImplementedError("--backprop_clip: experimental/unfinished in the reference (options.py:243-244); only l2_clip is built")
+            self.prop_grad_clipper.enable_hooks()
         if o.per_sample_grad and use_dp:
             pe.enable_hooks()
         if use_imm_sens:
@@ -332,6 +352,10 @@ class Trainer:
         if o.per_sample_grad and use_dp and not fused:
             d_loss.backward()
             pe.disable_hooks()
+        if o.backprop_clip and use_dp:
+            if not o.per_sample_grad:
+                d_loss.backward()
+            self.prop_grad_clipper.disable_hooks()
         if use_grad_clip:
             pe.clip()
             if o.grad_clip_split:
@@ -386,6 +410,8 @@ class Trainer:
 
         if self.explicit.get("keep") and use_grad_clip:
             self.last["summed_grad"] = [p.summed_grad.clone() for p in D.parameters()]
+        if o.bpc_during_g_train and o.backprop_clip and use_dp:
+            self.prop_grad_clipper.enable_hooks()
         self.d_optimizer.step()
         util.unfreeze(G)
 

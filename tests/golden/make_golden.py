@@ -191,6 +191,75 @@ def model_case(name, dataset, model, im_size, B, seed, latent=128, **kw):
     print(name, "g_loss %.6f" % out["g_loss"], "fake range", float(fake.min()), float(fake.max()))
 
 
+def reference_bpc_namespace():
+    """Functions and classes of the reference's backprop_clip.py, executed from its own source (its imports need torchinfo, absent)."""
+    import ast
+    from torch import nn
+    ns = {"torch": torch, "nn": nn, "np": np, "List": list, "os": os, "sys": sys, "__name__": "reference_backprop_clip"}
+    path = os.path.join(REF, "backprop_clip.py")
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    tree.body = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef))]
+    exec(compile(tree, path, "exec"), ns)
+    return ns
+
+
+def _sample(t, n=4096):
+    f = t.detach().reshape(-1)
+    return f[::max(1, f.numel() // n)][:n].numpy().copy()
+
+
+def bpc_case(name, model, B, seed, back=None, fwd=None, aas=0.2, awgs=1e-3, conditional=False):
+    """The reference's PGCWrapper / BackpropClipper.convert on its own MNIST discriminators.  BackpropClipper.__init__ calls
+    torchinfo.summary (absent) only to read each leaf layer's input / output size; forward hooks on one zero 1x1x28x28 batch
+    (its probe, backprop_clip.py:123) give the same sizes, then the object is filled in as its __init__ does (backprop_clip.py:
+    107-120) and its own convert() wraps the layers."""
+    ns = reference_bpc_namespace()
+    _, D = reference_init_models("MNIST", model=model, im_size=28, init_G=False, weights_seed=seed, conditional=conditional,
+                                 n_classes=10, conditional_arch="CGAN", aux_loss_type="cross_entropy")
+    hs = [m.register_forward_hook(lambda m, i, o: (setattr(m, "in_shape", list(i[0].shape[1:])), setattr(m, "out_shape", list(o.shape[1:])))[0])
+          for m in D.modules() if len(list(m.children())) < 1]
+    g = torch.Generator().manual_seed(seed)
+    y1 = torch.zeros(1, dtype=torch.long) if conditional else None
+    with torch.no_grad():
+        D(torch.zeros(1, 1, 28, 28), y1)
+    for h in hs:
+        h.remove()
+    pgc = object.__new__(ns["BackpropClipper"])
+    pgc.hooks_enabled, pgc.parameter_ind, pgc.layer_ind, pgc.device = True, 0, 0, "cpu"
+    pgc.back_clip_params = [] if back is None else list(back)
+    pgc.input_clip_params = [] if fwd is None else list(fwd)
+    pgc.auto_activation_scale, pgc.auto_weight_grad_scale, pgc.grad_l2_bounds = aas, awgs, []
+    pgc.convert(D, auto_params=(back is None or fwd is None))
+    # rows of very different size: some inputs / gradients are clipped, some are not
+    x = torch.rand(B, 1, 28, 28, generator=g) * torch.logspace(-2, 0, B).view(B, 1, 1, 1)
+    y = torch.randint(0, 10, (B,), generator=g) if conditional else None
+    w = torch.logspace(-3, 1, B)                     # per-sample loss weights: output gradients of very different size
+    res = dict(seed=seed, B=B, x=x.numpy(), w=w.numpy(), aas=aas, awgs=awgs,
+               grad_l2_bounds=np.asarray(pgc.grad_l2_bounds, dtype=np.float64),
+               back_clip_params=np.asarray(pgc.back_clip_params, dtype=np.float64),
+               input_clip_params=np.asarray(pgc.input_clip_params, dtype=np.float64),
+               wnorms=np.asarray([p.double().norm().item() for p in D.parameters()]))
+    if y is not None:
+        res["y"] = y.numpy()
+    if back is not None:
+        res["back_in"], res["fwd_in"] = np.asarray(back, dtype=np.float64), np.asarray(fwd, dtype=np.float64)
+    for tag, on in (("on", True), ("off", False)):
+        pgc.hooks_enabled = on
+        for p in D.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        out, _ = D(xi, y)
+        ((out.reshape(B) * w).sum() / B).backward()
+        res["out"] = out.detach().numpy()
+        res["gx_" + tag] = xi.grad.numpy()
+        res["gnorm_" + tag] = np.asarray([p.grad.double().norm().item() for p in D.parameters()])
+        for i, p in enumerate(D.parameters()):
+            res["g%d_%s" % (i, tag)] = _sample(p.grad)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
+    print(name, "bounds", pgc.grad_l2_bounds, "gnorm on", res["gnorm_on"], "off", res["gnorm_off"])
+
+
 def aux_loss_cases():
     g = torch.Generator().manual_seed(5)
     out = {}
@@ -235,6 +304,9 @@ if __name__ == "__main__":
     gp_case("gp_celeba64_cond_aux_b3", "CelebA", 64, 3, seed=14, conditional=True, aux_penalty=True)
     aux_loss_cases()
     logger_case()
+    bpc_case("bpc_mnist_dcrn_auto_b6", "DeepConvResNet", 6, seed=31)
+    bpc_case("bpc_mnist_vanilla_cond_auto_b8", "Vanilla", 8, seed=32, conditional=True, aas=0.05, awgs=1e-4)
+    bpc_case("bpc_mnist_dcrn_explicit_b5", "DeepConvResNet", 5, seed=33, back=[0.02, 0.01, 0.5], fwd=[3.0, 20.0, 10.0])
     upsample_conv_case()
     model_case("model_celeba64_gn_b2", "CelebA", "DeepConvResNet", 64, 2, seed=21)
     model_case("model_celeba64_bn_b3", "CelebA", "DeepConvResNet", 64, 3, seed=22, per_sample_grad=False)

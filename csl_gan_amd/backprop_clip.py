@@ -133,11 +133,19 @@ class BackpropClipper:
         was = model.training
         # the reference's probe has no label, so its conditional discriminators fail inside torchinfo; a zero label is passed here
         y = torch.zeros(input_size[0], dtype=torch.long, device=p.device) if getattr(model, "n_classes", 0) > 1 else None
-        with torch.no_grad():
-            model(torch.zeros(input_size, device=p.device, dtype=p.dtype), y)
+        from . import nn as hip_nn
+        log = {}
+        hip_nn.set_shape_log(log)          # the HIP convs chain NHWC tensors without going through Module.__call__
+        try:
+            with torch.no_grad():
+                model(torch.zeros(input_size, device=p.device, dtype=p.dtype), y)
+        finally:
+            hip_nn.set_shape_log(None)
+            for h in handles:
+                h.remove()
         model.train(was)
-        for h in handles:
-            h.remove()
+        for m, (i, o) in log.items():
+            m.in_shape, m.out_shape = i, o
 
     def enable_hooks(self):
         self.hooks_enabled = True

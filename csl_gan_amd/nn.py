@@ -97,10 +97,13 @@ class HipConv2d(nn.Conv2d, _PerSampleMixin):
             x = bpc.clip_input(x)              # backprop_clip.py:103 (PGCWrapper.forward)
         if self._per_sample_active() and residual is None:
             sink = self._sink
-            return _record_mask(self, HF.ConvPerSample.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act,
-                                                            sink.collector(self), sink.next_pass(self), self._wkey(w), bpc), self.act)
-        return _record_mask(self, HF.Conv.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act, residual, self._wkey(w),
-                                                1.0, None, bpc), self.act)
+            y = HF.ConvPerSample.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act, sink.collector(self), sink.next_pass(self),
+                                       self._wkey(w), bpc)
+        else:
+            y = HF.Conv.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act, residual, self._wkey(w), 1.0, None, bpc)
+        if _shape_log is not None:
+            _shape_log[self] = ((x.shape[3], x.shape[1], x.shape[2]), (y.shape[3], y.shape[1], y.shape[2]))
+        return _record_mask(self, y, self.act)
 
     def forward_shuffled(self, x_ps):
         """UpsampleConv's conv (DCResNet_models.py:16) on the depth-to-space tensor x_ps[N,2H,2W,C/4]: the reference convolves
@@ -124,6 +127,14 @@ class HipConv2d(nn.Conv2d, _PerSampleMixin):
         if not x.is_cuda:
             return _forward_cpu(self, super().forward, x)
         return HF.nchw_view(self.forward_nhwc(HF.nhwc(x)))
+
+
+_shape_log = None      # {layer: (in_shape, out_shape)} while BackpropClipper probes the model (the NHWC fast path skips module hooks)
+
+
+def set_shape_log(d):
+    global _shape_log
+    _shape_log = d
 
 
 def _forward_cpu(layer, plain_forward, x):

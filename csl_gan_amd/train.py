@@ -102,6 +102,7 @@ def main(argv=None):
             privacy_writer.writerow(["Epoch", "Epsilon"])
             privacy_log.flush()
 
+    tr.init_fixed_samples()                                # train.py:256-261
     print("\nStarting training...\n")
     tr.reset_stats()
     for it in range(opt.warmup_iter):                      # train.py:567-569: public / mean samples, no DP
@@ -142,6 +143,8 @@ def main(argv=None):
                 break
         if opt.log_every_epochs > 0 and (epoch + 1) % opt.log_every_epochs == 0:
             tr.log(epoch, 100)
+        if opt.sample_every_epochs > 0 and (epoch + 1) % opt.sample_every_epochs == 0:
+            tr.sample(epoch, batch_i)
         if opt.use_dp:
             eps, _ = tr.privacy_engine.get_privacy_spent(opt.delta)
             if privacy_writer is not None:

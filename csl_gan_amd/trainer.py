@@ -42,6 +42,7 @@ class Trainer:
         self.logger = self._make_logger(log_to)
         self.dev_stats = {}
         self.batches_per_epoch = opt.train_set_size / opt.batch_size
+        self.fixed_z = self.fixed_y = None  # set by init_fixed_samples (train.py:256-261); sample() is a no-op until then
         self.graphed = None                # GraphedDStep, created by setup_privacy_engine when --hip_graph is set
         self.last = {}                     # observables of the most recent D-step (device tensors), for tests
         self.explicit = {}                 # optional explicit random inputs (alpha / noise / mean-sample batches) for parity tests
@@ -499,6 +500,34 @@ class Trainer:
                 lg.stats[stat] *= 0 if lg.log_g_iter == 0 else lg.interval / lg.log_g_iter
             lg.log_g_iter = 0
             self.log(epoch, 100 * batch_i / self.batches_per_epoch, print_dp=use_dp)
+        if ((batch_i + 1) * o.batch_size) % o.sample_every == 0:
+            self.sample(epoch, batch_i)
+
+    # ---- train.py:256-261, 298-308 ------------------------------------------------------------
+    def init_fixed_samples(self):
+        o = self.opt
+        self.fixed_z = self.gen_z(o.sample_num)
+        if o.conditional:
+            self.fixed_y = torch.cat([torch.arange(o.n_classes) for _ in range(o.sample_num // o.n_classes)]).to(o.g_device)
+            self.fixed_z = self.fixed_z[:len(self.fixed_y)]
+        else:
+            self.fixed_y = self.gen_y(o.sample_num)
+
+    def sample(self, epoch, batch):
+        """G.eval() on the fixed latents -> samples/<epoch+1>-<batch>.png, n_classes images per row (rank 0 only under --dist)."""
+        o, G = self.opt, self.G
+        if self.fixed_z is None or self.rank != 0:
+            return None
+        import os
+        G.eval()
+        with torch.no_grad():
+            fake = G(self.fixed_z, self.fixed_y).to("cpu")
+            if o.dataset == "CelebA":
+                fake = util.denorm_celeba(fake)
+            path = os.path.join(o.output_dir + "samples/", "%d-%d.png" % (epoch + 1, batch))
+            util.save_image(fake, path, nrow=o.n_classes)
+        G.train()
+        return path
 
     def log(self, epoch, epoch_progress, print_dp=False):
         self.flush_stats()

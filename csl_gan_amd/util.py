@@ -13,6 +13,32 @@ def denorm_celeba(img):
     return ((img + 1) / 2).clamp(0, 1)
 
 
+def make_grid(images, nrow=8, padding=2, pad_value=0.0):
+    """torchvision.utils.make_grid (torchvision is absent; its published layout restated): [N,C,H,W] -> [3,H',W'] with `nrow`
+    images per row, `padding` pixels of `pad_value` around every image, single-channel images repeated to 3 channels."""
+    if images.dim() == 3:
+        images = images.unsqueeze(0)
+    if images.size(1) == 1:
+        images = images.expand(-1, 3, -1, -1)
+    n, c, h, w = images.shape
+    xmaps = min(nrow, n)
+    ymaps = -(-n // xmaps)
+    hh, ww = h + padding, w + padding
+    grid = images.new_full((c, hh * ymaps + padding, ww * xmaps + padding), pad_value)
+    for k in range(n):
+        y, x = divmod(k, xmaps)
+        grid[:, y * hh + padding:y * hh + padding + h, x * ww + padding:x * ww + padding + w] = images[k]
+    return grid
+
+
+def save_image(images, path, nrow=8, padding=2):
+    """torchvision.utils.save_image (train.py:305-306): the grid, x255 + 0.5, clamped, as an 8-bit RGB PNG."""
+    from PIL import Image
+    grid = make_grid(images.detach().float().cpu(), nrow=nrow, padding=padding)
+    arr = grid.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+    Image.fromarray(arr).save(path, format="PNG")
+
+
 def save_model(epoch, model, optimizer, loss, path):
     """Same on-disk dict as util.py:16-22 (epoch / model_state_dict / optimizer_state_dict / loss)."""
     state = {k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}

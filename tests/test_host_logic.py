@@ -302,3 +302,34 @@ def test_trainer_reset_stats_drops_pending_device_sums(tmp_path):
     tr._acc("D Real Acc", torch.tensor(50.0))
     tr.flush_stats()
     assert tr.logger.stats["D Real Acc"] == 50.0
+
+
+def test_make_grid_layout_and_png(tmp_path):
+    """torchvision.utils.make_grid / save_image restated (torchvision absent -> PNG bytes are parity-unpinned; the layout is the
+    published one: nrow images per row, 2-pixel zero border, x255 + 0.5 rounding)."""
+    from PIL import Image
+    from csl_gan_amd import util
+    imgs = torch.arange(5 * 1 * 4 * 3, dtype=torch.float32).reshape(5, 1, 4, 3) / 60.0
+    g = util.make_grid(imgs, nrow=2)
+    assert g.shape == (3, 3 * (4 + 2) + 2, 2 * (3 + 2) + 2)
+    assert torch.equal(g[0, 2:6, 2:5], imgs[0, 0]) and torch.equal(g[2, 2 + 6:6 + 6, 2 + 5:5 + 5], imgs[3, 0])
+    assert g[:, :2].abs().sum() == 0 and g[:, 14:18, 7:].abs().sum() == 0        # border; the empty 6th cell
+    p = str(tmp_path / "g.png")
+    util.save_image(imgs, p, nrow=2)
+    arr = np.asarray(Image.open(p))
+    assert arr.shape == (20, 12, 3) and arr.dtype == np.uint8
+    assert arr[2, 3, 0] == int(imgs[0, 0, 0, 1] * 255 + 0.5)
+
+
+def test_cli_writes_sample_grids(tmp_path):
+    """train.py:545-546,584-585: sample() every sample_every images and at the epoch boundary; conditional -> n_classes per row."""
+    import os
+    from PIL import Image
+    from csl_gan_amd import train as T
+    out = str(tmp_path / "run")
+    T.main(["MNIST", "--conditional", "-bs", "8", "-gd", "cpu", "-dd", "cpu", "-o", out, "--synthetic", "--max_iters", "4", "--manual_seed", "3",
+            "--sample_every", "16", "--sample_num", "20", "--log_every", "4096"])
+    files = sorted(os.listdir(os.path.join(out, "samples")))
+    assert files == ["1-1.png", "1-3.png"], files
+    im = Image.open(os.path.join(out, "samples", "1-1.png"))
+    assert im.size == (10 * 30 + 2, 2 * 30 + 2)

@@ -186,8 +186,9 @@ def test_dp_step_with_backprop_clip_feeds_the_engine_the_clipped_per_sample_grad
     exp = torch.zeros_like(got)
     for r in range(2 * B):
         out, _ = Do(rows[r:r + 1])
-        gr = torch.autograd.grad(out.sum(), list(Do.parameters()))
-        exp[:, r] = torch.stack([x.double().norm() for x in gr])
+        # the hooks see the gradient of the batch-MEAN loss (1/B per sample); the engine rescales per-sample gradients by B
+        gr = torch.autograd.grad(out.sum() / B, list(Do.parameters()))
+        exp[:, r] = torch.stack([x.double().norm() * B for x in gr])
     for i, (n, _) in enumerate(D.named_parameters()):
         err = (got[i] - exp[i]).abs().max().item() / exp[i].abs().max().item()
         assert err <= 1e-3, "%s: %.3e" % (n, err)

@@ -132,4 +132,10 @@ struct McParams {
     signed char ty[IG_MAX_TAPS], tx[IG_MAX_TAPS];   // kh-pad, kw-pad
 };
 
+// conv_c3.hip: the 3 -> 64 channel 5x5 stride-2 first layer on unpadded RGB input
+bool c3_fwd_eligible(const cslgan_conv_t* c, const float* residual);
+int launch_c3_fwd(const cslgan_conv_t* c, const float* x, const float* w, const float* bias, int act, float* y, hipStream_t st);
+bool c3_wgrad_eligible(const cslgan_conv_t* c, int group, int out_bf16, const void* gy);
+int launch_c3_wgrad(const cslgan_conv_t* c, const float* gy, const float* x, float alpha, float* gw, float* sq, hipStream_t st);
+
 }  // namespace cslgan

@@ -494,6 +494,9 @@ static int conv2d_fwd_impl(const cslgan_conv_t* c, const float* x, const float* 
     int rc = check_conv(c, "conv2d_fwd");
     if (rc) return rc;
     CSLGAN_REQUIRE(act >= 0 && act <= 3, "conv2d_fwd: unknown activation %d", act);
+    static const int c3_env = [] { const char* e = getenv("CSLGAN_C3"); return e ? atoi(e) : 1; }();
+    if (c3_env && c3_fwd_eligible(c, residual))          // the critic's RGB first layer (conv_c3.hip), exact fp32 in every compute mode
+        return launch_c3_fwd(c, x, w, bias, act, y, (hipStream_t)stream);
     KcParams p{};
     p.a = x; p.AH = c->H; p.AW = c->W; p.AC = c->C;
     p.VH = c->H; p.VW = c->W;

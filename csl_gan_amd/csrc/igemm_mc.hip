@@ -348,6 +348,9 @@ static int wgrad_grouped_impl(const cslgan_conv_t* c, const float* gy, const flo
     CSLGAN_REQUIRE(c->compute >= CSLGAN_COMPUTE_F32 && c->compute <= CSLGAN_COMPUTE_BF16X3, "conv2d_wgrad: unknown cslgan_conv_t.compute %d", c->compute);
     const int P = (c->H + 2 * c->pad - c->R) / c->stride + 1, Q = (c->W + 2 * c->pad - c->S) / c->stride + 1;
     CSLGAN_REQUIRE(P == c->P && Q == c->Q, "conv2d_wgrad: output %dx%d does not match P,Q=%d,%d", P, Q, c->P, c->Q);
+    static const int c3_env = [] { const char* e = getenv("CSLGAN_C3"); return e ? atoi(e) : 1; }();
+    if (c3_env && !row_scale && c3_wgrad_eligible(c, group, out_bf16, gy))     // the critic's RGB first layer (conv_c3.hip)
+        return launch_c3_wgrad(c, gy, x, alpha, gw, sq, (hipStream_t)stream);
     static const int wgh_env = [] { const char* e = getenv("CSLGAN_WGH"); return e ? atoi(e) : 1; }();
     if (wgh_env && !row_scale && c->compute == CSLGAN_COMPUTE_F32 && wgh_eligible(c, out_bf16, gy, x))
         return launch_wgh(c, gy, x, group, alpha, gw, sq, (hipStream_t)stream);

@@ -205,9 +205,9 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, ou
     K, R, S, C2 = w.shape
     if C2 != Cc:
         raise RuntimeError("conv2d_fwd: channel mismatch x C=%d, w C=%d" % (Cc, C2))
-    if Cc == 3 and R * S > 1:
-        # RGB input (the critic's first conv): a zero 4th channel makes every tap one aligned 16-byte load
-        # (scalar gathers ran at 22-32 TF); the zero channel adds nothing to the sums
+    if Cc == 3 and R * S > 1 and not _c3_layer(H, W, K, R, S, stride, pad, residual is None and H % 16 == 0 and W % 32 == 0):
+        # RGB input on a shape the first-layer kernel (csrc/conv_c3.hip) does not take: a zero 4th channel makes every tap one
+        # aligned 16-byte load (scalar gathers ran at 22-32 TF); the zero channel adds nothing to the sums
         x, w, Cc, wkey = _pad_c4(x), _pad_c4(w), 4, None
     c_alg = C2                    # channels the reference convolves (FLOP accounting)
     d, P, Q = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, kind="fwd")
@@ -280,6 +280,11 @@ def unfold_channels4(gwf):
     gw = torch.empty((K, R, S, 4 * Cq), device=gwf.device, dtype=torch.float32)
     check(_lib.lib().cslgan_fold_channels4_f32(_p(gwf), K * R * S, 4 * Cq, 1, _p(gw), _stream()), "unfold_channels4")
     return gw
+
+
+def _c3_layer(H, W, K, R, S, stride, pad, grid_ok):
+    """The critic's first conv as csrc/conv_c3.hip takes it (c3_shape there): 3 -> 64 channels, 5x5, stride 2, pad 2, even image."""
+    return K == 64 and R == 5 and S == 5 and stride == 2 and pad == 2 and H % 2 == 0 and W % 2 == 0 and grid_ok
 
 
 def _pad_c4(t):
@@ -400,8 +405,11 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
     _chk(gy, "gy"); _chk(x, "x")
     N, H, W, Cc = x.shape
     N2, P, Q, K = gy.shape
-    if Cc == 3 and R * S > 1 and row_scale is None and (out is None or out.dtype == torch.float32):
-        # RGB input: run on a zero-padded 4th channel (aligned 16-byte gathers), then drop that channel's (zero) gradients
+    c3 = (Cc == 3 and group == 1 and row_scale is None and (out is None or out.dtype == torch.float32)
+          and _c3_layer(H, W, K, R, S, stride, pad, Q in (16, 32, 64) and P % (128 // Q) == 0))
+    if Cc == 3 and R * S > 1 and row_scale is None and (out is None or out.dtype == torch.float32) and not c3:
+        # RGB input on a shape the first-layer kernel does not take: run on a zero-padded 4th channel (aligned 16-byte gathers),
+        # then drop that channel's (zero) gradients
         g4 = conv2d_wgrad_grouped(gy, _pad_c4(x), R, S, stride=stride, pad=pad, group=group, alpha=alpha, want_gw=want_gw, sq=sq)
         if g4 is None:
             return None
@@ -432,7 +440,7 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
         # norms only, but a layer with a handful of tiles and a long pixel loop (the 3-channel first conv) runs several
         # times faster when its pixels are split over workgroups, which needs a (small) output to accumulate into
         tiles = ((K + 63) // 64) * ((R * S * Cc + 127) // 128) * G
-        if tiles < 192 and group * P * Q >= 512 and G * K * R * S * Cc <= (1 << 22):
+        if not c3 and tiles < 192 and group * P * Q >= 512 and G * K * R * S * Cc <= (1 << 22):
             want_gw, scratch = True, True
     if want_gw:
         gw = out if out is not None else torch.empty((G, K, R, S, Cc), device=x.device, dtype=torch.float32)
@@ -469,7 +477,10 @@ def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, alpha=1.0, row_scale=None):
         out = torch.empty(K * R * S * Cc, device=x.device, dtype=torch.float32)
         clip_accum_noise([partial], [out])
         return out.view(K, R, S, Cc)
-    group = dense_wgrad_group(N, K, Cc, R, S, P * Q, stride=stride, out_hw=None if row_scale is not None else (P, Q))
+    if Cc == 3 and row_scale is None and _c3_layer(H, W, K, R, S, stride, pad, Q in (16, 32, 64) and P % (128 // Q) == 0):
+        group = 1            # first-layer kernel: per-image gradients (19 KB each), summed below
+    else:
+        group = dense_wgrad_group(N, K, Cc, R, S, P * Q, stride=stride, out_hw=None if row_scale is not None else (P, Q))
     slabs = conv2d_wgrad_grouped(gy, x, R, S, stride=stride, pad=pad, group=group, alpha=alpha, row_scale=row_scale)
     if slabs.shape[0] == 1:
         return slabs[0]

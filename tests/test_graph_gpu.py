@@ -51,11 +51,14 @@ def test_graph_replay_equals_eager_steps(tmp_path, name, argv, B, shape, cond):
     assert eager[1:5] == graph[1:5] == (n, n, n, [n] * len(eager[4])), (eager[1:5], graph[1:5])
     lr = 1e-4 if name == "celeba" else 2e-4                # d_lr defaults (options.py)
     for i, (a, b) in enumerate(zip(eager[0], graph[0])):
-        # same kernels, same inputs, same noise: only float atomics reorder between runs.  Adam (b1 = 0 for CelebA) moves a
-        # weight by ~lr * sign(g) per step, so an entry whose gradient is ~0 may differ by a step; the bulk must agree closely
+        # same kernels, same inputs, same noise: only float atomics reorder between runs.  Adam (b1 = 0 for CelebA) normalises every
+        # entry to a step of ~lr whatever the gradient's size, so reordering shows as a few per cent of lr on cancelling sums (bias
+        # gradients) and an entry whose gradient is ~0 may differ by whole steps.  Measured eager vs eager, eager vs graph and graph
+        # vs graph alike: mean |difference| <= 0.009 lr, max <= 2 lr after 6 steps.  Bar: mean under a tenth of ONE step, no entry
+        # beyond the n steps taken
         err = (a - b).abs()
         assert err.max().item() <= 2.1 * lr * n, "parameter %d differs between eager and replayed steps: %.3e" % (i, err.max().item())
-        assert (err > 0.02 * lr).double().mean().item() < 1e-2, "parameter %d: too many entries differ" % i
+        assert err.mean().item() <= 0.1 * lr, "parameter %d: mean difference %.3e lr" % (i, err.mean().item() / lr)
     for k, v in eager[6].items():
         w = graph[6][k]
         assert torch.allclose(torch.as_tensor(v, dtype=torch.float64), torch.as_tensor(w, dtype=torch.float64), rtol=2e-3, atol=1e-4), (k, v, w)

@@ -78,6 +78,12 @@ FWD_CASES = [
     (3, 16, 8, 64, 2, 3, 1, 1, True, 1, False, 0),
     (2, 8, 16, 64, 4, 3, 1, 1, True, 2, False, None),
     (5, 64, 64, 64, 3, 3, 1, 1, True, 3, False, None),
+    # the critic's RGB first layer on unpadded 12-byte pixels (csrc/conv_c3.hip): 8x16-pixel tiles
+    (5, 64, 64, 3, 64, 5, 2, 2, True, 1, False, None),
+    (3, 32, 32, 3, 64, 5, 2, 2, False, 0, False, None),
+    (2, 128, 128, 3, 64, 5, 2, 2, True, 1, False, None),
+    (2, 16, 96, 3, 64, 5, 2, 2, True, 2, False, None),
+    (260, 32, 32, 3, 64, 5, 2, 2, True, 1, False, None),      # more tiles than the persistent grid
 ]
 
 
@@ -194,6 +200,11 @@ WGRAD_CASES = [
     (6, 16, 16, 128, 128, 5, 2, 2),
     (4, 16, 16, 64, 64, 5, 1, 2),       # 64-channel m tiles
     (2, 16, 16, 128, 192, 3, 2, 1),
+    # the critic's RGB first layer (csrc/conv_c3.hip): strips of 8 / 4 / 2 output rows
+    (6, 32, 32, 3, 64, 5, 2, 2),
+    (4, 64, 64, 3, 64, 5, 2, 2),
+    (2, 128, 128, 3, 64, 5, 2, 2),
+    (2, 48, 64, 3, 64, 5, 2, 2),
 ]
 
 
@@ -793,3 +804,24 @@ def test_conv2d_dgrad_bf16x3(case):
     with ops.compute_dtype("bf16x3"):
         gx = ops.conv2d_dgrad(_nhwc(gy), _krsc(w), (H, W), stride=s, pad=p, mask=None if mask is None else _nhwc(mask))
     _close(gx.permute(0, 3, 1, 2), ref, what="bf16x3 dgrad %s" % (case,))
+
+
+@pytest.mark.parametrize("N,H,W", [(6, 64, 64), (3, 128, 128)])
+def test_first_layer_dense_wgrad_is_the_sum_of_the_per_image_kernel(N, H, W):
+    """conv2d_wgrad_dense on RGB input: per-image gradients from c3_wgrad_kernel + one column sum."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.zeros(64, 3, 5, 5, requires_grad=True)
+    y = F.conv2d(x, w, None, stride=2, padding=2)
+    gy = torch.randn(y.shape, generator=g)
+    ref, = torch.autograd.grad(y, w, gy)
+    timer = ops.LaunchTimer()
+    ops.set_launch_timer(timer)
+    try:
+        got = ops.conv2d_wgrad_dense(_nhwc(gy), _nhwc(x), 5, 5, stride=2, pad=2, alpha=0.5)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_launch_timer(None)
+    assert any("c3_wgrad_kernel" in k for k in timer.summary(by_kernel=True)), timer.summary(by_kernel=True).keys()
+    _close(got.permute(0, 3, 1, 2), 0.5 * ref, what="dense first-layer wgrad")

@@ -262,6 +262,122 @@ __global__ __launch_bounds__(256) void gram_sqnorm_small_kernel(const GramSmallP
     if (tid == 0) atomicAdd(p.sq + b, p.alpha2 * tot);
 }
 
+// ---- layers with at most 64 output pixels AND at most 64 input pixels per stride-parity class ------------------------------
+// (the critic's third conv: 16x16x128 -> 8x8x256, 5x5 stride 2).  The same pixel-pair identity as above, on 32x32 MFMA tiles:
+// per sample s^2 Gram matrices XX_c = X_c X_c^T (64 x 64 over the C channels) + GY GY^T (64 x 64 over K) = 6.3 MFLOP where the
+// tap-by-tap Gram form needs 28 and the product 105 — and no [N][K][R][S][C] gradient is written (419 MB per launch for that
+// layer at 128 samples, which made the per-sample product HBM-write bound).  The taps partition by class, so does the sum:
+//   ||gW_b||^2 = sum_c sum_{p,p'} (GY GY^T)[p,p'] * sum_{t in c} XX_c[loc(p,t), loc(p',t)]
+// One workgroup per (sample, class) — GY GY^T is recomputed per class (2.1 of the 6.3 MFLOP), which buys s^2 times the
+// workgroups of a per-sample launch (128 samples alone leave half the chip idle).  Wavefront w owns the tile (w >> 1, w & 1) of
+// both matrices; operands stream through one [64 rows][64 k] LDS block (16-byte loads, the next block in registers while the
+// MFMAs run); XX_c then goes to LDS and every lane assembles the tap sum for the 16 (p,p') entries it holds of GY GY^T.
+constexpr int G64_LD = 68;             // floats per row of the operand block
+constexpr int G64_XLD = 65;            // floats per row of the stored XX_c
+
+__global__ __launch_bounds__(256) void gram_sqnorm_cls64_kernel(const GramSmallParams p) {
+    __shared__ __attribute__((aligned(16))) float As[64 * G64_LD];
+    __shared__ float XXs[64 * G64_XLD];
+    __shared__ float s_red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int nc = p.s * p.s;
+    const int b = blockIdx.x / nc, c = blockIdx.x - b * nc;
+    const int xch = (p.C + 63) >> 6, gch = (p.K + 63) >> 6;
+    const int n_chunks = xch + gch;
+    const int l_row = tid >> 4, l_k = (tid & 15) * 4;          // loader: rows l_row + 16 i, 4 floats at l_k
+    const int Hc = p.Hc[c], Wc = p.Wc[c];
+    const int cy = c / p.s, cx = c - cy * p.s;
+
+    const float* src[4];                                       // this thread's four rows of the class image / of gy
+    bool xok[4], gok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = l_row + 16 * i;
+        const int ly = row / Wc, lx = row - ly * Wc;
+        xok[i] = row < Hc * Wc;
+        gok[i] = row < p.PQ;
+        src[i] = p.x + (((long long)b * p.H + (ly * p.s + cy)) * p.W + (lx * p.s + cx)) * p.C;
+    }
+    const float* gsrc = p.gy + (long long)b * p.PQ * p.K;
+    float4 rg[4];
+    auto load = [&](int q) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < xch) {
+                const int k0 = q * 64 + l_k;
+                if (xok[i] && k0 < p.C) v = *reinterpret_cast<const float4*>(src[i] + k0);
+            } else if (q < n_chunks) {
+                const int k0 = (q - xch) * 64 + l_k;
+                if (gok[i] && k0 < p.K) v = *reinterpret_cast<const float4*>(gsrc + (long long)(l_row + 16 * i) * p.K + k0);
+            }
+            rg[i] = v;
+        }
+    };
+    f32x16 accx, accg;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { accx[v] = 0.f; accg[v] = 0.f; }
+    const int rowA = (wid >> 1) * 32 + r, rowB = (wid & 1) * 32 + r;
+
+    load(0);
+    for (int q = 0; q < n_chunks; ++q) {
+        __syncthreads();                                  // every wavefront is done with the previous block
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&As[(l_row + 16 * i) * G64_LD + l_k]) = rg[i];
+        __syncthreads();
+        load(q + 1);                                      // zeros past the end
+        f32x16 a = q < xch ? accx : accg;                 // uniform
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {                     // k = 8g + 4h + e on both sides
+            const float4 af = *reinterpret_cast<const float4*>(&As[rowA * G64_LD + 8 * g + 4 * h]);
+            const float4 bf = *reinterpret_cast<const float4*>(&As[rowB * G64_LD + 8 * g + 4 * h]);
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, a, 0, 0, 0);
+        }
+        if (q < xch) accx = a; else accg = a;
+    }
+    // ---- XX_c -> LDS -----------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int v = 0; v < 16; ++v)
+        XXs[((wid >> 1) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h) * G64_XLD + (wid & 1) * 32 + r] = accx[v];
+    __syncthreads();
+    // ---- sum over this lane's 16 entries (p, p') of GY GY^T[p,p'] * sum_{t in c} XX_c[loc(p,t), loc(p',t)] ------------------
+    float prod = 0.f;
+    const int pb = (wid & 1) * 32 + r;                    // p' (column), fixed per lane
+    const int by = pb / p.Q, bx = pb - by * p.Q;
+    int ay[16], ax[16];                                   // p (row) of accumulator entry v
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int pa = (wid >> 1) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+        ay[v] = pa < p.PQ ? pa / p.Q : -100;
+        ax[v] = pa - (pa / p.Q) * p.Q;
+    }
+    float gx[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) gx[v] = 0.f;
+    if (pb < p.PQ) {
+        for (int t = 0; t < p.T; ++t) {
+            if (p.tcls[t] != c) continue;                 // uniform
+            const int dy = p.tdy[t], dx = p.tdx[t];
+            const int yb = by + dy, xb = bx + dx;
+            if ((unsigned)yb >= (unsigned)Hc || (unsigned)xb >= (unsigned)Wc) continue;
+            const float* col = &XXs[yb * Wc + xb];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int ya = ay[v] + dy, xa = ax[v] + dx;
+                if ((unsigned)ya < (unsigned)Hc && (unsigned)xa < (unsigned)Wc) gx[v] += col[(ya * Wc + xa) * G64_XLD];
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) prod = fmaf(accg[v], gx[v], prod);
+    }
+    const float tot = block_sum_256(prod, s_red);
+    if (tid == 0) atomicAdd(p.sq + b, p.alpha2 * tot);
+}
+
 }  // namespace cslgan
 
 using namespace cslgan;
@@ -281,15 +397,21 @@ int cslgan_conv2d_wgrad_sqnorm_gram_f32(const cslgan_conv_t* c, const float* gy,
     CSLGAN_REQUIRE(aligned16(gy) && aligned16(x), "wgrad_sqnorm_gram: operands must be 16-byte aligned");
     {   // few pixels per stride-parity class: assemble the unfolded Gram matrix from pixel-pair Gram matrices
         const int st = c->stride;
-        bool small = P * Q <= 16 && st >= 1 && st <= 2 && c->K % 64 == 0 && c->C % 16 == 0;
+        bool cls_ok = P * Q <= 64 && st >= 1 && st <= 2;
+        int max_pix = 0;
         GramSmallParams sp{};
-        for (int cls = 0; small && cls < st * st; ++cls) {
+        for (int cls = 0; cls_ok && cls < st * st; ++cls) {
             const int cy = cls / st, cx = cls % st;
             sp.Hc[cls] = c->H > cy ? (c->H - cy + st - 1) / st : 0;
             sp.Wc[cls] = c->W > cx ? (c->W - cx + st - 1) / st : 0;
-            small = small && sp.Hc[cls] * sp.Wc[cls] <= 16 && sp.Hc[cls] * sp.Wc[cls] >= 1;
+            const int pix = sp.Hc[cls] * sp.Wc[cls];
+            cls_ok = cls_ok && pix >= 1 && pix <= 64;
+            max_pix = pix > max_pix ? pix : max_pix;
         }
-        if (small) {
+        const bool small = cls_ok && P * Q <= 16 && max_pix <= 16 && c->K % 64 == 0 && c->C % 16 == 0;
+        static const int cls64_env = [] { const char* e = getenv("CSLGAN_GRAM_CLS64"); return e ? atoi(e) : 1; }();
+        const bool cls64 = cls_ok && !small && cls64_env && c->K % 4 == 0 && c->C % 4 == 0;
+        if (small || cls64) {
             auto fl = [](int v, int d) { return v >= 0 ? v / d : -((-v + d - 1) / d); };
             sp.gy = gy; sp.x = x; sp.N = c->N; sp.H = c->H; sp.W = c->W; sp.C = c->C; sp.K = c->K; sp.PQ = P * Q; sp.Q = Q;
             sp.T = c->R * c->S; sp.s = st; sp.alpha2 = alpha * alpha; sp.sq = sq;
@@ -300,9 +422,14 @@ int cslgan_conv2d_wgrad_sqnorm_gram_f32(const cslgan_conv_t* c, const float* gy,
                     sp.tdy[t] = (signed char)dy; sp.tdx[t] = (signed char)dx;
                     sp.tcls[t] = (signed char)((oy - dy * st) * st + (ox - dx * st));
                 }
-            note_kernel("gram_sqnorm_small_kernel");
-            hipLaunchKernelGGL(gram_sqnorm_small_kernel, dim3((unsigned)c->N), dim3(256), 0, (hipStream_t)stream, sp);
-            return check_launch("gram_sqnorm_small_kernel");
+            if (small) {
+                note_kernel("gram_sqnorm_small_kernel");
+                hipLaunchKernelGGL(gram_sqnorm_small_kernel, dim3((unsigned)c->N), dim3(256), 0, (hipStream_t)stream, sp);
+                return check_launch("gram_sqnorm_small_kernel");
+            }
+            note_kernel("gram_sqnorm_cls64_kernel");
+            hipLaunchKernelGGL(gram_sqnorm_cls64_kernel, dim3((unsigned)(c->N * st * st)), dim3(256), 0, (hipStream_t)stream, sp);
+            return check_launch("gram_sqnorm_cls64_kernel");
         }
     }
     GramParams p{};

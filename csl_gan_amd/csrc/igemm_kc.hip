@@ -413,12 +413,13 @@ int launch_kc(KcParams& p, hipStream_t st, long long out_elems) {
             p.ac_recip = (unsigned)(((1ull << 32) + (unsigned long long)p.AC - 1) / (unsigned long long)p.AC);
         }
     }
+    // 1..4 output channels: vector-ALU kernel, fp32 in every compute mode (a 32-wide MFMA tile would be 29/32 padding)
+    static const int skinny_env = [] { const char* e = getenv("CSLGAN_KC_SKINNY"); return e ? atoi(e) : 1; }();
+    if (skinny_env && !p.acc_classes && skinny_eligible(p)) return launch_skinny(p, st);
     if (p.bf16) {
         if (p.acc_classes) { set_error("igemm_kc: accumulated classes have no bf16 form"); return CSLGAN_ERR_INVALID_ARG; }
         return launch_kc_bf16(p, st, out_elems);
     }
-    static const int skinny_env = [] { const char* e = getenv("CSLGAN_KC_SKINNY"); return e ? atoi(e) : 1; }();
-    if (skinny_env && skinny_eligible(p)) return launch_skinny(p, st);
     static const int halo_env = [] { const char* e = getenv("CSLGAN_KC_HALO"); return e ? atoi(e) : 1; }();
     if (halo_env && halo_eligible(p)) return launch_halo(p, st);
     static const int patch_env = [] { const char* e = getenv("CSLGAN_KC_PATCH"); return e ? atoi(e) : 1; }();

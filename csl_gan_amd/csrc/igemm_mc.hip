@@ -289,7 +289,8 @@ __global__ __launch_bounds__(256) void bias_grad_grouped_vec_kernel(const float*
 int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, float* sq_accum, hipStream_t st);   // clip_kernels.hip
 
 bool wgh_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const void* x);      // igemm_wgh.hip
-int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st);
+int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st,
+               const float* row_scale);      // igemm_wgh.hip
 
 int launch_mc_bf16(McParams& p, bool vecA, bool vecB, hipStream_t st, int nsplit);        // igemm_bf16.hip
 
@@ -352,8 +353,8 @@ static int wgrad_grouped_impl(const cslgan_conv_t* c, const float* gy, const flo
     if (c3_env && !row_scale && c3_wgrad_eligible(c, group, out_bf16, gy))     // the critic's RGB first layer (conv_c3.hip)
         return launch_c3_wgrad(c, gy, x, alpha, gw, sq, (hipStream_t)stream);
     static const int wgh_env = [] { const char* e = getenv("CSLGAN_WGH"); return e ? atoi(e) : 1; }();
-    if (wgh_env && !row_scale && c->compute == CSLGAN_COMPUTE_F32 && wgh_eligible(c, out_bf16, gy, x))
-        return launch_wgh(c, gy, x, group, alpha, gw, sq, (hipStream_t)stream);
+    if (wgh_env && c->compute == CSLGAN_COMPUTE_F32 && wgh_eligible(c, out_bf16, gy, x))
+        return launch_wgh(c, gy, x, group, alpha, gw, sq, (hipStream_t)stream, row_scale);
     McParams p{};
     p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->P; p.Q = c->Q; p.Kc = c->K;
     p.T = c->R * c->S; p.Ndim = p.T * c->C; p.stride = c->stride; p.group = group; p.n_groups = c->N / group;

@@ -24,24 +24,27 @@ __device__ __forceinline__ float4 sbuf_load4(__amdgpu_buffer_rsrc_t r, unsigned 
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int NJ>
+// ALL: the classes of the launch (the four parity classes of a stride-2 data gradient) have the same grid and read the same
+// input patch: one workgroup stages the union halo once and runs the classes one after the other (a quarter of the halo traffic;
+// launch_skinny stores the union extents in every class).
+template <int NJ, bool ALL>
 __global__ __launch_bounds__(256) void igemm_skinny_kernel(const KcParams p) {
     __shared__ float4 Hs[SK_HALO * 16];
 
     const int tid = threadIdx.x;
     const int b = xcd_remap(blockIdx.x, p.tiles_m);
     int ci = 0;
+    if (!ALL) {
 #pragma unroll 1
-    while (ci + 1 < p.n_cls && b >= p.cls[ci + 1].tile0) ++ci;
+        while (ci + 1 < p.n_cls && b >= p.cls[ci + 1].tile0) ++ci;
+    }
     const KcClass& kc = p.cls[ci];
-    const int T = kc.T, HW_ = kc.halo_w, hpix = kc.halo_h * kc.halo_w;
-    const RowCoord rc0 = kc_decode_row((b - kc.tile0) * 64, kc.OHc, kc.OWc, 1);     // the patch's top-left pixel
+    const int HW_ = kc.halo_w, hpix = kc.halo_h * kc.halo_w;
+    const RowCoord rc0 = kc_decode_row((ALL ? b : b - kc.tile0) * 64, kc.OHc, kc.OWc, 1);     // the patch's top-left pixel
     const int y0 = rc0.oy + kc.ty_min, x0 = rc0.ox + kc.tx_min;
     const int img_base = rc0.img * p.AH * p.AW * SK_C;
 
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w + kc.w_off), 0,
-                                                                             p.w_bytes - 4u * (unsigned)kc.w_off, 0x00020000);
     // ---- halo: hpix pixels x 16 float4 ------------------------------------------------------------------
     constexpr int HREG = (SK_HALO * 16 + 255) / 256;
     float4 rh[HREG];
@@ -54,17 +57,7 @@ __global__ __launch_bounds__(256) void igemm_skinny_kernel(const KcParams p) {
         const bool ok = pix < hpix && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
         rh[j] = sbuf_load4(a_rsrc, ok ? 4u * (unsigned)(img_base + (iy * p.AW + ix) * SK_C + c4 * 4) : SOOB);
     }
-    // ---- this lane's filter values: 4 channels x T taps x NJ outputs ------------------------------------
     const int cl = tid & 15;
-    float4 wr[SK_MAXT][NJ];
-    int toff[SK_MAXT];
-#pragma unroll
-    for (int t = 0; t < SK_MAXT; ++t) {
-        toff[t] = t < T ? (((int)kc.ty[t] - kc.ty_min) * HW_ + ((int)kc.tx[t] - kc.tx_min)) * 16 : 0;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            wr[t][j] = sbuf_load4(w_rsrc, (t < T && j < p.Nn) ? 4u * (unsigned)(j * kc.Kdim + t * SK_C + cl * 4) : SOOB);
-    }
 #pragma unroll
     for (int j = 0; j < HREG; ++j) {
         const int idx = tid + 256 * j;
@@ -75,6 +68,22 @@ __global__ __launch_bounds__(256) void igemm_skinny_kernel(const KcParams p) {
     const int wid = tid >> 6, pg = (tid & 63) >> 4;
     float bv = 0.f;
     if (p.bias && cl < p.Nn) bv = p.bias[cl];
+#pragma unroll 1
+    for (int cc = ALL ? 0 : ci; cc < (ALL ? p.n_cls : ci + 1); ++cc) {
+    const KcClass& kk = p.cls[cc];
+    const int Tc = kk.T;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w + kk.w_off), 0,
+                                                                             p.w_bytes - 4u * (unsigned)kk.w_off, 0x00020000);
+    // ---- this lane's filter values: 4 channels x T taps x NJ outputs ------------------------------------
+    float4 wr[SK_MAXT][NJ];
+    int toff[SK_MAXT];
+#pragma unroll
+    for (int t = 0; t < SK_MAXT; ++t) {
+        toff[t] = t < Tc ? (((int)kk.ty[t] - kk.ty_min) * HW_ + ((int)kk.tx[t] - kk.tx_min)) * 16 : 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            wr[t][j] = sbuf_load4(w_rsrc, (t < Tc && j < p.Nn) ? 4u * (unsigned)(j * kk.Kdim + t * SK_C + cl * 4) : SOOB);
+    }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int q = wid * 16 + it * 4 + pg;            // pixel of the patch: 16 lanes each
@@ -85,7 +94,7 @@ __global__ __launch_bounds__(256) void igemm_skinny_kernel(const KcParams p) {
         for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
 #pragma unroll
         for (int t = 0; t < SK_MAXT; ++t) {
-            if (t < T) {                                  // uniform
+            if (t < Tc) {                                 // uniform
                 const float4 a = Hs[base + toff[t]];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
@@ -109,14 +118,15 @@ __global__ __launch_bounds__(256) void igemm_skinny_kernel(const KcParams p) {
             for (int j = 1; j < NJ; ++j) val = cl == j ? acc[j] : val;
             val += bv;
             const RowCoord rc = {rc0.img, rc0.oy + qy, rc0.ox + qx};
-            const int off = kc_out_offset(p, kc, rc);
-            if (p.res) val += p.res[kc_res_offset(p, kc, rc) + cl];
+            const int off = kc_out_offset(p, kk, rc);
+            if (p.res) val += p.res[kc_res_offset(p, kk, rc) + cl];
             if (p.act == CSLGAN_ACT_LRELU02) val = val > 0.f ? val : 0.2f * val;
             else if (p.act == CSLGAN_ACT_RELU) val = val > 0.f ? val : 0.f;
             else if (p.act == CSLGAN_ACT_TANH) val = tanhf(val);
             if (p.mask) val *= (p.mask[off + cl] > 0.f ? 1.f : 0.2f);
             p.out[off + cl] = val;
         }
+    }
     }
 }
 
@@ -152,17 +162,40 @@ int launch_skinny(KcParams& p, hipStream_t st) {
         k.tile0 = tm;                  // in 8x8 patches
         tm += k.M / 64;
     }
+    // classes with one grid (the parity classes of a stride-2 data gradient on an even image) share their input patch: one
+    // workgroup per patch cell runs them all from the union halo
+    bool all = p.n_cls > 1;
+    int uy0 = 127, uy1 = -128, ux0 = 127, ux1 = -128;
+    for (int c = 0; c < p.n_cls; ++c) {
+        const KcClass& k = p.cls[c];
+        all = all && k.OHc == p.cls[0].OHc && k.OWc == p.cls[0].OWc && k.M == p.cls[0].M;
+        uy0 = k.ty_min < uy0 ? k.ty_min : uy0; ux0 = k.tx_min < ux0 ? k.tx_min : ux0;
+        uy1 = k.ty_min + k.halo_h > uy1 ? k.ty_min + k.halo_h : uy1; ux1 = k.tx_min + k.halo_w > ux1 ? k.tx_min + k.halo_w : ux1;
+    }
+    static const int all_env = [] { const char* e = getenv("CSLGAN_SKINNY_ALL"); return e ? atoi(e) : 1; }();
+    all = all && all_env && (uy1 - uy0) * (ux1 - ux0) <= SK_HALO;
+    if (all) {
+        for (int c = 0; c < p.n_cls; ++c) {
+            KcClass& k = p.cls[c];
+            k.ty_min = uy0; k.tx_min = ux0; k.halo_h = uy1 - uy0; k.halo_w = ux1 - ux0;
+        }
+        tm = p.cls[0].M / 64;
+    }
     p.tiles_m = tm;
     p.tiles_n = 1;
     p.ksplit = 1;
     const dim3 grid((unsigned)tm), block(256);
-    note_kernel("igemm_skinny_kernel<%d>", p.Nn < 4 ? p.Nn : 4);
+    note_kernel("igemm_skinny_kernel<%d%s>", p.Nn < 4 ? p.Nn : 4, all ? ",all" : "");
+#define CSL_SKINNY(NJ_)                                                                              \
+    if (all) hipLaunchKernelGGL((igemm_skinny_kernel<NJ_, true>), grid, block, 0, st, p);            \
+    else hipLaunchKernelGGL((igemm_skinny_kernel<NJ_, false>), grid, block, 0, st, p);
     switch (p.Nn) {
-        case 1: hipLaunchKernelGGL((igemm_skinny_kernel<1>), grid, block, 0, st, p); break;
-        case 2: hipLaunchKernelGGL((igemm_skinny_kernel<2>), grid, block, 0, st, p); break;
-        case 3: hipLaunchKernelGGL((igemm_skinny_kernel<3>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((igemm_skinny_kernel<4>), grid, block, 0, st, p); break;
+        case 1: CSL_SKINNY(1) break;
+        case 2: CSL_SKINNY(2) break;
+        case 3: CSL_SKINNY(3) break;
+        default: CSL_SKINNY(4) break;
     }
+#undef CSL_SKINNY
     return check_launch("igemm_skinny_kernel");
 }
 

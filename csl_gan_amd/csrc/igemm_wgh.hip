@@ -17,7 +17,6 @@ namespace cslgan {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WG_BM = 128, WG_BC = 64, WG_MAXS = 5;
-constexpr int WG_LDG = WG_BM + 4;      // floats per pixel row of the gy patch in LDS
 constexpr int WG_LDX = WG_BC + 4;      // floats per pixel of the input slab in LDS
 constexpr int WG_MAXW = 7 * 2 + WG_MAXS;   // staged columns at stride 2
 
@@ -31,13 +30,15 @@ struct WghParams {
     int tiles_m, tiles_c, ppi;   // K/128, C/64, patches per image
     int ksplit;                  // workgroups per (group, tile, filter row): they take every ksplit-th patch and add atomically
     int xw;                      // staged columns: 7*stride + S
+    const float* row_scale;      // nullable [N]: gy of sample n is multiplied by row_scale[n] while it is staged (clip-weighted sums)
 };
 
 // TM = 32-row MFMA tiles per wavefront along m: 2 -> 128 output channels per workgroup, 1 -> 64 (K = 64 layers)
 template <int S, int TM>
 __global__ __launch_bounds__(256, 2) void igemm_wgh_kernel(const WghParams p) {
     constexpr int BM = 64 * TM;
-    __shared__ __attribute__((aligned(16))) float Gs[64 * WG_LDG];
+    constexpr int LDG = BM + 4;               // floats per pixel row of the gy patch in LDS
+    __shared__ __attribute__((aligned(16))) float Gs[64 * LDG];
     __shared__ __attribute__((aligned(16))) float Xs[8 * WG_MAXW * WG_LDX];
     __shared__ float s_red[4];
 
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgh_kernel(const WghParams p) {
         __syncthreads();                        // every wavefront is done with the previous patch
         // ---- gy patch: 64 pixels x BM channels, 4*TM float4 per thread, staged four at a time ------------------
         constexpr int M4 = BM / 4;             // float4 per pixel
+        const float rs = p.row_scale ? p.row_scale[img] : 1.f;
 #pragma unroll
         for (int half = 0; half < TM; ++half) {
             float4 v[4];
@@ -81,12 +83,13 @@ __global__ __launch_bounds__(256, 2) void igemm_wgh_kernel(const WghParams p) {
                 const int pix = idx / M4, m4 = idx - pix * M4;
                 const long long gpix = (img * p.P + py0 + (pix >> 3)) * p.Q + px0 + (pix & 7);
                 v[j] = *reinterpret_cast<const float4*>(p.gy + gpix * p.K + m0 + m4 * 4);
+                v[j].x *= rs; v[j].y *= rs; v[j].z *= rs; v[j].w *= rs;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int idx = tid + 256 * (half * 4 + j);
                 const int pix = idx / M4, m4 = idx - pix * M4;
-                *reinterpret_cast<float4*>(&Gs[pix * WG_LDG + m4 * 4]) = v[j];
+                *reinterpret_cast<float4*>(&Gs[pix * LDG + m4 * 4]) = v[j];
             }
         }
         // ---- input slab of filter row r: 8 rows x xw columns x 64 channels ------------------------------------
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgh_kernel(const WghParams p) {
             const int qy = q >> 3, qx = q & 7;
             float a[TM], b[S];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = Gs[q * WG_LDG + wm * 32 * TM + i * 32 + l31];
+            for (int i = 0; i < TM; ++i) a[i] = Gs[q * LDG + wm * 32 * TM + i * 32 + l31];
             const float* xrow = &Xs[(qy * p.xw + qx * p.stride) * WG_LDX + wn * 32 + l31];
 #pragma unroll
             for (int s = 0; s < S; ++s) b[s] = xrow[s * WG_LDX];
@@ -163,12 +166,14 @@ bool wgh_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const vo
            c->C % WG_BC == 0 && (c->P & 7) == 0 && (c->Q & 7) == 0 && aligned16(gy) && aligned16(x);
 }
 
-int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st) {
+int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st,
+               const float* row_scale) {
     WghParams p{};
-    p.gy = gy; p.x = x; p.gw = gw; p.sq = sq;
+    p.gy = gy; p.x = x; p.gw = gw; p.sq = sq; p.row_scale = row_scale;
     p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->P; p.Q = c->Q; p.K = c->K; p.R = c->R; p.S = c->S;
     p.stride = c->stride; p.pad = c->pad; p.group = group; p.n_groups = c->N / group; p.alpha = alpha;
-    const bool half_m = c->K % WG_BM != 0;       // K = 64, 192, ...: 64-channel m tiles
+    static const int half_env = [] { const char* e = getenv("CSLGAN_WGH_HALF"); return e ? atoi(e) : 0; }();
+    const bool half_m = c->K % WG_BM != 0 || (half_env && group == 1);       // K = 64, 192, ...: 64-channel m tiles
     p.tiles_m = half_m ? c->K / 64 : c->K / WG_BM; p.tiles_c = c->C / WG_BC; p.ppi = (c->P >> 3) * (c->Q >> 3);
     p.xw = 7 * c->stride + c->S;
     const long long base = (long long)p.n_groups * p.tiles_m * p.tiles_c * c->R;

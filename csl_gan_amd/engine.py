@@ -313,8 +313,8 @@ class PrivacyEngine(PerSampleSink):
     materialize="private" only the passes that are clipped are materialised; never-clipped passes (generated
                           data under grad_clip_split) contribute a dense sum computed by the same MFMA kernel
                           with coarse groups — 2.2 GB less written and re-read per pass for D64 at B=128.
-    materialize="ghost"   as "private", and layers with at most 16 output pixels per sample (the critic's last conv,
-                          76 % of its parameters) are never materialised at all: their norms come from the pixel-Gram kernel and their
+    materialize="ghost"   as "private", and layers with at most 64 output pixels per sample (the critic's last two convs and
+                          its linear head, 95 % of its parameters) are never materialised at all: their norms come from the pixel-Gram kernels and their
                           clipped sum from one clip-weighted dense wgrad inside clip() ("ghost clipping").  Those
                           parameters have no p.grad_sample.  Needs split clipping (accum_passes=False).
     `norms_only` (set around the adaptive-clipping pass) computes per-sample norms without storing gradients.

@@ -7,6 +7,7 @@ are [K,R,S,C].  Device tensors only — there is no CPU path in this module.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -363,15 +364,19 @@ def gram_norms_eligible(gy_shape, x_shape):
 
 
 def gram_norms_preferred(gy_shape, x_shape, stride):
-    """Shapes where the Gram form runs on the pixel-pair kernel (<= 16 output pixels and <= 16 input pixels per
-    stride-parity class): there it is far cheaper than the product, so the engine uses it for norms and ghost clipping."""
+    """Shapes where the Gram form runs on the pixel-pair kernels (output pixels and input pixels per stride-parity class both
+    <= 16: gram_sqnorm_small_kernel; both <= 64: gram_sqnorm_cls64_kernel): there it is far cheaper than the product (the critic's
+    conv3: 6.3 vs 105 MFLOP per sample, and no 419 MB of per-sample gradients), so the engine uses it for norms and ghost clipping."""
     _, P, Q, K = gy_shape
     _, H, W, Cc = x_shape
     if P * Q == 1 and H * W == 1:
         return True              # a linear layer: ||gy_b x_b^T||^2 = ||gy_b||^2 ||x_b||^2
-    if stride not in (1, 2) or P * Q > 16 or K % 64 or Cc % 32:
+    if stride not in (1, 2) or P * Q > _GRAM_MAX_PIX or K % 64 or Cc % 32:
         return False
-    return ((H + stride - 1) // stride) * ((W + stride - 1) // stride) <= 16
+    return ((H + stride - 1) // stride) * ((W + stride - 1) // stride) <= _GRAM_MAX_PIX
+
+
+_GRAM_MAX_PIX = int(os.environ.get("CSLGAN_GHOST_MAX_PIX", "64"))     # 16 restores the round-1 rule (ghost clipping for conv4 + linear only)
 
 
 def conv2d_wgrad_sqnorm_gram(gy, x, R, S, stride=1, pad=0, alpha=1.0, sq=None):
@@ -480,7 +485,7 @@ def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, alpha=1.0, row_scale=None):
     if Cc == 3 and row_scale is None and _c3_layer(H, W, K, R, S, stride, pad, Q in (16, 32, 64) and P % (128 // Q) == 0):
         group = 1            # first-layer kernel: per-image gradients (19 KB each), summed below
     else:
-        group = dense_wgrad_group(N, K, Cc, R, S, P * Q, stride=stride, out_hw=None if row_scale is not None else (P, Q))
+        group = dense_wgrad_group(N, K, Cc, R, S, P * Q, stride=stride, out_hw=(P, Q))
     slabs = conv2d_wgrad_grouped(gy, x, R, S, stride=stride, pad=pad, group=group, alpha=alpha, row_scale=row_scale)
     if slabs.shape[0] == 1:
         return slabs[0]

@@ -280,7 +280,8 @@ def test_dense_wgrad_group_and_gram_policy():
     # critic head conv: 8x8x256 -> 4x4x512, stride 2
     assert ops.gram_norms_preferred((128, 4, 4, 512), (128, 8, 8, 256), 2)
     assert ops.gram_norms_preferred((128, 1, 1, 1), (128, 1, 1, 8192), 1)            # linear layer
-    assert not ops.gram_norms_preferred((128, 8, 8, 256), (128, 16, 16, 128), 2)      # 64 output pixels: product kernel
+    assert ops.gram_norms_preferred((128, 8, 8, 256), (128, 16, 16, 128), 2)          # conv3: 64 output / 64 class pixels (cls64 kernel)
+    assert not ops.gram_norms_preferred((128, 16, 16, 128), (128, 32, 32, 64), 2)     # 256 output pixels: product kernel
     assert not ops.gram_norms_preferred((128, 4, 4, 100), (128, 8, 8, 256), 2)        # K % 64 != 0
 
 

@@ -637,7 +637,9 @@ def test_conv2d_fwd_bf16(case):
         y = ops.conv2d_fwd(_nhwc(x), _krsc(w), None if b is None else b.cuda(), stride=s, pad=p,
                            residual=None if rs is None else _nhwc(rs), act=act)
     assert ops.get_compute_dtype() == "fp32"
-    _close(y.permute(0, 3, 1, 2), ref(_bf(x), _bf(w)), rtol=1e-4, what="bf16 fwd vs rounded-operand reference %s" % (case,))
+    # 1..4 output channels (vector-ALU kernel) and the RGB first layer (conv_c3) compute in exact fp32 in every mode
+    exact = (K <= 4 and C == 64 and s == 1) or (C == 3 and K == 64 and R == 5 and s == 2 and H % 16 == 0 and W % 32 == 0 and res is None)
+    _close(y.permute(0, 3, 1, 2), ref(x, w) if exact else ref(_bf(x), _bf(w)), rtol=1e-4, what="bf16 fwd vs rounded-operand reference %s" % (case,))
     _close(y.permute(0, 3, 1, 2), ref(x, w), rtol=2e-2, what="bf16 fwd vs fp32 %s" % (case,))
 
 
@@ -649,7 +651,10 @@ def test_conv2d_dgrad_bf16(case):
     w = torch.randn(K, C, R, R, generator=g) / (K * R * R) ** 0.5
     P, Q = (H + 2 * p - R) // s + 1, (W + 2 * p - R) // s + 1
     gy = torch.randn(N, K, P, Q, generator=g)
-    ref = F.conv_transpose2d(_bf(gy), _bf(w), None, stride=s, padding=p, output_padding=(H + 2 * p - R - (P - 1) * s, W + 2 * p - R - (Q - 1) * s))
+    # 1..4 output channels from 64 input channels on 8x8-patchable class grids: the vector-ALU kernel, exact fp32 in every mode
+    exact = K == 64 and C <= 4 and H % s == 0 and W % s == 0 and (H // s) % 8 == 0 and (W // s) % 8 == 0
+    rnd = (lambda t: t) if exact else _bf
+    ref = F.conv_transpose2d(rnd(gy), rnd(w), None, stride=s, padding=p, output_padding=(H + 2 * p - R - (P - 1) * s, W + 2 * p - R - (Q - 1) * s))
     mask = None
     if use_mask:
         mask = torch.randn(N, C, H, W, generator=g)

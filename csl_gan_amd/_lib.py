@@ -17,7 +17,7 @@ EXPORTS = [
     "cslgan_version", "cslgan_last_error", "cslgan_last_kernel", "cslgan_device_count",
     "cslgan_sample_sqnorm_f32", "cslgan_sample_sqnorm_bf16", "cslgan_clip_factors_f32", "cslgan_clip_accum_noise_f32",
     "cslgan_clip_accum_noise_bf16", "cslgan_conv2d_wgrad_grouped_bf16out_f32",
-    "cslgan_l2_clip_rows_f32", "cslgan_row_l2norm_f32", "cslgan_row_l2norm_bwd_f32",
+    "cslgan_l2_clip_rows_f32", "cslgan_row_l2norm_f32", "cslgan_row_l2norm_bwd_f32", "cslgan_mean_sample_f32",
     "cslgan_conv2d_fwd_f32", "cslgan_conv2d_fwd_x3_f32", "cslgan_conv2d_dgrad_f32", "cslgan_conv2d_wgrad_grouped_f32",
     "cslgan_conv2d_wgrad_scaled_f32", "cslgan_conv2d_wgrad_sqnorm_gram_f32", "cslgan_conv2d_wgrad_skinny_f32", "cslgan_conv2d_s2_fwd_f32",
     "cslgan_depth_to_space_f32", "cslgan_fold_channels4_f32",
@@ -73,6 +73,7 @@ def lib():
         "cslgan_clip_factors_f32": [vp, i32, i64, vp, i32, f32, i64, vp, vp, vp],
         "cslgan_clip_accum_noise_f32": [C.POINTER(SegsT), i64, vp, i32, vp, u64, u64, f32, f32, vp],
         "cslgan_l2_clip_rows_f32": [vp, vp, i64, i64, f32, vp, vp],
+        "cslgan_mean_sample_f32": [vp, i32, i32, i64, vp, vp, i64, f32, f32, u64, u64, vp, vp],
         "cslgan_row_l2norm_f32": [vp, i64, i64, vp, vp],
         "cslgan_row_l2norm_bwd_f32": [vp, vp, vp, i64, i64, vp, vp],
         "cslgan_conv2d_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, vp, i32, vp, vp],

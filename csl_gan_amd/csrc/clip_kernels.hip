@@ -145,6 +145,41 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, fl
     z1 = r * sn;
 }
 
+// ---- MeanSampler.sample (mean_sampler.py:75-84): gather + per-image jitter + per-pixel noise in one pass -------------------
+//   out[i][e] = ms[label[i]][perm[i]][e] + noise_mean_std * z_i + noise_std * z_{i,e}     (Philox4x32-10 + Box-Muller)
+// The reference draws on the host and copies the batch to the device every step (train.py:200-202, 214-216); as torch ops on
+// the device it is an index kernel, two normal_ fills and two adds (five passes over the batch).
+__global__ __launch_bounds__(256) void mean_sample_kernel(const float* __restrict__ ms, const long long* __restrict__ labels,
+                                                          const long long* __restrict__ perms, int num_samples, long long len,
+                                                          float noise_mean_std, float noise_std, unsigned long long seed,
+                                                          unsigned long long offset, float* __restrict__ out) {
+    const long long i = blockIdx.y;
+    const long long e4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index inside the image
+    if (e4 * 4 >= len) return;
+    const long long lab = labels ? labels[i] : 0;
+    const float* src = ms + (lab * num_samples + perms[i]) * len;
+    uint32_t rnd[4];
+    float zi = 0.f, unused;
+    if (noise_mean_std > 0.f) {                         // the image's jitter: the same counter in every thread of the image
+        philox4x32_10((uint32_t)i, 0xFFFFFFFFu, (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+        box_muller(rnd[0], rnd[1], zi, unused);
+    }
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (noise_std > 0.f) {
+        philox4x32_10((uint32_t)e4, (uint32_t)i, (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+        box_muller(rnd[0], rnd[1], z[0], z[1]);
+        box_muller(rnd[2], rnd[3], z[2], z[3]);
+    }
+    const float j = noise_mean_std * zi;
+    if (e4 * 4 + 3 < len && (len & 3) == 0) {
+        const float4 v = *reinterpret_cast<const float4*>(src + e4 * 4);
+        *reinterpret_cast<float4*>(out + i * len + e4 * 4) =
+            make_float4(v.x + j + noise_std * z[0], v.y + j + noise_std * z[1], v.z + j + noise_std * z[2], v.w + j + noise_std * z[3]);
+    } else {
+        for (int k = 0; k < 4 && e4 * 4 + k < len; ++k) out[i * len + e4 * 4 + k] = src[e4 * 4 + k] + j + noise_std * z[k];
+    }
+}
+
 constexpr int CA_THREADS = 256;
 constexpr int CA_COLS = CA_THREADS * 4;  // columns per block
 
@@ -412,6 +447,22 @@ int cslgan_l2_clip_rows_f32(const float* in, float* out, int64_t n_rows, int64_t
     hipLaunchKernelGGL(l2_clip_scale_kernel, dim3(gx, (unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, in, out,
                        (long long)n_rows, (long long)len, C, norms_ws);
     return check_launch("l2_clip_scale_kernel");
+}
+
+int cslgan_mean_sample_f32(const float* mean_samples, int n_classes, int num_samples, int64_t len, const int64_t* labels,
+                           const int64_t* perms, int64_t n, float noise_mean_std, float noise_std, uint64_t seed, uint64_t offset,
+                           float* out, void* stream) {
+    CSLGAN_REQUIRE(mean_samples && perms && out, "mean_sample: null argument");
+    CSLGAN_REQUIRE(n_classes >= 1 && num_samples >= 1 && len >= 1 && n >= 0 && n <= 65535, "mean_sample: bad sizes");
+    CSLGAN_REQUIRE(labels || n_classes == 1, "mean_sample: labels are required with more than one class");
+    CSLGAN_REQUIRE(aligned16(mean_samples) && aligned16(out), "mean_sample: tensors must be 16-byte aligned");
+    if (n == 0) return CSLGAN_OK;
+    const long long f4 = (len + 3) / 4;
+    note_kernel("mean_sample_kernel");
+    hipLaunchKernelGGL(mean_sample_kernel, dim3((unsigned)((f4 + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, mean_samples,
+                       reinterpret_cast<const long long*>(labels), reinterpret_cast<const long long*>(perms), num_samples, (long long)len,
+                       noise_mean_std, noise_std, (unsigned long long)seed, (unsigned long long)offset, out);
+    return check_launch("mean_sample_kernel");
 }
 
 int cslgan_row_l2norm_f32(const float* in, int64_t n_rows, int64_t len, float* out_norm, void* stream) {

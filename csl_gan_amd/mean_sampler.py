@@ -26,6 +26,7 @@ class MeanSampler:
         self.smallest_class_size, self.n_classes = smallest_class_size, n_classes
         self.device, self.generator = torch.device(device), generator
         self.mean_samples = None
+        self._seed, self._draws = None, 0            # Philox stream of the device-side sample() (csrc/clip_kernels.hip)
         if path is not None:
             raise NotImplementedError("loading mean samples from image files needs PIL/torchvision transforms (out of scope)")
         if dataloader is not None:
@@ -48,6 +49,20 @@ class MeanSampler:
     def sample(self, size, noise_std=0.01, noise_mean_std=0.01, requested_labels=None):
         dev, gen = self.mean_samples.device, self.generator
         reps = (size - 1) // self.num_samples + 1
+        if dev.type == "cuda":
+            # `reps` uniform permutations in one sort (argsort of iid uniforms) instead of `reps` randperm calls, and the gather +
+            # jitter + noise in one HIP kernel (Philox keyed by a seed fixed at the first draw and a per-call counter)
+            perms = torch.rand(reps, self.num_samples, device=dev, generator=gen).argsort(dim=1).reshape(-1)[:size]
+            if requested_labels is None:
+                requested_labels = torch.randint(0, self.n_classes, (size,), device=dev, generator=gen)
+            requested_labels = requested_labels.to(dev)
+            if self._seed is None:
+                self._seed = int(gen.initial_seed() if gen is not None else torch.initial_seed()) ^ 0x6D65616E73616D70
+            from . import ops
+            self._draws += 1
+            r = ops.mean_sample(self.mean_samples, requested_labels if self.n_classes > 1 else None, perms, noise_mean_std, noise_std,
+                                self._seed, self._draws)
+            return r, (requested_labels if self.n_classes > 1 else None)
         perms = torch.cat([torch.randperm(self.num_samples, device=dev, generator=gen) for _ in range(reps)])[:size]
         if requested_labels is None:
             requested_labels = torch.randint(0, self.n_classes, (size,), device=dev, generator=gen)

@@ -637,6 +637,22 @@ def l2_clip_rows(t, Cval):
     return out.reshape(t.shape)
 
 
+def mean_sample(mean_samples, labels, perms, noise_mean_std, noise_std, seed, offset):
+    """MeanSampler.sample's gather + per-image jitter + per-pixel noise (mean_sampler.py:75-84) in one pass.
+    mean_samples [n_classes, num_samples, ...] fp32, labels / perms [n] int64 (labels None for one class)."""
+    _chk(mean_samples, "mean_samples")
+    n_cls, num = mean_samples.shape[0], mean_samples.shape[1]
+    n = perms.numel()
+    ln = mean_samples[0, 0].numel()
+    if perms.dtype != torch.int64 or not perms.is_cuda or (labels is not None and (labels.dtype != torch.int64 or not labels.is_cuda)):
+        raise RuntimeError("mean_sample: labels / perms must be int64 device tensors")
+    out = torch.empty((n,) + tuple(mean_samples.shape[2:]), device=mean_samples.device, dtype=torch.float32)
+    check(_lib.lib().cslgan_mean_sample_f32(_p(mean_samples), n_cls, num, ln, _p(labels), _p(perms.contiguous()), n,
+                                            float(noise_mean_std or 0.0), float(noise_std or 0.0), int(seed) & (2 ** 64 - 1),
+                                            int(offset) & (2 ** 64 - 1), _p(out), _stream()), "mean_sample")
+    return out
+
+
 def row_l2norm(t2d):
     _chk(t2d, "t")
     n, L = t2d.shape

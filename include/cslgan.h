@@ -104,6 +104,14 @@ int cslgan_clip_accum_noise_bf16(const cslgan_segs_t* segs, int64_t n_rows, cons
 int cslgan_l2_clip_rows_f32(const float* in, float* out, int64_t n_rows, int64_t len, float C,
                             float* norms_ws, void* stream);
 
+/* MeanSampler.sample (mean_sampler.py:75-84; called from train.py:200-202, 214-216) on device-resident mean samples:
+ *   out[i][:] = mean_samples[labels[i]][perms[i]][:] + noise_mean_std * z_i + noise_std * z_{i,:}
+ * mean_samples [n_classes][num_samples][len], labels (nullable when n_classes == 1) and perms [n] int64, out [n][len];
+ * z ~ N(0,1) from Philox4x32-10 keyed (seed, offset): the caller advances offset per call. */
+int cslgan_mean_sample_f32(const float* mean_samples, int n_classes, int num_samples, int64_t len, const int64_t* labels,
+                           const int64_t* perms, int64_t n, float noise_mean_std, float noise_std, uint64_t seed, uint64_t offset,
+                           float* out, void* stream);
+
 /* Row L2 norms of a [n_rows, len] matrix (gradient_penalty.py:52-53) and the backward of
  * norm: gin[r][j] = gnorm[r] * in[r][j] / norm[r]. */
 int cslgan_row_l2norm_f32(const float* in, int64_t n_rows, int64_t len, float* out_norm, void* stream);

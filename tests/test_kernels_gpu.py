@@ -830,3 +830,38 @@ def test_first_layer_dense_wgrad_is_the_sum_of_the_per_image_kernel(N, H, W):
         ops.set_launch_timer(None)
     assert any("c3_wgrad_kernel" in k for k in timer.summary(by_kernel=True)), timer.summary(by_kernel=True).keys()
     _close(got.permute(0, 3, 1, 2), 0.5 * ref, what="dense first-layer wgrad")
+
+
+def test_mean_sample_gather_jitter_noise():
+    """cslgan_mean_sample_f32 = MeanSampler.sample (mean_sampler.py:75-84): the right rows without noise; with noise the per-image
+    jitter is one constant per image ~ N(0, s1^2) and the per-pixel residual ~ N(0, s2^2); draws differ between calls."""
+    from csl_gan_amd.mean_sampler import MeanSampler
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    ms = MeanSampler(noise_std=0.12, num_samples=32, mean_size=1000, dataset_size=180000, n_classes=2, smallest_class_size=70000, device="cuda")
+    ms.mean_samples = torch.randn(2, 32, 3, 16, 16, generator=g).cuda()
+    labels = torch.randint(0, 2, (128,), generator=g).cuda()
+    r, y = ms.sample(128, noise_std=0, noise_mean_std=0, requested_labels=labels)
+    assert torch.equal(y, labels) and r.shape == (128, 3, 16, 16)
+    flat = ms.mean_samples.reshape(2, 32, -1)
+    for blk in range(4):            # every block of 32 draws is a permutation of the 32 mean samples of the requested classes
+        idx = []
+        for i in range(32 * blk, 32 * blk + 32):
+            match = (flat[labels[i]] == r[i].reshape(1, -1)).all(dim=1).nonzero()
+            assert match.numel() == 1
+            idx.append(int(match))
+        assert sorted(idx) == list(range(32))
+    s1, s2 = 0.05, 0.02
+    perms = torch.arange(128, device="cuda") % 32
+    a = ops.mean_sample(ms.mean_samples, labels, perms, s1, s2, seed=11, offset=1)
+    b = ops.mean_sample(ms.mean_samples, labels, perms, s1, s2, seed=11, offset=2)
+    a2 = ops.mean_sample(ms.mean_samples, labels, perms, s1, s2, seed=11, offset=1)
+    assert torch.equal(a, a2) and not torch.equal(a, b)
+    res = (a - ms.mean_samples[labels, perms]).reshape(128, -1)
+    jit = res.mean(dim=1)                                   # 768 pixels: the pixel noise averages to s2/sqrt(768) = 7e-4
+    assert abs(jit.std().item() - s1) < 0.25 * s1 and abs(jit.mean().item()) < 0.3 * s1
+    pix = res - jit.unsqueeze(1)
+    assert abs(pix.std().item() - s2) < 0.03 * s2
+    # one class: labels may be omitted
+    one = ops.mean_sample(ms.mean_samples[:1].contiguous(), None, perms, 0.0, 0.0, seed=1, offset=1)
+    assert torch.equal(one, ms.mean_samples[0, perms])

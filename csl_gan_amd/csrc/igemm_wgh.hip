@@ -172,8 +172,9 @@ int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int grou
     p.gy = gy; p.x = x; p.gw = gw; p.sq = sq; p.row_scale = row_scale;
     p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->P; p.Q = c->Q; p.K = c->K; p.R = c->R; p.S = c->S;
     p.stride = c->stride; p.pad = c->pad; p.group = group; p.n_groups = c->N / group; p.alpha = alpha;
-    static const int half_env = [] { const char* e = getenv("CSLGAN_WGH_HALF"); return e ? atoi(e) : 0; }();
-    const bool half_m = c->K % WG_BM != 0 || (half_env && group == 1);       // K = 64, 192, ...: 64-channel m tiles
+    // K = 64, 192, ...: 64-channel m tiles (forcing them on K = 128 to even out 640 workgroups over 512 slots was measured:
+    // 176 -> 171 us on conv2, 210 -> 235 us on conv3 — not kept)
+    const bool half_m = c->K % WG_BM != 0;
     p.tiles_m = half_m ? c->K / 64 : c->K / WG_BM; p.tiles_c = c->C / WG_BC; p.ppi = (c->P >> 3) * (c->Q >> 3);
     p.xw = 7 * c->stride + c->S;
     const long long base = (long long)p.n_groups * p.tiles_m * p.tiles_c * c->R;

@@ -353,7 +353,7 @@ static bool halo_x3_eligible(const KcParams& p);
 static int launch_halo_x3(KcParams& p, hipStream_t st);
 
 int launch_kc_bf16(KcParams& p, hipStream_t st, long long out_elems) {
-    if (p.bf16 == 3 && halo_x3_eligible(p)) return launch_halo_x3(p, st);
+    if (halo_x3_eligible(p)) return launch_halo_x3(p, st);      // needs the pre-split / pre-rounded filter (p.w3)
     for (int c = 0; c < p.n_cls; ++c) {
         KcClass& k = p.cls[c];
         k.patch = (k.T > 1 && k.OHc % 8 == 0 && k.OWc % 8 == 0) ? 1 : 0;
@@ -616,10 +616,13 @@ __global__ __launch_bounds__(256, 2) void igemm_mc_bf16_kernel(const McParams p)
 // pixel r = one ds_read_b128; the 32-byte pixel stride makes that read 2-way conflicted, which is cheaper than a padded image).
 constexpr int HX_MAX = 12 * 12;        // pixels per patch halo (8+4 squared: up to 5x5 taps)
 
-template <int BN>
+// NP = 3: fp32 from three bfloat16 pieces per operand (six MFMAs per step).  NP = 1: plain bf16 operands (--compute_dtype bf16),
+// one MFMA per step — the filter stream then needs 64 B per CU-cycle from L1/L2, so the ring of filter slices is four deep.
+template <int BN, int NP>
 __global__ __launch_bounds__(256, 2) void igemm_halo_x3_kernel(const KcParams p) {
+    constexpr int RING = NP == 1 ? 4 : 2;
     constexpr int BM = 128, TM = 2, TN = BN / 64;            // waves 2 (M: one patch each) x 2 (N)
-    __shared__ __attribute__((aligned(16))) uint2 Hs[3][2 * HX_MAX * 4];     // [piece][patch][pixel][4 x (4 ch bf16)]
+    __shared__ __attribute__((aligned(16))) uint2 Hs[NP][2 * HX_MAX * 4];     // [piece][patch][pixel][4 x (4 ch bf16)]
     __shared__ int s_tapoff[IG_MAX_TAPS];
     __shared__ int s_off[BM];
     __shared__ int s_roff[BM];
@@ -659,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_x3_kernel(const KcParams p)
     // cached per parameter version by the caller): lane (r, h), tile j, piece c reads 8 consecutive k of filter row
     // n0 + wn*TN*32 + j*32 + r = one 16-byte load, no conversion work in the loop
     // layout [piece][step][n][16 k] with step = chunk * T + tap: the 32 rows x 32 B one wave-load touches are 1 KB contiguous
-    const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w3), 0, 6u * (unsigned)p.Nn * (unsigned)kc.Kdim, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w3), 0, 2u * NP * (unsigned)p.Nn * (unsigned)kc.Kdim, 0x00020000);
     const unsigned piece_bytes = 2u * (unsigned)p.Nn * (unsigned)kc.Kdim;
     const unsigned step_bytes = 32u * (unsigned)p.Nn;
     unsigned b_off[TN];
@@ -668,7 +671,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_x3_kernel(const KcParams p)
         const int n = n0 + wn * TN * 32 + j * 32 + r;
         b_off[j] = n < p.Nn ? 32u * (unsigned)n + 16u * (unsigned)h : OOB16;
     }
-    u32x4 rb[2][3][TN];                                      // ring of two steps x three pieces (a third set spills: 256 VGPRs)
+    u32x4 rb[RING][NP][TN];                                  // ring of filter slices (three pieces: a third step spills, 256 VGPRs)
     const int n_steps = (p.AC >> 4) * T;
     auto load_b = [&](int step, int slot) {                 // filter slice of `step` (= chunk * T + tap); zeros past the end
         const unsigned kb = (unsigned)step * step_bytes;
@@ -676,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_x3_kernel(const KcParams p)
         for (int j = 0; j < TN; ++j) {
             const unsigned o = (step >= n_steps || b_off[j] == OOB16) ? OOB16 : b_off[j] + kb;
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
+            for (int c = 0; c < NP; ++c)
                 rb[slot][c][j] = __builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, (int)(o == OOB16 ? OOB16 : o + c * piece_bytes), 0, 0);
         }
     };
@@ -708,8 +711,12 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_x3_kernel(const KcParams p)
                 // the two 16-byte halves of a pixel are swapped on odd halo rows: the two patch rows a 16-lane ds_read_b128 group
                 // covers then hit disjoint banks (the plain 32-byte stride is 2-way conflicted; measured 73 % conflict cycles)
                 const int at = (pp * HX_MAX + pix) * 4 + (ch ^ (((pix / HW_) & 1) << 1));
-                const bf16x3_t t = split4_bf16(rh[j]);
-                Hs[0][at] = t.hi; Hs[1][at] = t.mid; Hs[2][at] = t.lo;
+                if (NP == 1) {
+                    Hs[0][at] = pack4_bf16(rh[j]);
+                } else {
+                    const bf16x3_t t = split4_bf16(rh[j]);
+                    Hs[0][at] = t.hi; Hs[NP > 1 ? 1 : 0][at] = t.mid; Hs[NP > 2 ? 2 : 0][at] = t.lo;
+                }
             }
         }
     };
@@ -732,18 +739,18 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_x3_kernel(const KcParams p)
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
     fetch_halo(0);
-    load_b(0, 0);
-    load_b(1, 1);
+#pragma unroll
+    for (int q = 0; q < RING; ++q) load_b(q, q);
     commit_halo();
     __syncthreads();
 
     // A fragments of the NEXT step are read from the halo image while this step's MFMAs run (the image only changes at chunk
     // boundaries, where the read follows the commit)
-    bf16x8 af_n[3][TM];
+    bf16x8 af_n[NP][TM];
     auto read_a = [&](int t) {
         const int tw = s_tapoff[t], toff = tw & ~1, odd = tw & 1;
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < NP; ++c)
 #pragma unroll
             for (int i = 0; i < TM; ++i) af_n[c][i] = *reinterpret_cast<const bf16x8*>(&Hs[c][(odd ? a_base[1][i] : a_base[0][i]) + toff]);
     };
@@ -756,15 +763,15 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_x3_kernel(const KcParams p)
         const int t_fetch = T > 3 ? T - 3 : 0;
         const bool last_chunk = (cc + 1) * 16 >= p.AC;
         if (t == t_fetch && !last_chunk) fetch_halo(cc + 1);
-        bf16x8 bf[3][TN], af[3][TM];
+        bf16x8 bf[NP][TN], af[NP][TM];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < NP; ++c) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[c][j] = __builtin_bit_cast(bf16x8, rb[SL][c][j]);
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[c][i] = af_n[c][i];
         }
-        load_b(s + 2, SL);
+        load_b(s + RING, SL);
         const bool boundary = t == T - 1;
         if (!boundary) read_a(t + 1);
 #pragma unroll
@@ -772,11 +779,13 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_x3_kernel(const KcParams p)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {      // smallest terms first
                 f32x16 a = acc[i][j];
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], a, 0, 0, 0);
+                if (NP == 3) {
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[NP - 1][j], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 1][i], bf[0][j], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP > 1 ? 1 : 0][i], bf[NP > 1 ? 1 : 0][j], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[NP > 1 ? 1 : 0][j], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP > 1 ? 1 : 0][i], bf[0][j], a, 0, 0, 0);
+                }
                 a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], a, 0, 0, 0);
                 acc[i][j] = a;
             }
@@ -789,9 +798,13 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_x3_kernel(const KcParams p)
             if (s + 1 < n_steps) read_a(0);
         }
     };
-    for (int s = 0; s < n_steps; s += 2) {
+    for (int s = 0; s < n_steps; s += RING) {
         k_step(s, 0);
         if (s + 1 < n_steps) k_step(s + 1, 1);
+        if (RING > 2) {
+            if (s + 2 < n_steps) k_step(s + 2, RING > 2 ? 2 : 0);
+            if (s + 3 < n_steps) k_step(s + 3, RING > 2 ? 3 : 0);
+        }
     }
     __syncthreads();
 
@@ -834,6 +847,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_x3_kernel(const KcParams p)
 
 // The KRSC filter w[n][t][c] split into its three bfloat16 pieces and re-laid STEP-major for igemm_halo_x3:
 //   w3[piece][step = (c/16) * T + t][n][c % 16]      (needs C % 16 == 0; every step's [Nn][16] slice is contiguous)
+template <int NP>
 __global__ void split_filter_x3_kernel(const float* __restrict__ w, int Nn, int T, int C, unsigned short* __restrict__ w3) {
     const long long n_el = (long long)Nn * T * C, n4 = n_el >> 2;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -843,17 +857,20 @@ __global__ void split_filter_x3_kernel(const float* __restrict__ w, int Nn, int 
         const int t = (int)(nt % T), n = (int)(nt / T);
         const long long dst = ((((long long)(c >> 4) * T + t) * Nn + n) << 4) + (c & 15);
         const bf16x3_t s3 = split4_bf16(reinterpret_cast<const float4*>(w)[i]);
-        *reinterpret_cast<uint2*>(w3 + dst) = s3.hi;
-        *reinterpret_cast<uint2*>(w3 + n_el + dst) = s3.mid;
-        *reinterpret_cast<uint2*>(w3 + 2 * n_el + dst) = s3.lo;
+        *reinterpret_cast<uint2*>(w3 + dst) = s3.hi;           // = the round-to-nearest-even bfloat16 of w: all the NP = 1 form needs
+        if (NP == 3) {
+            *reinterpret_cast<uint2*>(w3 + n_el + dst) = s3.mid;
+            *reinterpret_cast<uint2*>(w3 + 2 * n_el + dst) = s3.lo;
+        }
     }
 }
 
-int split_filter_x3(const float* w, int Nn, int T, int C, void* w3, hipStream_t st) {
+int split_filter_x3(const float* w, int Nn, int T, int C, void* w3, hipStream_t st, int pieces) {
     if (C % 16) return CSLGAN_OK;                     // the halo form does not take this shape: the workspace stays unused
     long long nb = ((long long)Nn * T * C / 4 + 255) / 256;
     nb = nb > 2048 ? 2048 : (nb < 1 ? 1 : nb);
-    hipLaunchKernelGGL(split_filter_x3_kernel, dim3((unsigned)nb), dim3(256), 0, st, w, Nn, T, C, reinterpret_cast<unsigned short*>(w3));
+    if (pieces == 1) hipLaunchKernelGGL(split_filter_x3_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, w, Nn, T, C, reinterpret_cast<unsigned short*>(w3));
+    else hipLaunchKernelGGL(split_filter_x3_kernel<3>, dim3((unsigned)nb), dim3(256), 0, st, w, Nn, T, C, reinterpret_cast<unsigned short*>(w3));
     return check_launch("split_filter_x3_kernel");
 }
 
@@ -899,9 +916,15 @@ static int launch_halo_x3(KcParams& p, hipStream_t st) {
     const bool wide = p.Nn > 64;
     p.tiles_n = wide ? (p.Nn + 127) / 128 : 1;
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);
-    note_kernel("igemm_halo_x3_kernel<%d>", wide ? 128 : 64);
-    if (wide) hipLaunchKernelGGL((igemm_halo_x3_kernel<128>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((igemm_halo_x3_kernel<64>), grid, block, 0, st, p);
+    const bool x3 = p.bf16 == 3;
+    note_kernel(x3 ? "igemm_halo_x3_kernel<%d>" : "igemm_halo_bf16_kernel<%d>", wide ? 128 : 64);
+    if (x3) {
+        if (wide) hipLaunchKernelGGL((igemm_halo_x3_kernel<128, 3>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((igemm_halo_x3_kernel<64, 3>), grid, block, 0, st, p);
+    } else {
+        if (wide) hipLaunchKernelGGL((igemm_halo_x3_kernel<128, 1>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((igemm_halo_x3_kernel<64, 1>), grid, block, 0, st, p);
+    }
     return check_launch("igemm_halo_x3_kernel");
 }
 

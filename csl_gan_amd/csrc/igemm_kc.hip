@@ -378,7 +378,7 @@ static long long tiles_for(const KcParams& p, int BM, int BN) {
 }
 
 int launch_kc_bf16(KcParams& p, hipStream_t st, long long out_elems);     // igemm_bf16.hip
-int split_filter_x3(const float* w, int Nn, int T, int C, void* w3, hipStream_t st);
+int split_filter_x3(const float* w, int Nn, int T, int C, void* w3, hipStream_t st, int pieces);
 bool halo_eligible(const KcParams& p);          // igemm_halo.hip
 int launch_halo(KcParams& p, hipStream_t st);
 bool skinny_eligible(const KcParams& p);        // igemm_skinny.hip
@@ -480,10 +480,11 @@ int cslgan_conv2d_fwd_f32(const cslgan_conv_t* c, const float* x, const float* w
 int cslgan_conv2d_fwd_x3_f32(const cslgan_conv_t* c, const float* x, const float* w, void* w3_ws, int repack, const float* bias,
                              const float* residual, int act, float* y, void* stream) {
     CSLGAN_REQUIRE(c && w && w3_ws, "conv2d_fwd_x3: null argument");
-    CSLGAN_REQUIRE(c->compute == CSLGAN_COMPUTE_BF16X3, "conv2d_fwd_x3: cslgan_conv_t.compute must be CSLGAN_COMPUTE_BF16X3");
+    CSLGAN_REQUIRE(c->compute == CSLGAN_COMPUTE_BF16X3 || c->compute == CSLGAN_COMPUTE_BF16,
+                   "conv2d_fwd_x3: cslgan_conv_t.compute must be CSLGAN_COMPUTE_BF16X3 or CSLGAN_COMPUTE_BF16");
     CSLGAN_REQUIRE(aligned16(w) && aligned16(w3_ws) && ((long long)c->K * c->R * c->S * c->C) % 4 == 0, "conv2d_fwd_x3: filter must be 16-byte aligned with a multiple of 4 elements");
     if (repack) {
-        int rc = split_filter_x3(w, c->K, c->R * c->S, c->C, w3_ws, (hipStream_t)stream);
+        int rc = split_filter_x3(w, c->K, c->R * c->S, c->C, w3_ws, (hipStream_t)stream, c->compute == CSLGAN_COMPUTE_BF16X3 ? 3 : 1);
         if (rc) return rc;
     }
     return conv2d_fwd_impl(c, x, w, w3_ws, bias, residual, act, y, stream);

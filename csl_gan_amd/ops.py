@@ -233,9 +233,9 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, ou
             _lib.lib().cslgan_conv2d_s2_fwd_f32(C.byref(d), _p(x), _p(w), _p(ws), repack, _p(bias), act, _p(y), _stream()),
             "conv2d_s2_fwd"), exec_flop=xflop, tag=lambda: "N%d %dx%d C%d K%d R%d s2 halo" % (N, H, W, Cc, K, R))
         return y
-    if d.compute == COMPUTE_BF16X3 and stride == 1 and R * S > 1 and Cc % 16 == 0 and K >= 64 and P % 8 == 0 and Q % 8 == 0:
-        # the LDS-halo form of the three-piece path reads the filter pre-split into bfloat16 pieces (cached per parameter version)
-        ws, repack = repack_cache.get("x3w", w, (3 * w.numel() + 1) // 2, wkey, version=wversion)
+    if d.compute in (COMPUTE_BF16X3, COMPUTE_BF16) and stride == 1 and R * S > 1 and Cc % 16 == 0 and K >= 64 and P % 8 == 0 and Q % 8 == 0:
+        # the LDS-halo form of the bf16 paths reads the filter pre-split into bfloat16 pieces / pre-rounded (cached per parameter version)
+        ws, repack = repack_cache.get("x3w" if d.compute == COMPUTE_BF16X3 else "bf16w", w, (3 * w.numel() + 1) // 2, wkey, version=wversion)
         _timed("conv2d_fwd", flop, nbytes, lambda: check(
             _lib.lib().cslgan_conv2d_fwd_x3_f32(C.byref(d), _p(x), _p(w), _p(ws), repack, _p(bias), _p(residual), act, _p(y), _stream()),
             "conv2d_fwd_x3"), exec_flop=xflop, tag=lambda: "N%d %dx%d C%d K%d R%d s%d" % (N, H, W, Cc, K, R, stride))

@@ -149,7 +149,8 @@ typedef struct {
 int cslgan_conv2d_fwd_f32(const cslgan_conv_t* p, const float* x, const float* w, const float* bias,
                           const float* residual, int act, float* y, void* stream);
 
-/* cslgan_conv2d_fwd_f32 with compute == CSLGAN_COMPUTE_BF16X3 and the filter pre-split into its three bfloat16 pieces:
+/* cslgan_conv2d_fwd_f32 with compute == CSLGAN_COMPUTE_BF16X3 and the filter pre-split into its three bfloat16 pieces
+ * (or compute == CSLGAN_COMPUTE_BF16 and the filter pre-rounded: one piece, the same layout):
  * w3_ws is a caller workspace of 3 * K*R*S*C bfloat16 (= 1.5 * K*R*S*C floats), rebuilt from w when repack != 0 and reused
  * otherwise (the caller knows when w changed).  Stride-1 convs on 8x8-patchable grids with C % 16 == 0 and K >= 64 then run on
  * the LDS-halo kernel whose filter operand goes straight from that workspace to registers; other shapes ignore it. */

@@ -401,10 +401,17 @@ def conv2d_wgrad_sqnorm_gram(gy, x, R, S, stride=1, pad=0, alpha=1.0, sq=None):
         both = sample_sqnorm([gy.reshape(N, K), x.reshape(N, Cc)])
         sq.view(-1).addcmul_(both[0], both[1], value=float(alpha) ** 2)
         return sq
-    flop = 2.0 * N * (P * Q) ** 2 * (K + R * S * Cc)
+    flop = 2.0 * N * (P * Q) ** 2 * (K + R * S * Cc)          # the tap-by-tap Gram form
+    cls_pix = ((H + stride - 1) // stride) * ((W + stride - 1) // stride)
+    if stride in (1, 2) and P * Q <= 16 and cls_pix <= 16:   # pixel-pair kernels: s^2 class Gram matrices (+ GY GY^T once / per class)
+        xflop = 2.0 * N * ((P * Q) ** 2 * K + stride * stride * cls_pix ** 2 * Cc)
+    elif stride in (1, 2) and P * Q <= 64 and cls_pix <= 64:
+        xflop = 2.0 * N * stride * stride * 64 * 64 * (K + Cc)
+    else:
+        xflop = flop
     _timed("conv2d_wgrad_gram_norms", flop, 4.0 * (gy.numel() + x.numel()), lambda: check(
         _lib.lib().cslgan_conv2d_wgrad_sqnorm_gram_f32(C.byref(d), _p(gy), _p(x), float(alpha), _p(sq), _stream()),
-        "conv2d_wgrad_sqnorm_gram"), tag=lambda: "N%d %dx%d C%d K%d R%d s%d" % (N, H, W, Cc, K, R, stride))
+        "conv2d_wgrad_sqnorm_gram"), exec_flop=xflop, tag=lambda: "N%d %dx%d C%d K%d R%d s%d" % (N, H, W, Cc, K, R, stride))
     return sq
 
 

@@ -115,7 +115,7 @@ def main():
 
     def step():
         tr.train_D(img, None, tr.gen_z(B), None, use_dp=True)
-        tr.dev_stats.clear()
+        pass  # statistics keep accumulating in place between log lines, as in training
 
     # Warm-up.  Its last steps are instrumented launch by launch (HIP events on the launch stream): they name the dominant
     # device kernel and give the per-kernel tables.  Inside the TIMED region only that kernel's launches carry events — two

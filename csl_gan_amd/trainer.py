@@ -41,6 +41,7 @@ class Trainer:
         self.g_optimizer, self.d_optimizer = self.init_optimizers()
         self.logger = self._make_logger(log_to)
         self.dev_stats = {}
+        self._pending_stats = []
         self.batches_per_epoch = opt.train_set_size / opt.batch_size
         self.fixed_z = self.fixed_y = None  # set by init_fixed_samples (train.py:256-261); sample() is a no-op until then
         self.graphed = None                # GraphedDStep, created by setup_privacy_engine when --hip_graph is set
@@ -380,9 +381,9 @@ class Trainer:
                 d_loss = d_loss + penalty
                 penalty_grad = autograd.grad(penalty, list(D.parameters()), create_graph=False, retain_graph=False, allow_unused=True)
                 with torch.no_grad():
-                    for p, g in zip(D.parameters(), penalty_grad):
-                        if g is not None:
-                            p.summed_grad.add_(g, alpha=o.batch_size)     # summed_grad is a sum, not a mean (train.py:431)
+                    pairs = [(p.summed_grad, g) for p, g in zip(D.parameters(), penalty_grad) if g is not None]
+                    if pairs:      # summed_grad is a sum, not a mean (train.py:431); one multi-tensor launch
+                        torch._foreach_add_([t for t, _ in pairs], [g for _, g in pairs], alpha=o.batch_size)
                     if self.explicit.get("keep"):
                         self.last["penalty_grads"] = [None if g is None else g.clone() for g in penalty_grad]
             else:
@@ -431,6 +432,7 @@ class Trainer:
                 self._acc("D Real Aux Acc", 100 * (d_real_aux.detach().argmax(dim=1) == labels).float().mean())
             self.last.update(d_real_loss=d_real_loss.detach(), d_fake_loss=d_fake_loss.detach(), penalty=penalty.detach(),
                              d_real=d_real.detach(), d_fake=d_fake.detach(), fake_img=fake_img)
+            self._commit_stats()
 
     # ---- train.py:502-517 ---------------------------------------------------------------------
     def train_G(self, z, y):
@@ -454,6 +456,7 @@ class Trainer:
         if o.is_acgan:
             self._acc("G Aux Loss", g_aux_loss.detach())
             self._acc("G Aux Acc", 100 * (d_fake_aux.detach().argmax(dim=1) == y.to(o.d_device)).float().mean())
+        self._commit_stats()
 
     def _average_G_grads(self):
         """G is replicated; its (non-private) gradients are averaged over ranks with ONE flat
@@ -550,20 +553,30 @@ class Trainer:
         cur = self.dev_stats.get(name)
         if cur is None or cur.shape != value.shape:
             self.dev_stats[name] = value.detach().clone()
+        elif value.is_cuda:
+            self._pending_stats.append((cur, value.detach()))     # folded in by _commit_stats: one multi-tensor add per step
         else:
             cur.add_(value.detach())
+
+    def _commit_stats(self):
+        """The step's statistic updates as ONE multi-tensor launch (they were a dozen 4-us kernels)."""
+        if self._pending_stats:
+            torch._foreach_add_([c for c, _ in self._pending_stats], [v for _, v in self._pending_stats])
+            self._pending_stats = []
 
     def reset_stats(self):
         """logger.reset_stats() of the reference (train.py:566, 576): the statistics live partly on the device here, so the
         pending device-side sums (everything accumulated since the last log line) must be dropped with them — otherwise the
         tail of one epoch leaks into the first log line of the next."""
         self.logger.reset_stats()
+        self._commit_stats()
         for k, v in self.dev_stats.items():
             if not k.startswith("_"):
                 v.zero_()
 
     def flush_stats(self):
         """Fold device-side sums into the Logger (this is where the host synchronises)."""
+        self._commit_stats()
         for k, v in list(self.dev_stats.items()):
             if k.startswith("_"):
                 continue

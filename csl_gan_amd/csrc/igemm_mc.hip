@@ -290,7 +290,8 @@ int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, flo
 
 bool wgh_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const void* x);      // igemm_wgh.hip
 int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st,
-               const float* row_scale);      // igemm_wgh.hip
+               const float* row_scale, int n_seg = 0, const int* seg_first = nullptr, float* const* seg_gw = nullptr,
+               float* const* seg_sq = nullptr);      // igemm_wgh.hip
 
 int launch_mc_bf16(McParams& p, bool vecA, bool vecB, hipStream_t st, int nsplit);        // igemm_bf16.hip
 
@@ -387,6 +388,22 @@ int cslgan_conv2d_wgrad_scaled_f32(const cslgan_conv_t* c, const float* gy, cons
                                    float alpha, float* gw, void* stream) {
     CSLGAN_REQUIRE(row_scale && gw, "conv2d_wgrad_scaled: null argument");
     return wgrad_grouped_impl(c, gy, x, group, alpha, gw, nullptr, stream, 0, row_scale);
+}
+
+int cslgan_conv2d_wgrad_blocks_f32(const cslgan_conv_t* c, const float* gy, const float* x, float alpha, int n_blocks,
+                                   const int32_t* block_first, float* const* gw, float* const* sq, void* stream) {
+    CSLGAN_REQUIRE(c && gy && x && block_first && gw && sq, "conv2d_wgrad_blocks: null argument");
+    CSLGAN_REQUIRE(n_blocks >= 1 && n_blocks <= CSLGAN_MAX_WGRAD_BLOCKS, "conv2d_wgrad_blocks: 1..%d blocks", CSLGAN_MAX_WGRAD_BLOCKS);
+    CSLGAN_REQUIRE(block_first[0] == 0, "conv2d_wgrad_blocks: the first block must start at sample 0");
+    for (int i = 1; i < n_blocks; ++i)
+        CSLGAN_REQUIRE(block_first[i] > block_first[i - 1] && block_first[i] < c->N, "conv2d_wgrad_blocks: block starts must increase inside [0, N)");
+    const int P = (c->H + 2 * c->pad - c->R) / c->stride + 1, Q = (c->W + 2 * c->pad - c->S) / c->stride + 1;
+    CSLGAN_REQUIRE(P == c->P && Q == c->Q, "conv2d_wgrad_blocks: output %dx%d does not match P,Q=%d,%d", P, Q, c->P, c->Q);
+    CSLGAN_REQUIRE(c->compute == CSLGAN_COMPUTE_F32 && wgh_eligible(c, 0, gy, x),
+                   "conv2d_wgrad_blocks: shape not taken by the LDS-resident kernel (fp32, stride 1-2, 2..5 columns, K %% 64, C %% 64, 8x8-patchable output)");
+    int first[CSLGAN_MAX_WGRAD_BLOCKS];
+    for (int i = 0; i < n_blocks; ++i) first[i] = block_first[i];
+    return launch_wgh(c, gy, x, 1, alpha, nullptr, nullptr, (hipStream_t)stream, nullptr, n_blocks, first, gw, sq);
 }
 
 int cslgan_bias_grad_grouped_f32(const float* gy, int N, int PQ, int K, int group, float alpha, float* gb, float* sq,

@@ -31,6 +31,12 @@ struct WghParams {
     int ksplit;                  // workgroups per (group, tile, filter row): they take every ksplit-th patch and add atomically
     int xw;                      // staged columns: 7*stride + S
     const float* row_scale;      // nullable [N]: gy of sample n is multiplied by row_scale[n] while it is staged (clip-weighted sums)
+    // row blocks with their own outputs (cslgan_conv2d_wgrad_blocks_f32): groups [seg_first[s], seg_first[s+1]) write
+    // seg_gw[s] + (g - seg_first[s]) * K*R*S*C (nothing when null) and add their squared norm into seg_sq[s][g - seg_first[s]]
+    int n_seg;
+    int seg_first[CSLGAN_MAX_WGRAD_BLOCKS + 1];
+    float* seg_gw[CSLGAN_MAX_WGRAD_BLOCKS];
+    float* seg_sq[CSLGAN_MAX_WGRAD_BLOCKS];
 };
 
 // TM = 32-row MFMA tiles per wavefront along m: 2 -> 128 output channels per workgroup, 1 -> 64 (K = 64 layers)
@@ -135,6 +141,15 @@ __global__ __launch_bounds__(256, 2) void igemm_wgh_kernel(const WghParams p) {
     float ss = 0.f;
     const long long row_len = (long long)p.R * S * p.C;      // floats per output channel m
     float* __restrict__ outg = p.gw ? p.gw + (long long)g * p.K * row_len : nullptr;
+    float* sqg = p.sq ? p.sq + g : nullptr;
+    if (p.n_seg > 0) {
+        int sg = 0;
+#pragma unroll 1
+        while (sg + 1 < p.n_seg && g >= p.seg_first[sg + 1]) ++sg;
+        const int gl = g - p.seg_first[sg];
+        outg = p.seg_gw[sg] ? p.seg_gw[sg] + (long long)gl * p.K * row_len : nullptr;
+        sqg = p.seg_sq[sg] ? p.seg_sq[sg] + gl : nullptr;
+    }
     const long long col0 = (long long)r * S * p.C;
     const int c = c0 + wn * 32 + l31;
 #pragma unroll
@@ -152,9 +167,9 @@ __global__ __launch_bounds__(256, 2) void igemm_wgh_kernel(const WghParams p) {
                     else *dst = val;
                 }
             }
-    if (p.sq && p.ksplit <= 1) {
+    if (sqg && p.ksplit <= 1) {
         const float tot = block_sum_256(ss, s_red);
-        if (tid == 0) atomicAdd(p.sq + g, tot);
+        if (tid == 0) atomicAdd(sqg, tot);
     }
 }
 
@@ -167,9 +182,12 @@ bool wgh_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const vo
 }
 
 int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st,
-               const float* row_scale) {
+               const float* row_scale, int n_seg, const int* seg_first, float* const* seg_gw, float* const* seg_sq) {
     WghParams p{};
     p.gy = gy; p.x = x; p.gw = gw; p.sq = sq; p.row_scale = row_scale;
+    p.n_seg = n_seg;
+    for (int i = 0; i < n_seg; ++i) { p.seg_first[i] = seg_first[i]; p.seg_gw[i] = seg_gw[i]; p.seg_sq[i] = seg_sq[i]; }
+    if (n_seg > 0) { p.seg_first[n_seg] = c->N / group; p.gw = nullptr; p.sq = nullptr; }
     p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->P; p.Q = c->Q; p.K = c->K; p.R = c->R; p.S = c->S;
     p.stride = c->stride; p.pad = c->pad; p.group = group; p.n_groups = c->N / group; p.alpha = alpha;
     // K = 64, 192, ...: 64-channel m tiles (forcing them on K = 128 to even out 640 workgroups over 512 slots was measured:
@@ -180,7 +198,7 @@ int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int grou
     const long long base = (long long)p.n_groups * p.tiles_m * p.tiles_c * c->R;
     const int n_patch = group * p.ppi;
     p.ksplit = 1;
-    if (gw && base < 768 && n_patch >= 8) {      // few tiles, long patch loops: split the patches, add atomically
+    if (gw && n_seg == 0 && base < 768 && n_patch >= 8) {      // few tiles, long patch loops: split the patches, add atomically
         long long want = (1280 + base - 1) / base;
         const long long cap = n_patch / 4;
         p.ksplit = (int)(want < cap ? want : cap);

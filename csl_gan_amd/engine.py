@@ -257,6 +257,12 @@ def _collect_roles(self, gz, x, R, S, stride, pad, has_bias):
     r0 = 0
     ghost = e._ghost_layer(gz, x, stride)
     held = None                       # ghost layer: ("dense" rows start, count, scale) waiting for the private rows after them
+    # equal row blocks of a layer the LDS-resident kernel takes: ONE launch for all blocks (three launches of 640 workgroups fill
+    # the chip's 512 slots 62 %, one of 1920 fills them 94 %); the blocks' outputs are collected here and launched after the loop
+    blocks = None
+    if (not ghost and len(e.row_roles) > 1 and e._gs_dtype == torch.float32 and isinstance(layer, nn.Conv2d)
+            and len({n for _, n in e.row_roles}) == 1 and len(e.row_roles) <= 4 and ops.wgrad_blocks_eligible(gz.shape, x.shape, R, S, stride)):
+        blocks = []
     for role, n in e.row_roles:
         g_, x_ = gz[r0:r0 + n], x[r0:r0 + n]
         row0 = r0
@@ -264,7 +270,10 @@ def _collect_roles(self, gz, x, R, S, stride, pad, has_bias):
         scale = float(n) if e.loss_reduction == "mean" else 1.0
         if role == "norms":
             _, sq = e._buffers(("norms", id(w)), 1, n, 0)
-            _weight_sqnorms(g_, x_, R, S, stride, pad, scale, sq[0])
+            if blocks is not None:
+                blocks.append((n, None, sq[0], None))
+            else:
+                _weight_sqnorms(g_, x_, R, S, stride, pad, scale, sq[0])
             if has_bias:
                 _, bsq = e._buffers(("norms", id(layer.bias)), 1, n, 0)
                 ops.bias_grad_grouped(g_, group=1, alpha=scale, want_gb=False, sq=bsq[0])
@@ -274,6 +283,8 @@ def _collect_roles(self, gz, x, R, S, stride, pad, has_bias):
                 held = None
             if ghost:
                 held = (row0, n, scale)
+            elif blocks is not None:
+                blocks.append((n, torch.empty((n, K * R * S * Cc), device=gz.device, dtype=torch.float32), None, "dense"))
             else:
                 e._add_dense(w, _dense_wgrad(g_, x_, R, S, stride, pad, scale))
             if has_bias:
@@ -286,8 +297,11 @@ def _collect_roles(self, gz, x, R, S, stride, pad, has_bias):
             self._ghost_rows(0, 1, g_, x_, R, S, stride, pad, scale, has_bias, joint=joint)
         else:
             buf, sq = e._buffers(w, 1, n, K * R * S * Cc, e._gs_dtype)
-            ops.conv2d_wgrad_grouped(g_, x_, R, S, stride=stride, pad=pad, group=1, alpha=scale,
-                                     out=buf[0].view(n, K, R, S, Cc), sq=sq[0])
+            if blocks is not None:
+                blocks.append((n, buf[0], sq[0], None))
+            else:
+                ops.conv2d_wgrad_grouped(g_, x_, R, S, stride=stride, pad=pad, group=1, alpha=scale,
+                                         out=buf[0].view(n, K, R, S, Cc), sq=sq[0])
             view = buf.view(1, n, K, R, S, Cc).permute(0, 1, 2, 5, 3, 4) if isinstance(layer, nn.Conv2d) else buf.view(1, n, K, Cc)
             view._cslgan_rows = buf.view(n, -1)
             w.grad_sample = view
@@ -301,6 +315,14 @@ def _collect_roles(self, gz, x, R, S, stride, pad, has_bias):
 
     if held is not None:
         e._add_dense(w, _dense_wgrad(gz[held[0]:held[0] + held[1]], x[held[0]:held[0] + held[1]], R, S, stride, pad, held[2]))
+    if blocks:
+        n = blocks[0][0]
+        ops.conv2d_wgrad_blocks(gz, x, R, S, stride, pad, float(n) if e.loss_reduction == "mean" else 1.0, [(bl[0], bl[1], bl[2]) for bl in blocks])
+        for _, slabs, _, kind in blocks:
+            if kind == "dense":              # the block's sum: one column sum over its per-sample slabs
+                tot = torch.empty(slabs.shape[1], device=slabs.device, dtype=torch.float32)
+                ops.clip_accum_noise([slabs], [tot])
+                e._add_dense(w, tot)
 
 
 _LayerCollector._collect_roles = _collect_roles

@@ -474,6 +474,46 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
     return None if scratch else gw
 
 
+def wgrad_blocks_eligible(gy_shape, x_shape, R, S, stride):
+    """Shapes cslgan_conv2d_wgrad_blocks_f32 takes (the LDS-resident fp32 kernel): mirrors wgh_eligible in csrc/igemm_wgh.hip."""
+    _, P, Q, K = gy_shape
+    Cc = x_shape[-1]
+    return (_compute == COMPUTE_F32 and stride in (1, 2) and 2 <= S <= 5 and K % 64 == 0 and Cc % 64 == 0 and P % 8 == 0 and Q % 8 == 0)
+
+
+def conv2d_wgrad_blocks(gy, x, R, S, stride, pad, alpha, blocks):
+    """Per-sample weight gradients of consecutive row blocks in ONE launch.  blocks: [(n_rows, gw_out or None, sq or None)] —
+    gw_out [n_rows, K*R*S*C] fp32 (None: nothing stored), sq [n_rows] accumulated (None: no norms)."""
+    _chk(gy, "gy"); _chk(x, "x")
+    N, H, W, Cc = x.shape
+    N2, P, Q, K = gy.shape
+    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad)
+    if N2 != N or (P2, Q2) != (P, Q) or sum(b[0] for b in blocks) != N:
+        raise RuntimeError("conv2d_wgrad_blocks: blocks / gy %s inconsistent with x %s" % (tuple(gy.shape), tuple(x.shape)))
+    nb = len(blocks)
+    first = (C.c_int32 * nb)()
+    gws, sqs = (C.c_void_p * nb)(), (C.c_void_p * nb)()
+    r0 = 0
+    for i, (n, gw, sq) in enumerate(blocks):
+        first[i] = r0
+        r0 += n
+        if gw is not None:
+            _chk(gw, "gw")
+            if gw.numel() != n * K * R * S * Cc:
+                raise RuntimeError("conv2d_wgrad_blocks: gw of block %d has %d elements, expected %d" % (i, gw.numel(), n * K * R * S * Cc))
+        if sq is not None:
+            _chk(sq, "sq")
+            if sq.numel() != n:
+                raise RuntimeError("conv2d_wgrad_blocks: sq of block %d needs %d entries" % (i, n))
+        gws[i] = None if gw is None else gw.data_ptr()
+        sqs[i] = None if sq is None else sq.data_ptr()
+    flop = 2.0 * N * P * Q * K * R * S * Cc
+    nbytes = 4.0 * (x.numel() + gy.numel() + sum(b[1].numel() for b in blocks if b[1] is not None))
+    _timed("conv2d_wgrad_grouped", flop, nbytes, lambda: check(
+        _lib.lib().cslgan_conv2d_wgrad_blocks_f32(C.byref(d), _p(gy), _p(x), float(alpha), nb, first, gws, sqs, _stream()),
+        "conv2d_wgrad_blocks"), tag=lambda: "N%d %dx%d C%d K%d R%d s%d g1 blocks%d" % (N, H, W, Cc, K, R, stride, nb))
+
+
 def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, alpha=1.0, row_scale=None):
     """The summed weight gradient [K,R,S,C] of a batch: slabs of the grouped MFMA kernel + a column sum, or the
     vector-ALU kernel for 1..4 output channels."""

@@ -173,6 +173,19 @@ int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* p, const float* gy, const float
 int cslgan_conv2d_wgrad_grouped_f32(const cslgan_conv_t* p, const float* gy, const float* x, int group,
                                     float alpha, float* gw, float* sq, void* stream);
 
+/* Per-sample weight gradients of a batch made of consecutive ROW BLOCKS with their own outputs, in one launch — the fused
+ * discriminator pass of train.py:204-245 + 382-389 carries the adaptive-clipping rows (norms only), the generated rows (only
+ * their sum is used) and the private rows (materialised) in one batch, and three launches of 640 workgroups each fill
+ * 512 slots 62 % where one launch of 1920 fills them 94 %.  Block b covers samples [block_first[b], block_first[b+1]) (the last
+ * one ends at N); sample n of block b writes gw[b] + (n - block_first[b]) * K*R*S*C (nothing when gw[b] is NULL) and adds
+ * ||alpha * g_n||^2 into sq[b][n - block_first[b]] (skipped when sq[b] is NULL; the caller zeroes).  gw and sq are HOST arrays of
+ * n_blocks device pointers.  fp32 only, on the shapes igemm_wgh takes (stride 1-2, 2..5 filter columns, K % 64 == 0,
+ * C % 64 == 0, P % 8 == 0, Q % 8 == 0); other shapes return CSLGAN_ERR_INVALID_ARG and the caller uses one
+ * cslgan_conv2d_wgrad_grouped_f32 call per block. */
+#define CSLGAN_MAX_WGRAD_BLOCKS 4
+int cslgan_conv2d_wgrad_blocks_f32(const cslgan_conv_t* p, const float* gy, const float* x, float alpha, int n_blocks,
+                                   const int32_t* block_first, float* const* gw, float* const* sq, void* stream);
+
 /* Stride-2 forward conv (the critic's convs, DCResNet_models.py:131) through the LDS-halo kernel: the four parity
  * sub-images of x are convolved at stride 1 and accumulated in one workgroup.  wcls_ws: K*R*R*C floats receiving the
  * filters regrouped by parity class (rebuilt when repack != 0).  Same result as cslgan_conv2d_fwd_f32, to which it falls

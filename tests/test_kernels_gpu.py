@@ -868,3 +868,30 @@ def test_mean_sample_gather_jitter_noise():
     # one class: labels may be omitted
     one = ops.mean_sample(ms.mean_samples[:1].contiguous(), None, perms, 0.0, 0.0, seed=1, offset=1)
     assert torch.equal(one, ms.mean_samples[0, perms])
+
+
+@pytest.mark.parametrize("case", [(6, 32, 32, 64, 128, 5, 2, 2), (9, 16, 16, 128, 64, 3, 1, 1)])
+def test_wgrad_row_blocks_in_one_launch(case):
+    """cslgan_conv2d_wgrad_blocks_f32: norms-only / stored / stored+norms blocks of one batch in one launch equal the per-block calls."""
+    ops = _ops()
+    N, H, W, C, K, R, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = _nhwc(torch.randn(N, C, H, W, generator=g))
+    P, Q = (H + 2 * p - R) // s + 1, (W + 2 * p - R) // s + 1
+    gy = _nhwc(torch.randn(N, K, P, Q, generator=g))
+    assert ops.wgrad_blocks_eligible(gy.shape, x.shape, R, R, s)
+    n = N // 3
+    L = K * R * R * C
+    sq_a, sq_c = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    gw_b, gw_c = torch.empty(n, L, device="cuda"), torch.empty(n, L, device="cuda")
+    ops.conv2d_wgrad_blocks(gy, x, R, R, s, p, 1.5, [(n, None, sq_a), (n, gw_b, None), (n, gw_c, sq_c)])
+    for i, (gw, sq) in enumerate(((None, sq_a), (gw_b, None), (gw_c, sq_c))):
+        sl = slice(i * n, (i + 1) * n)
+        rsq = torch.zeros(n, device="cuda")
+        ref = ops.conv2d_wgrad_grouped(gy[sl].contiguous(), x[sl].contiguous(), R, R, stride=s, pad=p, group=1, alpha=1.5, sq=rsq)
+        if gw is not None:
+            assert torch.equal(gw.view_as(ref), ref)
+        if sq is not None:
+            _close(sq, rsq, rtol=1e-6, what="block %d sq" % i)
+    with pytest.raises(RuntimeError):       # a shape the LDS-resident kernel does not take
+        ops.conv2d_wgrad_blocks(gy[:, :, :, :3].contiguous(), x, R, R, s, p, 1.0, [(N, None, torch.zeros(N, device="cuda"))])

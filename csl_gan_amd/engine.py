@@ -355,6 +355,7 @@ class PrivacyEngine(PerSampleSink):
         self._gs_dtype = torch.bfloat16 if grad_sample_dtype == "bf16" else torch.float32
         self.materialize, self.norms_only = materialize, False
         self.row_roles = None                   # set by Trainer.train_D_fused for one fused forward/backward
+        self._sq_arena, self._sq_off = None, 0
         self._dense = {}
         self._ghost = {}                        # id(weight) -> {pass: (gz, x, R, S, stride, pad, scale)} awaiting clip()
         self.use_side_stream = os.environ.get("CSLGAN_SIDE_STREAM", "0") == "1"
@@ -443,10 +444,20 @@ class PrivacyEngine(PerSampleSink):
         cur = self._bufs.get(key)
         if cur is None or cur[0].shape != (n_pass, B, numel):
             dev = self.params[0].device
-            cur = (torch.empty((n_pass, B, numel), device=dev, dtype=dtype),
-                   torch.zeros((n_pass, B), device=dev, dtype=torch.float32))
+            cur = (torch.empty((n_pass, B, numel), device=dev, dtype=dtype), self._sq_alloc(n_pass * B, dev).view(n_pass, B))
             self._bufs[key] = cur
         return cur
+
+    def _sq_alloc(self, n, dev):
+        """Zeroed [n] floats for a squared-norm accumulator.  A step asks for about twenty of these (one per parameter tensor and
+        row block); they are slices of ONE arena zeroed once per step (_reset_samples) instead of twenty 4-us fill launches.  The
+        first step — and any step that needs more than the arena holds — falls back to torch.zeros and sizes the next arena."""
+        n4 = (n + 3) & ~3
+        a, off = self._sq_arena, self._sq_off
+        self._sq_off = off + n4
+        if a is None or off + n4 > a.numel() or a.device != dev:
+            return torch.zeros(n, device=dev, dtype=torch.float32)
+        return a[off:off + n]
 
     # -- train.py:117,373,389 -----------------------------------------------------------------
     def enable_hooks(self):
@@ -673,6 +684,13 @@ class PrivacyEngine(PerSampleSink):
         for l in self.layers:
             self._fwd_count[l] = 0
         self._bufs.clear()
+        # squared-norm arena: sized by the largest step seen, zeroed here once for the next step
+        if self._sq_off > 0:
+            if self._sq_arena is None or self._sq_off > self._sq_arena.numel():
+                self._sq_arena = torch.zeros(self._sq_off, device=self.params[0].device, dtype=torch.float32)
+            else:
+                self._sq_arena.zero_()
+        self._sq_off = 0
         self._dense.clear()
         self._ghost.clear()
         self.row_roles = None

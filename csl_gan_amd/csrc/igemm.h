@@ -138,4 +138,10 @@ int launch_c3_fwd(const cslgan_conv_t* c, const float* x, const float* w, const 
 bool c3_wgrad_eligible(const cslgan_conv_t* c, int group, int out_bf16, const void* gy);
 int launch_c3_wgrad(const cslgan_conv_t* c, const float* gy, const float* x, float alpha, float* gw, float* sq, hipStream_t st);
 
+// linear_k1.hip: linear layers with one output unit as streams
+bool linear_k1_shape(const cslgan_conv_t* c);
+int launch_linear_k1_fwd(const cslgan_conv_t* c, const float* x, const float* w, const float* bias, const float* residual, int act,
+                         float* y, hipStream_t st);
+int launch_linear_k1_dgrad(const cslgan_conv_t* c, const float* gy, const float* w, const float* mask, float* gx, hipStream_t st);
+
 }  // namespace cslgan

@@ -499,6 +499,8 @@ static int conv2d_fwd_impl(const cslgan_conv_t* c, const float* x, const float* 
     static const int c3_env = [] { const char* e = getenv("CSLGAN_C3"); return e ? atoi(e) : 1; }();
     if (c3_env && c3_fwd_eligible(c, residual))          // the critic's RGB first layer (conv_c3.hip), exact fp32 in every compute mode
         return launch_c3_fwd(c, x, w, bias, act, y, (hipStream_t)stream);
+    if (linear_k1_shape(c) && aligned16(x) && aligned16(w))      // one output unit: a dot product per row (linear_k1.hip), fp32 in every mode
+        return launch_linear_k1_fwd(c, x, w, bias, residual, act, y, (hipStream_t)stream);
     KcParams p{};
     p.a = x; p.AH = c->H; p.AW = c->W; p.AC = c->C;
     p.VH = c->H; p.VW = c->W;
@@ -582,6 +584,8 @@ int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* c, const float* gy, const float
     int rc = check_conv(c, "conv2d_dgrad");
     if (rc) return rc;
     CSLGAN_REQUIRE(c->stride >= 1 && c->stride <= 2, "conv2d_dgrad: stride %d unsupported", c->stride);
+    if (linear_k1_shape(c) && aligned16(w) && aligned16(gx) && (!mask || aligned16(mask)))      // gx[n,:] = gy[n] * w: no repack needed
+        return launch_linear_k1_dgrad(c, gy, w, mask, gx, (hipStream_t)stream);
     const int s = c->stride;
     hipStream_t st = (hipStream_t)stream;
     RepackArgs ra{};

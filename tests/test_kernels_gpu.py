@@ -48,6 +48,8 @@ FWD_CASES = [
     (16, 8, 8, 256, 512, 5, 2, 2, True, 1, False, None),
     (128, 1, 1, 8192, 1, 1, 1, 0, False, 0, False, None),
     (128, 1, 1, 8192, 1, 1, 1, 0, True, 0, False, None),
+    (130, 1, 1, 8192, 1, 1, 1, 0, True, 1, False, 0),          # linear_k1 stream kernel with residual + LeakyReLU
+    (7, 1, 1, 512, 1, 1, 1, 0, False, 3, False, None),
     (3, 1, 1, 1000, 10, 1, 1, 0, True, 0, False, None),
     (2, 8, 8, 32, 48, 5, 1, 2, True, 0, False, 1),
     # shapes that take the LDS-halo kernel (stride 1, C % 32 == 0, 8x8-patchable grid, K >= 64)
@@ -159,6 +161,8 @@ DGRAD_CASES = [
     (2, 16, 16, 1, 64, 5, 2, 2, True),
     (2, 8, 8, 2, 64, 3, 1, 1, False),
     (4, 64, 64, 3, 64, 5, 2, 2, False),
+    (6, 1, 1, 8192, 1, 1, 1, 0, True),        # the critic's head: gx[n,:] = gy[n] * w (linear_k1 stream kernel), with a mask
+    (130, 1, 1, 512, 1, 1, 1, 0, False),
 ]
 
 

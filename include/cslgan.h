@@ -125,7 +125,8 @@ int cslgan_row_l2norm_bwd_f32(const float* in, const float* norm, const float* g
  *   CSLGAN_COMPUTE_BF16: operands rounded to bfloat16 (round-to-nearest-even) on their way into LDS, v_mfma_f32_32x32x16_bf16
  *                        with fp32 accumulate (BASELINE.json configs[4]; `--compute_dtype bf16`).  Honoured by conv2d_fwd,
  *                        conv2d_s2_fwd, conv2d_dgrad, conv2d_wgrad_grouped(_bf16out), conv2d_wgrad_scaled; the vector-ALU
- *                        (1..4 channel) and Gram-norm entries compute in fp32 regardless.
+ *                        (1..4 channel) kernels, the RGB first layer (3 -> 64, 5x5, stride 2), single-output linear layers and the
+ *                        Gram-norm entries compute in fp32 regardless (a fraction of a per cent of the FLOP).
  *   CSLGAN_COMPUTE_BF16X3: fp32 emulated on the bf16 matrix cores — every operand is split into three bfloat16 pieces
  *                        (x = hi + mid + lo, 3 x 8 mantissa bits = fp32's 24), a product is the sum of the six largest of the nine
  *                        piece products (each exact in fp32), fp32 accumulate: per-product error about one fp32 ulp at 2.67x the

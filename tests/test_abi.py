@@ -43,6 +43,20 @@ def test_invalid_arguments_fail_loudly_without_gpu(built_lib):
     d = _lib.ConvT(1, 8, 8, 4, 4, 5, 5, 2, 2, 0, 99, 99)
     rc = L.cslgan_conv2d_fwd_f32(ctypes.byref(d), 1, 1, None, None, 0, 1, None)
     assert rc == -1 and b"does not match" in L.cslgan_last_error()
+    # round-2 entries
+    rc = L.cslgan_mean_sample_f32(None, 1, 4, 16, None, None, 2, 0.0, 0.0, 1, 1, None, None)
+    assert rc == -1 and b"null" in L.cslgan_last_error()
+    rc = L.cslgan_mean_sample_f32(16, 2, 4, 16, None, 16, 2, 0.0, 0.0, 1, 1, 16, None)
+    assert rc == -1 and b"labels are required" in L.cslgan_last_error()
+    d2 = _lib.ConvT(6, 32, 32, 64, 128, 5, 5, 2, 2, 0, 16, 16)
+    first = (ctypes.c_int32 * 2)(0, 0)
+    ptrs = (ctypes.c_void_p * 2)(None, None)
+    rc = L.cslgan_conv2d_wgrad_blocks_f32(ctypes.byref(d2), 16, 16, 1.0, 2, first, ptrs, ptrs, None)
+    assert rc == -1 and b"must increase" in L.cslgan_last_error()
+    d3 = _lib.ConvT(6, 32, 32, 3, 128, 5, 5, 2, 2, 0, 16, 16)
+    first = (ctypes.c_int32 * 1)(0)
+    rc = L.cslgan_conv2d_wgrad_blocks_f32(ctypes.byref(d3), 16, 16, 1.0, 1, first, ptrs, ptrs, None)
+    assert rc == -1 and b"not taken by the LDS-resident kernel" in L.cslgan_last_error()
 
 
 def test_ops_refuse_cpu_tensors(built_lib):

@@ -144,4 +144,8 @@ int launch_linear_k1_fwd(const cslgan_conv_t* c, const float* x, const float* w,
                          float* y, hipStream_t st);
 int launch_linear_k1_dgrad(const cslgan_conv_t* c, const float* gy, const float* w, const float* mask, float* gx, hipStream_t st);
 
+// conv1x1.hip: 1x1 convs with 32 / 64 / 128 input channels as a stream over 128-row tiles
+bool conv1x1_eligible(const cslgan_conv_t* c, const float* x, const float* w, const float* residual);
+int launch_conv1x1(const cslgan_conv_t* c, const float* x, const float* w, const float* bias, int act, float* y, hipStream_t st);
+
 }  // namespace cslgan

@@ -499,6 +499,8 @@ static int conv2d_fwd_impl(const cslgan_conv_t* c, const float* x, const float* 
     static const int c3_env = [] { const char* e = getenv("CSLGAN_C3"); return e ? atoi(e) : 1; }();
     if (c3_env && c3_fwd_eligible(c, residual))          // the critic's RGB first layer (conv_c3.hip), exact fp32 in every compute mode
         return launch_c3_fwd(c, x, w, bias, act, y, (hipStream_t)stream);
+    if (conv1x1_eligible(c, x, w, residual))                     // the generator's shortcut convs (conv1x1.hip)
+        return launch_conv1x1(c, x, w, bias, act, y, (hipStream_t)stream);
     if (linear_k1_shape(c) && aligned16(x) && aligned16(w))      // one output unit: a dot product per row (linear_k1.hip), fp32 in every mode
         return launch_linear_k1_fwd(c, x, w, bias, residual, act, y, (hipStream_t)stream);
     KcParams p{};

@@ -60,6 +60,10 @@ FWD_CASES = [
     (3, 16, 24, 96, 80, 5, 1, 2, True, 0, False, 0),
     (2, 32, 32, 128, 128, 5, 1, 2, True, 0, False, None),
     (2, 8, 8, 32, 48, 1, 1, 0, True, 0, False, 0),
+    # 1x1 stream kernel (csrc/conv1x1.hip): 32 / 64 / 128 input channels, a ragged last row tile, residual + activation
+    (70, 32, 32, 32, 64, 1, 1, 0, True, 0, False, None),
+    (47, 40, 36, 64, 128, 1, 1, 0, True, 1, False, None),         # 67680 rows: a ragged last row tile
+    (3, 40, 36, 64, 128, 1, 1, 0, True, 1, False, 0),              # with a residual: the generic kernel
     (7, 1, 1, 794, 128, 1, 1, 0, True, 2, False, None),
     (5, 1, 1, 128, 1, 1, 1, 0, True, 0, False, None),
     (2, 16, 16, 64, 3, 3, 1, 1, True, 3, False, None),

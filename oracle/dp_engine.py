@@ -119,8 +119,11 @@ def calc_sample_norms(grad_samples: Sequence[torch.Tensor], flat: bool) -> List[
     """grad_samples: per-parameter tensors [n_passes, B, ...] -> list of [n_passes, B] norms.
 
     flat=True returns a one-element list holding the L2 norm over all parameters (train.py:311-315).
+    The squares are summed in float64: torch's CPU float32 ``norm`` over a 3.3 M-element row (D's last conv) is 1.3e-4 low
+    (sequential accumulation), which is an artefact of the host reduction, not part of the definition (the device reduces
+    by trees; tests/golden/dstep_*.npz hold float64 reductions of the reference classes' float32 gradients).
     """
-    per = [g.reshape(g.size(0), g.size(1), -1).norm(2, dim=2) for g in grad_samples]
+    per = [g.reshape(g.size(0), g.size(1), -1).double().norm(2, dim=2).to(g.dtype) for g in grad_samples]
     if flat:
         return [torch.stack(per, dim=0).norm(2, dim=0)]
     return per

@@ -81,7 +81,11 @@ def reference_init_models(dataset, model="DeepConvResNet", im_size=64, *, weight
 
 
 def gp_case(name, dataset, im_size, B, seed, one_sided=False, conditional=False, aux_penalty=False,
-            conditional_arch="ACGAN"):
+            conditional_arch="ACGAN", weight_scale=1.0):
+    """weight_scale k multiplies every parameter of the reference's D after construction.  At its initial weights the critic
+    has ||dD/dx|| ~ 0.01-0.03 << 1, so the penalty (||g||-1)^2 barely depends on ||g|| and the one-sided clamp
+    (gradient_penalty.py:54) zeroes everything; with k chosen so the per-sample input-gradient norms straddle 1 the
+    fixture's penalty, its clamp and its gradients are all sensitive.  The tests apply the same k to their D."""
     _, D = reference_init_models(dataset, "DeepConvResNet", im_size, init_G=False, conditional=conditional,
                                  n_classes=10 if dataset == "MNIST" else 2, conditional_arch=conditional_arch)
     g = torch.Generator().manual_seed(seed)
@@ -89,6 +93,26 @@ def gp_case(name, dataset, im_size, B, seed, one_sided=False, conditional=False,
     real = (torch.randn(B, ch, im_size, im_size, generator=g) * 0.5).clamp(-1, 1)
     fake = torch.tanh(torch.randn(B, ch, im_size, im_size, generator=g))
     labels = torch.randint(0, D.n_classes, (B,), generator=g) if conditional else None
+    if weight_scale == "straddle":      # k such that the median per-sample ||dD/dx_hat|| is 1 (D is nearly homogeneous of degree n_layers in k)
+        torch.manual_seed(seed + 7)
+        a4 = torch.rand(B, 1).view(B, 1, 1, 1)
+        w0 = [p.detach().clone() for p in D.parameters()]
+        weight_scale, n_layers = 1.0, len(D.blocks) + 1
+        for _ in range(6):
+            with torch.no_grad():
+                for p, w in zip(D.parameters(), w0):
+                    p.copy_(w).mul_(weight_scale)
+            xh = (a4 * real + (1 - a4) * fake).detach().requires_grad_(True)
+            gx, = torch.autograd.grad(D(xh, labels)[0].sum(), xh)
+            med = gx.reshape(B, -1).norm(2, dim=1).median().item()
+            weight_scale = float("%.4f" % (weight_scale * med ** (-1.0 / n_layers)))
+        with torch.no_grad():
+            for p, w in zip(D.parameters(), w0):
+                p.copy_(w)
+    if weight_scale != 1.0:
+        with torch.no_grad():
+            for p in D.parameters():
+                p.mul_(weight_scale)
     ptype = "WGAN-GP1" if one_sided else "WGAN-GP"
     out = {}
     for per_sample in (False, True):
@@ -106,6 +130,13 @@ def gp_case(name, dataset, im_size, B, seed, one_sided=False, conditional=False,
             out["grad_heads"] = np.stack([np.zeros(8, np.float32) if gr is None else
                                           gr.reshape(-1)[:8].numpy() for gr in grads])
         out["alpha"] = alpha.reshape(-1).numpy()
+    # ||dD(x_hat)/dx_hat|| per sample (gradient_penalty.py:48-52) on the reference's D, with the alpha recorded above
+    a4 = alpha.view(B, 1, 1, 1)
+    xh = (a4 * real + (1 - a4) * fake).detach().requires_grad_(True)
+    o_, _ = D(xh, labels)
+    gx, = torch.autograd.grad(o_, xh, torch.ones_like(o_))
+    out["input_grad_norms"] = gx.reshape(B, -1).double().norm(2, dim=1).numpy()
+    out["weight_scale"] = np.float64(weight_scale)
     with torch.no_grad():
         d_out, d_aux = D(real, labels)
     out.update(real=real.numpy(), fake=fake.numpy(), d_out_real=d_out.numpy(),
@@ -116,7 +147,7 @@ def gp_case(name, dataset, im_size, B, seed, one_sided=False, conditional=False,
         if d_aux is not None:
             out["d_aux_real"] = d_aux.numpy()
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
-    print(name, "penalty", out["penalty"], "norms", np.round(out["grad_norms"], 4))
+    print(name, "penalty", out["penalty"], "norms", np.round(out["grad_norms"], 4), "|dD/dx|", np.round(out["input_grad_norms"], 3))
 
 
 def upsample_conv_case():
@@ -189,6 +220,209 @@ def model_case(name, dataset, model, im_size, B, seed, latent=128, **kw):
             out["fake_eval"] = G(z, y).numpy()
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, "g_loss %.6f" % out["g_loss"], "fake range", float(fake.min()), float(fake.max()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# D-step observables (SURVEY §8c: "per-sample norms [layers,B], clip factors, pre-noise clipped sums") through the
+# reference's OWN G / D classes and loss methods.  The per-sample-gradient engine (the Opacus fork) is absent, so the
+# per-sample gradient is taken by its definition — one autograd call per sample through the reference's D — with the
+# fork's documented scaling for a mean-reduced loss (grad_sample_b = B * d(batch loss)/d theta through sample b alone;
+# for the separable mean losses of DCResNet_models.py:149-153 / MNIST_models.py:48-52 that IS the gradient of sample
+# b's own loss, asserted below).  The clip rule min(1, C/(||g||+1e-6)), the split / accumulated pass conventions and the
+# adaptive statistics of train.py:204-245 are then plain arithmetic on those reference-class gradients, written out here
+# (float64 reductions) without going through oracle/.
+# ---------------------------------------------------------------------------------------------------------------------
+def _per_sample_grads(D, x, y, batch_loss, want_aux=True):
+    """[B, *p.shape] per parameter (+ loss, out, aux): B autograd calls through the reference's D."""
+    params = list(D.parameters())
+    B = x.size(0)
+    out, aux = D(x, y) if want_aux else D(x, y, aux=False)
+    L = batch_loss(out, aux)
+    leaves = [out] + ([aux] if aux is not None else [])
+    cots = torch.autograd.grad(L, leaves, allow_unused=True)
+    res = [torch.zeros((B,) + tuple(p.shape)) for p in params]
+    for b in range(B):
+        yb = None if y is None else y[b:b + 1]
+        ob, ab = D(x[b:b + 1], yb) if want_aux else D(x[b:b + 1], yb, aux=False)
+        s = (ob * cots[0][b:b + 1]).sum()
+        if ab is not None and len(cots) > 1 and cots[1] is not None:
+            s = s + (ab * cots[1][b:b + 1]).sum()
+        gs = torch.autograd.grad(s * B, params, allow_unused=True)
+        for r, g_ in zip(res, gs):
+            if g_ is not None:
+                r[b] = g_
+    return res, L.detach(), out.detach(), None if aux is None else aux.detach()
+
+
+def _norms(gs):
+    """[L, B] float64 per-layer per-sample L2 norms."""
+    return torch.stack([g_.reshape(g_.size(0), -1).double().norm(2, dim=1) for g_ in gs])
+
+
+def _factors(norms, C):
+    """min(1, C/(norm + 1e-6)); C scalar (norms [B]) or per layer (norms [L,B], C [L])."""
+    C = torch.as_tensor(C, dtype=torch.float64)
+    if C.dim() == 1:
+        C = C.view(-1, 1)
+    return (C / (norms + 1e-6)).clamp(max=1.0)
+
+
+def _put_grads(out, key, tensors, scale=None):
+    """norms, strided entry samples and the per-tensor scale entry errors are measured against: max |entry|, or for a sum over
+    samples the largest entry of sum_b |f_b g_b| (a sum that cancels, e.g. an auxiliary-head bias, has rounding error
+    proportional to its terms, not to its result)."""
+    from dstep_inputs import sample_idx
+    out[key + "_norms"] = np.array([t.double().norm().item() for t in tensors])
+    out[key + "_absmax"] = np.array([t.abs().max().item() for t in tensors]) if scale is None else np.array([float(v) for v in scale])
+    for i, t in enumerate(tensors):
+        f = t.detach().reshape(-1)
+        out["%s_s%d" % (key, i)] = f[torch.from_numpy(sample_idx(f.numel()))].float().numpy()
+
+
+def dstep_case(name, dataset, model, im_size, B, seed, latent=128, penalty=True, geometry=None, adaptive_scalar=1.5, **kw):
+    sys.path.insert(0, HERE)
+    from dstep_inputs import checksums, dstep_inputs
+    if geometry is None:
+        G, D = reference_init_models(dataset, model, im_size, g_latent_dim=latent, **kw)
+    else:       # the 128x128 extension: the reference's generic DCResNet classes with the build's size table (init_util order)
+        cls = reference_model_classes()
+        torch.manual_seed(42)
+        G = cls["DCResNetGenerator"](z_dim=latent, channels=list(geometry["g_channels"]), first_filter_size=geometry["first"], out_ch=3,
+                                     bn=False, n_classes=0, emb_mode="concat")
+        D = cls["DCResNetDiscriminator"](channels=list(geometry["d_channels"]), last_filter_size=geometry["last"], n_classes=0,
+                                         emb_mode="concat", conditional_arch="ACGAN", aux_loss_type="wasserstein", aux_loss_scalar=1)
+        torch.manual_seed(1)
+    ncls = kw.get("n_classes", 2) if kw.get("conditional") else 0
+    ch = 1 if dataset == "MNIST" else 3
+    inp = dstep_inputs(seed, B, ch, im_size, latent, ncls, unit_range=(model == "Vanilla"))
+    use_aux = bool(ncls) and D.conditional_arch in ("ACGAN", "WCGAN")
+    params = list(D.parameters())
+    L = len(params)
+    G.train(); D.train()
+    out = dict(meta=np.array([B, im_size, seed, latent, ncls, ch]), input_checksums=checksums(inp),
+               d_weight_norms=np.array([p.detach().double().norm().item() for p in params]),
+               g_weight_norms=np.array([p.detach().double().norm().item() for p in G.parameters()]),
+               d_param_names=np.array([n for n, _ in D.named_parameters()]))
+
+    def real_loss(o, a, labels):
+        l = D.real_loss(o, "cpu")
+        return l + D.aux_loss(a, labels, "cpu", fake=False) if use_aux else l            # train.py:354-358
+
+    def fake_loss(o, a, y):
+        l = D.fake_loss(o, "cpu")
+        return l + D.aux_loss(a, y, "cpu", fake=True) if use_aux else l                  # train.py:345-351 (d_fake_aux_loss=True)
+
+    # ---- the two passes of train.py:382-387: pass 0 = generated batch, pass 1 = private batch ----
+    with torch.no_grad():
+        fake = G(inp["z"], inp["y"])
+    g_fake, l_fake, d_fake, d_fake_aux = _per_sample_grads(D, fake, inp["y"], lambda o, a: fake_loss(o, a, inp["y"]))
+    g_real, l_real, d_real, d_real_aux = _per_sample_grads(D, inp["img"], inp["labels"], lambda o, a: real_loss(o, a, inp["labels"]))
+    if not use_aux:         # separable mean loss: the hook-convention gradient is the gradient of sample b's own loss
+        for b in (0, B - 1):
+            ob, _ = D(inp["img"][b:b + 1], None if inp["labels"] is None else inp["labels"][b:b + 1])
+            gb = torch.autograd.grad(D.real_loss(ob, "cpu"), params, allow_unused=True)
+            for gs, g_ in zip(g_real, gb):
+                if g_ is not None:
+                    assert (gs[b] - g_).abs().max().item() <= 1e-5 * (g_.abs().max().item() + 1e-12)
+    n_fake, n_real = _norms(g_fake), _norms(g_real)
+    out.update(fake_sample=fake.reshape(-1)[::max(1, fake.numel() // 4096)][:4096].numpy(), fake_norm=fake.double().norm().item(),
+               d_real=d_real.numpy(), d_fake=d_fake.numpy(),
+               d_real_loss=np.float64(D.real_loss(d_real, "cpu").item()), d_fake_loss=np.float64(D.fake_loss(d_fake, "cpu").item()),
+               d_real_pass_loss=np.float64(l_real.item()), d_fake_pass_loss=np.float64(l_fake.item()),
+               layer_norms=torch.stack([n_fake, n_real], dim=1).numpy(),                  # [L, pass, B]   (train.py:311-315)
+               flat_norms=torch.stack([n_fake.norm(2, dim=0), n_real.norm(2, dim=0)]).numpy())   # [pass, B]
+    if use_aux:
+        out.update(d_real_aux=d_real_aux.numpy(), d_fake_aux=d_fake_aux.numpy())
+
+    # ---- adaptive statistics (train.py:204-245, split mode: the real loss only, on a public / mean-sample batch) ----
+    g_ad, _, _, _ = _per_sample_grads(D, inp["ms_adapt"], inp["ms_adapt_labels"], lambda o, a: real_loss(o, a, inp["ms_adapt_labels"]))
+    n_ad = _norms(g_ad)
+    r_mean, r_max = n_ad.mean(dim=1), n_ad.max(dim=1).values
+    out.update(adaptive_norms=n_ad.numpy(), adaptive_mean=r_mean.numpy(), adaptive_max=r_max.numpy(),
+               adaptive_scalar=np.float64(adaptive_scalar), c_adaptive_pl=(adaptive_scalar * r_mean).numpy(),
+               c_adaptive_flat=np.float64(adaptive_scalar * r_mean.norm(2).item()))
+    del g_ad
+
+    # ---- clip factors + pre-noise clipped sums ----
+    flat_real = n_real.norm(2, dim=0)
+    c_flat = float("%.3g" % flat_real.median().item())          # a constant C that clips about half of the private samples
+    c_pl = adaptive_scalar * r_mean
+    f_flat = _factors(flat_real, c_flat)                        # [B]
+    f_pl = _factors(n_real, c_pl)                               # [L, B]
+    f_aflat = _factors(flat_real, out["c_adaptive_flat"])
+    out.update(c_flat=np.float64(c_flat), factors_flat=f_flat.numpy(), factors_pl=f_pl.numpy(), factors_adaptive_flat=f_aflat.numpy())
+
+    def wsum(gs, f):            # sum_b f_b g_b in float64; f [B] or None
+        res = []
+        for i, g_ in enumerate(gs):
+            g64 = g_.double()
+            if f is not None:
+                fi = f[i] if f.dim() == 2 else f
+                g64 = g64 * fi.view(-1, *([1] * (g64.dim() - 1)))
+            res.append(g64.sum(dim=0))
+        return res
+
+    def term_scale(*gss):       # per tensor: largest entry of sum_b |g_b| over the given passes (>= any clipped sum's terms)
+        return [sum(g_.double().abs().sum(dim=0) for g_ in gs).max().item() for gs in zip(*gss)]
+
+    s_fake = wsum(g_fake, None)                                  # generated pass: never clipped in split mode (train.py:112-113)
+    sum_flat = [a + b for a, b in zip(s_fake, wsum(g_real, f_flat))]
+    sum_pl = [a + b for a, b in zip(s_fake, wsum(g_real, f_pl))]
+    tscale = term_scale(g_fake, g_real)
+    _put_grads(out, "sum_flat_split", sum_flat, tscale)
+    _put_grads(out, "sum_pl_split", sum_pl, tscale)
+    # accumulated passes (-gcs False): per-sample sum over passes, clipped together with one flat C
+    g_acc = [a + b for a, b in zip(g_fake, g_real)]
+    n_acc = _norms(g_acc).norm(2, dim=0)
+    c_acc = float("%.3g" % n_acc.median().item())
+    f_acc = _factors(n_acc, c_acc)
+    out.update(accum_flat_norms=n_acc.numpy(), c_accum=np.float64(c_acc), factors_accum=f_acc.numpy())
+    _put_grads(out, "sum_flat_accum", wsum(g_acc, f_acc), tscale)
+    del g_acc, g_fake, g_real
+
+    # ---- WGAN-GP on the public batch + parameter gradients (train.py:423-431) ----
+    if penalty:
+        a4 = inp["alpha"].view(B, 1, 1, 1)
+        # the reference draws alpha itself (gradient_penalty.py:33): hand it OUR alpha by patching torch.rand for this one call
+        real_rand = torch.rand
+        torch.rand = lambda *a, **k: inp["alpha"].view(B, 1).clone()
+        try:
+            pen = ref_gp.calc_penalty(D, ["WGAN-GP"], inp["ms_pen"], inp["ms_pen_labels"], fake, inp["y"], device="cpu", aux_penalty=True)
+        finally:
+            torch.rand = real_rand
+        pg = torch.autograd.grad(pen, params, allow_unused=True)
+        pg = [torch.zeros_like(p) if g_ is None else g_ for g_, p in zip(pg, params)]
+        xh = (a4 * inp["ms_pen"] + (1 - a4) * fake).detach().requires_grad_(True)
+        o_, _ = D(xh, inp["ms_pen_labels"])
+        gx, = torch.autograd.grad(o_, xh, torch.ones_like(o_))
+        out.update(penalty=np.float64(pen.item()), pen_input_grad_norms=gx.reshape(B, -1).double().norm(2, dim=1).numpy())
+        _put_grads(out, "pen_grad", pg)
+        sg_scale = [a + B * g_.abs().max().item() for a, g_ in zip(tscale, pg)]
+        _put_grads(out, "summed_grad_pl", [s_ + g_.double() * B for s_, g_ in zip(sum_pl, pg)], sg_scale)          # train.py:431
+        _put_grads(out, "summed_grad_flat", [s_ + g_.double() * B for s_, g_ in zip(sum_flat, pg)], sg_scale)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "L=%d" % L, "layer-norm means (real pass)", np.round(n_real.mean(dim=1).numpy(), 3), "c_flat", c_flat,
+          "clipped frac flat %.2f pl %.2f" % ((f_flat < 0.999).double().mean().item(), (f_pl < 0.999).double().mean().item()),
+          "penalty", out.get("penalty"))
+
+
+def survey_probe():
+    """SURVEY.md §8c quotes per-layer means of the per-sample gradient norms [0.146,0.024,0.694,0.059,0.969,0.137,1.402,0.410,
+    1.623] for the imported reference D64 'at seed 42/1, B=16' without recording the input batch.  Recovered: D built ALONE under
+    weights_seed 42 (no generator before it), manual_seed 1, x = randn(16,3,64,64).clamp(-1,1), the real loss — reproduces every
+    entry to the three decimals quoted.  Stored with full precision for the oracle / HIP tests."""
+    target = np.array([0.146, 0.024, 0.694, 0.059, 0.969, 0.137, 1.402, 0.410, 1.623])
+    _, D = reference_init_models("CelebA", "DeepConvResNet", 64, init_G=False)
+    torch.manual_seed(1)
+    x = torch.randn(16, 3, 64, 64).clamp(-1, 1)
+    gs, _, out, _ = _per_sample_grads(D, x, None, lambda o, a: D.real_loss(o, "cpu"))
+    n = _norms(gs)
+    m = n.mean(dim=1).numpy()
+    assert np.abs(m - target).max() < 1.5e-3, (m, target)
+    np.savez_compressed(os.path.join(HERE, "dstep_survey_probe.npz"), layer_norms=n.numpy(), layer_norm_means=m, survey_quote=target,
+                        d_real=out.numpy(), x_checksum=np.array([x.double().sum().item(), (x.double() ** 2).sum().item()]),
+                        d_weight_norms=np.array([p.detach().double().norm().item() for p in D.parameters()]))
+    print("survey probe reproduced:", np.round(m, 4), "max abs diff to the quoted vector", np.abs(m - target).max())
 
 
 def reference_bpc_namespace():
@@ -298,23 +532,53 @@ def logger_case():
 
 
 if __name__ == "__main__":
-    gp_case("gp_mnist_dcrn_b6", "MNIST", 28, 6, seed=11)
-    gp_case("gp_mnist_dcrn_b6_onesided", "MNIST", 28, 6, seed=12, one_sided=True)
-    gp_case("gp_celeba64_b4", "CelebA", 64, 4, seed=13)
-    gp_case("gp_celeba64_cond_aux_b3", "CelebA", 64, 3, seed=14, conditional=True, aux_penalty=True)
-    aux_loss_cases()
-    logger_case()
-    bpc_case("bpc_mnist_dcrn_auto_b6", "DeepConvResNet", 6, seed=31)
-    bpc_case("bpc_mnist_vanilla_cond_auto_b8", "Vanilla", 8, seed=32, conditional=True, aas=0.05, awgs=1e-4)
-    bpc_case("bpc_mnist_dcrn_explicit_b5", "DeepConvResNet", 5, seed=33, back=[0.02, 0.01, 0.5], fwd=[3.0, 20.0, 10.0])
-    upsample_conv_case()
-    model_case("model_celeba64_gn_b2", "CelebA", "DeepConvResNet", 64, 2, seed=21)
-    model_case("model_celeba64_bn_b3", "CelebA", "DeepConvResNet", 64, 3, seed=22, per_sample_grad=False)
-    model_case("model_celeba48_gn_b2", "CelebA", "DeepConvResNet", 48, 2, seed=23)
-    model_case("model_celeba64_cond_acgan_b4", "CelebA", "DeepConvResNet", 64, 4, seed=24, conditional=True, n_classes=2)
-    model_case("model_mnist_dcrn_gn_b4", "MNIST", "DeepConvResNet", 28, 4, seed=25, latent=16)
-    model_case("model_mnist_dcrn_cond_cgan_bn_b4", "MNIST", "DeepConvResNet", 28, 4, seed=26, latent=16, conditional=True,
-               n_classes=10, conditional_arch="CGAN", per_sample_grad=False)
-    model_case("model_mnist_vanilla_b8", "MNIST", "Vanilla", 28, 8, seed=27, latent=100)
-    model_case("model_mnist_vanilla_cond_b8", "MNIST", "Vanilla", 28, 8, seed=28, latent=100, conditional=True, n_classes=10,
-               aux_loss_type="cross_entropy")
+    only = set(sys.argv[1:])
+
+    def want(name):
+        return not only or name in only or any(name.startswith(o.rstrip("*")) for o in only if o.endswith("*"))
+
+    class _Run:
+        def __getattr__(self, fn):
+            return lambda name, *a, **k: globals()[fn](name, *a, **k) if want(name) else None
+    run = _Run()
+    run.gp_case("gp_mnist_dcrn_b6", "MNIST", 28, 6, seed=11)
+    run.gp_case("gp_mnist_dcrn_b6_onesided", "MNIST", 28, 6, seed=12, one_sided=True)
+    run.gp_case("gp_celeba64_b4", "CelebA", 64, 4, seed=13)
+    run.gp_case("gp_celeba64_cond_aux_b3", "CelebA", 64, 3, seed=14, conditional=True, aux_penalty=True)
+    # weights scaled so that ||dD/dx|| straddles 1: penalty, one-sided clamp and gradients all bite
+    # (two-sided: norms ~1.3, away from both 0 and 1; one-sided: the median norm is 1, so the clamp splits the batch)
+    run.gp_case("gp_mnist_dcrn_b6_scaled", "MNIST", 28, 6, seed=15, weight_scale=2.5)
+    run.gp_case("gp_mnist_dcrn_b6_onesided_scaled", "MNIST", 28, 6, seed=16, one_sided=True, weight_scale="straddle")
+    run.gp_case("gp_celeba64_b4_scaled", "CelebA", 64, 4, seed=17, weight_scale=2.5)
+    run.gp_case("gp_celeba64_b4_onesided_scaled", "CelebA", 64, 4, seed=18, one_sided=True, weight_scale="straddle")
+    run.gp_case("gp_celeba64_cond_aux_b3_scaled", "CelebA", 64, 3, seed=19, conditional=True, aux_penalty=True, weight_scale=2.5)
+    if want("aux_loss"):
+        aux_loss_cases()
+    if want("logger"):
+        logger_case()
+    run.bpc_case("bpc_mnist_dcrn_auto_b6", "DeepConvResNet", 6, seed=31)
+    run.bpc_case("bpc_mnist_vanilla_cond_auto_b8", "Vanilla", 8, seed=32, conditional=True, aas=0.05, awgs=1e-4)
+    run.bpc_case("bpc_mnist_dcrn_explicit_b5", "DeepConvResNet", 5, seed=33, back=[0.02, 0.01, 0.5], fwd=[3.0, 20.0, 10.0])
+    if want("upsample_conv"):
+        upsample_conv_case()
+    run.model_case("model_celeba64_gn_b2", "CelebA", "DeepConvResNet", 64, 2, seed=21)
+    run.model_case("model_celeba64_bn_b3", "CelebA", "DeepConvResNet", 64, 3, seed=22, per_sample_grad=False)
+    run.model_case("model_celeba48_gn_b2", "CelebA", "DeepConvResNet", 48, 2, seed=23)
+    run.model_case("model_celeba64_cond_acgan_b4", "CelebA", "DeepConvResNet", 64, 4, seed=24, conditional=True, n_classes=2)
+    run.model_case("model_mnist_dcrn_gn_b4", "MNIST", "DeepConvResNet", 28, 4, seed=25, latent=16)
+    run.model_case("model_mnist_dcrn_cond_cgan_bn_b4", "MNIST", "DeepConvResNet", 28, 4, seed=26, latent=16, conditional=True,
+                   n_classes=10, conditional_arch="CGAN", per_sample_grad=False)
+    run.model_case("model_mnist_vanilla_b8", "MNIST", "Vanilla", 28, 8, seed=27, latent=100)
+    run.model_case("model_mnist_vanilla_cond_b8", "MNIST", "Vanilla", 28, 8, seed=28, latent=100, conditional=True, n_classes=10,
+                   aux_loss_type="cross_entropy")
+    # D-step observables through the reference's classes
+    run.dstep_case("dstep_celeba64_b8", "CelebA", "DeepConvResNet", 64, 8, seed=41)                               # configs[2] geometry
+    run.dstep_case("dstep_celeba64_cond_acgan_b8", "CelebA", "DeepConvResNet", 64, 8, seed=42, conditional=True, n_classes=2)
+    run.dstep_case("dstep_mnist_vanilla_cond_b16", "MNIST", "Vanilla", 28, 16, seed=43, latent=100, penalty=False,     # configs[1]
+                   adaptive_scalar=1.0, conditional=True, n_classes=10, aux_loss_type="cross_entropy")
+    run.dstep_case("dstep_mnist_vanilla_b16", "MNIST", "Vanilla", 28, 16, seed=44, latent=100, penalty=False, adaptive_scalar=1.0)
+    run.dstep_case("dstep_mnist_dcrn_b6", "MNIST", "DeepConvResNet", 28, 6, seed=45, latent=16)
+    run.dstep_case("dstep_celeba128_b4", "CelebA", "DeepConvResNet", 128, 4, seed=46,                               # configs[4] geometry
+                   geometry=dict(g_channels=(512, 512, 256, 128, 64, 64), first=4, d_channels=(3, 64, 128, 256, 512), last=8))
+    if want("survey_probe"):
+        survey_probe()

@@ -1,0 +1,170 @@
+"""HIP ``Trainer.train_D`` directly against vectors computed through the REFERENCE's own classes (-m gpu).
+
+tests/golden/dstep_*.npz (make_golden.dstep_case) hold the D-step observables SURVEY.md §8(c) lists — per-layer per-sample
+gradient norms ``[L, pass, B]``, flat norms, clip factors, the pre-noise clipped sums, the adaptive statistics of
+train.py:204-245, the WGAN-GP penalty with its parameter gradients and ``summed_grad`` (train.py:431) — each computed
+with one autograd call per sample through the reference's G / D classes and loss methods and the clip rule written out in
+float64.  Nothing of oracle/ is involved here: parity of the device path does not rest on the oracle chain.
+
+Tolerance: 1e-3 (the north-star bar) — of each vector's scale for norms / factors / statistics / losses, of each gradient
+tensor's term scale (``*_absmax``: for a sum over samples the largest sum of |terms|) for the sampled entries and 1e-3 relative
+for tensor norms.  Both sides decide their own LeakyReLU / ReLU masks (a fixture cannot replay the device's): at B <= 16 no
+unit of these batches sits within fp32 rounding of zero, so the per-entry bound holds (the masked-oracle tests in
+test_dstep_gpu.py cover the general case).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden.dstep_inputs import DSTEP_CASES, load_case, sampled
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _close(got, exp, what, tol=TOL, scale=None):
+    got = np.asarray(torch.as_tensor(got).detach().cpu().double().numpy() if torch.is_tensor(got) else got, dtype=np.float64)
+    exp = np.asarray(exp, dtype=np.float64)
+    assert got.shape == exp.shape, (what, got.shape, exp.shape)
+    s = (np.abs(exp).max() if scale is None else scale) + 1e-30
+    err = np.abs(got - exp).max()
+    assert err <= tol * s, "%s: max abs err %.3e at scale %.3e (rel %.3e)" % (what, err, s, err / s)
+
+
+def _check_grads(z, key, tensors, what, tol=TOL):
+    top = float(z[key + "_absmax"].max())
+    for i, t in enumerate(tensors):
+        amax, nrm = float(z[key + "_absmax"][i]), float(z[key + "_norms"][i])
+        got = torch.zeros(1) if t is None else t
+        if amax <= 1e-7 * top:          # exactly-zero gradients (penalty bias gradients)
+            assert got.abs().max().item() <= 1e-5 * top, (what, i)
+            continue
+        gn = got.detach().double().norm().item()
+        assert abs(gn - nrm) <= tol * max(nrm, 1e-3 * float(z[key + "_norms"].max())), "%s[%d] norm %.6e vs %.6e" % (what, i, gn, nrm)
+        _close(sampled(got), z["%s_s%d" % (key, i)], "%s[%d] entries" % (what, i), tol=tol, scale=amax)
+
+
+def _trainer(tmp_path, name, z, mode_flags, materialize):
+    from csl_gan_amd import init_util, options
+    from csl_gan_amd.trainer import Trainer
+    dataset, _, _, latent, _, extra = DSTEP_CASES[name]
+    B = int(z["meta"][0])
+    argv = [dataset, "-dpm", "gc", "-nms", "4", "-bs", str(B), "-gd", "cuda:0", "-dd", "cuda:0", "-o", str(tmp_path), "--manual_seed", "1",
+            "--g_latent_dim", str(latent), "--sigma", "0.5", "--materialize", materialize, "-as", repr(float(z["adaptive_scalar"]))]
+    opt = options.parse(argv + extra + mode_flags)
+    G, D = init_util.init_models(opt)
+    np.testing.assert_allclose([p.detach().cpu().double().norm().item() for p in D.parameters()], z["d_weight_norms"], rtol=1e-5)
+    np.testing.assert_allclose([p.detach().cpu().double().norm().item() for p in G.parameters()], z["g_weight_norms"], rtol=1e-5)
+    assert [n for n, _ in D.named_parameters()] == list(z["d_param_names"])
+    tr = Trainer(opt, G, D, log_to=str(tmp_path / "log.csv"))
+    pe = tr.setup_privacy_engine()
+    pe.noise_multiplier = 0.0
+    return opt, tr
+
+
+def _run(tr, inp, has_pen):
+    cu = lambda t: None if t is None else t.cuda()
+    tr.explicit = dict(ms_adapt=inp["ms_adapt"], ms_adapt_labels=inp["ms_adapt_labels"], alpha=inp["alpha"], z_adapt=inp["z_adapt"].cuda(),
+                       keep=True)
+    if has_pen:
+        tr.explicit["pen_real"] = inp["ms_pen"]
+    tr.train_D(inp["img"].cuda(), cu(inp["labels"]), inp["z"].cuda(), cu(inp["y"]), use_dp=True)
+    torch.cuda.synchronize()
+    return tr.last
+
+
+def _private_cols(t, B):
+    """norms / factors of the private (real) pass: the last B columns ([L, 2B] when every pass is materialised, [L, B] otherwise)."""
+    t = t.reshape(t.shape[0], -1) if t.dim() > 1 else t.reshape(1, -1)
+    return t[:, -B:]
+
+
+CASES = [(n, m) for n in sorted(DSTEP_CASES) for m in ("all", "ghost")]
+
+
+@pytest.mark.parametrize("name,materialize", CASES)
+def test_train_D_adaptive_pl_matches_reference_vectors(tmp_path, golden_dir, name, materialize):
+    """BASELINE configs[2] mode: -gcm adaptive-pl (+ WGAN-GP on the public batch where the model has a penalty), on the fork's
+    layout (--materialize all) and on the benchmarked route (ghost clipping, fused passes)."""
+    z, inp = load_case(golden_dir, name)
+    has_pen = "penalty" in z.files
+    B = int(z["meta"][0])
+    opt, tr = _trainer(tmp_path, name, z, ["-gcm", "adaptive-pl"], materialize)
+    last = _run(tr, inp, has_pen)
+    fake = last["fake_img"].detach().cpu().contiguous()
+    _close(fake.reshape(-1)[::max(1, fake.numel() // 4096)][:4096], z["fake_sample"], "G(z)")
+    dscale = float(np.abs(z["d_real"]).max() + np.abs(z["d_fake"]).max())
+    _close(last["d_real"], z["d_real"], "d_real", scale=dscale)
+    _close(last["d_fake"], z["d_fake"], "d_fake", scale=dscale)
+    _close(last["d_real_loss"].reshape(1), [float(z["d_real_loss"])], "d_real_loss", scale=max(dscale, abs(float(z["d_real_loss"]))))
+    _close(last["d_fake_loss"].reshape(1), [float(z["d_fake_loss"])], "d_fake_loss", scale=max(dscale, abs(float(z["d_fake_loss"]))))
+    _close(last["adaptive_stats"], z["adaptive_mean"], "adaptive statistics (train.py:204-245)")
+    _close(last["clip_params"], z["c_adaptive_pl"], "adaptive per-layer C")
+    _close(_private_cols(last["norms"], B), z["layer_norms"][:, 1], "per-layer per-sample norms, private pass")
+    _close(_private_cols(last["clip_factors"], B), z["factors_pl"], "per-layer clip factors, private pass")
+    if materialize == "all":            # the fork's layout: pass 0 (generated batch) is materialised too
+        _close(last["norms"].reshape(len(z["layer_norms"]), -1)[:, :B], z["layer_norms"][:, 0], "per-layer per-sample norms, generated pass")
+    _check_grads(z, "sum_pl_split", last["summed_clipped"], "clipped sum (per-layer C, split passes)")
+    if has_pen:
+        assert abs(last["penalty"].item() - float(z["penalty"])) <= TOL * float(z["penalty"])
+        _check_grads(z, "pen_grad", last["penalty_grads"], "penalty parameter gradients")
+        _check_grads(z, "summed_grad_pl", last["summed_grad"], "summed_grad (train.py:431)")
+
+
+@pytest.mark.parametrize("name", sorted(DSTEP_CASES))
+def test_train_D_flat_clip_matches_reference_vectors(tmp_path, golden_dir, name):
+    """One constant flat C chosen to clip about half of the private samples; adaptive flat C; accumulated passes (-gcs False)."""
+    z, inp = load_case(golden_dir, name)
+    has_pen = "penalty" in z.files
+    B = int(z["meta"][0])
+    opt, tr = _trainer(tmp_path / "flat", name, z, ["-c", repr(float(z["c_flat"]))], "all")
+    last = _run(tr, inp, has_pen)
+    n = last["norms"].reshape(1, -1)
+    _close(n[:, :B], z["flat_norms"][0:1], "flat per-sample norms, generated pass")
+    _close(n[:, B:], z["flat_norms"][1:2], "flat per-sample norms, private pass")
+    _close(_private_cols(last["clip_factors"], B), z["factors_flat"].reshape(1, -1), "flat clip factors")
+    assert ((z["factors_flat"] < 0.999).any() and (z["factors_flat"] > 0.999).any())
+    _check_grads(z, "sum_flat_split", last["summed_clipped"], "clipped sum (flat C, split passes)")
+    if has_pen:
+        _check_grads(z, "summed_grad_flat", last["summed_grad"], "summed_grad (flat C)")
+    # the default (ghost) route with the same flat C
+    opt, tr = _trainer(tmp_path / "ghost", name, z, ["-c", repr(float(z["c_flat"]))], "ghost")
+    last = _run(tr, inp, has_pen)
+    _close(_private_cols(last["norms"], B), z["flat_norms"][1:2], "flat per-sample norms (ghost route)")
+    _check_grads(z, "sum_flat_split", last["summed_clipped"], "clipped sum (flat C, ghost route)")
+    # adaptive flat C = adaptive_scalar * ||r||_2 (train.py:243)
+    opt, tr = _trainer(tmp_path / "aflat", name, z, ["-gcm", "adaptive"], "all")
+    last = _run(tr, inp, has_pen)
+    _close(last["clip_params"].reshape(1), [float(z["c_adaptive_flat"])], "adaptive flat C")
+    _close(_private_cols(last["clip_factors"], B), z["factors_adaptive_flat"].reshape(1, -1), "adaptive flat clip factors")
+    # accumulated passes: per-sample sum over the generated and the private pass, clipped together
+    opt, tr = _trainer(tmp_path / "accum", name, z, ["-gcs", "False", "-c", repr(float(z["c_accum"]))], "all")
+    last = _run(tr, inp, has_pen)
+    _check_grads(z, "sum_flat_accum", last["summed_clipped"], "clipped sum (accumulated passes)")
+
+
+def test_survey_probe_vector_on_hip(tmp_path, golden_dir):
+    """SURVEY.md §8c's probe (reference D64 built alone under seed 42, x = randn(16,3,64,64).clamp(-1,1) under manual_seed 1,
+    real loss): per-layer per-sample norms through the HIP per-sample-gradient engine."""
+    import os
+    from csl_gan_amd import init_util, options
+    from csl_gan_amd.trainer import Trainer
+    z = np.load(os.path.join(golden_dir, "dstep_survey_probe.npz"))
+    opt = options.parse(["CelebA", "-dpm", "gc", "-nms", "4", "-bs", "16", "-gd", "cuda:0", "-dd", "cuda:0", "-o", str(tmp_path),
+                         "--manual_seed", "1", "--materialize", "all"])
+    _, D = init_util.init_models(opt, init_G=False)
+    np.testing.assert_allclose([p.detach().cpu().double().norm().item() for p in D.parameters()], z["d_weight_norms"], rtol=1e-5)
+    G, _ = init_util.init_models(opt, init_D=False)
+    tr = Trainer(opt, G, D, log_to=str(tmp_path / "log.csv"))
+    pe = tr.setup_privacy_engine()
+    torch.manual_seed(1)
+    x = torch.randn(16, 3, 64, 64).clamp(-1, 1)
+    np.testing.assert_allclose([x.double().sum().item(), (x.double() ** 2).sum().item()], z["x_checksum"], rtol=1e-9)
+    pe.zero_grad(); pe.enable_hooks()
+    out, _ = D(x.cuda())
+    D.real_loss(out, "cuda:0").backward()
+    pe.disable_hooks()
+    n = pe.sample_sqnorms(recompute=False)[:, :16].sqrt()
+    _close(out, z["d_real"], "D(x)")
+    _close(n, z["layer_norms"], "probe per-sample norms")
+    assert np.abs(n.mean(dim=1).cpu().numpy() - z["survey_quote"]).max() < 2e-3

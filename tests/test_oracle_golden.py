@@ -21,6 +21,12 @@ CASES = [
     ("gp_mnist_dcrn_b6_onesided", "MNIST", 28, True, False),
     ("gp_celeba64_b4", "CelebA", 64, False, False),
     ("gp_celeba64_cond_aux_b3", "CelebA", 64, False, True),
+    # weights scaled so ||dD/dx|| is ~1.3 (two-sided) or straddles 1 (one-sided): penalty, clamp and gradients all bite
+    ("gp_mnist_dcrn_b6_scaled", "MNIST", 28, False, False),
+    ("gp_mnist_dcrn_b6_onesided_scaled", "MNIST", 28, True, False),
+    ("gp_celeba64_b4_scaled", "CelebA", 64, False, False),
+    ("gp_celeba64_b4_onesided_scaled", "CelebA", 64, True, False),
+    ("gp_celeba64_cond_aux_b3_scaled", "CelebA", 64, False, True),
 ]
 
 
@@ -29,6 +35,11 @@ def test_penalty_matches_reference(golden_dir, name, dataset, im, one_sided, con
     z = _load(golden_dir, name)
     _, D = build_models(dataset=dataset, model="DeepConvResNet", im_size=im, weights_seed=42, manual_seed=1,
                         init_G=False, conditional=cond, n_classes=10 if dataset == "MNIST" else 2)
+    k = float(z["weight_scale"])
+    if k != 1.0:
+        with torch.no_grad():
+            for p in D.parameters():
+                p.mul_(k)
     # weight-init parity with the build that produced the fixture
     np.testing.assert_allclose([p.detach().double().norm().item() for p in D.parameters()], z["weight_norms"], rtol=1e-6)
     real, fake = torch.from_numpy(z["real"]), torch.from_numpy(z["fake"])
@@ -47,6 +58,15 @@ def test_penalty_matches_reference(golden_dir, name, dataset, im, one_sided, con
     np.testing.assert_allclose(heads, z["grad_heads"], rtol=1e-3, atol=1e-6)
     per = OP.calc_penalty(D, ptype, real, labels, fake, alpha, per_sample=True, aux_penalty=bool(z["meta"][5]))
     np.testing.assert_allclose(per.detach().numpy(), z["penalty_per_sample"], rtol=1e-4, atol=1e-6)
+    a4 = alpha.view(-1, 1, 1, 1)
+    xh = (a4 * real + (1 - a4) * fake).requires_grad_(True)
+    gx, = torch.autograd.grad(D(xh, labels)[0].sum(), xh)
+    np.testing.assert_allclose(gx.reshape(gx.size(0), -1).double().norm(2, dim=1).numpy(), z["input_grad_norms"], rtol=1e-5)
+    if name.endswith("_scaled"):        # the scaled fixtures bite: non-zero penalty and gradients, norms on both sides of 1 when one-sided
+        assert float(z["penalty"]) > 1e-4 and float(z["grad_norms"].max()) > 1e-2
+        if one_sided:
+            assert (z["input_grad_norms"] < 1).any() and (z["input_grad_norms"] > 1).any()
+            assert (z["penalty_per_sample"] == 0).any() and (z["penalty_per_sample"] > 0).any()
 
 
 def test_aux_loss_matches_reference(golden_dir):
@@ -140,3 +160,106 @@ def test_model_stacks_match_reference_classes(golden_dir, name, dataset, model, 
         G.eval()
         with torch.no_grad():
             np.testing.assert_allclose(G(zz, y).numpy(), z["fake_eval"], rtol=0, atol=1e-6)
+
+
+# ---- D-step observables: per-sample norms, clip factors, clipped sums, adaptive statistics, penalty gradients -------------
+# tests/golden/dstep_*.npz are computed through the reference's OWN G / D classes and loss methods (make_golden.dstep_case:
+# one autograd call per sample, clip rule written out in float64) — the oracle's hook engine and D-step must reproduce them.
+from tests.golden.dstep_inputs import DSTEP_CASES, load_case, sampled      # noqa: E402
+
+
+def _rel_close(got, exp, what, tol=1e-6, scale=None):
+    got, exp = np.asarray(got, dtype=np.float64), np.asarray(exp, dtype=np.float64)
+    assert got.shape == exp.shape, (what, got.shape, exp.shape)
+    s = (np.abs(exp).max() if scale is None else scale) + 1e-30
+    err = np.abs(got - exp).max()
+    assert err <= tol * s, "%s: max abs err %.3e at scale %.3e (rel %.3e)" % (what, err, s, err / s)
+
+
+def _check_grads(z, key, tensors, what, tol):
+    _rel_close([t.double().norm().item() for t in tensors], z[key + "_norms"], what + " norms", tol=tol, scale=float(z[key + "_norms"].max()))
+    for i, t in enumerate(tensors):
+        amax = float(z[key + "_absmax"][i])             # the tensor's error scale (for sums over samples: of their terms)
+        if amax <= 1e-7 * float(z[key + "_absmax"].max()):
+            assert t.abs().max().item() <= 1e-5 * float(z[key + "_absmax"].max()), (what, i)
+        else:
+            _rel_close(sampled(t), z["%s_s%d" % (key, i)], "%s[%d] entries" % (what, i), tol=tol, scale=amax)
+
+
+def _oracle_for(name, z, **cfg_kw):
+    from oracle.dstep import OracleDStep, StepConfig
+    dataset, model, im, latent, kw, _ = DSTEP_CASES[name]
+    G, D = build_models(dataset=dataset, model=model, im_size=im, weights_seed=42, manual_seed=1, g_latent_dim=latent, **kw)
+    np.testing.assert_allclose([p.detach().double().norm().item() for p in D.parameters()], z["d_weight_norms"], rtol=1e-6)
+    np.testing.assert_allclose([p.detach().double().norm().item() for p in G.parameters()], z["g_weight_norms"], rtol=1e-6)
+    assert [n for n, _ in D.named_parameters()] == list(z["d_param_names"])
+    cond = bool(kw.get("conditional"))
+    has_pen = "penalty" in z.files
+    cfg = StepConfig(dp_mode="gc", sigma=0.0, penalty=("WGAN-GP",) if has_pen else (), aux_penalty=True, use_aux_loss=cond,
+                     d_fake_aux_loss=True, adaptive_scalar=float(z["adaptive_scalar"]), **cfg_kw)
+    return OracleDStep(G, D, cfg), D
+
+
+def _step(oracle, inp, has_pen):
+    return oracle.step(inp["img"], inp["labels"], inp["z"], inp["y"], ms_adapt=inp["ms_adapt"], ms_adapt_labels=inp["ms_adapt_labels"],
+                       z_adapt=inp["z_adapt"], pen_real=inp["ms_pen"] if has_pen else None, pen_labels=inp["ms_pen_labels"],
+                       alpha=inp["alpha"], apply_update=False)
+
+
+@pytest.mark.parametrize("name", sorted(DSTEP_CASES))
+def test_dstep_observables_match_reference_classes(golden_dir, name):
+    z, inp = load_case(golden_dir, name)
+    has_pen = "penalty" in z.files
+    L = len(z["d_weight_norms"])
+    tol = 2e-6
+    # (1) adaptive per-layer clipping (BASELINE configs[2] mode) + penalty on the public batch
+    oracle, D = _oracle_for(name, z, grad_clip_mode="adaptive-pl", grad_clip_split=True)
+    obs = _step(oracle, inp, has_pen)
+    fake = obs["fake_img"]
+    _rel_close(fake.reshape(-1)[::max(1, fake.numel() // 4096)][:4096].numpy(), z["fake_sample"], "G(z)", tol=tol)
+    _rel_close(obs["d_real"].numpy(), z["d_real"], "d_real", tol=tol, scale=float(np.abs(z["d_real"]).max() + np.abs(z["d_fake"]).max()))
+    _rel_close(obs["d_fake"].numpy(), z["d_fake"], "d_fake", tol=tol, scale=float(np.abs(z["d_real"]).max() + np.abs(z["d_fake"]).max()))
+    assert obs["d_real_loss"] == pytest.approx(float(z["d_real_loss"]), rel=1e-5, abs=1e-7)
+    assert obs["d_fake_loss"] == pytest.approx(float(z["d_fake_loss"]), rel=1e-5, abs=1e-7)
+    _rel_close(obs["adaptive_stats"], z["adaptive_mean"], "adaptive statistics (train.py:204-245)", tol=tol)
+    _rel_close(obs["clip_params"], z["c_adaptive_pl"], "adaptive per-layer C", tol=tol)
+    _rel_close(obs["norms"].numpy(), z["layer_norms"], "per-layer per-sample norms [L, pass, B]", tol=tol)
+    _rel_close(obs["clip_factors"].numpy()[:, 1], z["factors_pl"], "per-layer clip factors (private pass)", tol=tol)
+    _check_grads(z, "sum_pl_split", obs["summed_clipped"], "clipped sum (per-layer C, split passes)", tol)
+    if has_pen:
+        assert obs["penalty"] == pytest.approx(float(z["penalty"]), rel=1e-5)
+        pg = [torch.zeros_like(p) if g is None else g for g, p in zip(obs["penalty_grads"], D.parameters())]
+        _check_grads(z, "pen_grad", pg, "penalty parameter gradients", 1e-5)
+        _check_grads(z, "summed_grad_pl", obs["summed_grad"], "summed_grad = clipped sum + B * penalty gradient (train.py:431)", 1e-5)
+    # (2) one flat constant C
+    oracle, D = _oracle_for(name, z, grad_clip_mode="standard", grad_clip_split=True, clipping_param=float(z["c_flat"]))
+    obs = _step(oracle, inp, has_pen)
+    _rel_close(obs["norms"].numpy()[0], z["flat_norms"], "flat per-sample norms [pass, B]", tol=tol)
+    _rel_close(obs["clip_factors"].numpy()[0, 1], z["factors_flat"], "flat clip factors", tol=tol)
+    _check_grads(z, "sum_flat_split", obs["summed_clipped"], "clipped sum (flat C, split passes)", tol)
+    if has_pen:
+        _check_grads(z, "summed_grad_flat", obs["summed_grad"], "summed_grad (flat C)", 1e-5)
+    # (3) adaptive flat C
+    oracle, D = _oracle_for(name, z, grad_clip_mode="adaptive", grad_clip_split=True)
+    obs = _step(oracle, inp, has_pen)
+    _rel_close(obs["clip_params"], float(z["c_adaptive_flat"]), "adaptive flat C", tol=tol)
+    _rel_close(obs["clip_factors"].numpy()[0, 1], z["factors_adaptive_flat"], "adaptive flat clip factors", tol=tol)
+    # (4) accumulated passes (-gcs False): per-sample sum over both passes, one flat C
+    oracle, D = _oracle_for(name, z, grad_clip_mode="standard", grad_clip_split=False, clipping_param=float(z["c_accum"]))
+    obs = _step(oracle, inp, has_pen)
+    _check_grads(z, "sum_flat_accum", obs["summed_clipped"], "clipped sum (accumulated passes)", tol)
+
+
+def test_survey_probe_vector(golden_dir):
+    """SURVEY.md §8c's probe: per-layer means of the per-sample gradient norms of the reference's D64 (built alone under seed 42),
+    x = randn(16,3,64,64).clamp(-1,1) under manual_seed 1, real loss."""
+    from oracle import dp_engine as E
+    z = np.load(os.path.join(golden_dir, "dstep_survey_probe.npz"))
+    _, D = build_models(dataset="CelebA", model="DeepConvResNet", im_size=64, weights_seed=42, manual_seed=1, init_G=False)
+    torch.manual_seed(1)
+    x = torch.randn(16, 3, 64, 64).clamp(-1, 1)
+    np.testing.assert_allclose([x.double().sum().item(), (x.double() ** 2).sum().item()], z["x_checksum"], rtol=1e-9)
+    gs = E.per_sample_grads_microbatch(D, lambda D_, xb, yb: D_.real_loss(D_(xb)[0]), x)
+    n = torch.stack([g.reshape(16, -1).double().norm(2, dim=1) for g in gs]).numpy()
+    _rel_close(n, z["layer_norms"], "probe per-sample norms", tol=2e-6)
+    assert np.abs(n.mean(axis=1) - z["survey_quote"]).max() < 1.5e-3

@@ -43,7 +43,8 @@ def sample_idx(numel, n=2048):
 # name -> (dataset, model, im_size, latent, conditional kwargs for oracle.nets.build_models, extra CLI flags of csl_gan_amd)
 DSTEP_CASES = {
     "dstep_celeba64_b8": ("CelebA", "DeepConvResNet", 64, 128, {}, []),
-    "dstep_celeba64_cond_acgan_b8": ("CelebA", "DeepConvResNet", 64, 128, dict(conditional=True, n_classes=2), ["--conditional"]),
+    "dstep_celeba64_cond_acgan_b8": ("CelebA", "DeepConvResNet", 64, 128, dict(conditional=True, n_classes=2),
+                                     ["--conditional", "-cpl"] + ["1"] * 11),     # the default per-layer table has 9 entries; ACGAN's D has 11 tensors
     "dstep_mnist_vanilla_cond_b16": ("MNIST", "Vanilla", 28, 100, dict(conditional=True, n_classes=10, aux_loss_type="cross_entropy"),
                                      ["--model", "Vanilla", "--conditional"]),
     "dstep_mnist_vanilla_b16": ("MNIST", "Vanilla", 28, 100, {}, ["--model", "Vanilla"]),

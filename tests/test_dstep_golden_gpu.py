@@ -8,10 +8,12 @@ float64.  Nothing of oracle/ is involved here: parity of the device path does no
 
 Tolerance: 1e-3 (the north-star bar) — of each vector's scale for norms / factors / statistics / losses, of each gradient
 tensor's term scale (``*_absmax``: for a sum over samples the largest sum of |terms|) for the sampled entries and 1e-3 relative
-for tensor norms.  Both sides decide their own LeakyReLU / ReLU masks (a fixture cannot replay the device's): at B <= 16 no
-unit of these batches sits within fp32 rounding of zero, so the per-entry bound holds (the masked-oracle tests in
-test_dstep_gpu.py cover the general case).
+for tensor norms.  Both sides decide their own LeakyReLU / ReLU masks (a fixture cannot replay the device's); measured
+(CSLGAN_GOLDEN_REPORT, 411 comparisons): everything agrees to 1e-6 .. 6e-4 except one flipped unit in the 128x128 case, which
+`_close(flips=True)` admits for gradient-tensor entries only (the masked-oracle tests in test_dstep_gpu.py cover the general case).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -22,12 +24,28 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
-def _close(got, exp, what, tol=TOL, scale=None):
+_REPORT = os.environ.get("CSLGAN_GOLDEN_REPORT")      # optional: append every comparison's relative error to this file
+
+
+def _close(got, exp, what, tol=TOL, scale=None, flips=False):
     got = np.asarray(torch.as_tensor(got).detach().cpu().double().numpy() if torch.is_tensor(got) else got, dtype=np.float64)
     exp = np.asarray(exp, dtype=np.float64)
     assert got.shape == exp.shape, (what, got.shape, exp.shape)
     s = (np.abs(exp).max() if scale is None else scale) + 1e-30
-    err = np.abs(got - exp).max()
+    d = np.abs(got - exp)
+    err = d.max()
+    if _REPORT:
+        with open(_REPORT, "a") as f:
+            f.write("%-70s rel %.3e  frac>tol %.4f  n %d  [%s]\n" % (what, err / s, float((np.abs(got - exp) > tol * s).mean()), got.size,
+                                                                 os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1]))
+    if flips and err > tol * s:
+        # One LeakyReLU unit of one sample within fp32 rounding of zero takes the other slope on the device: the handful of gradient
+        # entries that unit feeds move by a few 1e-3 while every other entry agrees to ~1e-6 (measured on dstep_celeba128_b4, whose
+        # critic evaluates 2e6 units per forward: 4 of 2048 sampled entries of conv1's penalty gradient at 1.5e-3, the remaining
+        # 2044 and every entry of the 64x64 cases <= 3e-6).  Allowed: <= 0.5 % of a tensor's entries, none beyond 5e-3.
+        assert (d > tol * s).mean() <= 5e-3 and err <= 5 * tol * s, "%s: %.4f of the entries beyond %.0e, max rel %.3e" % (
+            what, (d > tol * s).mean(), tol, err / s)
+        return
     assert err <= tol * s, "%s: max abs err %.3e at scale %.3e (rel %.3e)" % (what, err, s, err / s)
 
 
@@ -41,7 +59,7 @@ def _check_grads(z, key, tensors, what, tol=TOL):
             continue
         gn = got.detach().double().norm().item()
         assert abs(gn - nrm) <= tol * max(nrm, 1e-3 * float(z[key + "_norms"].max())), "%s[%d] norm %.6e vs %.6e" % (what, i, gn, nrm)
-        _close(sampled(got), z["%s_s%d" % (key, i)], "%s[%d] entries" % (what, i), tol=tol, scale=amax)
+        _close(sampled(got), z["%s_s%d" % (key, i)], "%s[%d] entries" % (what, i), tol=tol, scale=amax, flips=True)
 
 
 def _trainer(tmp_path, name, z, mode_flags, materialize):

@@ -5,6 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Both forms measure N ranks: started WITHOUT a torchrun environment and with --gpus N > 1, this process (which has not touched
+the GPU) launches the second form itself as a child, relays rank 0's JSON line and exits with the child's status; inside a
+torchrun environment --gpus must equal WORLD_SIZE (a mismatch is an error, not a warning) and the line's ``n_gpus`` is the
+world size the process group reports.
+
 One "step" = one `train_D` (train.py:360-500) of the headline configuration
     CelebA DCResNet, dp_mode=gc, -gcm adaptive-pl, -nms 32, WGAN-GP on mean samples, bs=128 per GPU
 on synthetic 3x64x64 data already resident in HBM: adaptive-clipping pass on mean samples, generator
@@ -87,6 +92,44 @@ def cpu_baseline():
             "sample": "%d oracle D-step(s) (config 3) at bs=128 after a bs=8 warm-up, %.1f s" % (n_steps, dt)}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Start `n` ranks of this script under torch.distributed.run (fresh child processes: this parent never initialises the
+    GPU, so nothing is exec'ed from a GPU process), relay the ranks' stdout (rank 0 prints the ONE JSON line) and stderr, and
+    return the launcher's exit status — non-zero if any rank failed."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def _launcher_selftest(mode):
+    """CPU rehearsal of the launcher contract (tests/test_host_logic.py): every rank joins a gloo group, all-reduces a one, rank 0
+    prints the JSON line with the world size the GROUP reports; mode "fail" makes the last rank exit non-zero first."""
+    import torch.distributed as dist
+    from csl_gan_amd import distributed as D
+    world, rank, _ = D.init("gloo")
+    if mode == "fail" and rank == world - 1:
+        sys.exit(3)
+    t = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(t)
+        D.barrier()
+    if rank == 0:
+        print(json.dumps({"n_gpus": dist.get_world_size() if dist.is_initialized() else 1, "sum": float(t)}))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,15 +141,25 @@ def main():
     ap.add_argument("--dump-shapes", type=str, default="", help="write the per-kernel, per-shape launch table (HIP-event times) to this file")
     ap.add_argument("--opt", type=str, default="", help="extra train.py flags for experiments, e.g. '--grad_sample_dtype bf16' "
                     "(the headline line is the run WITHOUT this)")
+    ap.add_argument("--launcher-selftest", type=str, default="", choices=["", "ok", "fail"], help=argparse.SUPPRESS)
     a = ap.parse_args()
+
+    in_torchrun = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if a.gpus > 1 and not in_torchrun:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+    if a.launcher_selftest:
+        return _launcher_selftest(a.launcher_selftest)
 
     from csl_gan_amd import distributed as D, ops
     # CSLGAN_DIST_BACKEND=gloo + CSLGAN_FORCE_DEVICE=0 rehearse the N>1 code path on a one-GPU box
     world, rank, local = D.init(os.environ.get("CSLGAN_DIST_BACKEND", "nccl"))
     if "CSLGAN_FORCE_DEVICE" in os.environ:
         local = int(os.environ["CSLGAN_FORCE_DEVICE"])
-    if world != a.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
+    if torch.distributed.is_initialized():
+        world = torch.distributed.get_world_size()        # what the process group (RCCL) reports, not what the environment claims
+    if world != a.gpus:
+        print("error: --gpus %d but the process group has %d rank(s)" % (a.gpus, world), file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):          # option parsing prints notices; stdout carries ONE JSON line

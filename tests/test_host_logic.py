@@ -334,3 +334,29 @@ def test_cli_writes_sample_grids(tmp_path):
     assert files == ["1-1.png", "1-3.png"], files
     im = Image.open(os.path.join(out, "samples", "1-1.png"))
     assert im.size == (10 * 30 + 2, 2 * 30 + 2)
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` outside a torchrun environment starts N ranks itself: rank 0's single JSON
+    line reports the world size the process group saw, and a failing rank makes the parent exit non-zero.  CPU rehearsal on
+    gloo through the hidden --launcher-selftest mode (the real step needs a GPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-selftest", "ok"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert json.loads(lines[0]) == {"n_gpus": 2, "sum": 2.0}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-selftest", "fail"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    # inside a torchrun environment a --gpus / WORLD_SIZE mismatch is an error
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env1, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 2 and "process group has 1 rank" in r.stderr

@@ -219,6 +219,11 @@ def main():
                                     "what": "the identical exact-fp32 step recorded once in a HIP graph and replayed (--hip_graph True)"}
         except Exception as e:      # a failed capture must not cost the headline line
             variant["hip_graph"] = {"error": repr(e)[:200]}
+        finally:
+            try:
+                gs.release()        # capturable Adam / static input buffers off again: the next variant is the plain eager step
+            except NameError:
+                pass
         tr.explicit = {}            # back to the eager step drawing its own mean-sample batches
         variant["fp32_auto"] = {"value": None}
         ops.set_compute_dtype("fp32_auto")

@@ -137,6 +137,8 @@ class DCResNetGenerator(Generator):
 
 
 class DCResNetDiscriminator(Discriminator):
+    linear_critic_losses = True     # real_loss = -mean(out), fake_loss = +mean(out): the trainer may evaluate them with one fused launch
+
     def __init__(self, channels, last_filter_size, **kwargs):
         super().__init__(**kwargs)
         channels = list(channels)       # the reference mutates its default list (DCResNet_models.py:115); we copy

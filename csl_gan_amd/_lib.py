@@ -23,7 +23,9 @@ EXPORTS = [
     "cslgan_depth_to_space_f32", "cslgan_fold_channels4_f32",
     "cslgan_bias_grad_grouped_f32", "cslgan_act_bwd_f32", "cslgan_groupnorm_act_f32", "cslgan_batchnorm_act_f32", "cslgan_batchnorm_eval_act_f32",
     "cslgan_norm_act_bwd_f32", "cslgan_norm_bwd_ws_floats",
-    "cslgan_adam_step_f32", "cslgan_adam_step_dev_f32",
+    "cslgan_adam_step_f32", "cslgan_adam_step_dev_f32", "cslgan_adam_multi_f32",
+    "cslgan_segment_means_f32", "cslgan_segment_means_bwd_f32", "cslgan_dstep_stats_f32", "cslgan_grad_log_stats_f32",
+    "cslgan_lerp_rows_f32", "cslgan_lipschitz_term_f32", "cslgan_lipschitz_term_bwd_f32",
 ]
 
 
@@ -95,6 +97,15 @@ def lib():
         "cslgan_batchnorm_eval_act_f32": [vp, vp, vp, vp, vp, i64, i32, f32, i32, vp, vp, i64, i32, vp, vp],
         "cslgan_adam_step_f32": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp],
         "cslgan_adam_step_dev_f32": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp],
+        "cslgan_adam_multi_f32": [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), f32, f32, f32, f32, f32,
+                                  i32, vp, vp],
+        "cslgan_segment_means_f32": [vp, i32, C.POINTER(C.c_int32), C.POINTER(f32), vp, vp, vp],
+        "cslgan_segment_means_bwd_f32": [vp, vp, i32, C.POINTER(C.c_int32), C.POINTER(f32), vp, vp],
+        "cslgan_dstep_stats_f32": [vp, i32, vp, i32, vp, vp, vp, vp, vp],
+        "cslgan_grad_log_stats_f32": [vp, i32, i64, i64, i32, vp, i32, f32, vp, vp, vp, vp, vp, vp],
+        "cslgan_lerp_rows_f32": [vp, vp, vp, i64, i64, vp, vp],
+        "cslgan_lipschitz_term_f32": [vp, i64, i64, i32, f32, vp, vp, vp, vp, vp],
+        "cslgan_lipschitz_term_bwd_f32": [vp, vp, vp, vp, i64, i64, i32, f32, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

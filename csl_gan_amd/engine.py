@@ -28,19 +28,50 @@ CLIP_EPS = 1e-6
 
 
 class HipAdam(torch.optim.Optimizer):
-    """torch.optim.Adam semantics (train.py:76) on the cslgan_adam_step_f32 kernel for device
-    parameters; CPU parameters (configs[0] plumbing) use the same update written with torch ops."""
+    """torch.optim.Adam semantics (train.py:76) on the cslgan_adam_multi_f32 kernel for device parameters — every tensor of a
+    parameter group in ONE launch; CPU parameters (configs[0] plumbing) use the same update written with torch ops.
+    optimizer.state keeps torch's layout (step, exp_avg, exp_avg_sq) so checkpoints interoperate."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        # capturable: the step count the bias corrections need lives in HBM (one int32 per parameter, advanced by a device op)
-        # instead of in the launch arguments, so a step recorded in a HIP graph stays correct on replay
+        # capturable: the step count the bias corrections need lives in HBM (one int32 per lock-step set of parameters, advanced
+        # by a device op) instead of in the launch arguments, so a step recorded in a HIP graph stays correct on replay.  The
+        # counters are private to the object — NOT optimizer.state: load_state_dict casts state tensors to the parameter's dtype
+        # and a checkpoint must hold nothing but torch.optim.Adam's keys — and are rebuilt from state["step"] when missing.
         self.capturable = False
+        self._step_dev = {}
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._step_dev = {}
+        for st in self.state.values():          # a checkpoint written by an older build may carry the device counter
+            st.pop("step_dev", None)
+            if isinstance(st.get("step"), torch.Tensor):
+                st["step"] = int(st["step"].item())
+
+    def prepare_capture(self):
+        """Create the device step counters NOW (eagerly), so that a capture records only their increment."""
+        self.capturable = True
+        for grp in self.param_groups:
+            ps = [p for p in grp["params"] if p.is_cuda]
+            by_step = {}
+            for p in ps:
+                by_step.setdefault(self.state[p].get("step", 0) if p in self.state else 0, []).append(p)
+            for step, plist in by_step.items():
+                self._counter(plist, step)
+
+    def _counter(self, plist, step_before):
+        key = tuple(id(p) for p in plist)
+        c = self._step_dev.get(key)
+        if c is None:
+            c = self._step_dev[key] = torch.full((1,), int(step_before), device=plist[0].device, dtype=torch.int32)
+        return c
 
     @torch.no_grad()
     def step(self, closure=None):
         for grp in self.param_groups:
             b1, b2 = grp["betas"]
+            dev = {}                                         # step value -> device parameters taking that step together
             for p in grp["params"]:
                 if p.grad is None:
                     continue
@@ -54,16 +85,7 @@ class HipAdam(torch.optim.Optimizer):
                 if p.is_cuda:
                     if g.stride() != p.stride() or not _dense(p):
                         g = _like_layout(g, p)
-                    step = st["step"]
-                    if self.capturable:
-                        if "step_dev" not in st:
-                            st["step_dev"] = torch.full((1,), st["step"] - 1, device=p.device, dtype=torch.int32)
-                        st["step_dev"].add_(1)
-                        step = st["step_dev"]
-                    ops.adam_step(_flat(p), _flat(g), _flat(st["exp_avg"]), _flat(st["exp_avg_sq"]), grp["lr"], b1, b2,
-                                  grp["eps"], grp["weight_decay"], step)
-                    # the kernel wrote p through its raw pointer: tell autograd (and ops.repack_cache) it changed
-                    torch.autograd.graph.increment_version(p)
+                    dev.setdefault(st["step"], []).append((p, g, st))
                 else:
                     if grp["weight_decay"]:
                         g = g.add(p, alpha=grp["weight_decay"])
@@ -72,6 +94,25 @@ class HipAdam(torch.optim.Optimizer):
                     v.mul_(b2).addcmul_(g, g, value=1 - b2)
                     denom = (v.sqrt() / (1 - b2 ** t) ** 0.5).add_(grp["eps"])
                     p.addcdiv_(m, denom, value=-grp["lr"] / (1 - b1 ** t))
+            for step, items in dev.items():
+                s = step
+                if self.capturable:
+                    s = self._counter([p for p, _, _ in items], step - 1)
+                    s.add_(1)
+                ops.adam_multi([_flat(p) for p, _, _ in items], [_flat(g) for _, g, _ in items],
+                               [_flat(st["exp_avg"]) for _, _, st in items], [_flat(st["exp_avg_sq"]) for _, _, st in items],
+                               grp["lr"], b1, b2, grp["eps"], grp["weight_decay"], s)
+                for p, _, _ in items:
+                    # the kernel wrote p through its raw pointer: tell autograd (and ops.repack_cache) it changed
+                    torch.autograd.graph.increment_version(p)
+
+    def bump_versions(self):
+        """After a HIP-graph replay of a recorded step (the replay runs no Python): mark every parameter as changed, so the
+        repack caches of ops.py and autograd's saved-tensor checks see the new weights."""
+        for grp in self.param_groups:
+            for p in grp["params"]:
+                if p.is_cuda:
+                    torch.autograd.graph.increment_version(p)
 
 
 def _dense(t):
@@ -605,6 +646,12 @@ class PrivacyEngine(PerSampleSink):
         if self._noise_ctr is not None:
             self._noise_ctr.fill_(int(n))
 
+    def ensure_noise_counter(self):
+        """Device mirror of _noise_calls (the Philox call index is read from HBM so a graph replay advances it)."""
+        if self._noise_ctr is None:
+            self._noise_ctr = torch.full((1,), self._noise_calls, device=self.params[0].device, dtype=torch.int64)
+        return self._noise_ctr
+
     def attach(self, optimizer):
         self.optimizer = optimizer
         engine = self
@@ -665,8 +712,7 @@ class PrivacyEngine(PerSampleSink):
         std_dev = None
         if self.noise_multiplier > 0:
             std_dev = (self._C_device(dev) * (self.noise_multiplier / (R ** 0.5))).expand(len(ps)).contiguous()
-        if self._noise_ctr is None:
-            self._noise_ctr = torch.full((1,), self._noise_calls, device=dev, dtype=torch.int64)
+        self.ensure_noise_counter()
         # Philox stream (seed, call, tensor, column): the call index is read from HBM, so a graph replay advances it too
         ops.clip_accum_noise(ins, grads, noise_std=std_dev, noises=noises, seed=self.seed, offset=0, call_counter=self._noise_ctr,
                              scale=1.0 / denom)

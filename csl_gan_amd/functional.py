@@ -52,14 +52,65 @@ class ActBwd(Function):
 
     @staticmethod
     def forward(ctx, g, y, slope):
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(y)
         ctx.slope = slope
         return ops.act_bwd(g.contiguous(), y, slope)
 
     @staticmethod
     def backward(ctx, gg):
+        if gg is None:
+            return None, None, None
         (y,) = ctx.saved_tensors
         return ActBwd.apply(gg, y, ctx.slope), None, None
+
+
+class SegmentMeans(Function):
+    """vec[s] = scale[s] * sum(x[row block s]), total = sum(vec): the critic's real_loss / fake_loss (DCResNet_models.py:149-153,
+    -mean / +mean) over the row blocks of ONE fused pass and their sum, in one launch; the backward writes the (piecewise constant)
+    cotangent in one launch (torch: three means, negations, adds, and their mirror image in the backward — ~17 launches)."""
+
+    @staticmethod
+    def forward(ctx, x, sizes, scale):
+        ctx.set_materialize_grads(False)
+        ctx.meta = (tuple(int(n) for n in sizes), tuple(float(c) for c in scale), x.shape)
+        return ops.segment_means(x.contiguous().reshape(-1), ctx.meta[0], ctx.meta[1])
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_vec, g_total):
+        if g_vec is None and g_total is None:
+            return None, None, None
+        sizes, scale, shape = ctx.meta
+        dev = (g_vec if g_vec is not None else g_total).device
+        g_vec = None if g_vec is None else g_vec.contiguous()
+        return ops.segment_means_bwd(g_total, g_vec, sizes, scale, shape, dev), None, None
+
+
+class LipschitzTerm(Function):
+    """coef * phi(||t_b||), phi(n) = (n-1)^2 or max(n-1,0)^2 (gradient_penalty.py:52-54), summed over the batch unless per_sample —
+    one launch forward, one backward (torch: norm, sub, clamp, pow, mean, mul, mul and their backward)."""
+
+    @staticmethod
+    def forward(ctx, t, one_sided, coef, per_sample):
+        t = t.contiguous()
+        norm, per, total = ops.lipschitz_term(t, one_sided, coef)
+        ctx.cfg = (bool(one_sided), float(coef), bool(per_sample))
+        ctx.save_for_backward(t, norm)
+        return per if per_sample else total
+
+    @staticmethod
+    def backward(ctx, g):
+        t, norm = ctx.saved_tensors
+        one_sided, coef, per_sample = ctx.cfg
+        if torch.is_grad_enabled() and (g.requires_grad or t.requires_grad):
+            # differentiable form (immediate sensitivity differentiates the parameter gradients once more): plain torch ops
+            n = t.norm(2, dim=1)
+            d = (n - 1).clamp(min=0) if one_sided else n - 1
+            gb = g if per_sample else g.expand(t.shape[0])
+            return (gb * coef * 2 * d / n).unsqueeze(1) * t, None, None, None
+        g = g.contiguous()
+        return ops.lipschitz_term_bwd(t, norm, None if per_sample else g, g if per_sample else None, one_sided, coef), None, None, None
 
 
 class BiasGrad(Function):
@@ -95,6 +146,7 @@ class Conv(Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, act, residual, wkey=None, alg_scale=1.0, wversion=None, bpc=None):
         y = ops.conv2d_fwd(x, w, b, stride=stride, pad=pad, residual=residual, act=act, wkey=wkey, alg_scale=alg_scale, wversion=wversion)
+        ctx.set_materialize_grads(False)      # an output nobody differentiates reaches backward as None, not as a zero tensor
         ctx.bpc = bpc              # backprop clipping (csl_gan_amd.backprop_clip): per-sample clip of the pre-activation gradient
         # the owning layer's cache token lets ops reuse repacked filters while the parameter is unchanged; a derived filter
         # (wversion given) must not be cached by the backward, whose caches key on w's own version counter
@@ -107,11 +159,16 @@ class Conv(Function):
 
     @staticmethod
     def backward(ctx, gy):
+        if gy is None:
+            return (None,) * 11
         x, w, y = ctx.saved_tensors
         stride, pad, act = ctx.cfg
         gz = gy
         if act in _SLOPE:
-            gz = ActBwd.apply(gy, y, _SLOPE[act])
+            # y.detach(): the slope pattern has zero derivative, so the double backward must not see an edge from this node back
+            # into the forward graph.  With the edge, autograd.grad(penalty, params) (train.py:427) walked the whole first-order
+            # forward again with zero-filled gradients — a wasted data-gradient chain per step (0.53 ms of 13.6 at bs=128).
+            gz = ActBwd.apply(gy, y.detach(), _SLOPE[act])
         elif act == ops.ACT_TANH:
             gz = gy * (1 - y * y)
         gz = gz.contiguous()
@@ -203,6 +260,7 @@ class NormAct(Function):
 class Dgrad(Function):
     @staticmethod
     def forward(ctx, gy, w, H, W, stride, pad, wkey=None):
+        ctx.set_materialize_grads(False)
         ctx.cfg = (H, W, stride, pad)
         ctx.wkey = wkey
         ctx.save_for_backward(gy, w)
@@ -210,6 +268,8 @@ class Dgrad(Function):
 
     @staticmethod
     def backward(ctx, ggx):
+        if ggx is None:
+            return (None,) * 7
         gy, w = ctx.saved_tensors
         H, W, stride, pad = ctx.cfg
         ggx = ggx.contiguous()
@@ -226,12 +286,15 @@ class Wgrad(Function):
 
     @staticmethod
     def forward(ctx, gy, x, R, S, stride, pad):
+        ctx.set_materialize_grads(False)
         ctx.cfg = (R, S, stride, pad)
         ctx.save_for_backward(gy, x)
         return ops.conv2d_wgrad_dense(gy, x, R, S, stride=stride, pad=pad)
 
     @staticmethod
     def backward(ctx, ggw):
+        if ggw is None:
+            return (None,) * 6
         gy, x = ctx.saved_tensors
         R, S, stride, pad = ctx.cfg
         ggw = ggw.contiguous()

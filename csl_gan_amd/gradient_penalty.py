@@ -35,10 +35,18 @@ def calc_WGAN_GP_penalty(model, real_data, real_labels, fake_data, fake_labels, 
     B = real_data.size(0)
     if alpha is None:
         alpha = torch.rand(B, 1)
-    a = alpha.reshape(B, *([1] * (real_data.dim() - 1))).to(device=real_data.device, dtype=real_data.dtype)
-    interpolates = a * real_data + (1 - a) * fake_data.to(real_data.device)
-    return weight * calc_lipschitz_penalty_WRT(model, interpolates, real_labels, device=device, per_sample=per_sample,
-                                               one_sided=one_sided, aux_penalty=aux_penalty)
+    fake_data = fake_data.to(real_data.device)
+    if real_data.is_cuda and real_data.dtype == torch.float32 and fake_data.shape == real_data.shape:
+        from . import ops
+        # one launch on the layout the critic's first conv reads (NHWC memory for images): no separate layout copy afterwards
+        fmt = torch.channels_last if real_data.dim() == 4 else torch.contiguous_format
+        interpolates = ops.lerp_rows(real_data.contiguous(memory_format=fmt), fake_data.contiguous(memory_format=fmt),
+                                     alpha.reshape(B).to(device=real_data.device, dtype=torch.float32).contiguous())
+    else:
+        a = alpha.reshape(B, *([1] * (real_data.dim() - 1))).to(device=real_data.device, dtype=real_data.dtype)
+        interpolates = a * real_data + (1 - a) * fake_data
+    return calc_lipschitz_penalty_WRT(model, interpolates, real_labels, device=device, per_sample=per_sample,
+                                      one_sided=one_sided, aux_penalty=aux_penalty, weight=weight)
 
 
 def _row_norms(g):
@@ -49,20 +57,28 @@ def _row_norms(g):
 
 
 def calc_lipschitz_penalty_WRT(model, inputs, input_labels=None, device="cpu", per_sample=False, one_sided=False,
-                               aux_penalty=True):
+                               aux_penalty=True, weight=1.0):
+    """weight: the factor the caller multiplies the result by (gradient_penalty.py:41: 10.0), folded into the fused device
+    kernel's coefficient together with the batch mean."""
     x = inputs.detach().requires_grad_(True)
     labels = None if input_labels is None else input_labels.detach()
     with HF.input_grads_only():
         out, aux_out = model(x, labels)
 
+    B = x.size(0)
+
     def term(scalar_outputs):
         g, = autograd.grad(outputs=scalar_outputs, inputs=x, grad_outputs=torch.ones_like(scalar_outputs),
                            create_graph=True, retain_graph=True, only_inputs=True)
-        d = _row_norms(g) - 1
-        return d.clamp(min=0) ** 2 if one_sided else d ** 2
+        flat = g.reshape(B, -1)
+        if flat.is_cuda and flat.dtype == torch.float32:
+            return HF.LipschitzTerm.apply(flat, one_sided, weight if per_sample else weight / B, per_sample)
+        d = flat.norm(2, dim=1) - 1
+        t = d.clamp(min=0) ** 2 if one_sided else d ** 2
+        return weight * (t if per_sample else t.mean())
 
     pen = term(out)
     if aux_penalty and aux_out is not None:
         for i in range(aux_out.size(1)):
             pen = pen + term(aux_out[:, i])
-    return pen if per_sample else pen.mean()
+    return pen

@@ -801,3 +801,125 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, weight_decay, step):
         return
     check(_lib.lib().cslgan_adam_step_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(b1), float(b2), float(eps),
                                           float(weight_decay), int(step), _stream()), "adam_step")
+
+
+def adam_multi(ps, gs, ms, vs, lr, b1, b2, eps, weight_decay, step):
+    """Adam over lists of flat fp32 tensors in ONE launch per <= 16 tensors.  step: int (1-based) or a device int32 [1] tensor."""
+    dev_step = isinstance(step, torch.Tensor)
+    if dev_step and (step.dtype != torch.int32 or not step.is_cuda):
+        raise RuntimeError("adam_multi: a tensor step must be a device int32 tensor")
+    for lst, nm in ((ps, "p"), (gs, "g"), (ms, "m"), (vs, "v")):
+        for t in lst:
+            _chk(t, nm)
+    L = _lib.lib()
+    VP = C.c_void_p
+    for i in range(0, len(ps), _lib.MAX_SEGS):
+        sub = range(i, min(i + _lib.MAX_SEGS, len(ps)))
+        n = len(sub)
+        arr = lambda lst: (VP * n)(*[lst[j].data_ptr() for j in sub])
+        check(L.cslgan_adam_multi_f32(n, arr(ps), arr(gs), arr(ms), arr(vs), (C.c_int64 * n)(*[ps[j].numel() for j in sub]), float(lr),
+                                      float(b1), float(b2), float(eps), float(weight_decay), 0 if dev_step else int(step),
+                                      _p(step) if dev_step else None, _stream()), "adam_multi")
+
+
+def _roles(sizes, scale):
+    n = len(sizes)
+    if not 1 <= n <= 8 or len(scale) != n:
+        raise RuntimeError("segment means: 1..8 row blocks with one scale each, got %d / %d" % (n, len(scale)))
+    return n, (C.c_int32 * n)(*[int(s) for s in sizes]), (C.c_float * n)(*[float(s) for s in scale])
+
+
+def segment_means(x, sizes, scale):
+    """vec[s] = scale[s] * sum(x[block s]), total = sum(vec): the critic's +-mean losses over the row blocks of one pass."""
+    _chk(x, "x")
+    if x.numel() != sum(sizes):
+        raise RuntimeError("segment_means: %d values for blocks %s" % (x.numel(), list(sizes)))
+    n, cs, sc = _roles(sizes, scale)
+    out = torch.empty(n + 1, device=x.device, dtype=torch.float32)
+    check(_lib.lib().cslgan_segment_means_f32(_p(x), n, cs, sc, _p(out), C.c_void_p(out.data_ptr() + 4 * n), _stream()), "segment_means")
+    return out[:n], out[n]
+
+
+def segment_means_bwd(g_total, g_vec, sizes, scale, shape, device):
+    n, cs, sc = _roles(sizes, scale)
+    gx = torch.empty(shape, device=device, dtype=torch.float32)
+    check(_lib.lib().cslgan_segment_means_bwd_f32(_p(g_total), _p(g_vec), n, cs, sc, _p(gx), _stream()), "segment_means_bwd")
+    return gx
+
+
+def dstep_stats(d_real, d_fake, real_loss, fake_loss, penalty, acc7):
+    """train.py:488-496 in one launch; acc7 (persistent, device) += the seven statistics (see include/cslgan.h)."""
+    for t, nm in ((d_real, "d_real"), (d_fake, "d_fake"), (real_loss, "real_loss"), (fake_loss, "fake_loss"), (acc7, "acc7")):
+        _chk(t, nm)
+    if acc7.numel() != 7:
+        raise RuntimeError("dstep_stats: acc7 must hold 7 floats")
+    if penalty is not None:
+        _chk(penalty, "penalty")
+    check(_lib.lib().cslgan_dstep_stats_f32(_p(d_real), d_real.numel(), _p(d_fake), d_fake.numel(), _p(real_loss), _p(fake_loss),
+                                            _p(penalty), _p(acc7), _stream()), "dstep_stats")
+
+
+def grad_log_stats(sq, col0, B, max_norm, per_layer, eps, acc):
+    """update_grad_logging (train.py:310-329) from the clip's squared norms sq [L, ld]; acc: [5, L or 1] persistent sums
+    (means, stds, maxes, clip norms, clipped fraction)."""
+    _chk(sq, "sq"); _chk(max_norm, "max_norm"); _chk(acc, "acc")
+    Lr, ld = sq.shape
+    rows = Lr if per_layer else 1
+    if tuple(acc.shape) != (5, rows) or max_norm.numel() < (rows if per_layer else 1):
+        raise RuntimeError("grad_log_stats: acc must be [5, %d] and max_norm hold %d value(s)" % (rows, rows))
+    a = [C.c_void_p(acc.data_ptr() + 4 * rows * i) for i in range(5)]
+    check(_lib.lib().cslgan_grad_log_stats_f32(_p(sq), Lr, ld, int(col0), int(B), _p(max_norm), 1 if per_layer else 0, float(eps),
+                                               a[0], a[1], a[2], a[3], a[4], _stream()), "grad_log_stats")
+
+
+def _mem_order(t):
+    return tuple(st for sz, st in zip(t.shape, t.stride()) if sz > 1)
+
+
+def lerp_rows(real, fake, alpha):
+    """alpha[b] * real[b] + (1 - alpha[b]) * fake[b] (gradient_penalty.py:36).  real / fake: same shape, same dense memory order
+    (contiguous or channels-last), batch outermost; the result has real's strides."""
+    _chk(alpha, "alpha")
+    for t, nm in ((real, "real"), (fake, "fake")):
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise RuntimeError("lerp_rows: %s must be a float32 device tensor" % nm)
+        if not (t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))):
+            raise RuntimeError("lerp_rows: %s is not dense" % nm)
+    if real.shape != fake.shape or _mem_order(real) != _mem_order(fake):
+        raise RuntimeError("lerp_rows: real and fake must share shape and memory order")
+    B = real.shape[0]
+    if alpha.numel() != B or (B > 1 and real.stride(0) * B != real.numel()):
+        raise RuntimeError("lerp_rows: alpha must hold one weight per row of a batch-outermost tensor")
+    out = torch.empty_strided(real.shape, real.stride(), device=real.device, dtype=torch.float32)
+    check(_lib.lib().cslgan_lerp_rows_f32(_p(real), _p(fake), _p(alpha), B, real.numel() // B, _p(out), _stream()), "lerp_rows")
+    return out
+
+
+_tickets = {}
+
+
+def _ticket(dev):
+    t = _tickets.get(dev)
+    if t is None:
+        t = _tickets[dev] = torch.zeros(1, device=dev, dtype=torch.int32)
+    return t
+
+
+def lipschitz_term(t2d, one_sided, coef):
+    """(norm [B], per [B], total []) with per = coef * (||t_b|| - 1)^2 (clamped at 0 from below when one_sided)."""
+    _chk(t2d, "t")
+    n, Ln = t2d.shape
+    buf = torch.empty(2 * n + 1, device=t2d.device, dtype=torch.float32)
+    check(_lib.lib().cslgan_lipschitz_term_f32(_p(t2d), n, Ln, 1 if one_sided else 0, float(coef), _p(buf),
+                                               C.c_void_p(buf.data_ptr() + 4 * n), C.c_void_p(buf.data_ptr() + 8 * n),
+                                               _p(_ticket(t2d.device)), _stream()), "lipschitz_term")
+    return buf[:n], buf[n:2 * n], buf[2 * n]
+
+
+def lipschitz_term_bwd(t2d, norm, g_total, g_per, one_sided, coef):
+    _chk(t2d, "t"); _chk(norm, "norm")
+    n, Ln = t2d.shape
+    out = torch.empty_like(t2d)
+    check(_lib.lib().cslgan_lipschitz_term_bwd_f32(_p(t2d), _p(norm), _p(g_total), _p(g_per), n, Ln, 1 if one_sided else 0, float(coef),
+                                                   _p(out), _stream()), "lipschitz_term_bwd")
+    return out

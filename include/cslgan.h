@@ -39,6 +39,7 @@ typedef enum {
 enum { CSLGAN_ACT_NONE = 0, CSLGAN_ACT_LRELU02 = 1, CSLGAN_ACT_RELU = 2, CSLGAN_ACT_TANH = 3 };
 
 #define CSLGAN_MAX_SEGS 16
+#define CSLGAN_MAX_ROLES 8      /* row blocks of one fused critic pass (adaptive / generated / private / penalty rows) */
 
 /* A batch of row-major [n_rows, len[i]] matrices (one per parameter tensor): the materialised
  * per-sample gradients p.grad_sample viewed as [passes*B, numel(p)]  (train.py:233,311-315). */
@@ -280,6 +281,43 @@ int cslgan_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n
 /* Same with the (1-based) step count read from device memory: a step captured in a HIP graph must not bake it in. */
 int cslgan_adam_step_dev_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
                              float b2, float eps, float weight_decay, const int32_t* step_dev, void* stream);
+
+/* Adam over n_seg <= CSLGAN_MAX_SEGS tensors in ONE launch (the optimizer's per-parameter loop, train.py:76,484).  step_dev
+ * (nullable): device int32 holding the 1-based step — when given, `step` is ignored (HIP-graph replay). */
+int cslgan_adam_multi_f32(int n_seg, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
+                          float lr, float b1, float b2, float eps, float weight_decay, int step, const int32_t* step_dev,
+                          void* stream);
+
+/* ---- fused glue of the D-step (csrc/step_kernels.hip): each replaces a run of 4-us elementwise / reduction launches ---- */
+/* The critic's losses over the row blocks of one pass (DCResNet_models.py:149-153: real_loss = -mean, fake_loss = +mean):
+ * vec[s] = scale[s] * sum(x[block s]), total = sum_s vec[s].  sizes / scale: HOST arrays of n_seg <= CSLGAN_MAX_ROLES entries. */
+int cslgan_segment_means_f32(const float* x, int n_seg, const int32_t* sizes, const float* scale, float* vec, float* total,
+                             void* stream);
+/* gx[i] = (g_total + g_vec[s(i)]) * scale[s(i)]; either gradient (device scalar / [n_seg]) may be NULL, not both. */
+int cslgan_segment_means_bwd_f32(const float* g_total, const float* g_vec, int n_seg, const int32_t* sizes, const float* scale,
+                                 float* gx, void* stream);
+/* train.py:488-496, the logger.stats[...] += lines of train_D: acc7 += {adv loss (G gate), D Adv Loss, D Real Loss, D Fake Loss,
+ * D Real Acc = 100*mean(d_real > 0), D Fake Acc = 100*mean(d_fake < 0), D Penalty (penalty may be NULL)}. */
+int cslgan_dstep_stats_f32(const float* d_real, int n_real, const float* d_fake, int n_fake, const float* real_loss,
+                           const float* fake_loss, const float* penalty, float* acc7, void* stream);
+/* update_grad_logging (train.py:310-329) from the squared norms the clip already holds: sq[n_layers, ld], logged columns
+ * [col0, col0 + B).  per_layer: one row of statistics per layer against max_norm[layer]; else ONE row from the flat norm
+ * sqrt(sum_l sq) against max_norm[0].  Adds mean / population std / max of the norms, the clip norm and the fraction of
+ * samples with min(1, C/(norm+eps)) < 0.999 to the five accumulators (each [n_layers] or [1]). */
+int cslgan_grad_log_stats_f32(const float* sq, int n_layers, int64_t ld, int64_t col0, int B, const float* max_norm, int per_layer,
+                              float eps, float* acc_mean, float* acc_std, float* acc_max, float* acc_c, float* acc_clipped,
+                              void* stream);
+/* gradient_penalty.py:36: out[b,:] = alpha[b] * real[b,:] + (1 - alpha[b]) * fake[b,:]. */
+int cslgan_lerp_rows_f32(const float* real, const float* fake, const float* alpha, int64_t n_rows, int64_t len, float* out,
+                         void* stream);
+/* gradient_penalty.py:52-54 (+ the weight and batch mean of :41,:65) in one launch: norm[b] = ||t[b,:]||, per[b] = coef *
+ * (norm-1)^2 (one_sided: max(norm-1,0)^2), total (nullable) = sum_b per[b].  ticket: one zero-initialised device uint32 the
+ * kernel uses to find its last workgroup and leaves at zero. */
+int cslgan_lipschitz_term_f32(const float* t, int64_t n_rows, int64_t len, int one_sided, float coef, float* norm, float* per,
+                              float* total, uint32_t* ticket, void* stream);
+/* gt[b,:] = (g_total + g_per[b]) * coef * 2 (norm_b - 1)[clamped] * t[b,:] / norm_b; either gradient may be NULL, not both. */
+int cslgan_lipschitz_term_bwd_f32(const float* t, const float* norm, const float* g_total, const float* g_per, int64_t n_rows,
+                                  int64_t len, int one_sided, float coef, float* gt, void* stream);
 
 #ifdef __cplusplus
 }

@@ -151,8 +151,23 @@ class DCResNetDiscriminator(Discriminator):
             self.linOut = HipLinear(size, 1, bias=False)
         if self.n_classes > 1 and self.conditional_arch in ("ACGAN", "WCGAN"):
             self.linOutAux = HipLinear(size, self.n_classes, bias=True)
+        # activation-backward fusion (csl_gan_amd.functional.fused_act_masks): every LeakyReLU output of this stack is consumed
+        # only by the next conv or by the linear heads, which apply its slope pattern in their data-gradient epilogue
+        for i, blk in enumerate(self.blocks):
+            blk.in_lrelu, blk.out_masked = i > 0, True
+        for head in (getattr(self, "linOut", None), getattr(self, "linOutAux", None)):
+            if head is not None:
+                head.in_lrelu = True
 
     def forward(self, x, y=None, aux=True):
+        # never with backprop clipping: its input clip sits between the activation and the next conv, so the slope pattern cannot
+        # move into that conv's data-gradient epilogue
+        if x.is_cuda and all(getattr(m, "_bpc", None) is None for m in self.modules()):
+            with HF.fused_act_masks():
+                return self._forward(x, y, aux)
+        return self._forward(x, y, aux)
+
+    def _forward(self, x, y=None, aux=True):
         B = x.size(0)
         o = x
         if self.emb_mode == "concat" and self.n_classes > 1:

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CSLGAN_LIB_PATH") or os.path.join(_HERE, "libcslgan_hip.so")      # override: kernel experiments
 MAX_SEGS = 16
-ABI_VERSION = 2          # include/cslgan.h CSLGAN_ABI_VERSION
+ABI_VERSION = 3          # include/cslgan.h CSLGAN_ABI_VERSION
 
 EXPORTS = [
     "cslgan_version", "cslgan_last_error", "cslgan_last_kernel", "cslgan_device_count",
@@ -92,8 +92,8 @@ def lib():
         "cslgan_conv2d_s2_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, i32, vp, i32, vp, vp],
         "cslgan_bias_grad_grouped_f32": [vp, i32, i32, i32, i32, f32, vp, vp, vp],
         "cslgan_act_bwd_f32": [vp, vp, i64, f32, vp, vp],
-        "cslgan_groupnorm_act_f32": [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, i32, vp, vp],
-        "cslgan_batchnorm_act_f32": [vp, vp, vp, i64, i32, f32, i32, f32, vp, vp, vp, vp, i64, i32, vp, vp],
+        "cslgan_groupnorm_act_f32": [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, i32, vp, vp, vp],
+        "cslgan_batchnorm_act_f32": [vp, vp, vp, i64, i32, f32, i32, f32, vp, vp, vp, vp, i64, i32, vp, vp, vp],
         "cslgan_batchnorm_eval_act_f32": [vp, vp, vp, vp, vp, i64, i32, f32, i32, vp, vp, i64, i32, vp, vp],
         "cslgan_adam_step_f32": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp],
         "cslgan_adam_step_dev_f32": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp],

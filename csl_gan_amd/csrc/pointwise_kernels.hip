@@ -41,9 +41,13 @@ __global__ void act_bwd_kernel(const float* __restrict__ g, const float* __restr
 // global atomic per channel per block.
 constexpr int NS_ROWS_MIN = 64;   // rows per block, lower bound (the launch picks a multiple: ~1024 blocks in all)
 
-template <bool VEC>
+// FUSED: `stats` is a persistent, zero-initialised scratch [2*n_stats] followed by a uint32 ticket; the last workgroup to
+// finish turns the scratch into the final (sum, centred sum of squares) pairs in `final_stats`, and leaves scratch and ticket
+// zeroed for the next launch — no memset before and no finalize launch after (two 4-us dispatches per normalisation layer).
+template <bool VEC, bool FUSED>
 __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x, long long rows_per_stat, int C, int cpg,
-                                                         int n_groups, int rows_per_block, float* __restrict__ stats) {
+                                                         int n_groups, int rows_per_block, float* __restrict__ stats,
+                                                         float* __restrict__ final_stats, long long n_stats) {
     extern __shared__ float s_acc[];   // [2*C]: S1, S2 per channel
     const int tid = threadIdx.x;
     for (int c = tid; c < 2 * C; c += 256) s_acc[c] = 0.f;
@@ -101,6 +105,31 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
         for (int j = 0; j < cpg; ++j) t += s_acc[2 * (g * cpg + j) + which];
         atomicAdd(&stats[2 * (sr * n_groups + g) + which], t);
     }
+    if (!FUSED) return;
+    __shared__ bool last;
+    __threadfence();
+    __syncthreads();
+    unsigned* ticket = reinterpret_cast<unsigned*>(stats + 2 * n_stats);
+    if (tid == 0) last = atomicAdd(ticket, 1u) == gridDim.x * gridDim.y - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const float cnt = (float)rows_per_stat * (float)cpg;
+    for (long long s = tid; s < n_stats; s += 256) {
+        const long long srow = s / n_groups;
+        const int g = (int)(s - srow * n_groups);
+        const float k = x[srow * rows_per_stat * C + g * cpg];
+        const float S1 = __hip_atomic_load(stats + 2 * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float S2 = __hip_atomic_load(stats + 2 * s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stats[2 * s] = 0.f;
+        stats[2 * s + 1] = 0.f;
+        const float m1 = S1 / cnt;
+        float css = S2 - S1 * m1;
+        if (css < 0.f) css = 0.f;
+        final_stats[2 * s] = (k + m1) * cnt;
+        final_stats[2 * s + 1] = css;
+    }
+    if (tid == 0) *ticket = 0u;
 }
 
 // (S1, S2) about the shift k  ->  (sum x, sum (x-mean)^2)
@@ -385,10 +414,11 @@ static bool norm_vec_ok(const float* x, const float* y, const float* xs, int C, 
 }
 
 static int launch_norm(const float* x, const float* gamma, const float* beta, long long R, long long rows_per_stat, int C, int cpg,
-                       int n_groups, float eps, int relu, float* stats, float* y, int d2s_H, int d2s_W, float* xs, hipStream_t st) {
+                       int n_groups, float eps, int relu, float* stats, float* y, int d2s_H, int d2s_W, float* xs, hipStream_t st,
+                       float* scratch = nullptr) {
     const long long n_row_groups = R / rows_per_stat;
     const long long n_stats = n_row_groups * n_groups;
-    if (hipMemsetAsync(stats, 0, sizeof(float) * 2 * n_stats, st) != hipSuccess) {
+    if (!scratch && hipMemsetAsync(stats, 0, sizeof(float) * 2 * n_stats, st) != hipSuccess) {
         set_error("norm: hipMemsetAsync failed");
         return CSLGAN_ERR_LAUNCH;
     }
@@ -398,8 +428,15 @@ static int launch_norm(const float* x, const float* gamma, const float* beta, lo
     rpb = rpb < NS_ROWS_MIN ? NS_ROWS_MIN : (rpb > 4096 ? 4096 : rpb);
     const dim3 grid((unsigned)((rows_per_stat + rpb - 1) / rpb), (unsigned)n_row_groups), block(256);
     const size_t lds = sizeof(float) * C;
-    if (vec) hipLaunchKernelGGL((norm_stats_kernel<true>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, stats);
-    else hipLaunchKernelGGL((norm_stats_kernel<false>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, stats);
+    if (scratch) {
+        if (vec) hipLaunchKernelGGL((norm_stats_kernel<true, true>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, scratch, stats, n_stats);
+        else hipLaunchKernelGGL((norm_stats_kernel<false, true>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, scratch, stats, n_stats);
+        const int rc1 = check_launch("norm_stats_kernel");
+        if (rc1) return rc1;
+        return launch_norm_apply(x, gamma, beta, R, rows_per_stat, C, cpg, n_groups, eps, relu, stats, y, d2s_H, d2s_W, xs, vec, st);
+    }
+    if (vec) hipLaunchKernelGGL((norm_stats_kernel<true, false>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, stats, (float*)nullptr, n_stats);
+    else hipLaunchKernelGGL((norm_stats_kernel<false, false>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, stats, (float*)nullptr, n_stats);
     int rc = check_launch("norm_stats_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(norm_stats_finalize_kernel, dim3((unsigned)((n_stats + 127) / 128)), dim3(128), 0, st, x, rows_per_stat, C, cpg,
@@ -477,7 +514,7 @@ int cslgan_act_bwd_f32(const float* g, const float* y, int64_t n, float slope, f
 }
 
 int cslgan_groupnorm_act_f32(const float* x, const float* gamma, const float* beta, int N, int HW, int C, int groups,
-                             float eps, int relu, float* stats_ws, float* y, int d2s_W, float* x_shuffled, void* stream) {
+                             float eps, int relu, float* stats_ws, float* y, int d2s_W, float* x_shuffled, float* scratch, void* stream) {
     CSLGAN_REQUIRE(x && gamma && beta && stats_ws && y, "groupnorm: null argument");
     CSLGAN_REQUIRE(N > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, "groupnorm: C=%d not divisible by groups=%d", C, groups);
     CSLGAN_REQUIRE(N <= 65535 && C <= 8192, "groupnorm: N or C too large");
@@ -485,12 +522,12 @@ int cslgan_groupnorm_act_f32(const float* x, const float* gamma, const float* be
     int rc = check_d2s(HW, C, d2s_W, x_shuffled, &H);
     if (rc) return rc;
     return launch_norm(x, gamma, beta, (long long)N * HW, HW, C, C / groups, groups, eps, relu, stats_ws, y, H, d2s_W, x_shuffled,
-                       (hipStream_t)stream);
+                       (hipStream_t)stream, scratch);
 }
 
 int cslgan_batchnorm_act_f32(const float* x, const float* gamma, const float* beta, int64_t rows, int C, float eps, int relu,
                              float momentum, float* running_mean, float* running_var, float* stats_ws, float* y,
-                             int64_t rows_per_image, int d2s_W, float* x_shuffled, void* stream) {
+                             int64_t rows_per_image, int d2s_W, float* x_shuffled, float* scratch, void* stream) {
     CSLGAN_REQUIRE(x && gamma && beta && stats_ws && y, "batchnorm: null argument");
     CSLGAN_REQUIRE(rows > 0 && C > 0 && C <= 8192, "batchnorm: bad sizes");
     CSLGAN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "batchnorm: running_mean/var must both be given or both null");
@@ -498,7 +535,7 @@ int cslgan_batchnorm_act_f32(const float* x, const float* gamma, const float* be
     CSLGAN_REQUIRE(d2s_W == 0 || (rows_per_image > 0 && rows % rows_per_image == 0), "batchnorm: rows_per_image must divide rows");
     int rc = check_d2s(rows_per_image, C, d2s_W, x_shuffled, &H);
     if (rc) return rc;
-    rc = launch_norm(x, gamma, beta, rows, rows, C, 1, C, eps, relu, stats_ws, y, H, d2s_W, x_shuffled, (hipStream_t)stream);
+    rc = launch_norm(x, gamma, beta, rows, rows, C, 1, C, eps, relu, stats_ws, y, H, d2s_W, x_shuffled, (hipStream_t)stream, scratch);
     if (rc) return rc;
     if (running_mean) {
         hipLaunchKernelGGL(bn_running_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, (hipStream_t)stream, stats_ws, C,

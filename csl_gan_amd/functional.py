@@ -37,6 +37,33 @@ class input_grads_only:
         _INPUT_GRADS_ONLY = self._prev
 
 
+_FUSE_MASKS = False
+
+
+class fused_act_masks:
+    """Context a model's forward opens when EVERY consumer of each flagged layer output is itself a flagged layer of the same
+    chain (DCResNetDiscriminator.forward: conv -> conv -> ... -> linear heads).  Inside it a layer with ``in_lrelu`` applies the
+    LeakyReLU(0.2) backward of the layer that produced its input in the epilogue of its own data-gradient kernel (the slope
+    pattern is recovered from the sign of that input), and a layer with ``out_masked`` skips its separate activation-backward
+    pass — one read + one write of every activation gradient less per backward.  Outside the context (a layer called on its
+    own) nothing is fused."""
+
+    def __enter__(self):
+        global _FUSE_MASKS
+        self._prev, _FUSE_MASKS = _FUSE_MASKS, True
+
+    def __exit__(self, *a):
+        global _FUSE_MASKS
+        _FUSE_MASKS = self._prev
+
+
+def mask_flags(layer, bpc=None):
+    """(in_mask, out_masked) for a layer's launch under the current context."""
+    if not _FUSE_MASKS:
+        return False, False
+    return bool(getattr(layer, "in_lrelu", False)), bool(getattr(layer, "out_masked", False)) and layer.act == ops.ACT_LRELU02
+
+
 def nhwc(x: torch.Tensor) -> torch.Tensor:
     """logical NCHW -> NHWC-contiguous view (copy only if x is not already channels-last)."""
     return x.permute(0, 2, 3, 1).contiguous()
@@ -144,9 +171,11 @@ def _dense_group(N: int, tiles: int = 1) -> int:
 
 class Conv(Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, residual, wkey=None, alg_scale=1.0, wversion=None, bpc=None):
+    def forward(ctx, x, w, b, stride, pad, act, residual, wkey=None, alg_scale=1.0, wversion=None, bpc=None, in_mask=False,
+                out_masked=False):
         y = ops.conv2d_fwd(x, w, b, stride=stride, pad=pad, residual=residual, act=act, wkey=wkey, alg_scale=alg_scale, wversion=wversion)
         ctx.set_materialize_grads(False)      # an output nobody differentiates reaches backward as None, not as a zero tensor
+        ctx.in_mask, ctx.out_masked = in_mask, out_masked
         ctx.bpc = bpc              # backprop clipping (csl_gan_amd.backprop_clip): per-sample clip of the pre-activation gradient
         # the owning layer's cache token lets ops reuse repacked filters while the parameter is unchanged; a derived filter
         # (wversion given) must not be cached by the backward, whose caches key on w's own version counter
@@ -160,11 +189,13 @@ class Conv(Function):
     @staticmethod
     def backward(ctx, gy):
         if gy is None:
-            return (None,) * 11
+            return (None,) * 13
         x, w, y = ctx.saved_tensors
         stride, pad, act = ctx.cfg
         gz = gy
-        if act in _SLOPE:
+        if ctx.out_masked:
+            pass            # the consumer's data-gradient epilogue already applied this layer's LeakyReLU slope pattern
+        elif act in _SLOPE:
             # y.detach(): the slope pattern has zero derivative, so the double backward must not see an edge from this node back
             # into the forward graph.  With the edge, autograd.grad(penalty, params) (train.py:427) walked the whole first-order
             # forward again with zero-filled gradients — a wasted data-gradient chain per step (0.53 ms of 13.6 at bs=128).
@@ -176,14 +207,14 @@ class Conv(Function):
             gz = ctx.bpc.clip_grad(gz)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = Dgrad.apply(gz, w, x.shape[1], x.shape[2], stride, pad, ctx.wkey)
+            gx = Dgrad.apply(gz, w, x.shape[1], x.shape[2], stride, pad, ctx.wkey, x.detach() if ctx.in_mask else None)
         if ctx.needs_input_grad[1] and not ctx.input_only:
             gw = Wgrad.apply(gz, x, w.shape[1], w.shape[2], stride, pad)
         if ctx.needs_input_grad[2] and not ctx.input_only:
             gb = BiasGrad.apply(gz)
         # the residual is added before the activation (ResBlockUp's "o + s", DCResNet_models.py:38): its gradient is gz
         gres = gz if (ctx.has_res and ctx.needs_input_grad[6]) else None
-        return gx, gw, gb, None, None, None, gres, None, None, None, None
+        return gx, gw, gb, None, None, None, gres, None, None, None, None, None, None
 
 
 class DepthToSpace(Function):
@@ -259,26 +290,29 @@ class NormAct(Function):
 
 class Dgrad(Function):
     @staticmethod
-    def forward(ctx, gy, w, H, W, stride, pad, wkey=None):
+    def forward(ctx, gy, w, H, W, stride, pad, wkey=None, mask=None):
+        """mask (optional, the conv's own input when that is a LeakyReLU(0.2) output): gx *= lrelu'(mask) in the kernel's epilogue."""
         ctx.set_materialize_grads(False)
         ctx.cfg = (H, W, stride, pad)
         ctx.wkey = wkey
-        ctx.save_for_backward(gy, w)
-        return ops.conv2d_dgrad(gy, w, (H, W), stride=stride, pad=pad, wkey=wkey)
+        ctx.save_for_backward(gy, w, mask)
+        return ops.conv2d_dgrad(gy, w, (H, W), stride=stride, pad=pad, wkey=wkey, mask=mask)
 
     @staticmethod
     def backward(ctx, ggx):
         if ggx is None:
-            return (None,) * 7
-        gy, w = ctx.saved_tensors
+            return (None,) * 8
+        gy, w, mask = ctx.saved_tensors
         H, W, stride, pad = ctx.cfg
         ggx = ggx.contiguous()
+        if mask is not None:        # the epilogue's pointwise factor, applied to the incoming cotangent first (it is linear)
+            ggx = ActBwd.apply(ggx, mask, 0.2)
         g_gy = g_w = None
         if ctx.needs_input_grad[0]:
             g_gy = Conv.apply(ggx, w, None, stride, pad, ops.ACT_NONE, None, ctx.wkey)
         if ctx.needs_input_grad[1]:
             g_w = Wgrad.apply(gy, ggx, w.shape[1], w.shape[2], stride, pad)
-        return g_gy, g_w, None, None, None, None, None
+        return g_gy, g_w, None, None, None, None, None, None
 
 
 class Wgrad(Function):
@@ -311,9 +345,10 @@ class ConvPerSample(Function):
     store (the Opacus-hook replacement, train.py:373,387) and returns only the data gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, sink, pass_idx, wkey=None, bpc=None):
+    def forward(ctx, x, w, b, stride, pad, act, sink, pass_idx, wkey=None, bpc=None, in_mask=False, out_masked=False):
         y = ops.conv2d_fwd(x, w, b, stride=stride, pad=pad, act=act)
         ctx.wkey, ctx.bpc = wkey, bpc
+        ctx.in_mask, ctx.out_masked = in_mask, out_masked
         ctx.cfg = (stride, pad, act)
         ctx.sink, ctx.pass_idx = sink, pass_idx
         ctx.has_bias = b is not None
@@ -326,7 +361,9 @@ class ConvPerSample(Function):
         stride, pad, act = ctx.cfg
         with torch.no_grad():
             gz = gy.contiguous()
-            if act in _SLOPE:
+            if ctx.out_masked:
+                pass        # already multiplied by this layer's slope pattern in the consumer's data-gradient epilogue
+            elif act in _SLOPE:
                 gz = ops.act_bwd(gz, y, _SLOPE[act])
             elif act == ops.ACT_TANH:
                 gz = gz * (1 - y * y)
@@ -346,8 +383,9 @@ class ConvPerSample(Function):
                 x.record_stream(side)
             gx = None
             if ctx.needs_input_grad[0]:
-                gx = ops.conv2d_dgrad(gz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad, wkey=ctx.wkey)
-        return gx, None, None, None, None, None, None, None, None, None
+                gx = ops.conv2d_dgrad(gz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad, wkey=ctx.wkey,
+                                      mask=x if ctx.in_mask else None)
+        return gx, None, None, None, None, None, None, None, None, None, None, None
 
 
 class RowL2Norm(Function):

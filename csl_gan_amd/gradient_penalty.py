@@ -17,7 +17,7 @@ def calc_penalty(model, penalty_types, real_data, real_labels, fake_data, fake_l
     omitted, exactly where the reference draws them (gradient_penalty.py:33)."""
     if weights is None:
         weights = [1 / len(penalty_types)] * len(penalty_types)
-    total = 0
+    total = None
     for w, kind in zip(weights, penalty_types):
         if kind.startswith("WGAN-GP"):
             p = calc_WGAN_GP_penalty(model, real_data, real_labels, fake_data, fake_labels, device=device,
@@ -26,8 +26,9 @@ def calc_penalty(model, penalty_types, real_data, real_labels, fake_data, fake_l
             raise Exception("DRAGAN penalty is not supported (it raises in the reference as well)")
         else:
             raise Exception("Unknown penalty type: " + kind)
-        total = total + w * p
-    return total
+        p = p if w == 1 else w * p          # (one penalty type: weight 1 — no "0 + 1 * p" launches and their backward)
+        total = p if total is None else total + p
+    return 0 if total is None else total
 
 
 def calc_WGAN_GP_penalty(model, real_data, real_labels, fake_data, fake_labels, device="cpu", per_sample=False,

@@ -95,12 +95,13 @@ class HipConv2d(nn.Conv2d, _PerSampleMixin):
         bpc = self._bpc
         if bpc is not None:
             x = bpc.clip_input(x)              # backprop_clip.py:103 (PGCWrapper.forward)
+        im, om = HF.mask_flags(self, bpc)
         if self._per_sample_active() and residual is None:
             sink = self._sink
             y = HF.ConvPerSample.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act, sink.collector(self), sink.next_pass(self),
-                                       self._wkey(w), bpc)
+                                       self._wkey(w), bpc, im, om)
         else:
-            y = HF.Conv.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act, residual, self._wkey(w), 1.0, None, bpc)
+            y = HF.Conv.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act, residual, self._wkey(w), 1.0, None, bpc, im, om)
         if _shape_log is not None:
             _shape_log[self] = ((x.shape[3], x.shape[1], x.shape[2]), (y.shape[3], y.shape[1], y.shape[2]))
         return _record_mask(self, y, self.act)
@@ -165,11 +166,12 @@ class HipLinear(nn.Linear, _PerSampleMixin):
         x4 = x.contiguous().reshape(B, 1, 1, self.in_features)
         w4 = self.weight.reshape(self.out_features, 1, 1, self.in_features)
         wkey = self._wtoken if w4.data_ptr() == self.weight.data_ptr() else None
+        im, om = HF.mask_flags(self, bpc)
         if self._per_sample_active():
             sink = self._sink
-            y = HF.ConvPerSample.apply(x4, w4, self.bias, 1, 0, self.act, sink.collector(self), sink.next_pass(self), wkey, bpc)
+            y = HF.ConvPerSample.apply(x4, w4, self.bias, 1, 0, self.act, sink.collector(self), sink.next_pass(self), wkey, bpc, im, om)
         else:
-            y = HF.Conv.apply(x4, w4, self.bias, 1, 0, self.act, None, wkey, 1.0, None, bpc)
+            y = HF.Conv.apply(x4, w4, self.bias, 1, 0, self.act, None, wkey, 1.0, None, bpc, im, om)
         return _record_mask(self, y.reshape(B, self.out_features), self.act)
 
 

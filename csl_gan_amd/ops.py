@@ -740,6 +740,19 @@ def _d2s_out(x, d2s, want_raw):
     return y, (torch.empty(shp, device=x.device, dtype=torch.float32) if want_raw else None), W
 
 
+_norm_scratch = {}
+
+
+def _scratch(dev, n_floats):
+    """Persistent zeroed accumulator of the normalisation statistics (+ the ticket word): the kernels leave it zeroed, so it is
+    filled once per device (and again only when a larger one is needed).  Launches are ordered on torch's current stream."""
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    t = _norm_scratch.get(key)
+    if t is None or t.numel() < n_floats + 1:
+        t = _norm_scratch[key] = torch.zeros(max(n_floats + 1, 16385), device=dev, dtype=torch.float32)
+    return t
+
+
 def groupnorm_act(x, gamma, beta, groups, eps=1e-5, relu=True, return_stats=False, d2s=False, want_raw=False):
     """GroupNorm(+ReLU).  d2s=True: the output is written depth-to-space shuffled ([N,2H,2W,C/4], see depth_to_space);
     want_raw=True additionally returns the raw x in that layout (one read of x feeds ResBlockUp's convUp and shortcut)."""
@@ -747,8 +760,10 @@ def groupnorm_act(x, gamma, beta, groups, eps=1e-5, relu=True, return_stats=Fals
     N, H, W, Cc = x.shape
     y, xs, dW = _d2s_out(x, d2s, want_raw)
     ws = torch.empty(2 * N * groups, device=x.device, dtype=torch.float32)
+    sc = _scratch(x.device, 2 * N * groups)
     check(_lib.lib().cslgan_groupnorm_act_f32(_p(x), _p(gamma), _p(beta), N, H * W, Cc, groups, float(eps), 1 if relu else 0,
-                                              _p(ws), _p(y), dW, _p(xs), _stream()), "groupnorm_act")
+                                              _p(ws), _p(y), dW, _p(xs), C.c_void_p(sc.data_ptr() + 4 * (sc.numel() - 1 - 2 * N * groups)),
+                                              _stream()), "groupnorm_act")
     out = (y, xs) if want_raw else y
     return (out, ws) if return_stats else out
 
@@ -767,7 +782,9 @@ def batchnorm_act(x, gamma, beta, running_mean=None, running_var=None, momentum=
         y, xs, dW, rpi = torch.empty_like(x), None, 0, 0
     ws = torch.empty(2 * Cc, device=x.device, dtype=torch.float32)
     check(_lib.lib().cslgan_batchnorm_act_f32(_p(x), _p(gamma), _p(beta), rows, Cc, float(eps), 1 if relu else 0, float(momentum),
-                                              _p(running_mean), _p(running_var), _p(ws), _p(y), rpi, dW, _p(xs), _stream()), "batchnorm_act")
+                                              _p(running_mean), _p(running_var), _p(ws), _p(y), rpi, dW, _p(xs),
+                                              C.c_void_p(_scratch(x.device, 2 * Cc).data_ptr() + 4 * (_scratch(x.device, 2 * Cc).numel() - 1 - 2 * Cc)),
+                                              _stream()), "batchnorm_act")
     out = (y, xs) if want_raw else y
     return (out, ws) if return_stats else out
 

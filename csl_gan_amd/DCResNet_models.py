@@ -151,42 +151,37 @@ class DCResNetDiscriminator(Discriminator):
             self.linOut = HipLinear(size, 1, bias=False)
         if self.n_classes > 1 and self.conditional_arch in ("ACGAN", "WCGAN"):
             self.linOutAux = HipLinear(size, self.n_classes, bias=True)
-        # activation-backward fusion (csl_gan_amd.functional.fused_act_masks): every LeakyReLU output of this stack is consumed
-        # only by the next conv or by the linear heads, which apply its slope pattern in their data-gradient epilogue
-        for i, blk in enumerate(self.blocks):
-            blk.in_lrelu, blk.out_masked = i > 0, True
-        for head in (getattr(self, "linOut", None), getattr(self, "linOutAux", None)):
-            if head is not None:
-                head.in_lrelu = True
 
     def forward(self, x, y=None, aux=True):
-        # never with backprop clipping: its input clip sits between the activation and the next conv, so the slope pattern cannot
-        # move into that conv's data-gradient epilogue
-        if x.is_cuda and all(getattr(m, "_bpc", None) is None for m in self.modules()):
-            with HF.fused_act_masks():
-                return self._forward(x, y, aux)
-        return self._forward(x, y, aux)
-
-    def _forward(self, x, y=None, aux=True):
         B = x.size(0)
         o = x
         if self.emb_mode == "concat" and self.n_classes > 1:
             planes = F.one_hot(y, self.n_classes).to(x.dtype).view(B, -1, 1, 1).expand(-1, -1, x.size(2), x.size(3))
             o = torch.cat((x, planes), dim=1)
+        fuse = False
         if o.is_cuda:
+            # Activation-backward fusion: every LeakyReLU output of this stack is consumed ONLY by the next conv or by the linear
+            # heads, so each consumer applies the producer's slope pattern in the epilogue of its data-gradient kernel and the
+            # producer skips its own activation-backward pass (a read + a write of every activation gradient less).  Never with
+            # backprop clipping: its input clip sits between the activation and the next conv.
+            fuse = all(getattr(m, "_bpc", None) is None for m in self.modules())
             o = HF.nhwc(o)
+            prev_lrelu = False
             for blk in self.blocks:
-                o = blk.forward_nhwc(o)             # conv + bias + LeakyReLU(0.2) in one kernel
+                o = blk.forward_nhwc(o, in_mask=fuse and prev_lrelu, out_masked=fuse)      # conv + bias + LeakyReLU(0.2) in one kernel
+                prev_lrelu = blk.act == ops.ACT_LRELU02
+            fuse = fuse and prev_lrelu
             o = HF.nchw_view(o)
         else:
             for blk in self.blocks:
                 o = blk(o)
         o = o.reshape(B, -1)                        # (c,h,w) feature order, as the reference's linOut expects
-        out_aux = self.linOutAux(o) if aux and hasattr(self, "linOutAux") else None
+        head = (lambda lin: lin(o, in_mask=True)) if fuse else (lambda lin: lin(o))
+        out_aux = head(self.linOutAux) if aux and hasattr(self, "linOutAux") else None
         if out_aux is not None and self.conditional_arch == "WCGAN":
             out = (out_aux * F.one_hot(y, self.n_classes)).sum(dim=1)
         else:
-            out = self.linOut(o)
+            out = head(self.linOut)
         return out, out_aux
 
     def real_loss(self, output, device):

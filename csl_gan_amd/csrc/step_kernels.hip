@@ -88,22 +88,33 @@ __global__ void grad_log_stats_kernel(const float* __restrict__ sq, int n_layers
     __shared__ float red[4];
     const int row = blockIdx.x;
     const float c = C[per_layer ? row : 0];
-    float s1 = 0.f, s2 = 0.f, mx = 0.f, cl = 0.f;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    auto norm_of = [&](int b) {
         float q;
         if (per_layer) q = sq[row * ld + col0 + b];
         else {
             q = 0.f;
             for (int l = 0; l < n_layers; ++l) q += sq[l * ld + col0 + b];
         }
-        const float n = sqrtf(q);
+        return sqrtf(q);
+    };
+    float s1 = 0.f, mx = 0.f, cl = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float n = norm_of(b);
         s1 += n;
-        s2 += q;
         mx = fmaxf(mx, n);
         cl += fminf(1.f, c / (n + eps)) < 0.999f ? 1.f : 0.f;
     }
+    __shared__ float s_mean;
     const float t1 = block_sum_256(s1, red);
+    if (threadIdx.x == 0) s_mean = t1 / (float)B;
     __syncthreads();
+    const float mean = s_mean;
+    // second pass over the B norms: sum (n - mean)^2 (E[n^2] - mean^2 cancels catastrophically when the norms are nearly equal)
+    float s2 = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float d = norm_of(b) - mean;
+        s2 = fmaf(d, d, s2);
+    }
     const float t2 = block_sum_256(s2, red);
     __syncthreads();
     const float t3 = block_sum_256(cl, red);
@@ -115,10 +126,8 @@ __global__ void grad_log_stats_kernel(const float* __restrict__ sq, int n_layers
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float mean = t1 / (float)B;
-        const float var = fmaxf(t2 / (float)B - mean * mean, 0.f);
         acc_mean[row] += mean;
-        acc_std[row] += sqrtf(var);
+        acc_std[row] += sqrtf(t2 / (float)B);
         acc_max[row] += fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         acc_c[row] += c;
         acc_clipped[row] += t3 / (float)B;

@@ -37,33 +37,6 @@ class input_grads_only:
         _INPUT_GRADS_ONLY = self._prev
 
 
-_FUSE_MASKS = False
-
-
-class fused_act_masks:
-    """Context a model's forward opens when EVERY consumer of each flagged layer output is itself a flagged layer of the same
-    chain (DCResNetDiscriminator.forward: conv -> conv -> ... -> linear heads).  Inside it a layer with ``in_lrelu`` applies the
-    LeakyReLU(0.2) backward of the layer that produced its input in the epilogue of its own data-gradient kernel (the slope
-    pattern is recovered from the sign of that input), and a layer with ``out_masked`` skips its separate activation-backward
-    pass — one read + one write of every activation gradient less per backward.  Outside the context (a layer called on its
-    own) nothing is fused."""
-
-    def __enter__(self):
-        global _FUSE_MASKS
-        self._prev, _FUSE_MASKS = _FUSE_MASKS, True
-
-    def __exit__(self, *a):
-        global _FUSE_MASKS
-        _FUSE_MASKS = self._prev
-
-
-def mask_flags(layer, bpc=None):
-    """(in_mask, out_masked) for a layer's launch under the current context."""
-    if not _FUSE_MASKS:
-        return False, False
-    return bool(getattr(layer, "in_lrelu", False)), bool(getattr(layer, "out_masked", False)) and layer.act == ops.ACT_LRELU02
-
-
 def nhwc(x: torch.Tensor) -> torch.Tensor:
     """logical NCHW -> NHWC-contiguous view (copy only if x is not already channels-last)."""
     return x.permute(0, 2, 3, 1).contiguous()
@@ -209,7 +182,7 @@ class Conv(Function):
         if ctx.needs_input_grad[0]:
             gx = Dgrad.apply(gz, w, x.shape[1], x.shape[2], stride, pad, ctx.wkey, x.detach() if ctx.in_mask else None)
         if ctx.needs_input_grad[1] and not ctx.input_only:
-            gw = Wgrad.apply(gz, x, w.shape[1], w.shape[2], stride, pad)
+            gw = Wgrad.apply(gz, x, w.shape[1], w.shape[2], stride, pad, ctx.in_mask)
         if ctx.needs_input_grad[2] and not ctx.input_only:
             gb = BiasGrad.apply(gz)
         # the residual is added before the activation (ResBlockUp's "o + s", DCResNet_models.py:38): its gradient is gz
@@ -319,8 +292,12 @@ class Wgrad(Function):
     """Dense weight gradient: grouped slabs on the MFMA kernel, then a column sum."""
 
     @staticmethod
-    def forward(ctx, gy, x, R, S, stride, pad):
+    def forward(ctx, gy, x, R, S, stride, pad, in_mask=False):
+        """in_mask: x is a LeakyReLU(0.2) output whose producer relies on its consumers to apply the slope pattern
+        (fused_act_masks): the gradient this node sends to x (immediate sensitivity differentiates weight gradients with respect
+        to the inputs) must carry it too."""
         ctx.set_materialize_grads(False)
+        ctx.in_mask = in_mask
         ctx.cfg = (R, S, stride, pad)
         ctx.save_for_backward(gy, x)
         return ops.conv2d_wgrad_dense(gy, x, R, S, stride=stride, pad=pad)
@@ -328,7 +305,7 @@ class Wgrad(Function):
     @staticmethod
     def backward(ctx, ggw):
         if ggw is None:
-            return (None,) * 6
+            return (None,) * 7
         gy, x = ctx.saved_tensors
         R, S, stride, pad = ctx.cfg
         ggw = ggw.contiguous()
@@ -336,8 +313,8 @@ class Wgrad(Function):
         if ctx.needs_input_grad[0]:
             g_gy = Conv.apply(x, ggw, None, stride, pad, ops.ACT_NONE, None)
         if ctx.needs_input_grad[1]:
-            g_x = Dgrad.apply(gy, ggw, x.shape[1], x.shape[2], stride, pad)
-        return g_gy, g_x, None, None, None, None
+            g_x = Dgrad.apply(gy, ggw, x.shape[1], x.shape[2], stride, pad, None, x.detach() if ctx.in_mask else None)
+        return g_gy, g_x, None, None, None, None, None
 
 
 class ConvPerSample(Function):

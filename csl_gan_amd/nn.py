@@ -89,13 +89,20 @@ class HipConv2d(nn.Conv2d, _PerSampleMixin):
         self.act = act
         self._wtoken = next(_tokens)
 
-    def forward_nhwc(self, x, residual=None):
-        """x: NHWC-contiguous device tensor -> NHWC output (+ residual before the activation)."""
+    def forward_nhwc(self, x, residual=None, in_mask=False, out_masked=False):
+        """x: NHWC-contiguous device tensor -> NHWC output (+ residual before the activation).
+
+        Activation-backward fusion, decided by the MODEL that owns the chain (DCResNetDiscriminator.forward):
+          in_mask     x is the LeakyReLU(0.2) output of a layer that was called with out_masked: this layer multiplies the data
+                      gradient it sends to x by that slope pattern (recovered from the sign of x) in its kernel's epilogue;
+          out_masked  every consumer of this layer's output does so, hence this layer skips its own activation-backward pass."""
         w = self.weight.permute(0, 2, 3, 1).contiguous()
         bpc = self._bpc
         if bpc is not None:
             x = bpc.clip_input(x)              # backprop_clip.py:103 (PGCWrapper.forward)
-        im, om = HF.mask_flags(self, bpc)
+        im, om = bool(in_mask), bool(out_masked) and self.act == ops.ACT_LRELU02
+        if (im or om) and bpc is not None:
+            raise RuntimeError("activation-backward fusion and backprop clipping cannot be combined on one layer")
         if self._per_sample_active() and residual is None:
             sink = self._sink
             y = HF.ConvPerSample.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act, sink.collector(self), sink.next_pass(self),
@@ -156,7 +163,8 @@ class HipLinear(nn.Linear, _PerSampleMixin):
         self.act = act
         self._wtoken = next(_tokens)
 
-    def forward(self, x):
+    def forward(self, x, in_mask=False):
+        """in_mask: see HipConv2d.forward_nhwc."""
         if not x.is_cuda:
             return _forward_cpu(self, super().forward, x)
         B = x.shape[0]
@@ -166,7 +174,7 @@ class HipLinear(nn.Linear, _PerSampleMixin):
         x4 = x.contiguous().reshape(B, 1, 1, self.in_features)
         w4 = self.weight.reshape(self.out_features, 1, 1, self.in_features)
         wkey = self._wtoken if w4.data_ptr() == self.weight.data_ptr() else None
-        im, om = HF.mask_flags(self, bpc)
+        im, om = bool(in_mask) and bpc is None, False
         if self._per_sample_active():
             sink = self._sink
             y = HF.ConvPerSample.apply(x4, w4, self.bias, 1, 0, self.act, sink.collector(self), sink.next_pass(self), wkey, bpc, im, om)

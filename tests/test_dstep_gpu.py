@@ -445,7 +445,7 @@ def test_train_G_gradients_exact_without_activations(tmp_path):
             m.relu = False
     for m in D.modules():
         if isinstance(m, HipConv2d):
-            m.act = ops.ACT_NONE
+            m.act = ops.ACT_NONE            # (the critic's forward then fuses no activation backward either: it asks each layer's act)
     tr = Trainer(opt, G, D, log_to=str(tmp_path / "log.csv"))
     Go, Do = build_models(dataset="MNIST", model="DeepConvResNet", im_size=28, weights_seed=opt.weights_seed, manual_seed=1,
                           per_sample_grad=True, g_latent_dim=latent)

@@ -72,8 +72,8 @@ def test_graph_replay_equals_eager_steps(tmp_path, name, argv, B, shape, cond, s
     # PRIMARY: the noised gradients of the recorded step's first replay — identical weights, inputs, RNG draws and Philox counter on
     # both sides, BEFORE Adam: only float atomics reorder.  Smooth networks: 1e-5 of each tensor's scale.  With the activations on,
     # reordering can flip a LeakyReLU unit that sits within rounding of zero (measured on the CelebA case: 5.7e-4 on conv1's
-    # gradient, eager against eager alike): 2e-3 there.
-    tol1 = 1e-5 if smooth else 2e-3
+    # gradient, 2.8e-3 on its cancelling bias gradient, eager against eager alike): 1e-2 there.
+    tol1 = 1e-5 if smooth else 1e-2
     for i, (a, b) in enumerate(zip(eager[7][0], graph[7][0])):
         scale = a.abs().max().item() + 1e-30
         assert (a - b).abs().max().item() <= tol1 * scale, "noised gradient %d of the first replayed step: rel %.3e" % (
@@ -82,7 +82,7 @@ def test_graph_replay_equals_eager_steps(tmp_path, name, argv, B, shape, cond, s
     # which they would not if the replay had kept the capture-time weights, Adam step count or noise offset
     for i, (a, b) in enumerate(zip(eager[7][1], graph[7][1])):
         scale = a.abs().max().item() + 1e-30
-        assert (a - b).abs().max().item() <= 3e-3 * scale, "noised gradient %d of the second replayed step: rel %.3e" % (
+        assert (a - b).abs().max().item() <= (1e-3 if smooth else 1e-2) * scale, "noised gradient %d of the second replayed step: rel %.3e" % (
             i, (a - b).abs().max().item() / scale)
     assert any((a - b).abs().max().item() > 1e-3 * a.abs().max().item() for a, b in zip(eager[7][0], eager[7][1])), "steps 3 and 4 must differ"
     lr = 1e-4 if name.startswith("celeba") else 2e-4       # d_lr defaults (options.py)
@@ -177,7 +177,8 @@ def test_capturable_adam_checkpoint_roundtrip():
 
     pa, oa = make(True)
     run(pa, oa, [0, 1])
-    sd = oa.state_dict()
+    import copy
+    sd = copy.deepcopy(oa.state_dict())          # load_state_dict keeps tensors that need no cast: without the copy both optimizers share moments
     assert all(set(st) == {"step", "exp_avg", "exp_avg_sq"} for st in sd["state"].values()), [set(st) for st in sd["state"].values()]
     pb, ob = make(True)
     with torch.no_grad():

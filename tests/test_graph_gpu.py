@@ -112,7 +112,10 @@ def test_graph_replay_interleaved_with_generator_steps(tmp_path, name, argv, B, 
     from csl_gan_amd.mean_sampler import MeanSampler
     from csl_gan_amd.trainer import GraphedDStep, Trainer
     from oracle.nets import build_models
-    opt = options.parse(argv + ["-bs", str(B), "-gd", "cuda:0", "-dd", "cuda:0", "-o", str(tmp_path), "--manual_seed", "1"])
+    # learning rates 20x the defaults: after eight steps the weights have moved by about their own size, so a replay or an eager
+    # launch that used capture-time filters would be off by O(1), far above the activation-flip noise of a gradient comparison
+    opt = options.parse(argv + ["-bs", str(B), "-gd", "cuda:0", "-dd", "cuda:0", "-o", str(tmp_path), "--manual_seed", "1", "--d_lr", "0.002",
+                                "--g_lr", "0.002"])
     G, D = init_util.init_models(opt)
     ms = None
     if opt.num_mean_samples > 0:
@@ -150,7 +153,10 @@ def test_graph_replay_interleaved_with_generator_steps(tmp_path, name, argv, B, 
     od, _ = D(xd)
     gd, = torch.autograd.grad(od.sum(), xd)
     assert (od.detach().cpu() - oo.detach()).abs().max().item() <= 1e-3 * oo.detach().abs().max().item(), "eager D forward uses stale re-packed filters"
-    assert (gd.cpu() - go).abs().max().item() <= 2e-3 * go.abs().max().item(), "eager D data gradient uses stale re-packed filters"
+    # a gradient through LeakyReLU units: a unit within rounding of zero may take the other slope on the device and moves that sample's
+    # gradient by a per cent or two — relative L2 (measured 1e-3 .. 2e-2 of max |g| per entry in the flip case), decisive against O(1)
+    l2 = ((gd.cpu() - go).norm() / go.norm()).item()
+    assert l2 <= 3e-2, "eager D data gradient uses stale re-packed filters: relative L2 error %.3e" % l2
 
 
 def test_capturable_adam_checkpoint_roundtrip():

@@ -82,19 +82,37 @@ class _RepackCache:
         self.d, self.max = {}, max_entries      # callers pass wkey (a never-reused per-module token, csl_gan_amd.nn) only for module-owned filters
 
     def get(self, kind, w, numel, wkey=None, version=None):
-        """version: the autograd version to key on when `w` is itself derived from a parameter (its own counter is always 0)."""
+        """version: the autograd version to key on when `w` is itself derived from a parameter (its own counter is always 0).
+        A hit from another stream than the one that packed the buffer waits for that pack (the D-step runs its gradient-penalty
+        branch on a second stream, and both branches read the critic's re-packed filters)."""
         if wkey is None:          # not known to be a live parameter (a temporary may reuse an address): never cache
             return torch.empty(numel, device=w.device, dtype=torch.float32), 1
         key = (kind, wkey, w.data_ptr(), tuple(w.shape))
         ver = w._version if version is None else version
         hit = self.d.get(key)
+        cur = torch.cuda.current_stream()
         if hit is not None and hit[0] == ver and hit[1].numel() == numel and hit[1].device == w.device:
+            if hit[2] != cur.cuda_stream and hit[3] is not None:
+                cur.wait_event(hit[3])
+            self._fresh = None
             return hit[1], 0
         if len(self.d) >= self.max:
             self.d.clear()
         ws = torch.empty(numel, device=w.device, dtype=torch.float32)
-        self.d[key] = (ver, ws)
+        self.d[key] = [ver, ws, cur.cuda_stream, None]
+        self._fresh = key
         return ws, 1
+
+    def packed(self):
+        """Called right after the launch that filled the most recent fresh buffer: marks the point other streams must wait for."""
+        key = getattr(self, "_fresh", None)
+        if key is not None and key in self.d and self.multi_stream:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.d[key][3] = ev
+        self._fresh = None
+
+    multi_stream = False        # set while a second stream is in use (Trainer): events are only recorded then
 
     def clear(self):
         self.d.clear()
@@ -232,6 +250,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, ou
         _timed("conv2d_fwd", flop, nbytes, lambda: check(
             _lib.lib().cslgan_conv2d_s2_fwd_f32(C.byref(d), _p(x), _p(w), _p(ws), repack, _p(bias), act, _p(y), _stream()),
             "conv2d_s2_fwd"), exec_flop=xflop, tag=lambda: "N%d %dx%d C%d K%d R%d s2 halo" % (N, H, W, Cc, K, R))
+        repack_cache.packed()
         return y
     if d.compute in (COMPUTE_BF16X3, COMPUTE_BF16) and stride == 1 and R * S > 1 and Cc % 16 == 0 and K >= 64 and P % 8 == 0 and Q % 8 == 0:
         # the LDS-halo form of the bf16 paths reads the filter pre-split into bfloat16 pieces / pre-rounded (cached per parameter version)
@@ -239,6 +258,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, ou
         _timed("conv2d_fwd", flop, nbytes, lambda: check(
             _lib.lib().cslgan_conv2d_fwd_x3_f32(C.byref(d), _p(x), _p(w), _p(ws), repack, _p(bias), _p(residual), act, _p(y), _stream()),
             "conv2d_fwd_x3"), exec_flop=xflop, tag=lambda: "N%d %dx%d C%d K%d R%d s%d" % (N, H, W, Cc, K, R, stride))
+        repack_cache.packed()
         return y
     _timed("conv2d_fwd", flop, nbytes, lambda: check(
         _lib.lib().cslgan_conv2d_fwd_f32(C.byref(d), _p(x), _p(w), _p(bias), _p(residual), act, _p(y), _stream()),
@@ -275,6 +295,7 @@ def fold_channels4(w, wkey=None):
     wf, fresh = repack_cache.get("fold4", w, w.numel() // 4, wkey)
     if fresh:
         check(_lib.lib().cslgan_fold_channels4_f32(_p(w), K * R * S, Cc, 0, _p(wf), _stream()), "fold_channels4")
+        repack_cache.packed()
     return wf.view(K, R, S, Cc // 4)
 
 
@@ -319,6 +340,7 @@ def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None, wkey=None):
     _timed("conv2d_dgrad", flop, nbytes, lambda: check(
         _lib.lib().cslgan_conv2d_dgrad_f32(C.byref(d), _p(gy), _p(w), _p(ws), repack, _p(mask), _p(gx), _stream()), "conv2d_dgrad"),
         tag=lambda: "N%d %dx%d C%d K%d R%d s%d" % (N, H, W, Cc, K, R, stride))
+    repack_cache.packed()
     return gx
 
 

@@ -277,7 +277,41 @@ class Trainer:
         return (use_dp and o.dp_mode == "gc" and o.grad_clip_split and getattr(pe, "lean", False)
                 and getattr(o, "fuse_passes", True) and not o.backprop_clip)
 
-    def _fused_passes(self, img, labels, z, y):
+    # ---- gradient penalty on a second stream ---------------------------------------------------------
+    def _penalty_overlap_ok(self, use_dp):
+        """The public-data gradient penalty (train.py:423-431) depends only on the generated batch and on mean samples — not on
+        the critic pass over the private batch — and its 128-row launches (64-256 workgroups) leave most of the 256 CUs idle.  It
+        runs on a second stream beside the fused 384-row pass and joins before its gradients are added to summed_grad.  Order of
+        the activation-mask recordings differs, so parity tests with a recorder installed keep the serial order."""
+        import os
+        from . import nn as hnn
+        o = self.opt
+        return (os.environ.get("CSLGAN_GP_STREAM", "1") == "1" and use_dp and o.dp_mode == "gc" and o.per_sample_grad
+                and len(o.penalty) > 0 and o.penalty_use_public_data and hnn._mask_recorder is None and self.D is not None
+                and next(self.D.parameters()).is_cuda)
+
+    def _launch_penalty(self, img, labels, fake_img, y):
+        from . import ops
+        o, D, pe = self.opt, self.D, self.privacy_engine
+        if getattr(self, "_gp_stream", None) is None:
+            self._gp_stream = torch.cuda.Stream(device=next(D.parameters()).device)
+        side, cur = self._gp_stream, torch.cuda.current_stream()
+        ops.repack_cache.multi_stream = True
+        was_enabled = pe.enabled
+        pe.disable_hooks()                      # the penalty's critic passes are ordinary autograd, not per-sample passes
+        side.wait_stream(cur)
+        try:
+            with torch.cuda.stream(side):
+                pen_real, pen_labels = self.get_penalty_data(img, labels)
+                penalty = calc_penalty(D, o.penalty, pen_real, pen_labels, fake_img, y, device=o.d_device, aux_penalty=o.aux_penalty,
+                                       alpha=self.explicit.get("alpha"))
+                grads = autograd.grad(penalty, list(D.parameters()), create_graph=False, retain_graph=False, allow_unused=True)
+        finally:
+            if was_enabled:
+                pe.enable_hooks()
+        self._pending_penalty = (penalty, grads)
+
+    def _fused_passes(self, img, labels, z, y, on_fake=None):
         """[adaptive mean-sample pass] + generated pass + real pass as ONE discriminator forward/backward over the
         concatenated batch.  D has no batch-coupled layer, every block keeps its own mean-reduced loss and the
         engine treats the row blocks by role, so every number equals the three separate passes of the reference
@@ -299,6 +333,8 @@ class Trainer:
         yg = None if y is None else y.to(o.g_device)
         with torch.no_grad():
             fake_img = self.G(z, yg).to(o.d_device)
+        if on_fake is not None:
+            on_fake(fake_img.detach())
         blocks += [fake_img, img]
         roles += [("dense", B), ("private", B)]
         lab += [None if y is None else y.to(o.d_device), labels]
@@ -360,10 +396,12 @@ class Trainer:
         if use_imm_sens:
             img.requires_grad = True
         fused = self._can_fuse(use_dp)
+        self._pending_penalty = None
         if fused:
             pe.zero_grad()
+            on_fake = (lambda f: self._launch_penalty(img, labels, f, y)) if self._penalty_overlap_ok(use_dp) else None
             (d_fake, d_fake_aux, d_fake_loss, d_fake_aux_loss, fake_img,
-             d_real, d_real_aux, d_real_loss, d_real_aux_loss) = self._fused_passes(img, labels, z, y)
+             d_real, d_real_aux, d_real_loss, d_real_aux_loss) = self._fused_passes(img, labels, z, y, on_fake)
             d_loss = None           # already differentiated; the gc branch below never reads it again
         else:
             if use_grad_clip and o.grad_clip_mode.startswith("adaptive"):
@@ -387,8 +425,21 @@ class Trainer:
                 self.update_grad_logging()     # after clip(): reuses its norms (the reference logs first, train.py:397)
                 self.last["summed_clipped"] = [p.summed_grad.clone() for p in D.parameters()] if self.explicit.get("keep") else None
 
-        penalty = torch.zeros((), device=o.d_device)
-        if len(o.penalty) > 0:
+        penalty = torch.zeros((), device=o.d_device) if self._pending_penalty is None else None
+        if self._pending_penalty is not None:
+            # launched on the second stream right after the generator forward (_launch_penalty): join, then train.py:429-431
+            penalty, penalty_grad = self._pending_penalty
+            self._pending_penalty = None
+            torch.cuda.current_stream().wait_stream(self._gp_stream)
+            if use_grad_clip:
+                pe.accumulate_batch()
+            with torch.no_grad():
+                pairs = [(p.summed_grad, g) for p, g in zip(D.parameters(), penalty_grad) if g is not None]
+                if pairs:
+                    torch._foreach_add_([t for t, _ in pairs], [g for _, g in pairs], alpha=o.batch_size)
+                if self.explicit.get("keep"):
+                    self.last["penalty_grads"] = [None if g is None else g.clone() for g in penalty_grad]
+        elif len(o.penalty) > 0:
             pen_real, pen_labels = self.get_penalty_data(img, labels)
             alpha = self.explicit.get("alpha")
             kw = dict(device=o.d_device, aux_penalty=o.aux_penalty, alpha=alpha)

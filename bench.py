@@ -36,6 +36,7 @@ import torch  # noqa: E402
 FLOP_PER_IMG_STEP = 14.3e9
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA (never the 2:1-sparsity headline)
+PEAK_HBM_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E
 B_PER_GPU = 128
 
 
@@ -170,8 +171,24 @@ def main():
         tr.train_D(img, None, tr.gen_z(B), None, use_dp=True)
         pass  # statistics keep accumulating in place between log lines, as in training
 
+    def time_region(fn, n):
+        """n calls of fn bracketed by barrier + synchronize on both sides; MAX over ranks of the wall time."""
+        torch.cuda.synchronize()
+        D.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        D.barrier()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt_], device="cuda")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt_ = float(t)
+        return dt_
+
     # Warm-up.  Its last steps are instrumented launch by launch (HIP events on the launch stream): they name the dominant
-    # device kernel and give the per-kernel tables.  Inside the TIMED region only that kernel's launches carry events — two
+    # device kernel and give the per-kernel tables.  Inside the eager TIMED region only that kernel's launches carry events — two
     # event records per launch cost the host ~5 us, i.e. ~1 ms per step if every one of the ~170 launches were watched.
     n_probe = min(3, a.warmup)
     for _ in range(a.warmup - n_probe):
@@ -185,61 +202,45 @@ def main():
     ops.set_launch_timer(None)
     pk = {k: v for k, v in probe.summary(by_kernel=True).items() if v["exec_flop"] > 0}
     dom_name = max(pk.values(), key=lambda k: k["ms"])["name"] if pk else None
-    D.barrier()
+    # Region A — the step launched eagerly, the dominant kernel's launches bracketed by HIP events (the roofline figure)
     timer = ops.LaunchTimer(only=probe.keys_of_kernel(dom_name) if dom_name else set())
     ops.set_launch_timer(timer)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    D.barrier()
-    dt = time.perf_counter() - t0
+    dt_eager = time_region(step, a.steps)
     ops.set_launch_timer(None)
-    if world > 1:
-        t = torch.tensor([dt], device="cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t)
-    # the same step on the other fp32-accurate arithmetic (fp32_auto: three-bfloat16-piece products on the bf16 matrix cores
-    # for the launches where they are faster, csl_gan_amd/ops.py:_kc_compute) — reported beside the headline, never as it
+    # Region B — the same step as the framework runs it by default on one GPU (--hip_graph True): recorded once in a HIP graph
+    # (both streams of the step) and replayed.  This is the headline when it exists; events cannot be placed inside a replay, so the
+    # roofline keeps region A's event times (same kernels, same shapes; rocprofv3 of this command covers both regions).
+    dt, launch_mode, graph_err = dt_eager, "eager", None
+    gs = getattr(tr, "graphed", None)
+    if gs is not None and world == 1:
+        try:
+            for _ in range(gs.warmup + 2):
+                gs(img, None)
+            dt, launch_mode = time_region(lambda: gs(img, None), a.steps), "hip_graph"
+        except Exception as e:      # a failed capture must not cost the line: the eager region stands
+            graph_err = repr(e)[:200]
     variant = None
     if not a.opt and world == 1 and not a.no_variants:
         variant = {}
-        try:        # the same step replayed from a HIP graph (no per-launch host work; trainer.GraphedDStep)
-            from csl_gan_amd.trainer import GraphedDStep
-            gs = GraphedDStep(tr, warmup=1)
-            for _ in range(3):
-                gs(img, None)
-            torch.cuda.synchronize()
-            tg = time.perf_counter()
-            for _ in range(a.steps):
-                gs(img, None)
-            torch.cuda.synchronize()
-            dg = time.perf_counter() - tg
-            variant["hip_graph"] = {"value": round(world * B * a.steps / dg, 2), "unit": "images/sec", "ms_per_step": round(dg / a.steps * 1e3, 3),
-                                    "what": "the identical exact-fp32 step recorded once in a HIP graph and replayed (--hip_graph True)"}
-        except Exception as e:      # a failed capture must not cost the headline line
-            variant["hip_graph"] = {"error": repr(e)[:200]}
-        finally:
-            try:
-                gs.release()        # capturable Adam / static input buffers off again: the next variant is the plain eager step
-            except NameError:
-                pass
-        tr.explicit = {}            # back to the eager step drawing its own mean-sample batches
-        variant["fp32_auto"] = {"value": None}
+        if launch_mode == "hip_graph":
+            variant["eager"] = {"value": round(world * B * a.steps / dt_eager, 2), "unit": "images/sec", "ms_per_step": round(dt_eager / a.steps * 1e3, 3),
+                                "what": "the identical step launched kernel by kernel from Python (--hip_graph False); the roofline events were taken here"}
+        elif graph_err:
+            variant["hip_graph"] = {"error": graph_err}
+        # the same step on the other fp32-accurate arithmetic (fp32_auto: three-bfloat16-piece products on the bf16 matrix cores for
+        # the launches where they are faster, csl_gan_amd/ops.py:_kc_compute) — reported beside the headline, never as it
+        saved_explicit, tr.explicit = tr.explicit, {}            # the eager step draws its own mean-sample batches
         ops.set_compute_dtype("fp32_auto")
         for _ in range(2):
             step()
-        torch.cuda.synchronize()
-        tv = time.perf_counter()
-        for _ in range(a.steps):
-            step()
-        torch.cuda.synchronize()
-        dv = time.perf_counter() - tv
+        dv = time_region(step, a.steps)
         ops.set_compute_dtype(getattr(opt, "compute_dtype", "fp32"))
-        variant.update({"fp32_auto": {"value": round(world * B * a.steps / dv, 2), "unit": "images/sec", "ms_per_step": round(dv / a.steps * 1e3, 3),
-                                 "what": "--compute_dtype fp32_auto: large forward / data-gradient launches run fp32 emulated from three "
-                                         "bfloat16 pieces per operand (six bf16 MFMAs per product step; error vs fp64 <= the exact-fp32 "
-                                         "kernels', tests/test_kernels_gpu.py::test_bf16x3_*), everything else the exact fp32 MFMA kernels"}})
+        tr.explicit = saved_explicit
+        ops.repack_cache.clear()
+        variant["fp32_auto"] = {"value": round(world * B * a.steps / dv, 2), "unit": "images/sec", "ms_per_step": round(dv / a.steps * 1e3, 3),
+                                "what": "--compute_dtype fp32_auto, launched eagerly: large forward / data-gradient launches run fp32 emulated "
+                                        "from three bfloat16 pieces per operand (six bf16 MFMAs per product step; error vs fp64 <= the "
+                                        "exact-fp32 kernels', tests/test_kernels_gpu.py::test_bf16x3_*), everything else the exact fp32 MFMA kernels"}
     # secondary metric: the full train() loop, a G step forced on every n_d_steps-th iteration
     loop = None
     if a.loop_steps > 0:
@@ -247,18 +248,7 @@ def main():
         lbl = torch.zeros(B, dtype=torch.long)
         for i in range(opt.n_d_steps):
             tr.train(0, i, img, lbl, use_dp=True)
-        torch.cuda.synchronize()
-        D.barrier()
-        t1 = time.perf_counter()
-        for i in range(a.loop_steps):
-            tr.train(0, i, img, lbl, use_dp=True)
-        torch.cuda.synchronize()
-        D.barrier()
-        dl = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([dl], device="cuda")
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            dl = float(t)
+        dl = time_region(lambda it=iter(range(10 ** 9)): tr.train(0, next(it), img, lbl, use_dp=True), a.loop_steps)
         loop = {"metric": "full train() loop, G step every %d iterations" % opt.n_d_steps, "value": round(world * B * a.loop_steps / dl, 2),
                 "unit": "images/sec", "iterations": a.loop_steps, "ms_per_iteration": round(dl / a.loop_steps * 1e3, 3)}
     if rank != 0:
@@ -296,10 +286,25 @@ def main():
                 "note": "achieved = FLOP the kernel executes / its summed HIP-event time; reference_algorithmic_tflops charges the "
                         "UpsampleConv layers at the reference's 4x redundant channel count and is NOT a roofline fraction",
                 "launches_per_step": dom["n"] / a.steps, "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
-                "share_of_step": round(dom["ms"] / (dt * 1e3), 3),
+                "share_of_step": round(dom["ms"] / (dt_eager * 1e3), 3),
+                "measured_in": "HIP events around this kernel's launches over the %d eagerly launched timed steps (%.3f ms/step)%s" % (
+                    a.steps, dt_eager / a.steps * 1e3,
+                    "; the headline region replays the same launches from a HIP graph, where events cannot be placed" if launch_mode == "hip_graph" else ""),
                 "launch_shapes": {v["name"][len(dom["name"]) + 1:]: {"n_per_step": v["n"] / a.steps, "avg_ms": round(v["ms"] / v["n"], 4),
                                                                      "tflops": round(v["exec_flop"] / (v["ms"] * 1e-3) / 1e12, 1)}
                                   for v in worst[:8]}}
+    # the HBM group: clip_accum_noise over the materialised per-sample gradients / slabs, from the instrumented steps
+    roof_hbm = None
+    ck = kernels.get("clip_accum_noise_kernel<float>")
+    if ck and ck["ms"] > 0:
+        gbs = ck["bytes"] / (ck["ms"] * 1e-3) / 1e9
+        roof_hbm = {"bound": "hbm", "kernel": "clip_accum_noise_kernel<float>", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBPS, 4), "launches_per_step": ck["n"] / n_pr, "MB_per_step": round(ck["bytes"] / n_pr / 1e6, 1),
+                    "avg_launch_us": round(ck["ms"] / ck["n"] * 1e3, 2),
+                    "note": "algorithmic bytes of each launch (rows x row length read once + one output row) / HIP-event time, instrumented "
+                            "warm-up steps; SURVEY §8d's materialised-path figure is 34.5 MB/img/clipped pass — ghost clipping materialises only "
+                            "conv1 + conv2 (5 %% of the parameters), so the kernel moves %.1f MB per step instead of 4.4 GB and is launch-latency "
+                            "sized" % (ck["bytes"] / n_pr / 1e6)}
     exec_flop_step = sum(v["exec_flop"] for v in kernels.values()) / n_pr
     if a.dump_shapes:
         with open(a.dump_shapes, "w") as f:
@@ -316,7 +321,7 @@ def main():
         "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
         "config": {"workload": "CelebA DCResNet D-step: dp_mode=gc -gcm adaptive-pl -nms 32, WGAN-GP on mean samples, 3x%dx%d" % (opt.im_size, opt.im_size),
                    "compute_dtype": getattr(opt, "compute_dtype", "fp32"),
-                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                   "launch": launch_mode, "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                    "materialize": getattr(opt, "materialize", "all"), "grad_sample_dtype": getattr(opt, "grad_sample_dtype", "fp32"),
                    "fuse_passes": bool(getattr(opt, "fuse_passes", False)),
                    "step": "train_D (adaptive pass + G fwd + 2 D passes + per-sample grads + clip + GP + noise + Adam)"},
@@ -326,9 +331,10 @@ def main():
         ("step_frac_of_bf16_mfma_peak" if bf16 else "step_frac_of_fp32_mfma_peak"): round(exec_flop_step / (dt / a.steps) / 1e12 / step_peak, 4),
         "step_tflops_reference_algorithmic": None if a.opt else round(FLOP_PER_IMG_STEP * ips / world / 1e12, 2),
         "roofline": roof,
+        "roofline_hbm": roof_hbm,
         "secondary": loop,
         "variants": variant,
-        "tables_from": "%d launch-by-launch instrumented warm-up step(s); roofline from the timed region" % n_pr,
+        "tables_from": "%d launch-by-launch instrumented warm-up step(s); roofline from the eagerly launched timed region" % n_pr,
         "entries_ms_per_step": {k: round(v["ms"] / n_pr, 3) for k, v in sorted(entries.items(), key=lambda kv: -kv[1]["ms"])},
         "kernels_ms_per_step": {k: {"ms": round(v["ms"] / n_pr, 3), "n": v["n"] / n_pr,
                                     "tflops": round(v["exec_flop"] / (v["ms"] * 1e-3) / 1e12, 1) if v["exec_flop"] else None,

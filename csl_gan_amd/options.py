@@ -16,8 +16,9 @@ Additions of this build (all optional, none changes a reference default):
                        kernels, fp32 accumulate; BASELINE.json configs[4]).  With bf16
                        the per-sample norms must be norms of the gradients that are actually summed, so ghost clipping (whose
                        Gram norms are computed in fp32) is replaced by --materialize private
-  --hip_graph B        record the DP D-step (dp_mode=gc, full batches) once in a HIP graph and replay it (trainer.GraphedDStep):
-                       removes the host-side launch overhead that bounds the small models
+  --hip_graph B        (default True) record the DP D-step (dp_mode=gc, full batches, one process) once in a HIP graph and replay it
+                       (trainer.GraphedDStep): no per-launch host work, and the step's second stream (gradient-penalty branch)
+                       overlaps by dependency instead of by host timing; partial batches and every other mode run eagerly
   --moving_avg_beta B  the smoothing factor train.py:249 reads as opt.moving_avg_beta but options.py never defines
                        (imm_sens_scaling_mode=moving-avg-pl raises AttributeError in the reference without it)
   --materialize M      per-sample gradients kept in HBM: "all" passes (the fork's p.grad_sample layout) or only
@@ -164,7 +165,7 @@ _ARGS = [
     (("--fuse_passes",), dict(type=str2bool, default=True)),
     (("--grad_sample_dtype",), dict(type=str, choices=["fp32", "bf16"], default="fp32")),
     (("--moving_avg_beta",), dict(type=float, default=None)),
-    (("--hip_graph",), dict(type=str2bool, default=False)),
+    (("--hip_graph",), dict(type=str2bool, default=True)),
     (("--compute_dtype",), dict(type=str, choices=["fp32", "bf16", "bf16x3", "fp32_auto"], default="fp32")),
 ]
 ALWAYS_KEEP = ["g_device", "d_device", "num_workers", "resume_path", "resume_epochs"]

@@ -628,6 +628,18 @@ class PrivacyEngine(PerSampleSink):
             t = self._idx_cache[key] = torch.tensor(list(idx), device=device)
         return t
 
+    def add_to_grad_sample(self, param, rows, pass_idx=0):
+        """p.grad_sample[pass_idx, i] += rows[i] (train.py:447) on the dense [passes*B, numel] buffer behind the view; rows are
+        [B, numel] in the parameter's memory order.  Needs the parameter materialised (--materialize all)."""
+        gs = getattr(param, "grad_sample", None)
+        if gs is None:
+            raise RuntimeError("add_to_grad_sample: the parameter has no p.grad_sample (use --materialize all)")
+        dense = _rows(gs)
+        B = gs.shape[1]
+        if rows.shape != (B, dense.shape[1]):
+            raise RuntimeError("add_to_grad_sample: rows %s, expected %s" % (tuple(rows.shape), (B, dense.shape[1])))
+        dense[pass_idx * B:(pass_idx + 1) * B].add_(rows.to(dense.dtype))
+
     def accum_grads_across_passes(self):
         """The cross-pass sum (train.py:402) already happened inside clip(): rows = passes x samples."""
         return None

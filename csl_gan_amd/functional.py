@@ -37,6 +37,28 @@ class input_grads_only:
         _INPUT_GRADS_ONLY = self._prev
 
 
+_PS_SINK = None
+
+
+class per_sample_param_grads:
+    """Context for the SECOND-order sweep of a per-sample gradient penalty (train.py:433-450, penalties computed on private
+    data): the reference differentiates penalties[i] for every sample i separately (B autograd calls over the whole batch
+    graph).  penalties[i] depends on row i alone, so the per-sample parameter gradients are the per-sample (group = 1) weight
+    gradients of ONE sweep of sum_i penalties[i]: inside this context every second-order weight-gradient node hands its
+    per-sample rows [B, numel(param)] (parameter memory order) to sink(param, rows) and returns no dense gradient."""
+
+    def __init__(self, sink, params):
+        self.sink, self.by_ptr = sink, {p.data_ptr(): p for p in params}
+
+    def __enter__(self):
+        global _PS_SINK
+        self._prev, _PS_SINK = _PS_SINK, self
+
+    def __exit__(self, *a):
+        global _PS_SINK
+        _PS_SINK = self._prev
+
+
 def nhwc(x: torch.Tensor) -> torch.Tensor:
     """logical NCHW -> NHWC-contiguous view (copy only if x is not already channels-last)."""
     return x.permute(0, 2, 3, 1).contiguous()
@@ -284,7 +306,15 @@ class Dgrad(Function):
         if ctx.needs_input_grad[0]:
             g_gy = Conv.apply(ggx, w, None, stride, pad, ops.ACT_NONE, None, ctx.wkey)
         if ctx.needs_input_grad[1]:
-            g_w = Wgrad.apply(gy, ggx, w.shape[1], w.shape[2], stride, pad)
+            ps = _PS_SINK
+            param = None if ps is None else ps.by_ptr.get(w.data_ptr())
+            if param is not None:
+                with torch.no_grad():
+                    K, R, S, Cc = w.shape
+                    rows = ops.conv2d_wgrad_grouped(gy.contiguous(), ggx, R, S, stride=stride, pad=pad, group=1, alpha=1.0)
+                    ps.sink(param, rows.reshape(rows.shape[0], -1))
+            else:
+                g_w = Wgrad.apply(gy, ggx, w.shape[1], w.shape[2], stride, pad)
         return g_gy, g_w, None, None, None, None, None, None
 
 

@@ -228,6 +228,10 @@ def finalize(opt, make_dirs=True):
     if opt.model == "Vanilla" and (opt.g_label_emb_mode, opt.d_label_emb_mode) != ("concat", "concat"):
         raise Exception("Vanilla model with embedded labels not implemented")
 
+    if pen_dp and not opt.penalty_use_public_data and opt.dp_mode == "gc" and getattr(opt, "materialize", "all") != "all":
+        print("penalty_use_public_data=False: using --materialize all (the per-sample penalty gradients are added to p.grad_sample of "
+              "every parameter, train.py:447)")
+        opt.materialize = "all"
     if getattr(opt, "compute_dtype", "fp32") == "bf16" and opt.materialize == "ghost":
         print("compute_dtype=bf16: using --materialize private (ghost clipping's Gram norms are fp32 norms of unrounded products)")
         opt.materialize = "private"

@@ -445,12 +445,13 @@ class Trainer:
             kw = dict(device=o.d_device, aux_penalty=o.aux_penalty, alpha=alpha)
             if use_dp and o.per_sample_grad:
                 if not o.penalty_use_public_data:
-                    raise NotImplementedError("per-sample gradient penalty on private data (train.py:434-450) leaks memory in the "
-                                              "reference and is not built; use mean samples / public data")
-                if use_grad_clip:
-                    pe.accumulate_batch()
-                penalty = calc_penalty(D, o.penalty, pen_real, pen_labels, fake_img, y, **kw)
-                penalty_grad = autograd.grad(penalty, list(D.parameters()), create_graph=False, retain_graph=False, allow_unused=True)
+                    penalty = self._per_sample_penalty(pen_real, pen_labels, fake_img, y, kw, use_grad_clip)
+                    penalty_grad = []
+                else:
+                    if use_grad_clip:
+                        pe.accumulate_batch()
+                    penalty = calc_penalty(D, o.penalty, pen_real, pen_labels, fake_img, y, **kw)
+                    penalty_grad = autograd.grad(penalty, list(D.parameters()), create_graph=False, retain_graph=False, allow_unused=True)
                 with torch.no_grad():
                     pairs = [(p.summed_grad, g) for p, g in zip(D.parameters(), penalty_grad) if g is not None]
                     if pairs:      # summed_grad is a sum, not a mean (train.py:431); one multi-tensor launch
@@ -510,6 +511,32 @@ class Trainer:
             self.last.update(d_real_loss=d_real_loss.detach(), d_fake_loss=d_fake_loss.detach(), penalty=penalty.detach(),
                              d_real=d_real.detach(), d_fake=d_fake.detach(), fake_img=fake_img)
             self._commit_stats()
+
+    # ---- train.py:433-450 ---------------------------------------------------------------------
+    def _per_sample_penalty(self, pen_real, pen_labels, fake_img, y, kw, use_grad_clip):
+        """Gradient penalty evaluated on PRIVATE data (--penalty_use_public_data False): the penalty of sample i is part of that
+        sample's loss, so its parameter gradient is added to p.grad_sample[0, i] (train.py:447 — pass index 0 as the reference
+        writes it) and the batch is clipped again (train.py:449-450).  The reference takes B separate autograd.grad calls, each
+        through the whole batch graph; penalties[i] depends on row i only, so ONE second-order sweep of sum_i penalties[i] with
+        per-sample (group = 1) weight-gradient kernels gives the same B gradients (csl_gan_amd.functional.per_sample_param_grads).
+        The first-order bias terms of the penalty are identically zero."""
+        from . import functional as HF
+        o, D, pe = self.opt, self.D, self.privacy_engine
+        if not use_grad_clip:
+            raise NotImplementedError("per-sample gradient penalties are defined for dp_mode=gc (train.py:433-450)")
+        if not all(hasattr(p, "grad_sample") for p in D.parameters()):
+            raise RuntimeError("--penalty_use_public_data False edits p.grad_sample of every parameter: run with --materialize all")
+        print("WARNING: Per sample penalty currently causes a memory leak.") if getattr(self, "_warn_ps_pen", True) else None
+        self._warn_ps_pen = False          # the reference prints this every step (train.py:436); once is enough here
+        penalties = calc_penalty(D, o.penalty, pen_real, pen_labels, fake_img, y, per_sample=True, **kw)
+        with HF.per_sample_param_grads(lambda p, rows: pe.add_to_grad_sample(p, rows, 0), list(D.parameters())):
+            autograd.grad(penalties.sum(), list(D.parameters()), create_graph=False, retain_graph=False, allow_unused=True)
+        pe.clip(recompute_norms=True)
+        pe.accumulate_batch()
+        with torch.no_grad():
+            if self.explicit.get("keep"):
+                self.last["summed_clipped_with_penalty"] = [p.summed_grad.clone() for p in D.parameters()]
+        return penalties.detach().mean(dim=0)
 
     # ---- train.py:502-517 ---------------------------------------------------------------------
     def train_G(self, z, y):

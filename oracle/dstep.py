@@ -151,9 +151,23 @@ class OracleDStep:
             summed = E.clip_and_sum(gsamp, self.max_grad_norm, accum_passes=not cfg.grad_clip_split,
                                     num_private_passes=1 if cfg.grad_clip_split else None)
             obs["summed_clipped"] = [s.clone() for s in summed]
-            if len(cfg.penalty) > 0:
-                if not cfg.penalty_use_public_data:
-                    raise NotImplementedError("per-sample penalty path (train.py:434-450) not restated")
+            if len(cfg.penalty) > 0 and not cfg.penalty_use_public_data:
+                # train.py:433-450, literally: the penalty is evaluated on the private batch per sample, one autograd call per
+                # sample adds its parameter gradient to p.grad_sample[0, i] (pass index 0, as written there), then clip() again
+                penalties = P.calc_penalty(D, list(cfg.penalty), img, labels, fake, alpha, per_sample=True, aux_penalty=cfg.aux_penalty)
+                penalty = penalties.mean(dim=0)
+                for i in range(len(penalties)):
+                    pg = torch.autograd.grad(penalties[i], params, retain_graph=True, allow_unused=True)
+                    with torch.no_grad():
+                        for p, g in zip(params, pg):
+                            if g is not None:
+                                p.grad_sample[0, i] += g
+                gsamp = [p.grad_sample for p in params]
+                summed = E.clip_and_sum(gsamp, self.max_grad_norm, accum_passes=not cfg.grad_clip_split,
+                                        num_private_passes=1 if cfg.grad_clip_split else None)
+                obs["summed_clipped_with_penalty"] = [s.clone() for s in summed]
+                obs["norms_with_penalty"] = torch.stack(E.calc_sample_norms(gsamp, flat=not cfg.per_layer)).clone()
+            elif len(cfg.penalty) > 0:
                 penalty = P.calc_penalty(D, list(cfg.penalty), pen_real, pen_labels, fake, alpha, aux_penalty=cfg.aux_penalty)
                 pg = torch.autograd.grad(penalty, params, allow_unused=True)
                 obs["penalty_grads"] = [None if g is None else g.clone() for g in pg]

@@ -617,3 +617,41 @@ def test_train_D_bf16_compute_matches_fp32_oracle(tmp_path, dataset, extra, B, l
         _close_grad(a, b, "summed_grad[%d] (bf16 compute)" % i, l2_tol=2e-1)
     _close_grad(torch.cat([a.reshape(-1).cpu() for a in last["summed_grad"]]), torch.cat([b.reshape(-1) for b in obs["summed_grad"]]),
                 "whole summed gradient (bf16 compute)", l2_tol=5e-2)
+
+
+@pytest.mark.parametrize("dataset,extra,B,latent", [
+    ("MNIST", ["--model", "DeepConvResNet", "--penalty", "WGAN-GP", "-c", "3.0"], 6, 16),
+    ("CelebA", ["-c", "2.0"], 4, 128),
+    ("MNIST", ["--model", "DeepConvResNet", "--penalty", "WGAN-GP", "-gcs", "False", "-c", "6.0"], 6, 16),
+])
+def test_train_D_per_sample_penalty_on_private_data(tmp_path, dataset, extra, B, latent):
+    """--penalty_use_public_data False (train.py:433-450): the gradient penalty is evaluated on the private batch per sample, its
+    parameter gradient of sample i is added to p.grad_sample[0, i] and the batch is clipped again.  The oracle restates the
+    reference's loop (one autograd call per sample); the device takes ONE second-order sweep with per-sample weight-gradient
+    kernels.  Shared activation masks, 1e-3 per entry on the clipped sums; norms after the edit at 1e-3."""
+    opt, tr, pe, oracle, Do = _setup(tmp_path, dataset, extra + ["--penalty_use_public_data", "False", "-nms", "0"], B, latent)
+    assert opt.materialize == "all" and not opt.penalty_use_public_data
+    oracle.cfg.penalty_use_public_data = False
+    oracle.cfg.sigma = 0.0
+    pe.noise_multiplier = 0.0
+    g = torch.Generator().manual_seed(79)
+    ch, im = (1, 28) if dataset == "MNIST" else (3, 64)
+    img = (torch.randn(B, ch, im, im, generator=g) * 0.5).clamp(-1, 1)
+    z, alpha = torch.randn(B, latent, generator=g), torch.rand(B, generator=g)
+    tr.explicit = dict(alpha=alpha, keep=True)
+    with _masks(G=tr.G, D=tr.D) as rec:
+        tr.train_D(img.cuda(), None, z.cuda(), None, use_dp=True)
+    torch.cuda.synchronize()
+    last = tr.last
+    with _masked_oracle(rec, G=oracle.G, D=Do) as player:
+        obs = oracle.step(img, None, z, None, alpha=alpha, apply_update=False)
+        assert player.exhausted()
+    _close(last["penalty"], obs["penalty"], "mean per-sample penalty")
+    for i, (a, b) in enumerate(zip(last["summed_clipped"], obs["summed_clipped"])):
+        _close(a, b, "first clip, summed_clipped[%d]" % i)
+    for i, (a, b) in enumerate(zip(last["summed_clipped_with_penalty"], obs["summed_clipped_with_penalty"])):
+        _close(a, b, "second clip (penalty gradients in p.grad_sample[0]), summed[%d]" % i)
+    for i, (a, b) in enumerate(zip(last["summed_grad"], obs["summed_grad"])):
+        _close(a, b, "summed_grad[%d]" % i)
+    # the edit changed the sums: the penalty gradients are not a rounding-level contribution
+    assert any((a - b).abs().max().item() > 1e-2 * b.abs().max().item() for a, b in zip(obs["summed_clipped_with_penalty"], obs["summed_clipped"]))

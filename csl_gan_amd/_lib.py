@@ -75,7 +75,7 @@ def lib():
         "cslgan_clip_factors_f32": [vp, i32, i64, vp, i32, f32, i64, vp, vp, vp],
         "cslgan_clip_accum_noise_f32": [C.POINTER(SegsT), i64, vp, i32, vp, u64, u64, f32, f32, vp],
         "cslgan_l2_clip_rows_f32": [vp, vp, i64, i64, f32, vp, vp],
-        "cslgan_mean_sample_f32": [vp, i32, i32, i64, vp, vp, i64, f32, f32, u64, u64, vp, vp],
+        "cslgan_mean_sample_f32": [vp, i32, i32, i64, vp, vp, i64, f32, f32, u64, u64, vp, vp, vp],
         "cslgan_row_l2norm_f32": [vp, i64, i64, vp, vp],
         "cslgan_row_l2norm_bwd_f32": [vp, vp, vp, i64, i64, vp, vp],
         "cslgan_conv2d_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, vp, i32, vp, vp],

@@ -149,16 +149,54 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, fl
 //   out[i][e] = ms[label[i]][perm[i]][e] + noise_mean_std * z_i + noise_std * z_{i,e}     (Philox4x32-10 + Box-Muller)
 // The reference draws on the host and copies the batch to the device every step (train.py:200-202, 214-216); as torch ops on
 // the device it is an index kernel, two normal_ fills and two adds (five passes over the batch).
+// perms == NULL: the kernel draws the permutations itself — image i takes entry (i mod num_samples) of the (i / num_samples)-th
+// uniform random permutation of the num_samples mean samples (torch.cat of randperms, mean_sampler.py:76), found by ranking
+// num_samples Philox keys in LDS (num_samples <= MS_MAX_PERM); labels == NULL with n_classes > 1: labels drawn uniformly
+// (mean_sampler.py:77) and written to labels_out.  What were a rand, an argsort (arange + copies + bitonic sort), a randint and
+// the index arithmetic around them — eight launches per draw, two draws per D-step — happens inside the gather.
+constexpr int MS_MAX_PERM = 1024;
 __global__ __launch_bounds__(256) void mean_sample_kernel(const float* __restrict__ ms, const long long* __restrict__ labels,
-                                                          const long long* __restrict__ perms, int num_samples, long long len,
+                                                          const long long* __restrict__ perms, int num_samples, int n_classes, long long len,
                                                           float noise_mean_std, float noise_std, unsigned long long seed,
-                                                          unsigned long long offset, float* __restrict__ out) {
+                                                          unsigned long long offset, float* __restrict__ out,
+                                                          long long* __restrict__ labels_out) {
     const long long i = blockIdx.y;
     const long long e4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index inside the image
-    if (e4 * 4 >= len) return;
-    const long long lab = labels ? labels[i] : 0;
-    const float* src = ms + (lab * num_samples + perms[i]) * len;
     uint32_t rnd[4];
+    long long perm_i;
+    if (perms) {
+        perm_i = perms[i];
+    } else {
+        __shared__ uint32_t s_key[MS_MAX_PERM];
+        __shared__ int s_sel;
+        const uint32_t rep = (uint32_t)(i / num_samples);
+        const int pos = (int)(i % num_samples);
+        for (int j = threadIdx.x; j < num_samples; j += blockDim.x) {
+            philox4x32_10((uint32_t)j, rep, (uint32_t)offset, 0x7065726Du ^ (uint32_t)(offset >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+            s_key[j] = rnd[0];
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < num_samples; j += blockDim.x) {
+            const uint32_t kj = s_key[j];
+            int rank = 0;
+            for (int m = 0; m < num_samples; ++m) {
+                const uint32_t km = s_key[m];
+                rank += (km < kj || (km == kj && m < j)) ? 1 : 0;
+            }
+            if (rank == pos) s_sel = j;
+        }
+        __syncthreads();
+        perm_i = s_sel;
+    }
+    long long lab = 0;
+    if (labels) lab = labels[i];
+    else if (n_classes > 1) {
+        philox4x32_10((uint32_t)i, 0x6C61626Cu, (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+        lab = (long long)(((unsigned long long)rnd[0] * (unsigned long long)n_classes) >> 32);
+    }
+    if (labels_out && blockIdx.x == 0 && threadIdx.x == 0) labels_out[i] = lab;
+    if (e4 * 4 >= len) return;
+    const float* src = ms + (lab * num_samples + perm_i) * len;
     float zi = 0.f, unused;
     if (noise_mean_std > 0.f) {                         // the image's jitter: the same counter in every thread of the image
         philox4x32_10((uint32_t)i, 0xFFFFFFFFu, (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
@@ -451,17 +489,19 @@ int cslgan_l2_clip_rows_f32(const float* in, float* out, int64_t n_rows, int64_t
 
 int cslgan_mean_sample_f32(const float* mean_samples, int n_classes, int num_samples, int64_t len, const int64_t* labels,
                            const int64_t* perms, int64_t n, float noise_mean_std, float noise_std, uint64_t seed, uint64_t offset,
-                           float* out, void* stream) {
-    CSLGAN_REQUIRE(mean_samples && perms && out, "mean_sample: null argument");
+                           float* out, int64_t* labels_out, void* stream) {
+    CSLGAN_REQUIRE(mean_samples && out, "mean_sample: null argument");
     CSLGAN_REQUIRE(n_classes >= 1 && num_samples >= 1 && len >= 1 && n >= 0 && n <= 65535, "mean_sample: bad sizes");
-    CSLGAN_REQUIRE(labels || n_classes == 1, "mean_sample: labels are required with more than one class");
+    CSLGAN_REQUIRE(perms || num_samples <= MS_MAX_PERM, "mean_sample: in-kernel permutations need num_samples <= %d", MS_MAX_PERM);
+    CSLGAN_REQUIRE(labels || labels_out || n_classes == 1, "mean_sample: with more than one class give labels, or labels_out to receive drawn ones");
     CSLGAN_REQUIRE(aligned16(mean_samples) && aligned16(out), "mean_sample: tensors must be 16-byte aligned");
     if (n == 0) return CSLGAN_OK;
     const long long f4 = (len + 3) / 4;
     note_kernel("mean_sample_kernel");
     hipLaunchKernelGGL(mean_sample_kernel, dim3((unsigned)((f4 + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, mean_samples,
-                       reinterpret_cast<const long long*>(labels), reinterpret_cast<const long long*>(perms), num_samples, (long long)len,
-                       noise_mean_std, noise_std, (unsigned long long)seed, (unsigned long long)offset, out);
+                       reinterpret_cast<const long long*>(labels), reinterpret_cast<const long long*>(perms), num_samples, n_classes,
+                       (long long)len, noise_mean_std, noise_std, (unsigned long long)seed, (unsigned long long)offset, out,
+                       reinterpret_cast<long long*>(labels_out));
     return check_launch("mean_sample_kernel");
 }
 

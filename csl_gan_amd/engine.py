@@ -277,8 +277,8 @@ def _ghost_rows(self, pass_idx, n_pass, gz, x, R, S, stride, pad, scale, has_bia
 _LayerCollector._ghost_rows = _ghost_rows
 
 
-def _dense_wgrad(gz, x, R, S, stride, pad, scale, row_scale=None):
-    return ops.conv2d_wgrad_dense(gz, x, R, S, stride=stride, pad=pad, alpha=scale, row_scale=row_scale).reshape(-1)
+def _dense_wgrad(gz, x, R, S, stride, pad, scale, row_scale=None, out=None):
+    return ops.conv2d_wgrad_dense(gz, x, R, S, stride=stride, pad=pad, alpha=scale, row_scale=row_scale, out=out).reshape(-1)
 
 
 def _dense_bgrad(gz, scale):
@@ -606,15 +606,24 @@ class PrivacyEngine(PerSampleSink):
                     continue
                 fi = (f[i] if per_layer else f).reshape(n_pass, B)
                 total = None
+                single = len(stash) == 1            # one clipped pass: the weighted sum is written straight into summed_grad
                 for k, (gz, x, R, S, stride, pad, scale, joint) in sorted(stash.items()):
+                    dst = outs[i] if single else None
                     if joint is None:
-                        part = _dense_wgrad(gz, x, R, S, stride, pad, scale, row_scale=fi[k].contiguous())
+                        part = _dense_wgrad(gz, x, R, S, stride, pad, scale, row_scale=fi[k].contiguous(), out=dst)
                     else:
                         gzj, xj, n_d, scale_d = joint
-                        rs = torch.cat([torch.full((n_d,), float(scale_d), device=f.device, dtype=torch.float32), fi[k] * float(scale)])
-                        part = _dense_wgrad(gzj, xj, R, S, stride, pad, 1.0, row_scale=rs)
+                        # row weights of the joint launch: [scale_d] * n_d (never-clipped rows; a constant prefix kept across
+                        # steps) followed by f_b * scale — one launch per step instead of fill + mul + cat
+                        key = ("rs", id(p), n_d, float(scale_d), B, str(f.device))
+                        rs = self._idx_cache.get(key)
+                        if rs is None:
+                            rs = self._idx_cache[key] = torch.full((n_d + B,), float(scale_d), device=f.device, dtype=torch.float32)
+                        torch.mul(fi[k], float(scale), out=rs[n_d:])
+                        part = _dense_wgrad(gzj, xj, R, S, stride, pad, 1.0, row_scale=rs, out=dst)
                     total = part if total is None else total.add_(part)
-                outs[i].copy_(total)
+                if not single:
+                    outs[i].copy_(total)
         if self._dense:       # sums of the never-clipped passes (lean modes)
             idx = [i for i, p in enumerate(ps) if id(p) in self._dense]
             ops.clip_accum_noise([self._dense[id(ps[i])].view(1, -1) for i in idx], [outs[i] for i in idx], beta=1.0)

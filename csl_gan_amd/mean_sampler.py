@@ -50,19 +50,19 @@ class MeanSampler:
         dev, gen = self.mean_samples.device, self.generator
         reps = (size - 1) // self.num_samples + 1
         if dev.type == "cuda":
-            # `reps` uniform permutations in one sort (argsort of iid uniforms) instead of `reps` randperm calls, and the gather +
-            # jitter + noise in one HIP kernel (Philox keyed by a seed fixed at the first draw and a per-call counter)
-            perms = torch.rand(reps, self.num_samples, device=dev, generator=gen).argsort(dim=1).reshape(-1)[:size]
-            if requested_labels is None:
-                requested_labels = torch.randint(0, self.n_classes, (size,), device=dev, generator=gen)
-            requested_labels = requested_labels.to(dev)
+            # ONE HIP kernel: the permutations (ranked Philox keys), the labels when none are requested, the gather, the jitter and
+            # the noise — Philox keyed by a seed fixed at the first draw and a per-call counter (both checkpointed by the trainer)
             if self._seed is None:
                 self._seed = int(gen.initial_seed() if gen is not None else torch.initial_seed()) ^ 0x6D65616E73616D70
             from . import ops
             self._draws += 1
-            r = ops.mean_sample(self.mean_samples, requested_labels if self.n_classes > 1 else None, perms, noise_mean_std, noise_std,
-                                self._seed, self._draws)
-            return r, (requested_labels if self.n_classes > 1 else None)
+            perms = None
+            if self.num_samples > 1024:          # beyond the kernel's LDS ranking: permutations from one device sort
+                perms = torch.rand(reps, self.num_samples, device=dev, generator=gen).argsort(dim=1).reshape(-1)[:size]
+            labels = None if (requested_labels is None or self.n_classes == 1) else requested_labels.to(dev)
+            r, labels = ops.mean_sample(self.mean_samples, labels, perms, noise_mean_std, noise_std, self._seed, self._draws, n=size,
+                                        want_labels=True)
+            return r, (labels if self.n_classes > 1 else None)
         perms = torch.cat([torch.randperm(self.num_samples, device=dev, generator=gen) for _ in range(reps)])[:size]
         if requested_labels is None:
             requested_labels = torch.randint(0, self.n_classes, (size,), device=dev, generator=gen)
@@ -73,6 +73,14 @@ class MeanSampler:
         if noise_std is not None and noise_std > 0:
             r = r + torch.empty(r.shape, device=dev).normal_(0, noise_std, generator=gen)
         return r, (requested_labels if self.n_classes > 1 else None)
+
+    def state_dict(self):
+        """The device-side draw stream (seed fixed at the first draw, per-call counter): saved next to the engine state so a
+        resumed run continues the stream instead of repeating the first run's draws (the reference's host draws restart too)."""
+        return {"seed": self._seed, "draws": self._draws}
+
+    def load_state_dict(self, st):
+        self._seed, self._draws = (None if st.get("seed") is None else int(st["seed"])), int(st.get("draws", 0))
 
     def get_privacy_cost(self, target_delta=1e-6, alphas=ALPHAS):
         pixel_sensitivity = 1 / self.mean_size / 2

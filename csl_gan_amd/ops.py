@@ -536,9 +536,9 @@ def conv2d_wgrad_blocks(gy, x, R, S, stride, pad, alpha, blocks):
         "conv2d_wgrad_blocks"), tag=lambda: "N%d %dx%d C%d K%d R%d s%d g1 blocks%d" % (N, H, W, Cc, K, R, stride, nb))
 
 
-def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, alpha=1.0, row_scale=None):
+def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, alpha=1.0, row_scale=None, out=None):
     """The summed weight gradient [K,R,S,C] of a batch: slabs of the grouped MFMA kernel + a column sum, or the
-    vector-ALU kernel for 1..4 output channels."""
+    vector-ALU kernel for 1..4 output channels.  out (optional, flat fp32 [K*R*S*C]): destination of the sum."""
     N, H, W, Cc = x.shape
     _, P, Q, K = gy.shape
     if (K <= 4 and Cc == 64 and stride == 1 and R * S <= 9 and P % 8 == 0 and Q % 8 == 0 and row_scale is None):
@@ -552,7 +552,7 @@ def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, alpha=1.0, row_scale=None):
         _timed("conv2d_wgrad_grouped", flop, 4.0 * (x.numel() + gy.numel()), lambda: check(
             _lib.lib().cslgan_conv2d_wgrad_skinny_f32(C.byref(d), _p(gy), _p(x), float(alpha), _p(partial), nb, _stream()),
             "conv2d_wgrad_skinny"), tag=lambda: "N%d %dx%d C%d K%d R%d skinny" % (N, H, W, Cc, K, R))
-        out = torch.empty(K * R * S * Cc, device=x.device, dtype=torch.float32)
+        out = torch.empty(K * R * S * Cc, device=x.device, dtype=torch.float32) if out is None else out
         clip_accum_noise([partial], [out])
         return out.view(K, R, S, Cc)
     if Cc == 3 and row_scale is None and _c3_layer(H, W, K, R, S, stride, pad, Q in (16, 32, 64) and P % (128 // Q) == 0):
@@ -561,10 +561,13 @@ def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, alpha=1.0, row_scale=None):
         group = dense_wgrad_group(N, K, Cc, R, S, P * Q, stride=stride, out_hw=(P, Q))
     slabs = conv2d_wgrad_grouped(gy, x, R, S, stride=stride, pad=pad, group=group, alpha=alpha, row_scale=row_scale)
     if slabs.shape[0] == 1:
+        if out is not None:
+            out.copy_(slabs[0].reshape(-1))
+            return out.view(slabs.shape[1:])
         return slabs[0]
-    out = torch.empty(slabs.shape[1:], device=x.device, dtype=torch.float32)
+    out = torch.empty(slabs[0].numel(), device=x.device, dtype=torch.float32) if out is None else out
     clip_accum_noise([slabs.reshape(slabs.shape[0], -1)], [out.view(-1)])
-    return out
+    return out.view(slabs.shape[1:])
 
 
 def norm_act_bwd(x, dy, y, gamma, stats, rows_per_stat, groups, eps, relu):
@@ -710,19 +713,30 @@ def l2_clip_rows(t, Cval):
     return out.reshape(t.shape)
 
 
-def mean_sample(mean_samples, labels, perms, noise_mean_std, noise_std, seed, offset):
+def mean_sample(mean_samples, labels, perms, noise_mean_std, noise_std, seed, offset, n=None, want_labels=False):
     """MeanSampler.sample's gather + per-image jitter + per-pixel noise (mean_sampler.py:75-84) in one pass.
-    mean_samples [n_classes, num_samples, ...] fp32, labels / perms [n] int64 (labels None for one class)."""
+    mean_samples [n_classes, num_samples, ...] fp32, labels / perms [n] int64 or None: missing permutations (and, with several
+    classes, missing labels) are drawn inside the kernel; n is then required.  want_labels: also return the labels used."""
     _chk(mean_samples, "mean_samples")
     n_cls, num = mean_samples.shape[0], mean_samples.shape[1]
-    n = perms.numel()
+    if perms is not None:
+        n = perms.numel()
+    elif n is None:
+        raise RuntimeError("mean_sample: n is required when the kernel draws the permutations")
+    elif num > 1024:
+        raise RuntimeError("mean_sample: in-kernel permutations need num_samples <= 1024")
     ln = mean_samples[0, 0].numel()
-    if perms.dtype != torch.int64 or not perms.is_cuda or (labels is not None and (labels.dtype != torch.int64 or not labels.is_cuda)):
-        raise RuntimeError("mean_sample: labels / perms must be int64 device tensors")
+    for t, nm in ((labels, "labels"), (perms, "perms")):
+        if t is not None and (t.dtype != torch.int64 or not t.is_cuda or t.numel() != n):
+            raise RuntimeError("mean_sample: %s must be an int64 device tensor of %d entries" % (nm, n))
     out = torch.empty((n,) + tuple(mean_samples.shape[2:]), device=mean_samples.device, dtype=torch.float32)
-    check(_lib.lib().cslgan_mean_sample_f32(_p(mean_samples), n_cls, num, ln, _p(labels), _p(perms.contiguous()), n,
+    lab_out = torch.empty(n, device=mean_samples.device, dtype=torch.int64) if (want_labels and labels is None and n_cls > 1) else None
+    check(_lib.lib().cslgan_mean_sample_f32(_p(mean_samples), n_cls, num, ln, None if labels is None else _p(labels.contiguous()),
+                                            None if perms is None else _p(perms.contiguous()), n,
                                             float(noise_mean_std or 0.0), float(noise_std or 0.0), int(seed) & (2 ** 64 - 1),
-                                            int(offset) & (2 ** 64 - 1), _p(out), _stream()), "mean_sample")
+                                            int(offset) & (2 ** 64 - 1), _p(out), _p(lab_out), _stream()), "mean_sample")
+    if want_labels:
+        return out, (labels if labels is not None else lab_out)
     return out
 
 

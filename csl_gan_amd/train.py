@@ -59,8 +59,11 @@ def build_mean_sampler(opt, dataset, rank=0, world=1):
 
 def _save_engine(tr, path):
     if tr.privacy_engine is not None:
+        st = tr.privacy_engine.state_dict()
+        if tr.mean_sampler is not None:
+            st["mean_sampler"] = tr.mean_sampler.state_dict()
         with open(path, "w") as f:
-            json.dump(tr.privacy_engine.state_dict(), f)
+            json.dump(st, f)
 
 
 def main(argv=None):
@@ -114,7 +117,10 @@ def main(argv=None):
         pe_path = (opt.resume_path or "") + "saves/PE-" + str(opt.resume_epochs) + ".json"
         if opt.resume_epochs > 0 and os.path.exists(pe_path):      # extension: the reference restarts epsilon at 0
             with open(pe_path) as f:
-                pe.load_state_dict(json.load(f))
+                st = json.load(f)
+            pe.load_state_dict(st)
+            if mean_sampler is not None and "mean_sampler" in st:
+                mean_sampler.load_state_dict(st["mean_sampler"])
 
     # train.py:555-563, 538-539: -p wraps the training loop in torch.profiler (wait 1 / warm-up 1 / active 5 steps, one
     # profiler.step() per batch) and prints the key-averages table sorted by self CPU time, row_limit = n_classes

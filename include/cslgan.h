@@ -108,10 +108,13 @@ int cslgan_l2_clip_rows_f32(const float* in, float* out, int64_t n_rows, int64_t
 /* MeanSampler.sample (mean_sampler.py:75-84; called from train.py:200-202, 214-216) on device-resident mean samples:
  *   out[i][:] = mean_samples[labels[i]][perms[i]][:] + noise_mean_std * z_i + noise_std * z_{i,:}
  * mean_samples [n_classes][num_samples][len], labels (nullable when n_classes == 1) and perms [n] int64, out [n][len];
- * z ~ N(0,1) from Philox4x32-10 keyed (seed, offset): the caller advances offset per call. */
+ * z ~ N(0,1) from Philox4x32-10 keyed (seed, offset): the caller advances offset per call.
+ * perms == NULL (num_samples <= 1024): the kernel draws them — image i takes entry i mod num_samples of the (i / num_samples)-th
+ * uniform random permutation (torch.cat of randperms, mean_sampler.py:76).  labels == NULL with n_classes > 1: uniform labels
+ * are drawn (mean_sampler.py:77).  labels_out (nullable, [n] int64) receives the labels used. */
 int cslgan_mean_sample_f32(const float* mean_samples, int n_classes, int num_samples, int64_t len, const int64_t* labels,
                            const int64_t* perms, int64_t n, float noise_mean_std, float noise_std, uint64_t seed, uint64_t offset,
-                           float* out, void* stream);
+                           float* out, int64_t* labels_out, void* stream);
 
 /* Row L2 norms of a [n_rows, len] matrix (gradient_penalty.py:52-53) and the backward of
  * norm: gin[r][j] = gnorm[r] * in[r][j] / norm[r]. */

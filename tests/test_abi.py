@@ -44,10 +44,19 @@ def test_invalid_arguments_fail_loudly_without_gpu(built_lib):
     rc = L.cslgan_conv2d_fwd_f32(ctypes.byref(d), 1, 1, None, None, 0, 1, None)
     assert rc == -1 and b"does not match" in L.cslgan_last_error()
     # round-2 entries
-    rc = L.cslgan_mean_sample_f32(None, 1, 4, 16, None, None, 2, 0.0, 0.0, 1, 1, None, None)
+    rc = L.cslgan_mean_sample_f32(None, 1, 4, 16, None, None, 2, 0.0, 0.0, 1, 1, None, None, None)
     assert rc == -1 and b"null" in L.cslgan_last_error()
-    rc = L.cslgan_mean_sample_f32(16, 2, 4, 16, None, 16, 2, 0.0, 0.0, 1, 1, 16, None)
-    assert rc == -1 and b"labels are required" in L.cslgan_last_error()
+    rc = L.cslgan_mean_sample_f32(16, 2, 4, 16, None, 16, 2, 0.0, 0.0, 1, 1, 16, None, None)
+    assert rc == -1 and b"give labels" in L.cslgan_last_error()
+    rc = L.cslgan_mean_sample_f32(16, 1, 4096, 16, None, None, 2, 0.0, 0.0, 1, 1, 16, None, None)
+    assert rc == -1 and b"in-kernel permutations" in L.cslgan_last_error()
+    # round-3 entries (csrc/step_kernels.hip)
+    rc = L.cslgan_segment_means_f32(16, 9, (ctypes.c_int32 * 9)(*[1] * 9), (ctypes.c_float * 9)(*[1.0] * 9), 16, None, None)
+    assert rc == -1 and b"n_seg" in L.cslgan_last_error()
+    rc = L.cslgan_lipschitz_term_f32(16, 4, 8, 0, 1.0, 16, 16, None, None, None)
+    assert rc == -1 and b"null" in L.cslgan_last_error()
+    rc = L.cslgan_grad_log_stats_f32(16, 9, 128, 64, 128, 16, 1, 1e-6, 16, 16, 16, 16, 16, None)
+    assert rc == -1 and b"outside a row" in L.cslgan_last_error()
     d2 = _lib.ConvT(6, 32, 32, 64, 128, 5, 5, 2, 2, 0, 16, 16)
     first = (ctypes.c_int32 * 2)(0, 0)
     ptrs = (ctypes.c_void_p * 2)(None, None)

@@ -106,6 +106,10 @@ def test_mean_sampler_sample_and_cost():
     assert eps > 0 and alpha > 1
     ms1 = MeanSampler(noise_std=0.24, num_samples=4, mean_size=1000, dataset_size=180000, n_classes=2, smallest_class_size=70000)
     assert ms1.get_privacy_cost(1e-6)[0] < eps
+    # the device-side draw stream survives a checkpoint (saved inside the engine-state JSON by csl_gan_amd.train)
+    ms._seed, ms._draws = 0x1234ABCD5678, 17
+    ms1.load_state_dict(json.loads(json.dumps(ms.state_dict())))
+    assert (ms1._seed, ms1._draws) == (0x1234ABCD5678, 17)
 
 
 def test_state_dict_keys_and_shapes_match_reference_layout():

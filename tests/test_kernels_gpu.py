@@ -876,6 +876,29 @@ def test_mean_sample_gather_jitter_noise():
     # one class: labels may be omitted
     one = ops.mean_sample(ms.mean_samples[:1].contiguous(), None, perms, 0.0, 0.0, seed=1, offset=1)
     assert torch.equal(one, ms.mean_samples[0, perms])
+    # in-kernel draws: labels when none are requested (uniform over the classes), new permutations on every call, and the
+    # cat-of-randperms structure (mean_sampler.py:76) for a batch that is not a multiple of num_samples
+    r1, y1 = ms.sample(128, noise_std=0, noise_mean_std=0)
+    r2, y2 = ms.sample(128, noise_std=0, noise_mean_std=0)
+    assert y1.shape == (128,) and int(y1.min()) >= 0 and int(y1.max()) <= 1 and 30 < int(y1.sum()) < 98 and not torch.equal(y1, y2)
+    assert torch.equal(r1, ms.mean_samples[y1, _match_rows(flat, y1, r1)]) and not torch.equal(r1, r2)
+    big = MeanSampler(noise_std=0.12, num_samples=200, mean_size=1000, dataset_size=180000, device="cuda")
+    big.mean_samples = torch.randn(1, 200, 1, 4, 4, generator=g).cuda()
+    rb, yb = big.sample(450, noise_std=0, noise_mean_std=0)
+    assert yb is None
+    idx = _match_rows(big.mean_samples.reshape(1, 200, -1), torch.zeros(450, dtype=torch.long, device="cuda"), rb).tolist()
+    assert sorted(idx[:200]) == list(range(200)) and sorted(idx[200:400]) == list(range(200)) and len(set(idx[400:])) == 50
+    assert idx[:200] != idx[200:400] and idx[:200] != list(range(200))
+
+
+def _match_rows(flat, labels, r):
+    """index of the mean sample each drawn image equals (noise-free draws)."""
+    out = []
+    for i in range(r.shape[0]):
+        m = (flat[labels[i]] == r[i].reshape(1, -1)).all(dim=1).nonzero()
+        assert m.numel() == 1
+        out.append(int(m))
+    return torch.tensor(out, device=r.device)
 
 
 @pytest.mark.parametrize("case", [(6, 32, 32, 64, 128, 5, 2, 2), (9, 16, 16, 128, 64, 3, 1, 1)])

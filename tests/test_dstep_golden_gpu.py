@@ -42,8 +42,9 @@ def _close(got, exp, what, tol=TOL, scale=None, flips=False):
         # One LeakyReLU unit of one sample within fp32 rounding of zero takes the other slope on the device: the handful of gradient
         # entries that unit feeds move by a few 1e-3 while every other entry agrees to ~1e-6 (measured on dstep_celeba128_b4, whose
         # critic evaluates 2e6 units per forward: 4 of 2048 sampled entries of conv1's penalty gradient at 1.5e-3, the remaining
-        # 2044 and every entry of the 64x64 cases <= 3e-6).  Allowed: <= 0.5 % of a tensor's entries, none beyond 5e-3.
-        assert (d > tol * s).mean() <= 5e-3 and err <= 5 * tol * s, "%s: %.4f of the entries beyond %.0e, max rel %.3e" % (
+        # 2044 and every entry of the 64x64 cases <= 3e-6; another box: one of conv2's 128 bias-gradient entries at 1.08e-3).
+        # Allowed: <= 0.5 % of a tensor's entries (at least two), none beyond 5e-3.
+        assert (d > tol * s).sum() <= max(2, 5e-3 * d.size) and err <= 5 * tol * s, "%s: %.4f of the entries beyond %.0e, max rel %.3e" % (
             what, (d > tol * s).mean(), tol, err / s)
         return
     assert err <= tol * s, "%s: max abs err %.3e at scale %.3e (rel %.3e)" % (what, err, s, err / s)

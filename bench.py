@@ -196,9 +196,17 @@ def main():
     torch.cuda.synchronize()
     probe = ops.LaunchTimer()
     ops.set_launch_timer(probe)
+    # the per-kernel tables are ISOLATED measurements: the step's second stream (gradient-penalty branch beside the critic pass) is
+    # switched off for these steps only — with it, concurrent kernels share the CUs and each one's event time is stretched
+    gp_stream_env = os.environ.get("CSLGAN_GP_STREAM")
+    os.environ["CSLGAN_GP_STREAM"] = "0"
     for _ in range(n_probe):
         step()
     torch.cuda.synchronize()
+    if gp_stream_env is None:
+        del os.environ["CSLGAN_GP_STREAM"]
+    else:
+        os.environ["CSLGAN_GP_STREAM"] = gp_stream_env
     ops.set_launch_timer(None)
     pk = {k: v for k, v in probe.summary(by_kernel=True).items() if v["exec_flop"] > 0}
     dom_name = max(pk.values(), key=lambda k: k["ms"])["name"] if pk else None
@@ -334,7 +342,8 @@ def main():
         "roofline_hbm": roof_hbm,
         "secondary": loop,
         "variants": variant,
-        "tables_from": "%d launch-by-launch instrumented warm-up step(s); roofline from the eagerly launched timed region" % n_pr,
+        "tables_from": "%d launch-by-launch instrumented warm-up step(s) run on ONE stream (isolated kernel times); roofline from the "
+                       "eagerly launched timed region; both timed regions run the step's two streams" % n_pr,
         "entries_ms_per_step": {k: round(v["ms"] / n_pr, 3) for k, v in sorted(entries.items(), key=lambda kv: -kv[1]["ms"])},
         "kernels_ms_per_step": {k: {"ms": round(v["ms"] / n_pr, 3), "n": v["n"] / n_pr,
                                     "tflops": round(v["exec_flop"] / (v["ms"] * 1e-3) / 1e12, 1) if v["exec_flop"] else None,

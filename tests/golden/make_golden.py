@@ -279,7 +279,8 @@ def _put_grads(out, key, tensors, scale=None):
         out["%s_s%d" % (key, i)] = f[torch.from_numpy(sample_idx(f.numel()))].float().numpy()
 
 
-def dstep_case(name, dataset, model, im_size, B, seed, latent=128, penalty=True, geometry=None, adaptive_scalar=1.5, **kw):
+def dstep_case(name, dataset, model, im_size, B, seed, latent=128, penalty=True, geometry=None, adaptive_scalar=1.5,
+               private_penalty=False, **kw):
     sys.path.insert(0, HERE)
     from dstep_inputs import checksums, dstep_inputs
     if geometry is None:
@@ -400,6 +401,28 @@ def dstep_case(name, dataset, model, im_size, B, seed, latent=128, penalty=True,
         sg_scale = [a + B * g_.abs().max().item() for a, g_ in zip(tscale, pg)]
         _put_grads(out, "summed_grad_pl", [s_ + g_.double() * B for s_, g_ in zip(sum_pl, pg)], sg_scale)          # train.py:431
         _put_grads(out, "summed_grad_flat", [s_ + g_.double() * B for s_, g_ in zip(sum_flat, pg)], sg_scale)
+        # ---- the penalty evaluated on the PRIVATE batch per sample (train.py:433-450): the reference's own loop — one
+        # autograd.grad(penalties[i], D.parameters()) per sample — with penalties from its calc_penalty(per_sample=True); each
+        # gradient is added to p.grad_sample[0, i] (pass 0, as written there) and the batch is clipped again.  In split mode pass 0
+        # is never clipped and the private pass's norms are unchanged, so the second clip's sum is the first one + sum_i grad_i.
+        if private_penalty:
+            torch.rand = lambda *a, **k: inp["alpha"].view(B, 1).clone()
+            try:
+                pens = ref_gp.calc_penalty(D, ["WGAN-GP"], inp["img"], inp["labels"], fake, inp["y"], device="cpu", per_sample=True,
+                                           aux_penalty=True)
+            finally:
+                torch.rand = real_rand
+            tot = [torch.zeros_like(p, dtype=torch.float64) for p in params]
+            tot_abs = [torch.zeros_like(p, dtype=torch.float64) for p in params]
+            for i in range(B):
+                gi = torch.autograd.grad(pens[i], params, retain_graph=True, allow_unused=True)
+                for t_, ta_, g_ in zip(tot, tot_abs, gi):
+                    if g_ is not None:
+                        t_ += g_.double()
+                        ta_ += g_.double().abs()
+            out.update(private_penalties=pens.detach().numpy(), private_penalty_mean=np.float64(pens.mean().item()))
+            pscale = [a + t_.max().item() for a, t_ in zip(tscale, tot_abs)]
+            _put_grads(out, "sum_flat_split_private_pen", [s_ + t_ for s_, t_ in zip(sum_flat, tot)], pscale)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, "L=%d" % L, "layer-norm means (real pass)", np.round(n_real.mean(dim=1).numpy(), 3), "c_flat", c_flat,
           "clipped frac flat %.2f pl %.2f" % ((f_flat < 0.999).double().mean().item(), (f_pl < 0.999).double().mean().item()),
@@ -572,12 +595,12 @@ if __name__ == "__main__":
     run.model_case("model_mnist_vanilla_cond_b8", "MNIST", "Vanilla", 28, 8, seed=28, latent=100, conditional=True, n_classes=10,
                    aux_loss_type="cross_entropy")
     # D-step observables through the reference's classes
-    run.dstep_case("dstep_celeba64_b8", "CelebA", "DeepConvResNet", 64, 8, seed=41)                               # configs[2] geometry
+    run.dstep_case("dstep_celeba64_b8", "CelebA", "DeepConvResNet", 64, 8, seed=41, private_penalty=True)         # configs[2] geometry
     run.dstep_case("dstep_celeba64_cond_acgan_b8", "CelebA", "DeepConvResNet", 64, 8, seed=42, conditional=True, n_classes=2)
     run.dstep_case("dstep_mnist_vanilla_cond_b16", "MNIST", "Vanilla", 28, 16, seed=43, latent=100, penalty=False,     # configs[1]
                    adaptive_scalar=1.0, conditional=True, n_classes=10, aux_loss_type="cross_entropy")
     run.dstep_case("dstep_mnist_vanilla_b16", "MNIST", "Vanilla", 28, 16, seed=44, latent=100, penalty=False, adaptive_scalar=1.0)
-    run.dstep_case("dstep_mnist_dcrn_b6", "MNIST", "DeepConvResNet", 28, 6, seed=45, latent=16)
+    run.dstep_case("dstep_mnist_dcrn_b6", "MNIST", "DeepConvResNet", 28, 6, seed=45, latent=16, private_penalty=True)
     run.dstep_case("dstep_celeba128_b4", "CelebA", "DeepConvResNet", 128, 4, seed=46,                               # configs[4] geometry
                    geometry=dict(g_channels=(512, 512, 256, 128, 64, 64), first=4, d_channels=(3, 64, 128, 256, 512), last=8))
     if want("survey_probe"):

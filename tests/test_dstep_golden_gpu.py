@@ -187,3 +187,20 @@ def test_survey_probe_vector_on_hip(tmp_path, golden_dir):
     _close(out, z["d_real"], "D(x)")
     _close(n, z["layer_norms"], "probe per-sample norms")
     assert np.abs(n.mean(dim=1).cpu().numpy() - z["survey_quote"]).max() < 2e-3
+
+
+@pytest.mark.parametrize("name", ["dstep_celeba64_b8", "dstep_mnist_dcrn_b6"])
+def test_train_D_private_penalty_matches_reference_loop(tmp_path, golden_dir, name):
+    """--penalty_use_public_data False (train.py:433-450) against vectors from the reference's own per-sample loop
+    (make_golden.dstep_case, private_penalty): the device's ONE second-order sweep with per-sample weight-gradient kernels must give
+    the sum the reference's B separate autograd calls give."""
+    z, inp = load_case(golden_dir, name)
+    opt, tr = _trainer(tmp_path, name, z, ["-c", repr(float(z["c_flat"])), "--penalty_use_public_data", "False", "-nms", "0"], "all")
+    assert opt.materialize == "all"
+    tr.explicit = dict(alpha=inp["alpha"], keep=True)
+    tr.train_D(inp["img"].cuda(), None, inp["z"].cuda(), None, use_dp=True)
+    torch.cuda.synchronize()
+    last = tr.last
+    assert abs(last["penalty"].item() - float(z["private_penalty_mean"])) <= TOL * float(z["private_penalty_mean"])
+    _check_grads(z, "sum_flat_split", last["summed_clipped"], "first clip")
+    _check_grads(z, "sum_flat_split_private_pen", last["summed_clipped_with_penalty"], "second clip with the per-sample penalty gradients")

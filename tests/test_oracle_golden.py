@@ -263,3 +263,16 @@ def test_survey_probe_vector(golden_dir):
     n = torch.stack([g.reshape(16, -1).double().norm(2, dim=1) for g in gs]).numpy()
     _rel_close(n, z["layer_norms"], "probe per-sample norms", tol=2e-6)
     assert np.abs(n.mean(axis=1) - z["survey_quote"]).max() < 1.5e-3
+
+
+@pytest.mark.parametrize("name", ["dstep_celeba64_b8", "dstep_mnist_dcrn_b6"])
+def test_per_sample_private_penalty_matches_reference_loop(golden_dir, name):
+    """train.py:433-450 (--penalty_use_public_data False): vectors from the reference's own loop — calc_penalty(per_sample=True) and
+    one autograd.grad per sample on the reference's D — against the oracle's restatement of that branch."""
+    z, inp = load_case(golden_dir, name)
+    oracle, D = _oracle_for(name, z, grad_clip_mode="standard", grad_clip_split=True, clipping_param=float(z["c_flat"]))
+    oracle.cfg.penalty_use_public_data = False
+    obs = oracle.step(inp["img"], inp["labels"], inp["z"], inp["y"], alpha=inp["alpha"], apply_update=False)
+    assert obs["penalty"] == pytest.approx(float(z["private_penalty_mean"]), rel=1e-5)
+    _check_grads(z, "sum_flat_split", obs["summed_clipped"], "first clip", 2e-6)
+    _check_grads(z, "sum_flat_split_private_pen", obs["summed_clipped_with_penalty"], "second clip, penalty gradients in p.grad_sample[0]", 1e-5)

@@ -400,6 +400,8 @@ class PrivacyEngine(PerSampleSink):
         self._dense = {}
         self._ghost = {}                        # id(weight) -> {pass: (gz, x, R, S, stride, pad, scale)} awaiting clip()
         self.use_side_stream = os.environ.get("CSLGAN_SIDE_STREAM", "0") == "1"
+        self._clip_two_streams = os.environ.get("CSLGAN_CLIP_STREAM", "1") == "1"
+        self._clip_side = None
         self._side, self._side_dirty = None, False
         self.module = module
         self.batch_size, self.sample_size = batch_size, sample_size
@@ -600,34 +602,49 @@ class PrivacyEngine(PerSampleSink):
         else:
             f_mat = f[self._index_tensor(mat_idx, f.device)].contiguous() if per_layer else f
             ops.clip_accum_noise(mats, [outs[i] for i in mat_idx], factors=f_mat)
-            for i, p in enumerate(ps):       # ghost layers: sum_b f_b g_b as one clip-weighted dense wgrad per pass
+            # ghost layers: sum_b f_b g_b as one clip-weighted dense wgrad per pass.  The layers' launches are independent and each
+            # under-fills the chip (128 - 640 workgroups): every second one goes to a second stream (CSLGAN_CLIP_STREAM=0: off)
+            ghosts = [i for i, p in enumerate(ps) if self._ghost.get(id(p)) is not None]
+            two = self._clip_two_streams and len(ghosts) > 1
+            cur = torch.cuda.current_stream()
+            if two:
+                if self._clip_side is None:
+                    self._clip_side = torch.cuda.Stream(device=ps[0].device)
+                self._clip_side.wait_stream(cur)
+            for n_g, i in enumerate(ghosts):
+                p = ps[i]
                 stash = self._ghost.get(id(p))
-                if stash is None:
-                    continue
-                fi = (f[i] if per_layer else f).reshape(n_pass, B)
-                total = None
-                single = len(stash) == 1            # one clipped pass: the weighted sum is written straight into summed_grad
-                for k, (gz, x, R, S, stride, pad, scale, joint) in sorted(stash.items()):
-                    dst = outs[i] if single else None
-                    if joint is None:
-                        part = _dense_wgrad(gz, x, R, S, stride, pad, scale, row_scale=fi[k].contiguous(), out=dst)
-                    else:
-                        gzj, xj, n_d, scale_d = joint
-                        # row weights of the joint launch: [scale_d] * n_d (never-clipped rows; a constant prefix kept across
-                        # steps) followed by f_b * scale — one launch per step instead of fill + mul + cat
-                        key = ("rs", id(p), n_d, float(scale_d), B, str(f.device))
-                        rs = self._idx_cache.get(key)
-                        if rs is None:
-                            rs = self._idx_cache[key] = torch.full((n_d + B,), float(scale_d), device=f.device, dtype=torch.float32)
-                        torch.mul(fi[k], float(scale), out=rs[n_d:])
-                        part = _dense_wgrad(gzj, xj, R, S, stride, pad, 1.0, row_scale=rs, out=dst)
-                    total = part if total is None else total.add_(part)
-                if not single:
-                    outs[i].copy_(total)
+                with torch.cuda.stream(self._clip_side if (two and n_g % 2 == 1) else cur):
+                    self._clip_ghost_layer(i, p, stash, f, per_layer, n_pass, B, outs)
+            if two:
+                cur.wait_stream(self._clip_side)
         if self._dense:       # sums of the never-clipped passes (lean modes)
             idx = [i for i, p in enumerate(ps) if id(p) in self._dense]
             ops.clip_accum_noise([self._dense[id(ps[i])].view(1, -1) for i in idx], [outs[i] for i in idx], beta=1.0)
         self._accumulated = False
+
+    def _clip_ghost_layer(self, i, p, stash, f, per_layer, n_pass, B, outs):
+        """One ghost layer of clip(): sum_b f_b g_b as clip-weighted dense weight gradient(s) into outs[i]."""
+        fi = (f[i] if per_layer else f).reshape(n_pass, B)
+        total = None
+        single = len(stash) == 1            # one clipped pass: the weighted sum is written straight into summed_grad
+        for k, (gz, x, R, S, stride, pad, scale, joint) in sorted(stash.items()):
+            dst = outs[i] if single else None
+            if joint is None:
+                part = _dense_wgrad(gz, x, R, S, stride, pad, scale, row_scale=fi[k].contiguous(), out=dst)
+            else:
+                gzj, xj, n_d, scale_d = joint
+                # row weights of the joint launch: [scale_d] * n_d (never-clipped rows; a constant prefix kept across
+                # steps) followed by f_b * scale — one launch per step instead of fill + mul + cat
+                key = ("rs", id(p), n_d, float(scale_d), B, str(f.device))
+                rs = self._idx_cache.get(key)
+                if rs is None:
+                    rs = self._idx_cache[key] = torch.full((n_d + B,), float(scale_d), device=f.device, dtype=torch.float32)
+                torch.mul(fi[k], float(scale), out=rs[n_d:])
+                part = _dense_wgrad(gzj, xj, R, S, stride, pad, 1.0, row_scale=rs, out=dst)
+            total = part if total is None else total.add_(part)
+        if not single:
+            outs[i].copy_(total)
 
     def _index_tensor(self, idx, device):
         """Device copy of a small index list, uploaded once (a host->device copy per step is also not graph-capturable)."""

@@ -272,12 +272,15 @@ def main():
     dom = timed.get(dom_name) if dom_name else None
     roof = None
     if dom:
-        traffic = None
-        try:        # fabric bytes per launch of that kernel from the committed rocprofv3 PMC passes (scripts/collect_profiles.sh)
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        traffic, traffic_src = None, None
+        try:        # fabric bytes per launch of that kernel from the newest committed rocprofv3 PMC passes (scripts/collect_profiles.sh)
+            import glob
+            src = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+            with open(src) as f:
                 pk = {k.replace(" ", ""): v for k, v in json.load(f)["per_kernel"].items()}
             v = pk.get(dom["name"].replace(" ", ""))
             traffic = None if v is None else round((v["fetch_MB_per_launch"] + v["write_MB_per_launch"]) * 1e6)
+            traffic_src = "profiles/" + os.path.basename(src) + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"
         except Exception:
             traffic = None
         # a bf16x3 kernel issues SIX bf16 MFMAs per logical fp32 multiply-add step: its executed matrix FLOP are 6x the logical
@@ -286,7 +289,7 @@ def main():
         peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom["name"] else PEAK_FP32_MFMA_TFLOPS
         worst = sorted((v for k, v in timed_shapes.items() if k.startswith(dom["name"])), key=lambda v: -v["ms"])
         roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic,
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_from": traffic_src,
                 "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]),
                 "flop_per_launch_executed": round(mfma_mult * dom["exec_flop"] / dom["n"]),
                 "logical_fp32_tflops": round(dom["exec_flop"] / (dom["ms"] * 1e-3) / 1e12, 2),

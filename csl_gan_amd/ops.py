@@ -779,9 +779,19 @@ def _d2s_out(x, d2s, want_raw):
 _norm_scratch = {}
 
 
+_NORM_FUSED = os.environ.get("CSLGAN_NORM_FUSED", "0") == "1"
+
+
 def _scratch(dev, n_floats):
-    """Persistent zeroed accumulator of the normalisation statistics (+ the ticket word): the kernels leave it zeroed, so it is
+    """None unless CSLGAN_NORM_FUSED=1 (A/B switch).  Measured on MI355X: finishing the statistics in the stats kernel's last
+    workgroup needs a device-scope release fence in EVERY workgroup, and with one L2 per XCD that fence writes the XCD's L2 back —
+    the 64x64 layer's stats kernel went 30 -> 146 us (0.47 ms per step lost against two 4-us launches saved per layer).  The
+    default is therefore the three-launch form: memset, stats (atomics), finalize.
+
+    Persistent zeroed accumulator of the normalisation statistics (+ the ticket word): the kernels leave it zeroed, so it is
     filled once per device (and again only when a larger one is needed).  Launches are ordered on torch's current stream."""
+    if not _NORM_FUSED:
+        return None
     key = (dev, torch.cuda.current_stream().cuda_stream)
     t = _norm_scratch.get(key)
     if t is None or t.numel() < n_floats + 1:
@@ -796,10 +806,9 @@ def groupnorm_act(x, gamma, beta, groups, eps=1e-5, relu=True, return_stats=Fals
     N, H, W, Cc = x.shape
     y, xs, dW = _d2s_out(x, d2s, want_raw)
     ws = torch.empty(2 * N * groups, device=x.device, dtype=torch.float32)
-    sc = _scratch(x.device, 2 * N * groups)
+    sc = _scratch(x.device, 2 * N * groups + N)
     check(_lib.lib().cslgan_groupnorm_act_f32(_p(x), _p(gamma), _p(beta), N, H * W, Cc, groups, float(eps), 1 if relu else 0,
-                                              _p(ws), _p(y), dW, _p(xs), C.c_void_p(sc.data_ptr() + 4 * (sc.numel() - 1 - 2 * N * groups)),
-                                              _stream()), "groupnorm_act")
+                                              _p(ws), _p(y), dW, _p(xs), _p(sc), _stream()), "groupnorm_act")
     out = (y, xs) if want_raw else y
     return (out, ws) if return_stats else out
 
@@ -819,8 +828,7 @@ def batchnorm_act(x, gamma, beta, running_mean=None, running_var=None, momentum=
     ws = torch.empty(2 * Cc, device=x.device, dtype=torch.float32)
     check(_lib.lib().cslgan_batchnorm_act_f32(_p(x), _p(gamma), _p(beta), rows, Cc, float(eps), 1 if relu else 0, float(momentum),
                                               _p(running_mean), _p(running_var), _p(ws), _p(y), rpi, dW, _p(xs),
-                                              C.c_void_p(_scratch(x.device, 2 * Cc).data_ptr() + 4 * (_scratch(x.device, 2 * Cc).numel() - 1 - 2 * Cc)),
-                                              _stream()), "batchnorm_act")
+                                              _p(_scratch(x.device, 2 * Cc + 1)), _stream()), "batchnorm_act")
     out = (y, xs) if want_raw else y
     return (out, ws) if return_stats else out
 

@@ -251,8 +251,8 @@ int cslgan_fold_channels4_f32(const float* in, int64_t rows, int C, int unfold, 
  * y[n][2h+i][2w+j][c'] = act(norm(x))[n][h][w][4c'+2i+j] (C % 4 == 0); x_shuffled (nullable) receives the raw x in the
  * same layout — the inputs of ResBlockUp's convUp and shortcut (DCResNet_models.py:29-34) from one read of x.
  * d2s_W == 0: y has x's layout and x_shuffled must be NULL.
- * scratch (nullable): persistent device buffer of 2*N*groups floats + one uint32, zero-initialised by the caller ONCE; the
- * statistics are then accumulated there and finalised by the kernel's last workgroup, which leaves it zeroed (no memset, no
+ * scratch (nullable): persistent device buffer of 2*N*groups floats + N uint32 tickets, zero-initialised by the caller ONCE; the
+ * statistics are then accumulated there and finalised by the last workgroup of each image, which leaves it zeroed (no memset, no
  * finalize launch).  One scratch must not be shared by launches on different streams. */
 int cslgan_groupnorm_act_f32(const float* x, const float* gamma, const float* beta, int N, int HW, int C,
                              int groups, float eps, int relu, float* stats_ws, float* y, int d2s_W, float* x_shuffled,
@@ -265,7 +265,7 @@ int cslgan_groupnorm_act_f32(const float* x, const float* gamma, const float* be
  * = H*W is only read when d2s_W > 0). */
 int cslgan_batchnorm_act_f32(const float* x, const float* gamma, const float* beta, int64_t rows, int C, float eps,
                              int relu, float momentum, float* running_mean, float* running_var, float* stats_ws,
-                             float* y, int64_t rows_per_image, int d2s_W, float* x_shuffled, float* scratch /* as above, 2*C + 1 */,
+                             float* y, int64_t rows_per_image, int d2s_W, float* x_shuffled, float* scratch /* as above, 2*C floats + 1 ticket */,
                              void* stream);
 
 /* Eval-mode BatchNorm2d (+ optional ReLU): y = act((x - running_mean) / sqrt(running_var + eps) * gamma + beta) — the

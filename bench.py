@@ -197,16 +197,17 @@ def main():
     probe = ops.LaunchTimer()
     ops.set_launch_timer(probe)
     # the per-kernel tables are ISOLATED measurements: the step's second stream (gradient-penalty branch beside the critic pass) is
-    # switched off for these steps only — with it, concurrent kernels share the CUs and each one's event time is stretched
-    gp_stream_env = os.environ.get("CSLGAN_GP_STREAM")
-    os.environ["CSLGAN_GP_STREAM"] = "0"
+    # and the clip phase's second stream are switched off for these steps only — with them, concurrent kernels share the CUs and each one's event time is stretched
+    saved_env = {k: os.environ.get(k) for k in ("CSLGAN_GP_STREAM", "CSLGAN_CLIP_STREAM")}
+    os.environ.update({k: "0" for k in saved_env})
     for _ in range(n_probe):
         step()
     torch.cuda.synchronize()
-    if gp_stream_env is None:
-        del os.environ["CSLGAN_GP_STREAM"]
-    else:
-        os.environ["CSLGAN_GP_STREAM"] = gp_stream_env
+    for k, v in saved_env.items():
+        if v is None:
+            del os.environ[k]
+        else:
+            os.environ[k] = v
     ops.set_launch_timer(None)
     pk = {k: v for k, v in probe.summary(by_kernel=True).items() if v["exec_flop"] > 0}
     dom_name = max(pk.values(), key=lambda k: k["ms"])["name"] if pk else None

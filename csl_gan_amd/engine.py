@@ -400,7 +400,6 @@ class PrivacyEngine(PerSampleSink):
         self._dense = {}
         self._ghost = {}                        # id(weight) -> {pass: (gz, x, R, S, stride, pad, scale)} awaiting clip()
         self.use_side_stream = os.environ.get("CSLGAN_SIDE_STREAM", "0") == "1"
-        self._clip_two_streams = os.environ.get("CSLGAN_CLIP_STREAM", "1") == "1"
         self._clip_side = None
         self._side, self._side_dirty = None, False
         self.module = module
@@ -605,7 +604,7 @@ class PrivacyEngine(PerSampleSink):
             # ghost layers: sum_b f_b g_b as one clip-weighted dense wgrad per pass.  The layers' launches are independent and each
             # under-fills the chip (128 - 640 workgroups): every second one goes to a second stream (CSLGAN_CLIP_STREAM=0: off)
             ghosts = [i for i, p in enumerate(ps) if self._ghost.get(id(p)) is not None]
-            two = self._clip_two_streams and len(ghosts) > 1
+            two = os.environ.get("CSLGAN_CLIP_STREAM", "1") == "1" and len(ghosts) > 1
             cur = torch.cuda.current_stream()
             if two:
                 if self._clip_side is None:

@@ -240,14 +240,32 @@ def main():
         # the launches where they are faster, csl_gan_amd/ops.py:_kc_compute) — reported beside the headline, never as it
         saved_explicit, tr.explicit = tr.explicit, {}            # the eager step draws its own mean-sample batches
         ops.set_compute_dtype("fp32_auto")
+        ops.repack_cache.clear()
         for _ in range(2):
             step()
         dv = time_region(step, a.steps)
+        dvg = None
+        if launch_mode == "hip_graph":
+            try:
+                from csl_gan_amd.trainer import GraphedDStep
+                gs2 = GraphedDStep(tr, warmup=1)
+                for _ in range(3):
+                    gs2(img, None)
+                dvg = time_region(lambda: gs2(img, None), a.steps)
+            except Exception:
+                dvg = None
+            finally:
+                try:
+                    gs2.release()
+                except NameError:
+                    pass
         ops.set_compute_dtype(getattr(opt, "compute_dtype", "fp32"))
         tr.explicit = saved_explicit
         ops.repack_cache.clear()
-        variant["fp32_auto"] = {"value": round(world * B * a.steps / dv, 2), "unit": "images/sec", "ms_per_step": round(dv / a.steps * 1e3, 3),
-                                "what": "--compute_dtype fp32_auto, launched eagerly: large forward / data-gradient launches run fp32 emulated "
+        best = dv if dvg is None else min(dv, dvg)
+        variant["fp32_auto"] = {"value": round(world * B * a.steps / best, 2), "unit": "images/sec", "ms_per_step": round(best / a.steps * 1e3, 3),
+                                "ms_per_step_eager": round(dv / a.steps * 1e3, 3), "ms_per_step_hip_graph": None if dvg is None else round(dvg / a.steps * 1e3, 3),
+                                "what": "--compute_dtype fp32_auto: large forward / data-gradient launches run fp32 emulated "
                                         "from three bfloat16 pieces per operand (six bf16 MFMAs per product step; error vs fp64 <= the "
                                         "exact-fp32 kernels', tests/test_kernels_gpu.py::test_bf16x3_*), everything else the exact fp32 MFMA kernels"}
     # secondary metric: the full train() loop, a G step forced on every n_d_steps-th iteration

@@ -6,6 +6,13 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+def _case_seed(case):
+    """Deterministic per-case seed (crc32 of the case's repr): a red case can be replayed — hash() of a tuple holding None is
+    address-based on Python 3.10 and differs between processes."""
+    import zlib
+    return zlib.crc32(repr(case).encode()) % 100000
+
+
 pytestmark = pytest.mark.gpu
 
 
@@ -97,7 +104,7 @@ FWD_CASES = [
 def test_conv2d_fwd(case):
     ops = _ops()
     N, H, W, C, K, R, s, p, has_b, act, ups, res = case
-    g = torch.Generator().manual_seed(hash(case) % 10000)
+    g = torch.Generator().manual_seed(_case_seed(case))
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
     b = torch.randn(K, generator=g) if has_b else None
@@ -174,7 +181,7 @@ DGRAD_CASES = [
 def test_conv2d_dgrad(case):
     ops = _ops()
     N, H, W, C, K, R, s, p, use_mask = case
-    g = torch.Generator().manual_seed(hash(case) % 10000)
+    g = torch.Generator().manual_seed(_case_seed(case))
     x = torch.randn(N, C, H, W, generator=g, requires_grad=True)
     w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
     y = F.conv2d(x, w, None, stride=s, padding=p)
@@ -222,7 +229,7 @@ def test_conv2d_wgrad_grouped(case, group):
     ops = _ops()
     N, H, W, C, K, R, s, p = case
     group = N if group == 0 else group
-    g = torch.Generator().manual_seed(hash(case) % 10000)
+    g = torch.Generator().manual_seed(_case_seed(case))
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.zeros(K, C, R, R, requires_grad=True)
     alpha = 1.7
@@ -630,7 +637,7 @@ def test_conv2d_fwd_bf16(case):
     order differs: 1e-4 of scale), and against the unrounded fp32 conv at the bf16 tolerance 2e-2 of scale."""
     ops = _ops()
     N, H, W, C, K, R, s, p, has_b, act, ups, res = case
-    g = torch.Generator().manual_seed(hash(case) % 10000)
+    g = torch.Generator().manual_seed(_case_seed(case))
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
     b = torch.randn(K, generator=g) if has_b else None
@@ -788,7 +795,7 @@ def test_conv2d_fwd_bf16x3(case):
     the same fp32 torch reference at the same tolerance as the exact-fp32 kernels."""
     ops = _ops()
     N, H, W, C, K, R, s, p, has_b, act, ups, res = case
-    g = torch.Generator().manual_seed(hash(case) % 10000)
+    g = torch.Generator().manual_seed(_case_seed(case))
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
     b = torch.randn(K, generator=g) if has_b else None

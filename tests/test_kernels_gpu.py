@@ -933,3 +933,83 @@ def test_wgrad_row_blocks_in_one_launch(case):
             _close(sq, rsq, rtol=1e-6, what="block %d sq" % i)
     with pytest.raises(RuntimeError):       # a shape the LDS-resident kernel does not take
         ops.conv2d_wgrad_blocks(gy[:, :, :, :3].contiguous(), x, R, R, s, p, 1.0, [(N, None, torch.zeros(N, device="cuda"))])
+
+
+# ---- round 3: the fused glue kernels of csrc/step_kernels.hip against plain torch -----------------------------------------------
+def test_segment_means_forward_backward():
+    """cslgan_segment_means_f32 (+ _bwd) = the critic's -mean / +mean losses over row blocks and their sum (DCResNet_models.py:149-153)."""
+    from csl_gan_amd import functional as HF
+    g = torch.Generator().manual_seed(1)
+    sizes, signs = [128, 128, 100], [-1.0, 1.0, -1.0]
+    x = torch.randn(sum(sizes), 1, generator=g)
+    xr = x.clone().requires_grad_(True)
+    parts = torch.split(xr, sizes)
+    ref_vec = torch.stack([s * p.mean() for s, p in zip(signs, parts)])
+    (ref_vec.sum() + 0.5 * ref_vec[1]).backward()
+    xd = x.cuda().requires_grad_(True)
+    vec, total = HF.SegmentMeans.apply(xd, sizes, [s / n for s, n in zip(signs, sizes)])
+    (total + 0.5 * vec[1]).backward()
+    assert torch.allclose(vec.detach().cpu(), ref_vec.detach(), rtol=1e-5, atol=1e-7)
+    assert torch.allclose(total.detach().cpu(), ref_vec.detach().sum(), rtol=1e-5, atol=1e-7)
+    assert torch.allclose(xd.grad.cpu(), xr.grad, rtol=1e-6, atol=1e-9)
+
+
+def test_dstep_and_grad_log_statistics():
+    """cslgan_dstep_stats_f32 = train.py:488-496; cslgan_grad_log_stats_f32 = train.py:310-329 (per layer and flat); both ADD to their sums."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    d_real, d_fake = torch.randn(96, 1, generator=g), torch.randn(128, 1, generator=g)
+    rl, fl, pen = torch.tensor(-0.3), torch.tensor(0.7), torch.tensor(9.5)
+    acc = torch.full((7,), 1.0).cuda()
+    ops.dstep_stats(d_real.cuda(), d_fake.cuda(), rl.cuda(), fl.cuda(), pen.cuda(), acc)
+    want = 1.0 + torch.tensor([0.4, 0.4, -0.3, 0.7, 100 * (d_real > 0).float().mean(), 100 * (d_fake < 0).float().mean(), 9.5])
+    assert torch.allclose(acc.cpu(), want, rtol=1e-5)
+    L, B = 9, 128
+    sq = (torch.rand(L, 3 * B, generator=g) * 4).pow(2)
+    sq[1] = (1.0 + 1e-4 * torch.rand(3 * B, generator=g)).pow(2)           # nearly equal norms: the std must not cancel away
+    C = torch.rand(L, generator=g) * 2 + 0.5
+    n = sq[:, 2 * B:].sqrt()
+    for per_layer in (True, False):
+        nn_ = n if per_layer else sq[:, 2 * B:].sum(dim=0, keepdim=True).sqrt()
+        cc = C if per_layer else C[:1]
+        rows = L if per_layer else 1
+        acc = torch.zeros(5, rows).cuda()
+        for _ in range(2):
+            ops.grad_log_stats(sq.cuda(), 2 * B, B, cc.cuda().contiguous(), per_layer, 1e-6, acc)
+        f = (cc.view(-1, 1) / (nn_ + 1e-6)).clamp(max=1.0)
+        want = 2 * torch.stack([nn_.mean(1), nn_.std(1, unbiased=False), nn_.max(1).values, cc, (f < 0.999).float().mean(1)])
+        got = acc.cpu()
+        assert torch.allclose(got[[0, 2, 3, 4]], want[[0, 2, 3, 4]], rtol=1e-5, atol=1e-7), per_layer
+        assert torch.allclose(got[1], want[1], rtol=2e-3, atol=1e-7), (per_layer, got[1], want[1])
+
+
+@pytest.mark.parametrize("one_sided,per_sample", [(False, False), (True, False), (False, True), (True, True)])
+def test_lipschitz_term_and_lerp(one_sided, per_sample):
+    """cslgan_lerp_rows_f32 = gradient_penalty.py:36; cslgan_lipschitz_term_f32 (+ _bwd) = :52-54 with the weight and batch mean."""
+    from csl_gan_amd import functional as HF
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    B, shape = 24, (3, 16, 16)
+    real, fake, alpha = torch.randn((B,) + shape, generator=g), torch.randn((B,) + shape, generator=g), torch.rand(B, generator=g)
+    a4 = alpha.view(B, 1, 1, 1)
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        out = ops.lerp_rows(real.cuda().contiguous(memory_format=fmt), fake.cuda().contiguous(memory_format=fmt), alpha.cuda())
+        assert torch.allclose(out.cpu(), a4 * real + (1 - a4) * fake, rtol=1e-6, atol=1e-7)
+    t = torch.randn(B, 3 * 16 * 16, generator=g) * torch.linspace(0.01, 0.12, B).view(B, 1)          # norms on both sides of 1
+    coef = 10.0 if per_sample else 10.0 / B
+    tr_ = t.clone().requires_grad_(True)
+    d = tr_.norm(2, dim=1) - 1
+    ref = 10.0 * ((d.clamp(min=0) if one_sided else d) ** 2)
+    ref = ref if per_sample else ref.mean()
+    w = torch.linspace(0.5, 1.5, B)
+    ((ref * w).sum() if per_sample else ref * 1.7).backward()
+    td = t.cuda().requires_grad_(True)
+    got = HF.LipschitzTerm.apply(td, one_sided, coef, per_sample)
+    ((got * w.cuda()).sum() if per_sample else got * 1.7).backward()
+    nrm = t.norm(2, dim=1)
+    assert (nrm < 1).any() and (nrm > 1).any()
+    assert torch.allclose(got.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-6)
+    assert torch.allclose(td.grad.cpu(), tr_.grad, rtol=1e-4, atol=1e-7)
+    # twice in a row: the kernel's ticket word is left at zero
+    got2 = HF.LipschitzTerm.apply(td.detach(), one_sided, coef, per_sample)
+    assert torch.allclose(got2.cpu(), got.detach().cpu())

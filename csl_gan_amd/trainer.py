@@ -529,8 +529,18 @@ class Trainer:
         print("WARNING: Per sample penalty currently causes a memory leak.") if getattr(self, "_warn_ps_pen", True) else None
         self._warn_ps_pen = False          # the reference prints this every step (train.py:436); once is enough here
         penalties = calc_penalty(D, o.penalty, pen_real, pen_labels, fake_img, y, per_sample=True, **kw)
-        with HF.per_sample_param_grads(lambda p, rows: pe.add_to_grad_sample(p, rows, 0), list(D.parameters())):
-            autograd.grad(penalties.sum(), list(D.parameters()), create_graph=False, retain_graph=False, allow_unused=True)
+        seen = set()
+
+        def sink(p, rows):
+            seen.add(id(p))
+            pe.add_to_grad_sample(p, rows, 0)
+        with HF.per_sample_param_grads(sink, list(D.parameters())):
+            dense = autograd.grad(penalties.sum(), list(D.parameters()), create_graph=False, retain_graph=False, allow_unused=True)
+        # every weight the penalty depends on must have gone through the per-sample sink (a layer whose filter is not a zero-copy
+        # view of its parameter would have produced a dense gradient instead, which this branch cannot use)
+        stray = [n for (n, p), g in zip(D.named_parameters(), dense) if g is not None and id(p) not in seen]
+        if stray:
+            raise RuntimeError("per-sample penalty: parameters %s received a dense instead of a per-sample gradient" % stray)
         pe.clip(recompute_norms=True)
         pe.accumulate_batch()
         with torch.no_grad():

@@ -34,10 +34,28 @@ class ISPrivacyEngine:
         if any(not p.is_cuda for p in self.params):
             raise RuntimeError("ISPrivacyEngine needs the discriminator on a HIP device")
         self.steps, self.seed, self._noise_calls = 0, 0, 0
-        self.batch_sensitivity = None
         self._sens_dev = None
+        self._sens_last, self._sens_host = None, None
         self.optimizer, self.grad_reducer = None, None
         self.host_noise = None
+
+    @property
+    def batch_sensitivity(self):
+        """float (or ndarray with per_param) as train.py:332-338 reads it.  The value lives on the device; the host copy — a
+        synchronisation — is made only when somebody reads this attribute (the trainer's logging accumulates on the device)."""
+        if self._sens_host is None and self._sens_last is not None:
+            host = self._sens_last.detach().cpu().numpy().astype(np.float64)
+            self._sens_host = host if self.per_param else float(host[0])
+        return self._sens_host
+
+    @batch_sensitivity.setter
+    def batch_sensitivity(self, v):
+        self._sens_host, self._sens_last = v, None
+
+    @property
+    def batch_sensitivity_device(self):
+        """The same values as a device tensor ([n_params] with per_param, else [1]); no synchronisation."""
+        return self._sens_last
 
     # hooks are a gc-mode concept; train.py never calls them in is mode, kept for interface symmetry
     def enable_hooks(self):
@@ -89,8 +107,7 @@ class ISPrivacyEngine:
             from .distributed import average_across_ranks
             average_across_ranks(sens, use_max=True)
         self._sens_dev = sens
-        host = sens.detach().cpu().numpy().astype(np.float64)
-        self.batch_sensitivity = host if self.per_param else float(host[0])
+        self._sens_last, self._sens_host = sens.detach(), None
         for p, g in zip(ps, grads):
             p.grad = None if g is None else g.detach()
 

@@ -244,7 +244,24 @@ class Trainer:
         pe.set_scaling_vec([vec[i] * beta + n * (1 - beta) for i, n in enumerate(norms)])
 
     def update_is_logging(self):
-        s = self.privacy_engine.batch_sensitivity
+        """train.py:332-338 without the per-step host read: the mean accumulates on the device, the running minimum / maximum of
+        the interval too; flush_stats folds them into the Logger with the reference's conventions (values scaled by the logging
+        interval because the Logger divides by it; the non-per-param minimum starts from 99999)."""
+        pe = self.privacy_engine
+        s = getattr(pe, "batch_sensitivity_device", None)
+        if s is None:                      # a foreign engine without the device view: the reference's host arithmetic
+            self._is_log_host(pe.batch_sensitivity)
+            return
+        s = s.detach().reshape(-1)
+        self._acc("IS Mean", s.clone() if self.opt.imm_sens_per_param else s.reshape(()).clone())
+        for key, op in (("_is_min", torch.minimum), ("_is_max", torch.maximum)):
+            cur = self.dev_stats.get(key)
+            if cur is None:
+                self.dev_stats[key] = s.clone()
+            else:
+                op(cur, s, out=cur)
+
+    def _is_log_host(self, s):
         lg = self.logger
         lg.stats["IS Mean"] += s
         scaled = s * lg.interval
@@ -254,6 +271,19 @@ class Trainer:
         else:
             lg.stats["IS Min"] = min(99999 if lg.stats["IS Min"] < 1e-8 else lg.stats["IS Min"], scaled)
             lg.stats["IS Max"] = max(lg.stats["IS Max"], scaled)
+
+    def _flush_is_extrema(self):
+        lg = self.logger
+        mn, mx = self.dev_stats.pop("_is_min", None), self.dev_stats.pop("_is_max", None)
+        if mn is None:
+            return
+        mn, mx = mn.cpu().numpy().astype(np.float64) * lg.interval, mx.cpu().numpy().astype(np.float64) * lg.interval
+        if self.opt.imm_sens_per_param:
+            lg.stats["IS Min"] = mn if isinstance(lg.stats["IS Min"], float) else np.minimum(lg.stats["IS Min"], mn)
+            lg.stats["IS Max"] = np.maximum(lg.stats["IS Max"], mx)
+        else:
+            lg.stats["IS Min"] = min(99999 if lg.stats["IS Min"] < 1e-8 else lg.stats["IS Min"], float(mn[0]))
+            lg.stats["IS Max"] = max(lg.stats["IS Max"], float(mx[0]))
 
     # ---- train.py:345-358 ---------------------------------------------------------------------
     def calc_d_fake_loss(self, img, labels, z, y):
@@ -708,6 +738,8 @@ class Trainer:
         tail of one epoch leaks into the first log line of the next."""
         self.logger.reset_stats()
         self._commit_stats()
+        self.dev_stats.pop("_is_min", None)
+        self.dev_stats.pop("_is_max", None)
         for k, v in self.dev_stats.items():
             if not k.startswith("_"):
                 v.zero_()
@@ -715,6 +747,7 @@ class Trainer:
     def flush_stats(self):
         """Fold device-side sums into the Logger (this is where the host synchronises)."""
         self._commit_stats()
+        self._flush_is_extrema()
         for k, v in list(self.dev_stats.items()):
             if k.startswith("_"):
                 continue

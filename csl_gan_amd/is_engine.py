@@ -36,6 +36,7 @@ class ISPrivacyEngine:
         self.steps, self.seed, self._noise_calls = 0, 0, 0
         self._sens_dev = None
         self._sens_last, self._sens_host = None, None
+        self._noise_ctr = None                  # device mirror of _noise_calls (the Philox call index of a replayed step)
         self.optimizer, self.grad_reducer = None, None
         self.host_noise = None
 
@@ -68,7 +69,18 @@ class ISPrivacyEngine:
         self.scaling_vec = list(vec)
 
     def _set_seed(self, seed):
-        self.seed, self._noise_calls = int(seed), 0
+        self.seed = int(seed)
+        self._set_noise_calls(0)
+
+    def _set_noise_calls(self, n):
+        self._noise_calls = int(n)
+        if self._noise_ctr is not None:
+            self._noise_ctr.fill_(int(n))
+
+    def ensure_noise_counter(self):
+        if self._noise_ctr is None:
+            self._noise_ctr = torch.full((1,), self._noise_calls, device=self.params[0].device, dtype=torch.int64)
+        return self._noise_ctr
 
     def backward(self, loss, inputs):
         """Parameter gradients plus immediate sensitivities (train.py:457)."""
@@ -143,8 +155,11 @@ class ISPrivacyEngine:
         std = (sens * (self.noise_multiplier / (B * R ** 0.5))).contiguous()
         noises = None if self.host_noise is None else [z.to(dev) for z in self.host_noise]
         # out = (g + std*z) / R   — g is already the batch-mean gradient of this rank
+        # Philox stream (seed, call, tensor, column): the call index is read from HBM, so a graph replay advances it too
+        ctr = self.ensure_noise_counter()
         ops.clip_accum_noise(ins, outs, noise_std=std if self.noise_multiplier > 0 else None, noises=noises, seed=self.seed,
-                             offset=self._noise_calls, scale=1.0 / R)
+                             offset=0, call_counter=ctr, scale=1.0 / R)
+        ctr.add_(1)
         if self.grad_reducer is not None:
             self.grad_reducer(flat)
         self._noise_calls += 1
@@ -156,7 +171,8 @@ class ISPrivacyEngine:
                 "noise_multiplier": self.noise_multiplier, "sample_rate": self.sample_rate}
 
     def load_state_dict(self, st):
-        self.steps, self.seed, self._noise_calls = st["steps"], int(st["seed"]), int(st["noise_calls"])
+        self.steps, self.seed = st["steps"], int(st["seed"])
+        self._set_noise_calls(st["noise_calls"])
         self.scaling_vec = st.get("scaling_vec")
 
     def get_privacy_spent(self, target_delta=None):

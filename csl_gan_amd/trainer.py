@@ -100,7 +100,8 @@ class Trainer:
         pe.attach(self.d_optimizer)
         pe._set_seed(o.manual_seed + 7919 * self.rank)
         self.privacy_engine = pe
-        if getattr(o, "hip_graph", False) and o.dp_mode == "gc" and self.world_size == 1 and not o.backprop_clip:
+        if (getattr(o, "hip_graph", False) and self.world_size == 1 and not o.backprop_clip
+                and (o.dp_mode == "gc" or (o.dp_mode == "is" and o.imm_sens_scaling_mode != "moving-avg-pl"))):
             self.graphed = GraphedDStep(self)
         return pe
 
@@ -254,12 +255,13 @@ class Trainer:
             return
         s = s.detach().reshape(-1)
         self._acc("IS Mean", s.clone() if self.opt.imm_sens_per_param else s.reshape(()).clone())
-        for key, op in (("_is_min", torch.minimum), ("_is_max", torch.maximum)):
+        # running extrema of the logging interval in PERSISTENT buffers updated in place (a replayed step keeps updating the same
+        # memory); +-inf marks "nothing seen since the last flush"
+        for key, op, init in (("_is_min", torch.minimum, float("inf")), ("_is_max", torch.maximum, float("-inf"))):
             cur = self.dev_stats.get(key)
-            if cur is None:
-                self.dev_stats[key] = s.clone()
-            else:
-                op(cur, s, out=cur)
+            if cur is None or cur.shape != s.shape:
+                cur = self.dev_stats[key] = torch.full_like(s, init)
+            op(cur, s, out=cur)
 
     def _is_log_host(self, s):
         lg = self.logger
@@ -274,16 +276,21 @@ class Trainer:
 
     def _flush_is_extrema(self):
         lg = self.logger
-        mn, mx = self.dev_stats.pop("_is_min", None), self.dev_stats.pop("_is_max", None)
+        mn, mx = self.dev_stats.get("_is_min"), self.dev_stats.get("_is_max")
         if mn is None:
             return
-        mn, mx = mn.cpu().numpy().astype(np.float64) * lg.interval, mx.cpu().numpy().astype(np.float64) * lg.interval
+        mn_h, mx_h = mn.cpu().numpy().astype(np.float64), mx.cpu().numpy().astype(np.float64)
+        mn.fill_(float("inf"))
+        mx.fill_(float("-inf"))
+        if not np.isfinite(mn_h).all():          # no immediate-sensitivity step since the last flush
+            return
+        mn_h, mx_h = mn_h * lg.interval, mx_h * lg.interval
         if self.opt.imm_sens_per_param:
-            lg.stats["IS Min"] = mn if isinstance(lg.stats["IS Min"], float) else np.minimum(lg.stats["IS Min"], mn)
-            lg.stats["IS Max"] = np.maximum(lg.stats["IS Max"], mx)
+            lg.stats["IS Min"] = mn_h if isinstance(lg.stats["IS Min"], float) else np.minimum(lg.stats["IS Min"], mn_h)
+            lg.stats["IS Max"] = np.maximum(lg.stats["IS Max"], mx_h)
         else:
-            lg.stats["IS Min"] = min(99999 if lg.stats["IS Min"] < 1e-8 else lg.stats["IS Min"], float(mn[0]))
-            lg.stats["IS Max"] = max(lg.stats["IS Max"], float(mx[0]))
+            lg.stats["IS Min"] = min(99999 if lg.stats["IS Min"] < 1e-8 else lg.stats["IS Min"], float(mn_h[0]))
+            lg.stats["IS Max"] = max(lg.stats["IS Max"], float(mx_h[0]))
 
     # ---- train.py:345-358 ---------------------------------------------------------------------
     def calc_d_fake_loss(self, img, labels, z, y):
@@ -738,8 +745,9 @@ class Trainer:
         tail of one epoch leaks into the first log line of the next."""
         self.logger.reset_stats()
         self._commit_stats()
-        self.dev_stats.pop("_is_min", None)
-        self.dev_stats.pop("_is_max", None)
+        for key, init in (("_is_min", float("inf")), ("_is_max", float("-inf"))):
+            if key in self.dev_stats:
+                self.dev_stats[key].fill_(init)
         for k, v in self.dev_stats.items():
             if not k.startswith("_"):
                 v.zero_()
@@ -799,8 +807,9 @@ class GraphedDStep:
     def __init__(self, trainer, use_graph=True, warmup=2):
         self.tr, self.use_graph, self.warmup = trainer, use_graph, warmup
         o = trainer.opt
-        if not (o.use_dp and o.dp_mode == "gc"):
-            raise NotImplementedError("GraphedDStep covers the gradient-clipping D-step (dp_mode=gc)")
+        if not (o.use_dp and o.dp_mode in ("gc", "is")) or (o.dp_mode == "is" and o.imm_sens_scaling_mode == "moving-avg-pl"):
+            raise NotImplementedError("GraphedDStep covers the DP D-steps whose host never reads the device inside the step: dp_mode=gc "
+                                      "and dp_mode=is (not the moving-average scaling mode, which reads gradient norms on the host)")
         self.graph, self.bufs = None, None
         self._prev = (trainer.d_optimizer.capturable, trainer.explicit)
         trainer.d_optimizer.capturable = True
@@ -823,8 +832,9 @@ class GraphedDStep:
             b["alpha"] = torch.empty(B, device=dev)
         self.bufs = b
 
+    @torch.no_grad()
     def _fill(self, img, labels):
-        b = self.bufs
+        b = self.bufs                  # (no_grad: in is mode the static image buffer is a leaf that requires grad, train.py:375)
         b["img"].copy_(img, non_blocking=True)
         if labels is not None:
             b["labels"].copy_(labels, non_blocking=True)

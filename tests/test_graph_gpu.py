@@ -62,6 +62,10 @@ def _run(tmp_path, tag, argv, B, use_graph, n_steps, img_shape, conditional, smo
     # BASELINE configs[2] (headline): adaptive per-layer clipping, ghost + fused passes, WGAN-GP on mean samples
     ("celeba_smooth", ["CelebA", "-dpm", "gc", "-gcm", "adaptive-pl", "-nms", "8", "--sigma", "0.5"], 8, (3, 64, 64), False, True),
     ("celeba", ["CelebA", "-dpm", "gc", "-gcm", "adaptive-pl", "-nms", "8", "--sigma", "0.5"], 8, (3, 64, 64), False, False),
+    # immediate sensitivity (BASELINE configs[3] mode): BatchNorm generator, per-parameter sensitivities, nine double-backward sweeps
+    ("mnist_is", ["MNIST", "--model", "DeepConvResNet", "--penalty", "WGAN-GP", "-dpm", "is", "-ispp", "True", "-nms", "4", "--g_latent_dim", "16"],
+     8, (1, 28, 28), False, False),
+    ("celeba_is", ["CelebA", "-dpm", "is", "-nms", "4", "--sigma", "0.5"], 4, (3, 64, 64), False, False),
 ])
 def test_graph_replay_equals_eager_steps(tmp_path, name, argv, B, shape, cond, smooth):
     n = 6

@@ -344,17 +344,20 @@ def main():
                     ("%6.1f TF" % (v["exec_flop"] / (v["ms"] * 1e-3) / 1e12)) if v["exec_flop"] else ("%7.1f GB/s" % (v["bytes"] / (v["ms"] * 1e-3) / 1e9))))
     bf16 = getattr(opt, "compute_dtype", "fp32") == "bf16"
     step_peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    mode = ("dp_mode=gc -gcm %s" % opt.grad_clip_mode) if opt.dp_mode == "gc" else ("dp_mode=is -ispp %s" % bool(opt.imm_sens_per_param))
     line = {
-        "metric": "images/sec/GPU CelebA DCResNet dp_mode=gc bs=128 at 1/2/4/8 MI355X",
+        # the BASELINE.json metric for the default command; with --opt the line names what was actually run
+        "metric": "images/sec/GPU CelebA DCResNet dp_mode=%s bs=%d at 1/2/4/8 MI355X" % (opt.dp_mode, B),
         "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-        "config": {"workload": "CelebA DCResNet D-step: dp_mode=gc -gcm adaptive-pl -nms 32, WGAN-GP on mean samples, 3x%dx%d" % (opt.im_size, opt.im_size),
+        "config": {"workload": "CelebA DCResNet D-step: %s -nms %d, WGAN-GP on mean samples, 3x%dx%d" % (mode, opt.num_mean_samples, opt.im_size, opt.im_size),
                    "compute_dtype": getattr(opt, "compute_dtype", "fp32"),
                    "launch": launch_mode, "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                    "materialize": getattr(opt, "materialize", "all"), "grad_sample_dtype": getattr(opt, "grad_sample_dtype", "fp32"),
                    "fuse_passes": bool(getattr(opt, "fuse_passes", False)),
-                   "step": "train_D (adaptive pass + G fwd + 2 D passes + per-sample grads + clip + GP + noise + Adam)"},
+                   "step": ("train_D (adaptive pass + G fwd + 2 D passes + per-sample grads + clip + GP + noise + Adam)" if opt.dp_mode == "gc" else
+                            "train_D (G fwd + D passes + create_graph gradients + one double-backward sweep per sensitivity + GP + noise + Adam)")},
         "per_gpu": round(ips / world, 2),
         "step_gflop_executed_per_image": round(exec_flop_step / B / 1e9, 3),
         "step_tflops_executed": round(exec_flop_step / (dt / a.steps) / 1e12, 2),

@@ -303,6 +303,15 @@ __global__ __launch_bounds__(CA_THREADS) void clip_accum_noise_kernel(CaArgs a, 
 }
 
 // ---- row helpers ----------------------------------------------------------------------------
+__global__ void zero_floats_kernel(float* __restrict__ p, long long n, int vec) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        if (i < n) reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (i < n) {
+        p[i] = 0.f;
+    }
+}
+
 __global__ void sqrt_kernel(float* __restrict__ v, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] = sqrtf(v[i]);
@@ -331,6 +340,14 @@ __global__ void row_l2norm_bwd_kernel(const float* __restrict__ in, const float*
         o[j] = p[j] * f;
 }
 
+int zero_floats(float* p, size_t n_floats, hipStream_t st) {
+    if (n_floats == 0) return CSLGAN_OK;
+    const int vec = (aligned16(p) && n_floats % 4 == 0) ? 1 : 0;
+    const long long n = (long long)(vec ? n_floats / 4 : n_floats);
+    hipLaunchKernelGGL(zero_floats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, vec);
+    return check_launch("zero_floats_kernel");
+}
+
 static bool aligned_to(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(a - 1)) == 0; }
 
 static int launch_sqnorm(const float* const* in, const long long* len, const long long* stride, int n_seg,
@@ -348,10 +365,7 @@ static int launch_sqnorm(const float* const* in, const long long* len, const lon
     }
     a.chunk_prefix[n_seg] = tot;
     for (int s = n_seg; s < CSLGAN_MAX_SEGS; ++s) { a.in[s] = nullptr; a.len[s] = 0; a.row_stride[s] = 0; a.vec_ok[s] = 0; a.chunk_prefix[s + 1] = tot; }
-    if (hipMemsetAsync(out_sq, 0, sizeof(float) * n_seg * n_rows, st) != hipSuccess) {
-        set_error("sample_sqnorm: hipMemsetAsync failed");
-        return CSLGAN_ERR_LAUNCH;
-    }
+    if (int rc = zero_floats(out_sq, (size_t)n_seg * (size_t)n_rows, st)) return rc;
     if (tot == 0 || n_rows == 0) return CSLGAN_OK;
     note_kernel(bf16 ? "sample_sqnorm_kernel<bf16>" : "sample_sqnorm_kernel<float>");
     if (bf16) hipLaunchKernelGGL(sample_sqnorm_kernel<unsigned short>, dim3(tot, (unsigned)n_rows), dim3(SQ_THREADS), 0, st, a, n_rows, out_sq);

@@ -51,6 +51,11 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+// Zeroes n_floats floats on the stream with a kernel of this library (clip_kernels.hip).  hipMemsetAsync is not used anywhere:
+// as a memset node of a captured HIP graph (ROCm 7.2) a 128-byte fill replayed with one stale dword per 16 bytes
+// (scripts/dbg_is6.py: row norms of a finite input came back 7.6e8 / NaN on every fourth row), and a fill kernel is an
+// ordinary kernel node.
+int zero_floats(float* p, size_t n_floats, hipStream_t st);
 __device__ __forceinline__ bool aligned16_dev(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace cslgan

@@ -335,9 +335,8 @@ static int launch_kc_bf16_tile(KcParams& p, bool vecA, bool vecB, hipStream_t st
         p.ksplit = want < cap ? want : cap;
         if (p.ksplit < 1) p.ksplit = 1;
     }
-    if (p.ksplit > 1 && hipMemsetAsync(p.out, 0, sizeof(float) * (size_t)out_elems, st) != hipSuccess) {
-        set_error("igemm_kc_bf16: hipMemsetAsync failed");
-        return CSLGAN_ERR_LAUNCH;
+    if (p.ksplit > 1) {
+        if (int rc = zero_floats(p.out, (size_t)out_elems, st)) return rc;
     }
     const dim3 grid((unsigned)(tiles * p.ksplit)), block(256);
     note_kernel(NSPLIT == 1 ? "igemm_kc_bf16_kernel<%d,%d>" : "igemm_kc_bf16x3_kernel<%d,%d>", BM, BN);
@@ -944,9 +943,8 @@ int launch_mc_bf16(McParams& p, bool vecA, bool vecB, hipStream_t st, int nsplit
             if (p.ksplit < 1) p.ksplit = 1;
         }
     }
-    if (p.ksplit > 1 && hipMemsetAsync(p.gw, 0, sizeof(float) * (size_t)p.n_groups * p.Kc * p.Ndim, st) != hipSuccess) {
-        set_error("wgrad_bf16: hipMemsetAsync failed");
-        return CSLGAN_ERR_LAUNCH;
+    if (p.ksplit > 1) {
+        if (int rc = zero_floats(p.gw, (size_t)p.n_groups * p.Kc * p.Ndim, st)) return rc;
     }
     const long long nb = (long long)p.n_groups * p.tiles_m * p.tiles_n * p.ksplit;
     if (nb > 0x7fffffffll) { set_error("wgrad_bf16: grid too large"); return CSLGAN_ERR_INVALID_ARG; }

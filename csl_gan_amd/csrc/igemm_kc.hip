@@ -355,10 +355,7 @@ static int launch_kc_tile(KcParams& p, bool vecA, bool vecB, hipStream_t st, lon
         if (p.ksplit < 1) p.ksplit = 1;
     }
     if (p.ksplit > 1) {
-        if (hipMemsetAsync(p.out, 0, sizeof(float) * (size_t)out_elems, st) != hipSuccess) {
-            set_error("igemm_kc: hipMemsetAsync failed");
-            return CSLGAN_ERR_LAUNCH;
-        }
+        if (int rc = zero_floats(p.out, (size_t)out_elems, st)) return rc;
     }
     const dim3 grid((unsigned)(tiles * p.ksplit)), block(256);
     // NBUF = 1 (single LDS buffer, 4 workgroups/CU) was measured slower on every shape of the D-step

@@ -313,10 +313,7 @@ static int launch_mc_tile(McParams& p, bool vecA, bool vecB, hipStream_t st) {
         }
     }
     if (p.ksplit > 1) {
-        if (hipMemsetAsync(p.gw, 0, sizeof(float) * (size_t)p.n_groups * p.Kc * p.Ndim, st) != hipSuccess) {
-            set_error("wgrad: hipMemsetAsync failed");
-            return CSLGAN_ERR_LAUNCH;
-        }
+        if (int rc = zero_floats(p.gw, (size_t)p.n_groups * p.Kc * p.Ndim, st)) return rc;
     }
     const long long nb = (long long)p.n_groups * p.tiles_m * p.tiles_n * p.ksplit;
     if (nb > 0x7fffffffll) { set_error("wgrad: grid too large"); return CSLGAN_ERR_INVALID_ARG; }

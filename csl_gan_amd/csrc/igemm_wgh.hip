@@ -205,9 +205,8 @@ int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int grou
         if (p.ksplit < 1) p.ksplit = 1;
     }
     const size_t out_floats = (size_t)p.n_groups * c->K * c->R * c->S * c->C;
-    if (p.ksplit > 1 && hipMemsetAsync(gw, 0, sizeof(float) * out_floats, st) != hipSuccess) {
-        set_error("wgrad: hipMemsetAsync failed");
-        return CSLGAN_ERR_LAUNCH;
+    if (p.ksplit > 1) {
+        if (int rc = zero_floats(gw, out_floats, st)) return rc;
     }
     const long long nb = base * p.ksplit;
     if (nb > 0x7fffffffll) { set_error("wgrad: grid too large"); return CSLGAN_ERR_INVALID_ARG; }

@@ -425,9 +425,8 @@ static int launch_norm(const float* x, const float* gamma, const float* beta, lo
     long long rpb = (rows_per_stat * n_row_groups / 1024 + NS_ROWS_MIN - 1) / NS_ROWS_MIN * NS_ROWS_MIN;
     rpb = rpb < NS_ROWS_MIN ? NS_ROWS_MIN : (rpb > 4096 ? 4096 : rpb);
     const dim3 grid((unsigned)((rows_per_stat + rpb - 1) / rpb), (unsigned)n_row_groups), block(256);
-    if (!(scratch && grid.x <= 64) && hipMemsetAsync(stats, 0, sizeof(float) * 2 * n_stats, st) != hipSuccess) {
-        set_error("norm: hipMemsetAsync failed");
-        return CSLGAN_ERR_LAUNCH;
+    if (!(scratch && grid.x <= 64)) {
+        if (int rc = zero_floats(stats, (size_t)2 * n_stats, st)) return rc;
     }
     const size_t lds = sizeof(float) * C;
     if (scratch && grid.x <= 64) {         // few workgroups per row group share a ticket (BatchNorm's single row group: classic path)
@@ -598,7 +597,7 @@ int cslgan_norm_act_bwd_f32(const float* x, const float* dy, const float* y, con
     const int cpg = C / groups;
     float* ab = ws;                         // [nrg][C][2]
     float* gs = ws + nrg * C * 2;           // [nrg*groups][2]
-    if (hipMemsetAsync(ab, 0, sizeof(float) * nrg * C * 2, st) != hipSuccess) { set_error("norm_bwd: memset failed"); return CSLGAN_ERR_LAUNCH; }
+    if (int rc = zero_floats(ab, (size_t)nrg * C * 2, st)) return rc;
     const bool vec = (C % 4 == 0) && ((C / 4) <= 256) && (256 % (C / 4) == 0) && aligned16(x) && aligned16(dy) && (!relu || aligned16(y));
     long long rpb = (rows / 1024 + NS_ROWS_MIN - 1) / NS_ROWS_MIN * NS_ROWS_MIN;
     rpb = rpb < NS_ROWS_MIN ? NS_ROWS_MIN : (rpb > 4096 ? 4096 : rpb);

@@ -100,10 +100,11 @@ class Trainer:
         pe.attach(self.d_optimizer)
         pe._set_seed(o.manual_seed + 7919 * self.rank)
         self.privacy_engine = pe
-        # gc only.  The immediate-sensitivity step is capturable since round 3 (no host read inside it) and GraphedDStep accepts it,
-        # but its replays are NOT trusted yet: at B >= 24 the sensitivity sweeps of the second and later replays return garbage
-        # although every piece replays correctly in isolation (scripts/dbg_is*.py) — eager until that is understood.
-        if getattr(o, "hip_graph", False) and o.dp_mode == "gc" and self.world_size == 1 and not o.backprop_clip:
+        # gc, and immediate sensitivity (no host read inside the step since round 3).  The IS replays were wrong until the library
+        # stopped using hipMemsetAsync: as a memset node of a captured graph a 128-byte fill (the accumulator of the per-sample
+        # input-gradient norms, B >= 24) replayed with a stale dword per 16 bytes — csrc/common.h zero_floats.
+        if (getattr(o, "hip_graph", False) and self.world_size == 1 and not o.backprop_clip
+                and (o.dp_mode == "gc" or (o.dp_mode == "is" and o.imm_sens_scaling_mode != "moving-avg-pl"))):
             self.graphed = GraphedDStep(self)
         return pe
 

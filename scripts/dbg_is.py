@@ -34,7 +34,12 @@ def bad():
 for it in range(6):
     img = (torch.rand(B, 3, 64, 64, generator=g) * 2 - 1)
     lab = torch.zeros(B, dtype=torch.long)
-    tr.train(0, it, img, lab, use_dp=True)
+    if os.environ.get("DBG_DIRECT"):
+        tr.graphed(img.cuda(), None)
+        if it == 0 and os.environ.get("DBG_DIRECT") == "2":
+            tr.train_G(tr.gen_z(B), None)
+    else:
+        tr.train(0, it, img, lab, use_dp=True)
     torch.cuda.synchronize()
     import numpy as np
     tr.privacy_engine._sens_host = None

@@ -81,3 +81,15 @@ def test_missing_library_raises(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.HipLibraryMissing):
         _lib.lib()
+
+
+def test_library_sources_do_not_use_hip_memset():
+    """A hipMemsetAsync captured into a HIP graph replayed wrong fills on ROCm 7.2 (tests/test_kernels_gpu.py::
+    test_zeroed_accumulators_replay_correctly_in_a_captured_graph); accumulators are zeroed by the library's own kernel."""
+    import glob, os, re
+    src = os.path.join(os.path.dirname(__file__), "..", "csl_gan_amd", "csrc")
+    files = glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h"))
+    assert files
+    for f in files:
+        code = re.sub(r"//[^\n]*", "", open(f).read())
+        assert not re.search(r"\bhipMemset\w*\s*\(", code), "%s calls hipMemset*: use cslgan::zero_floats" % os.path.basename(f)

@@ -24,10 +24,7 @@ def test_cli_smoke_matrix(tmp_path, dataset, mode, cond):
                          "--log_every", str(bs * 3)] + (["--conditional"] if cond else []))
     torch.cuda.synchronize()
     assert tr.privacy_engine.steps == iters
-    if mode == "gc":
-        assert tr.graphed is not None and tr.graphed.graph is not None, "the gc D-step should have been recorded and replayed"
-    else:
-        assert tr.graphed is None          # immediate sensitivity is launched eagerly (trainer.setup_privacy_engine)
+    assert tr.graphed is not None and tr.graphed.graph is not None, "the D-step should have been recorded and replayed"
     for p in list(tr.D.parameters()) + list(tr.G.parameters()):
         assert torch.isfinite(p).all()
     rows = open(os.path.join(str(tmp_path), "log.csv")).read().strip().splitlines()

@@ -65,6 +65,12 @@ def _run(tmp_path, tag, argv, B, use_graph, n_steps, img_shape, conditional, smo
     # larger batches: image-sized tensors leave the allocator's small-block pool at B >= 24, the full benchmark size is 128
     ("celeba_smooth_b32", ["CelebA", "-dpm", "gc", "-gcm", "adaptive-pl", "-nms", "8", "--sigma", "0.5"], 32, (3, 64, 64), False, True),
     ("celeba_smooth_b128", ["CelebA", "-dpm", "gc", "-gcm", "adaptive-pl", "-nms", "32", "--sigma", "0.5"], 128, (3, 64, 64), False, True),
+    # BASELINE configs[3]: immediate sensitivity (one value, and one per parameter tensor).  B = 32: the batch whose replays were
+    # wrong while the library zeroed its norm accumulators with hipMemsetAsync (csrc/common.h zero_floats)
+    ("celeba_is_smooth_b32", ["CelebA", "-dpm", "is", "-nms", "8", "--sigma", "0.5"], 32, (3, 64, 64), False, True),
+    ("celeba_ispp_smooth_b32", ["CelebA", "-dpm", "is", "-ispp", "True", "-nms", "8", "--sigma", "0.5"], 32, (3, 64, 64), False, True),
+    ("celeba_ispp_b32", ["CelebA", "-dpm", "is", "-ispp", "True", "-nms", "8", "--sigma", "0.5"], 32, (3, 64, 64), False, False),
+    ("mnist_is_cond", ["MNIST", "--model", "Vanilla", "--conditional", "-dpm", "is", "--sigma", "1"], 64, (1, 28, 28), True, True),
 ])
 def test_graph_replay_equals_eager_steps(tmp_path, name, argv, B, shape, cond, smooth):
     n = 6
@@ -77,15 +83,20 @@ def test_graph_replay_equals_eager_steps(tmp_path, name, argv, B, shape, cond, s
     # reordering can flip a LeakyReLU unit that sits within rounding of zero (measured on the CelebA case: 5.7e-4 on conv1's
     # gradient, 2.8e-3 on its cancelling bias gradient, eager against eager alike): 1e-2 there.
     tol1 = (3e-5 if B >= 128 else 1e-5) if smooth else 1e-2          # B = 128: 1.05e-5 measured on a bias gradient (atomic order)
+    if not smooth and "is" in argv:
+        tol1 = 3e-2             # the noise scale is itself a max over samples of a double-backward norm: 1.3e-2 measured (unit flips)
+    # tensors whose gradient is analytically zero (a conv bias in front of a GroupNorm; is mode adds almost no noise to them, so
+    # what is left is rounding residue of terms of the step's overall gradient size) are held to 1e-2 of that overall size
+    floor = 1e-2 * max(a.abs().max().item() for a in eager[7][0])
     for i, (a, b) in enumerate(zip(eager[7][0], graph[7][0])):
-        scale = a.abs().max().item() + 1e-30
+        scale = max(a.abs().max().item(), floor) + 1e-30
         assert (a - b).abs().max().item() <= tol1 * scale, "noised gradient %d of the first replayed step: rel %.3e" % (
             i, (a - b).abs().max().item() / scale)
     # the next replay runs on weights one Adam step later (every entry moved by ~lr * sign(g)): the gradients still agree closely,
     # which they would not if the replay had kept the capture-time weights, Adam step count or noise offset
     for i, (a, b) in enumerate(zip(eager[7][1], graph[7][1])):
-        scale = a.abs().max().item() + 1e-30
-        assert (a - b).abs().max().item() <= (1e-3 if smooth else 1e-2) * scale, "noised gradient %d of the second replayed step: rel %.3e" % (
+        scale = max(a.abs().max().item(), floor) + 1e-30
+        assert (a - b).abs().max().item() <= (1e-3 if smooth else max(1e-2, tol1)) * scale, "noised gradient %d of the second replayed step: rel %.3e" % (
             i, (a - b).abs().max().item() / scale)
     assert any((a - b).abs().max().item() > 1e-3 * a.abs().max().item() for a, b in zip(eager[7][0], eager[7][1])), "steps 3 and 4 must differ"
     lr = 1e-4 if name.startswith("celeba") else 2e-4       # d_lr defaults (options.py)
@@ -94,10 +105,15 @@ def test_graph_replay_equals_eager_steps(tmp_path, name, argv, B, shape, cond, s
         # atomic reordering shows as a few per cent of lr on cancelling sums and whole steps where the gradient is ~0
         err = (a - b).abs()
         assert err.max().item() <= 2.1 * lr * n, "parameter %d differs between eager and replayed steps: %.3e" % (i, err.max().item())
+        if eager[7][0][i].abs().max().item() < floor:
+            continue            # gradient of rounding residue only: Adam turns its sign pattern into steps of +-lr
         assert err.mean().item() <= 0.1 * lr, "parameter %d: mean difference %.3e lr" % (i, err.mean().item() / lr)
     for k, v in eager[6].items():
         w = graph[6][k]
-        assert torch.allclose(torch.as_tensor(v, dtype=torch.float64), torch.as_tensor(w, dtype=torch.float64), rtol=2e-3, atol=1e-4), (k, v, w)
+        assert torch.allclose(torch.as_tensor(v, dtype=torch.float64), torch.as_tensor(w, dtype=torch.float64),
+                              rtol=2e-3 if smooth or "is" not in argv else 1e-2, atol=5e-4 if "is" in argv else 1e-4), (k, v, w)
+        # is mode: 2.6e-3 measured on the sensitivity maxima with the activations on; 1.7e-4 absolute on a mean critic output of
+        # -0.033 (the zero-gradient biases above take +-lr Adam steps whose signs are rounding residue, on either side)
 
 
 @pytest.mark.parametrize("name,argv,B,shape,cond,latent", [

@@ -1013,3 +1013,43 @@ def test_lipschitz_term_and_lerp(one_sided, per_sample):
     # twice in a row: the kernel's ticket word is left at zero
     got2 = HF.LipschitzTerm.apply(td.detach(), one_sided, coef, per_sample)
     assert torch.allclose(got2.cpu(), got.detach().cpu())
+
+
+def test_zeroed_accumulators_replay_correctly_in_a_captured_graph():
+    """The kernels that accumulate with float atomics zero their output first (csrc/common.h zero_floats).  That zeroing used to be
+    hipMemsetAsync, which as a memset node of a captured HIP graph replayed a 128-byte fill with a stale dword in every 16 bytes —
+    every fourth per-sample norm of a 32-row batch came back as garbage from the second replay on, once an image-sized eager
+    allocation + host-to-device copy had happened between replays.  Same conditions here: 32 x 12288 rows (the immediate-sensitivity
+    input-gradient norms at B = 32), per-sample squared norms, GroupNorm statistics, and a split-K convolution."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    rows = (torch.randn(32, 12288, generator=g) * 1e-5).cuda()
+    seg = [(torch.randn(32, n, generator=g) * 0.1).cuda() for n in (1728, 64)]
+    xg = _nhwc(torch.randn(4, 64, 8, 8, generator=g))
+    gam, bet = torch.randn(64, generator=g).cuda(), torch.randn(64, generator=g).cuda()
+    xc, wc = _nhwc(torch.randn(2, 512, 4, 4, generator=g)), torch.randn(64, 5, 5, 512, generator=g).cuda() * 0.05     # 32 rows: K is split
+    def step():
+        return ops.row_l2norm(rows), ops.sample_sqnorm(seg), ops.groupnorm_act(xg, gam, bet, 32, relu=False), ops.conv2d_fwd(xc, wc, stride=1, pad=2)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        outs = step()
+    for k in range(5):
+        fresh = [(torch.rand(32, 3, 64, 64, generator=g) * 2 - 1).cuda() for _ in range(2)]      # eager allocations + H2D between replays
+        with torch.no_grad():
+            rows.copy_(fresh[0].reshape(32, -1) * 1e-5 * (k + 1))
+            seg[0].mul_(1.1)
+            xg.add_(0.1)
+            xc.mul_(0.9)
+        gr.replay()
+        torch.cuda.synchronize()
+        del fresh
+        _close(outs[0], rows.double().norm(dim=1).float(), rtol=1e-5, what="row norms, replay %d" % k)
+        _close(outs[1], torch.stack([(t.double() ** 2).sum(1) for t in seg]).float(), rtol=1e-5, what="per-sample squared norms, replay %d" % k)
+        _close(outs[2].permute(0, 3, 1, 2), F.group_norm(xg.permute(0, 3, 1, 2), 32, gam, bet), what="groupnorm, replay %d" % k)
+        _close(outs[3].permute(0, 3, 1, 2), F.conv2d(xc.permute(0, 3, 1, 2), wc.permute(0, 3, 1, 2), padding=2), rtol=2e-3, what="split-K conv, replay %d" % k)

@@ -167,8 +167,11 @@ class DCResNetDiscriminator(Discriminator):
             fuse = all(getattr(m, "_bpc", None) is None for m in self.modules())
             o = HF.nhwc(o)
             prev_lrelu = False
+            # --storage_dtype bf16: the conv layers' outputs (and with them their gradients) live in HBM as bfloat16; the heads
+            # answer in fp32 (csl_gan_amd.ops.set_storage_dtype)
+            od = torch.bfloat16 if ops.storage_bf16() else None
             for blk in self.blocks:
-                o = blk.forward_nhwc(o, in_mask=fuse and prev_lrelu, out_masked=fuse)      # conv + bias + LeakyReLU(0.2) in one kernel
+                o = blk.forward_nhwc(o, in_mask=fuse and prev_lrelu, out_masked=fuse, out_dtype=od)   # conv + bias + LeakyReLU(0.2) in one kernel
                 prev_lrelu = blk.act == ops.ACT_LRELU02
             fuse = fuse and prev_lrelu
             o = HF.nchw_view(o)

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CSLGAN_LIB_PATH") or os.path.join(_HERE, "libcslgan_hip.so")      # override: kernel experiments
 MAX_SEGS = 16
-ABI_VERSION = 3          # include/cslgan.h CSLGAN_ABI_VERSION
+ABI_VERSION = 4          # include/cslgan.h CSLGAN_ABI_VERSION
 
 EXPORTS = [
     "cslgan_version", "cslgan_last_error", "cslgan_last_kernel", "cslgan_device_count",
@@ -26,6 +26,8 @@ EXPORTS = [
     "cslgan_adam_step_f32", "cslgan_adam_step_dev_f32", "cslgan_adam_multi_f32",
     "cslgan_segment_means_f32", "cslgan_segment_means_bwd_f32", "cslgan_dstep_stats_f32", "cslgan_grad_log_stats_f32",
     "cslgan_lerp_rows_f32", "cslgan_lipschitz_term_f32", "cslgan_lipschitz_term_bwd_f32",
+    "cslgan_conv2d_fwd_bf16s", "cslgan_conv2d_dgrad_bf16s", "cslgan_conv2d_wgrad_grouped_bf16s", "cslgan_cast_f32_bf16", "cslgan_cast_bf16_f32",
+    "cslgan_act_bwd_bf16", "cslgan_bias_grad_grouped_bf16",
 ]
 
 
@@ -106,6 +108,13 @@ def lib():
         "cslgan_lerp_rows_f32": [vp, vp, vp, i64, i64, vp, vp],
         "cslgan_lipschitz_term_f32": [vp, i64, i64, i32, f32, vp, vp, vp, vp, vp],
         "cslgan_lipschitz_term_bwd_f32": [vp, vp, vp, vp, i64, i64, i32, f32, vp, vp],
+        "cslgan_conv2d_fwd_bf16s": [C.POINTER(ConvT), vp, vp, vp, i32, vp, vp, i32, i32, vp, i32, vp],
+        "cslgan_conv2d_dgrad_bf16s": [C.POINTER(ConvT), vp, vp, vp, i32, vp, vp, i32, vp],
+        "cslgan_conv2d_wgrad_grouped_bf16s": [C.POINTER(ConvT), vp, vp, i32, f32, vp, i32, vp, vp],
+        "cslgan_cast_f32_bf16": [vp, vp, i64, vp],
+        "cslgan_cast_bf16_f32": [vp, vp, i64, vp],
+        "cslgan_act_bwd_bf16": [vp, vp, i64, f32, vp, vp],
+        "cslgan_bias_grad_grouped_bf16": [vp, i32, i32, i32, i32, f32, vp, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)

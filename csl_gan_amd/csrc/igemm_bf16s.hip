@@ -1,0 +1,754 @@
+// bf16 STORAGE path (BASELINE.json configs[4]: "CelebA 128x128 DCResNet bf16 ... HBM-bound per-sample grads"; SURVEY §8(d)
+// "bf16 storage / fp32 accumulate").  gfx950 only.
+//
+// igemm_bf16.hip computes on the bf16 matrix cores but reads fp32 tensors and rounds them on the way into LDS: a 128x128
+// tile then moves 32 KB per 1.05 MFLOP and the kernels sit on L2 bandwidth at 0.10-0.13 of the bf16 MFMA peak.  Here the
+// ACTIVATIONS, the ACTIVATION GRADIENTS and a pre-rounded copy of the FILTERS are bfloat16 in HBM (fp32 master weights, fp32
+// accumulation, fp32 weight gradients / norms / clip / noise / Adam):
+//
+//   igemm_kcs_kernel   forward conv / linear and data gradient: a 16-byte global load is 8 consecutive k of one row = exactly
+//                      one operand of v_mfma_f32_32x32x16_bf16, stored to LDS as it is (no conversion, half the bytes of the
+//                      fp32 loader, K tile 64); the epilogue (bias, residual, activation, LeakyReLU mask) writes bf16 or fp32.
+//   igemm_mcs_kernel   grouped / per-sample weight gradient: the reduction index (pixel) is the slow one of both operands, so a
+//                      thread loads the same 8 channels of 8 consecutive pixels (8 x 16 bytes, a pixel row's 256 bytes
+//                      coalesced across 16 lanes) and transposes the 8x8 block in registers into 8 LDS operands.
+//   round / repack     the fp32 master filter rounded once per parameter version (plain KRSC order for the forward conv,
+//                      per-parity-class [C][taps][K] matrices for the data gradient), cached by the caller.
+//   casts, activation backward, bias gradient on bf16 tensors.
+//
+// Numerics: every product is bf16(a)*bf16(b) exactly, summed in fp32; what is new against CSLGAN_COMPUTE_BF16 on fp32 tensors is
+// ONE extra rounding per stored activation / activation gradient (relative 2^-9), i.e. the same order as the operand rounding
+// the matrix core needs anyway.
+//
+// Replaces (reference file:line): nn.Conv2d / nn.Linear forward and autograd data gradients (DCResNet_models.py:131-132,145),
+// the Opacus-fork per-sample weight gradients (train.py:373,387), F.leaky_relu's backward, bias gradients.
+#include <stdlib.h>
+#include "common.h"
+#include "igemm.h"
+
+namespace cslgan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned S_OOB16 = 0xFFFFFFF0u;
+
+__device__ __forceinline__ unsigned short f2bf(float v) {      // round to nearest even (v_cvt_pk_bf16_f32 semantics)
+    const f32x2 t = {v, 0.f};
+    return (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2)) & 0xffffu);
+}
+__device__ __forceinline__ unsigned f2bf_pk(float lo, float hi) {
+    const f32x2 t = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+}
+__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+
+// ---- K-contiguous form on bf16 tensors -------------------------------------------------------------------------------------
+struct KsParams {
+    const void* a;               // bf16 [img][AH][AW][AC]
+    unsigned a_bytes, w_bytes;
+    unsigned ac_recip;           // ceil(2^32 / AC)
+    int AH, AW, AC, VH, VW, sy, sx;
+    const void* w;               // bf16 class matrices [Nn][Kdim] at element offset cls[].w_off
+    int Nn;
+    void* out;                   // bf16 or fp32 (template)
+    int OHf, OWf, osy, osx, ldo, dense_out;
+    const float* bias;
+    const void* res;             // same indexing as out; bf16 when res_bf16
+    int res_bf16;
+    const void* mask;            // same indexing as out; bf16 when mask_bf16
+    int mask_bf16;
+    int act;
+    int n_cls, tiles_m, tiles_n;
+    KcClass cls[IG_MAX_CLS];
+};
+
+constexpr int KS_BK = 64;        // k per LDS tile = 8 entries of 8 bf16 (16 bytes)
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool OUT_BF16>
+__global__ __launch_bounds__(256, 2) void igemm_kcs_kernel(const KsParams p) {
+    constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
+    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "bad tile");
+    constexpr int A_ES = BM + 1, B_ES = BN + 1;             // uint4 (16-byte) units per LDS entry, padded by 16 B
+    constexpr int A_PASS = BM / 32, B_PASS = BN / 32;
+    __shared__ __attribute__((aligned(16))) uint4 As[2][8 * A_ES];
+    __shared__ __attribute__((aligned(16))) uint4 Bs[2][8 * B_ES];
+    __shared__ int s_tap[IG_MAX_TAPS];
+    __shared__ int s_off[BM];
+
+    const int tid = threadIdx.x;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int tile_mg = wg / p.tiles_n, tile_n = wg - tile_mg * p.tiles_n;
+    int ci = 0;
+#pragma unroll 1
+    while (ci + 1 < p.n_cls && tile_mg >= p.cls[ci + 1].tile0) ++ci;
+    const KcClass& kc = p.cls[ci];
+    const int M = kc.M, OHc = kc.OHc, OWc = kc.OWc, Kdim = kc.Kdim;
+    const int m0 = (tile_mg - kc.tile0) * BM, n0 = tile_n * BN;
+
+    if (tid < IG_MAX_TAPS) s_tap[tid] = ((int)kc.ty[tid] << 16) | ((int)kc.tx[tid] & 0xffff);
+
+    const int lrow = tid >> 3;   // 0..31
+    const int e = tid & 7;       // LDS entry (8 consecutive k) within the 64-k tile: 8 lanes read 128 contiguous bytes of a row
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(p.w) + kc.w_off), 0, p.w_bytes - 2u * (unsigned)kc.w_off, 0x00020000);
+    int a_img[A_PASS], a_iy[A_PASS], a_ix[A_PASS];
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        const bool ok = m < M;
+        const RowCoord rc = kc_decode_row(ok ? m : 0, OHc, OWc, kc.patch);
+        a_img[i] = rc.img * p.AH * p.AW * p.AC;
+        a_iy[i] = ok ? rc.oy * p.sy : -(1 << 20);
+        a_ix[i] = rc.ox * p.sx;
+    }
+    unsigned b_off[B_PASS];
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i) {
+        const int n = n0 + lrow + 32 * i;
+        b_off[i] = n < p.Nn ? 2u * (unsigned)n * (unsigned)Kdim : S_OOB16;
+    }
+    __syncthreads();
+
+    u32x4 ra[A_PASS], rb[B_PASS];
+    auto load_tile = [&](int kt) {
+        const int kb = kt * KS_BK + e * 8;
+        const bool kin = kb < Kdim;
+        const int t = kin ? (int)__umulhi((unsigned)kb, p.ac_recip) : 0;
+        const int c = kb - t * p.AC;
+        const int tap = s_tap[t];
+        const int ty = tap >> 16, tx = (int)(short)(tap & 0xffff);
+#pragma unroll
+        for (int i = 0; i < A_PASS; ++i) {
+            const int iy = a_iy[i] + ty, ix = a_ix[i] + tx;
+            const bool ok = kin && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(ok ? 2u * (unsigned)(a_img[i] + (iy * p.AW + ix) * p.AC + c) : S_OOB16), 0, 0);
+        }
+        const unsigned kofs = kin ? 2u * (unsigned)kb : S_OOB16;
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i)
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)((b_off[i] == S_OOB16 || kofs == S_OOB16) ? S_OOB16 : b_off[i] + kofs), 0, 0);
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_PASS; ++i) As[buf][e * A_ES + lrow + 32 * i] = __builtin_bit_cast(uint4, ra[i]);
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) Bs[buf][e * B_ES + lrow + 32 * i] = __builtin_bit_cast(uint4, rb[i]);
+    };
+
+    const int lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wid / WAVES_N, wn = wid - wm * WAVES_N;
+    const int arow0 = wm * TM * 32 + r, brow0 = wn * TN * 32 + r;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    const int nk = (Kdim + KS_BK - 1) / KS_BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        load_tile(kt + 1);       // past the last tile every offset is out of range -> zeros, never read
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = __builtin_bit_cast(bf16x8, As[buf][(2 * s + h) * A_ES + arow0 + i * 32]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = __builtin_bit_cast(bf16x8, Bs[buf][(2 * s + h) * B_ES + brow0 + j * 32]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: output offsets per row (residual and mask share them), then bias / residual / activation / mask ----------
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int off = -1;
+        if (m < M) {
+            if (p.dense_out && !kc.patch) {
+                off = m * p.ldo;
+            } else {
+                const RowCoord rc = kc_decode_row(m, OHc, OWc, kc.patch);
+                off = ((rc.img * p.OHf + rc.oy * p.osy + kc.oy0) * p.OWf + rc.ox * p.osx + kc.ox0) * p.ldo;
+            }
+        }
+        s_off[tid] = off;
+    }
+    __syncthreads();
+    const unsigned short* __restrict__ res_h = reinterpret_cast<const unsigned short*>(p.res);
+    const float* __restrict__ res_f = reinterpret_cast<const float*>(p.res);
+    const unsigned short* __restrict__ mask_h = reinterpret_cast<const unsigned short*>(p.mask);
+    const float* __restrict__ mask_f = reinterpret_cast<const float*>(p.mask);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + r;
+        if (n >= p.Nn) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = wm * TM * 32 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                const int off = s_off[row];
+                if (off < 0) continue;
+                float val = acc[i][j][v] + bv;
+                if (p.res) val += p.res_bf16 ? bf2f(res_h[off + n]) : res_f[off + n];
+                if (p.act == CSLGAN_ACT_LRELU02) val = val > 0.f ? val : 0.2f * val;
+                else if (p.act == CSLGAN_ACT_RELU) val = val > 0.f ? val : 0.f;
+                else if (p.act == CSLGAN_ACT_TANH) val = tanhf(val);
+                if (p.mask) {
+                    const float mv = p.mask_bf16 ? bf2f(mask_h[off + n]) : mask_f[off + n];
+                    val *= (mv > 0.f ? 1.f : 0.2f);
+                }
+                if (OUT_BF16) reinterpret_cast<unsigned short*>(p.out)[off + n] = f2bf(val);
+                else reinterpret_cast<float*>(p.out)[off + n] = val;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_kcs_tile(KsParams& p, bool out_bf16, hipStream_t st) {
+    int tm = 0;
+    for (int c = 0; c < p.n_cls; ++c) {
+        p.cls[c].tile0 = tm;
+        tm += (p.cls[c].M + BM - 1) / BM;
+    }
+    p.tiles_m = tm;
+    p.tiles_n = (p.Nn + BN - 1) / BN;
+    const long long tiles = (long long)p.tiles_m * p.tiles_n;
+    if (tiles > 0x7fffffffll) { set_error("igemm_kcs: grid too large"); return CSLGAN_ERR_INVALID_ARG; }
+    const dim3 grid((unsigned)tiles), block(256);
+    note_kernel("igemm_kcs_kernel<%d,%d>", BM, BN);
+    if (out_bf16) hipLaunchKernelGGL((igemm_kcs_kernel<BM, BN, WM, WN, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_kcs_kernel<BM, BN, WM, WN, false>), grid, block, 0, st, p);
+    return check_launch("igemm_kcs_kernel");
+}
+
+static int launch_kcs(KsParams& p, bool out_bf16, hipStream_t st) {
+    long long rows = 0, rows128 = 0;
+    for (int c = 0; c < p.n_cls; ++c) { rows += p.cls[c].M; rows128 += (p.cls[c].M + 127) / 128; }
+    if (rows <= 0 || p.Nn <= 0) return CSLGAN_OK;
+    const long long n_img = p.cls[0].M / ((long long)p.cls[0].OHc * p.cls[0].OWc);
+    const long long a_b = 2ll * n_img * p.AH * p.AW * p.AC;
+    long long w_end = 0, kmax = 0;
+    for (int c = 0; c < p.n_cls; ++c) {
+        const long long en = (long long)p.cls[c].w_off + (long long)p.Nn * p.cls[c].Kdim;
+        w_end = en > w_end ? en : w_end;
+        kmax = p.cls[c].Kdim > kmax ? p.cls[c].Kdim : kmax;
+        CSLGAN_REQUIRE(p.cls[c].Kdim % 8 == 0 && p.cls[c].w_off % 8 == 0, "igemm_kcs: reduction length must be a multiple of 8");
+    }
+    CSLGAN_REQUIRE(p.AC % 8 == 0 && aligned16(p.a) && aligned16(p.w), "igemm_kcs: channels must be a multiple of 8 and operands 16-byte aligned");
+    CSLGAN_REQUIRE(a_b < 0xFFFFFFF0ll && 2 * w_end < 0xFFFFFFF0ll, "igemm_kcs: operand larger than 4 GB");
+    CSLGAN_REQUIRE((kmax + KS_BK) * (long long)p.AC < (1ll << 32), "igemm_kcs: K too large for reciprocal division");
+    p.a_bytes = (unsigned)a_b;
+    p.w_bytes = (unsigned)(2 * w_end);
+    p.ac_recip = (unsigned)(((1ull << 32) + (unsigned long long)p.AC - 1) / (unsigned long long)p.AC);
+    for (int c = 0; c < p.n_cls; ++c) {
+        KcClass& k = p.cls[c];
+        k.patch = (k.T > 1 && k.OHc % 8 == 0 && k.OWc % 8 == 0) ? 1 : 0;
+    }
+    if (p.Nn <= 64) return launch_kcs_tile<128, 64, 2, 2>(p, out_bf16, st);
+    if (rows128 * ((p.Nn + 127) / 128) >= 256) return launch_kcs_tile<128, 128, 2, 2>(p, out_bf16, st);
+    return launch_kcs_tile<64, 128, 1, 4>(p, out_bf16, st);
+}
+
+// ---- filters: fp32 master -> bf16 operand copies ----------------------------------------------------------------------------
+__global__ void round_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, long long n) {
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(in)[i];
+        reinterpret_cast<uint2*>(out)[i] = make_uint2(f2bf_pk(v.x, v.y), f2bf_pk(v.z, v.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[(n4 << 2) + threadIdx.x] = f2bf(in[(n4 << 2) + threadIdx.x]);
+}
+
+__global__ void widen_bf16_kernel(const unsigned short* __restrict__ in, float* __restrict__ out, long long n) {
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const uint2 v = reinterpret_cast<const uint2*>(in)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                                                        __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[(n4 << 2) + threadIdx.x] = bf2f(in[(n4 << 2) + threadIdx.x]);
+}
+
+static unsigned stream_blocks(long long n_items) {
+    long long nb = (n_items + 255) / 256;
+    return (unsigned)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb));
+}
+
+// data-gradient classes: wt[off_cls + (c*Tc + t)*K + k] = bf16(w[((k*R + kh)*S + kw)*C + c]) for the (kh, kw) of the class's tap t
+struct DgradRepack {
+    int K, R, S, C, n_cls;
+    int cls_off[IG_MAX_CLS], cls_T[IG_MAX_CLS];
+    signed char kh[IG_MAX_CLS][IG_MAX_TAPS], kw[IG_MAX_CLS][IG_MAX_TAPS];
+};
+
+__global__ void repack_dgrad_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wt, DgradRepack a) {
+    const int cls = blockIdx.y;
+    const int Tc = a.cls_T[cls];
+    const long long total = (long long)a.C * Tc * a.K;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % a.K);
+        const long long rest = i / a.K;
+        const int t = (int)(rest % Tc), c = (int)(rest / Tc);
+        wt[a.cls_off[cls] + i] = f2bf(w[(((long long)k * a.R + a.kh[cls][t]) * a.S + a.kw[cls][t]) * a.C + c]);
+    }
+}
+
+// ---- M-contiguous form (weight gradient) on bf16 tensors ----------------------------------------------------------------------
+//   gw[g][m][n] = alpha * sum_{k in group g} GY[k][m] * X(k, n),   k -> (img, oy, ox),  n -> (tap, c)
+struct MsParams {
+    const void* gy;      // bf16 [N][P][Q][Kc]
+    const void* x;       // bf16 [N][H][W][C]
+    int N, H, W, C, P, Q, Kc, T, Ndim, stride, group, n_groups;
+    float alpha;
+    void* gw;            // [n_groups][Kc][Ndim] fp32 (bf16 when out_bf16) or null
+    int out_bf16;
+    float* sq;           // [n_groups] or null
+    int tiles_m, tiles_n, ksplit;
+    signed char ty[IG_MAX_TAPS], tx[IG_MAX_TAPS];
+};
+
+constexpr int MS_BK = 64;        // pixels per LDS tile
+
+// Q8: Q % 8 == 0, so the 8 consecutive pixels a thread gathers lie in one output row of one image (one decode per tile)
+template <bool Q8>
+__global__ __launch_bounds__(256, 2) void igemm_mcs_kernel(const MsParams p) {
+    constexpr int ES = 128 + 1;                              // uint4 units per LDS entry (128 rows x 16 B + 16 B pad)
+    __shared__ __attribute__((aligned(16))) uint4 As[2][8 * ES];
+    __shared__ __attribute__((aligned(16))) uint4 Bs[2][8 * ES];
+    __shared__ float s_red[4];
+
+    const int tid = threadIdx.x;
+    const int per_g = p.tiles_m * p.tiles_n;
+    const int split = p.ksplit > 1 ? blockIdx.x % p.ksplit : 0;
+    const int bid = p.ksplit > 1 ? blockIdx.x / p.ksplit : blockIdx.x;
+    const int g = bid / per_g;
+    const int tl = bid - g * per_g;
+    const int tile_m = tl / p.tiles_n, tile_n = tl - tile_m * p.tiles_n;
+    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const int PQ = p.P * p.Q;
+    const int Ktot = p.group * PQ;
+    const long long pix_base = (long long)g * p.group * PQ;
+
+    const bool is_a = tid < 128;
+    const int lt = tid & 127;
+    const int c8 = (lt & 15) * 8;        // first of this thread's 8 rows (m or n) within the tile: 16 lanes cover 256 contiguous bytes of a pixel
+    const int kg = lt >> 4;              // its group of 8 pixels within the 64-pixel tile = its LDS entry
+    // X columns are fixed per thread: 8 consecutive n share a tap (C % 8 == 0)
+    const int nb = n0 + c8;
+    const bool b_ok = nb < p.Ndim;
+    const int b_t = b_ok ? nb / p.C : 0;
+    const int b_c = nb - b_t * p.C;
+    const int b_ty = p.ty[b_t], b_tx = p.tx[b_t];
+    const bool a_ok = m0 + c8 < p.Kc;
+    const unsigned short* __restrict__ gyh = reinterpret_cast<const unsigned short*>(p.gy);
+    const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(p.x);
+
+    uint4 rv[8];
+    auto load_tile = [&](int kt) {
+        const int kk0 = kt * MS_BK + kg * 8;
+        if (is_a) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (a_ok && kk0 + j < Ktot) v = *reinterpret_cast<const uint4*>(gyh + (pix_base + kk0 + j) * p.Kc + m0 + c8);
+                rv[j] = v;
+            }
+        } else if (Q8) {
+            const int il = kk0 / PQ;
+            const int pix = kk0 - il * PQ;
+            const int oy = pix / p.Q, ox0 = pix - oy * p.Q;
+            const long long img = (long long)g * p.group + il;
+            const int iy = oy * p.stride + b_ty;
+            const bool row_ok = b_ok && kk0 < Ktot && iy >= 0 && iy < p.H;
+            const unsigned short* src = xh + ((img * p.H + iy) * p.W) * p.C + b_c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ix = (ox0 + j) * p.stride + b_tx;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (row_ok && ix >= 0 && ix < p.W) v = *reinterpret_cast<const uint4*>(src + (long long)ix * p.C);
+                rv[j] = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kk = kk0 + j;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (b_ok && kk < Ktot) {
+                    const int il = kk / PQ;
+                    const int pix = kk - il * PQ;
+                    const int oy = pix / p.Q, ox = pix - oy * p.Q;
+                    const long long img = (long long)g * p.group + il;
+                    const int iy = oy * p.stride + b_ty, ix = ox * p.stride + b_tx;
+                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = *reinterpret_cast<const uint4*>(xh + ((img * p.H + iy) * p.W + ix) * p.C + b_c);
+                }
+                rv[j] = v;
+            }
+        }
+    };
+    // rv[j] = channels c8..c8+7 of pixel j  ->  entry kg, row c8+ch: the 8 pixels of channel ch (an 8x8 transpose of 16-bit values).
+    // Row R of an entry is stored at slot swz(R) = (R & ~7) | ((R + (R >> 3)) & 7): the 8 lanes that write the same channel of 8
+    // consecutive row blocks (128 bytes apart) land on 8 different 16-byte bank groups, and a 32-row fragment read still covers
+    // the same 512 contiguous bytes.  (Rotating the DATA per lane instead made rv[] dynamically indexed -> scratch.)
+    auto store_tile = [&](int buf) {
+        uint4* dst = (is_a ? As[buf] : Bs[buf]) + kg * ES + c8;
+        const int rot = (c8 >> 3) & 7;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            unsigned w4[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const uint4 a = rv[2 * jj], b = rv[2 * jj + 1];
+                const unsigned lo = (ch >> 1) == 0 ? a.x : ((ch >> 1) == 1 ? a.y : ((ch >> 1) == 2 ? a.z : a.w));
+                const unsigned hi = (ch >> 1) == 0 ? b.x : ((ch >> 1) == 1 ? b.y : ((ch >> 1) == 2 ? b.z : b.w));
+                w4[jj] = (ch & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+            }
+            dst[(ch + rot) & 7] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        }
+    };
+    auto swz = [](int R) { return (R & ~7) | ((R + (R >> 3)) & 7); };
+
+    const int lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int arow[2] = {swz(wm * 64 + r), swz(wm * 64 + r + 32)}, brow[2] = {swz(wn * 64 + r), swz(wn * 64 + r + 32)};
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    const int nk_all = (Ktot + MS_BK - 1) / MS_BK;
+    int kt0 = 0, nk = nk_all;
+    if (p.ksplit > 1) {
+        const int per = (nk_all + p.ksplit - 1) / p.ksplit;
+        kt0 = split * per;
+        nk = kt0 + per < nk_all ? kt0 + per : nk_all;
+        if (kt0 >= nk) return;      // uniform across the workgroup
+    }
+    load_tile(kt0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = __builtin_bit_cast(bf16x8, As[buf][(2 * s + h) * ES + arow[i]]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = __builtin_bit_cast(bf16x8, Bs[buf][(2 * s + h) * ES + brow[j]]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: scale, store, per-group sum of squares (as igemm_mc) ------------------------
+    float ss = 0.f;
+    float* __restrict__ outg = (p.gw && !p.out_bf16) ? reinterpret_cast<float*>(p.gw) + (long long)g * p.Kc * p.Ndim : nullptr;
+    unsigned short* __restrict__ outh = (p.gw && p.out_bf16) ? reinterpret_cast<unsigned short*>(p.gw) + (long long)g * p.Kc * p.Ndim : nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + r;
+        if (n >= p.Ndim) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (m >= p.Kc) continue;
+                float val = p.alpha * acc[i][j][v];
+                if (p.out_bf16) {      // what is stored is what gets clipped: norm of the rounded value
+                    const unsigned short u = f2bf(val);
+                    if (outh) outh[(long long)m * p.Ndim + n] = u;
+                    val = bf2f(u);
+                }
+                ss = fmaf(val, val, ss);
+                if (outg) {
+                    if (p.ksplit > 1) atomicAdd(&outg[(long long)m * p.Ndim + n], val);
+                    else outg[(long long)m * p.Ndim + n] = val;
+                }
+            }
+        }
+    }
+    if (p.sq && p.ksplit <= 1) {
+        const float tot = block_sum_256(ss, s_red);
+        if (tid == 0) atomicAdd(p.sq + g, tot);
+    }
+}
+
+int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, float* sq_accum, hipStream_t st);   // clip_kernels.hip
+
+// ---- pointwise kernels on bf16 tensors -----------------------------------------------------------------------------------------
+// out = g * (y > 0 ? 1 : slope): LeakyReLU / ReLU backward from the OUTPUT's sign, 8 values per lane
+__global__ __launch_bounds__(256) void act_bwd_bf16_kernel(const uint4* __restrict__ g, const uint4* __restrict__ y, long long n8, float slope,
+                                                           uint4* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const uint4 gv = g[i], yv = y[i];
+        const unsigned gs[4] = {gv.x, gv.y, gv.z, gv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+        unsigned o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float g0 = __uint_as_float(gs[q] << 16), g1 = __uint_as_float(gs[q] & 0xffff0000u);
+            const float y0 = __uint_as_float(ys[q] << 16), y1 = __uint_as_float(ys[q] & 0xffff0000u);
+            o[q] = f2bf_pk(y0 > 0.f ? g0 : slope * g0, y1 > 0.f ? g1 : slope * g1);
+        }
+        out[i] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// gb[g][k] = alpha * sum over the group's pixels of gy[., k] (bf16 gy, fp32 sums); K % 8 == 0, K <= 2048, 256 % (K/8) == 0
+__global__ __launch_bounds__(256) void bias_grad_bf16_kernel(const unsigned short* __restrict__ gy, int PQ, int K, int group, float alpha,
+                                                             float* __restrict__ gb, float* __restrict__ sq) {
+    extern __shared__ float s_part[];            // [K]
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int c8n = K >> 3, c8 = tid % c8n, sl = tid / c8n, nsl = 256 / c8n;
+    const int g = blockIdx.x;
+    const long long npix = (long long)group * PQ;
+    const unsigned short* base = gy + (long long)g * npix * K + 8 * c8;
+    for (int i = tid; i < K; i += 256) s_part[i] = 0.f;
+    __syncthreads();
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    long long px = sl;
+    for (; px + 3 * nsl < npix; px += 4 * nsl) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(base + (px + u * nsl) * K);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned d[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { acc[2 * q] += __uint_as_float(d[q] << 16); acc[2 * q + 1] += __uint_as_float(d[q] & 0xffff0000u); }
+        }
+    }
+    for (; px < npix; px += nsl) {
+        const uint4 v = *reinterpret_cast<const uint4*>(base + px * K);
+        const unsigned d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { acc[2 * q] += __uint_as_float(d[q] << 16); acc[2 * q + 1] += __uint_as_float(d[q] & 0xffff0000u); }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) atomicAdd(&s_part[8 * c8 + q], acc[q]);
+    __syncthreads();
+    float ss = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        const float v = alpha * s_part[k];
+        if (gb) gb[(long long)g * K + k] = v;
+        ss = fmaf(v, v, ss);
+    }
+    if (sq) {
+        const float tot = block_sum_256(ss, red);
+        if (tid == 0) atomicAdd(sq + g, tot);
+    }
+}
+
+}  // namespace cslgan
+
+using namespace cslgan;
+
+static int check_conv_s(const cslgan_conv_t* c, const char* who) {
+    CSLGAN_REQUIRE(c->N > 0 && c->H > 0 && c->W > 0 && c->C > 0 && c->K > 0 && c->R > 0 && c->S > 0 && c->stride > 0 && c->pad >= 0,
+                   "%s: non-positive dimension", who);
+    CSLGAN_REQUIRE(c->R * c->S <= IG_MAX_TAPS, "%s: %dx%d filter has more than %d taps", who, c->R, c->S, IG_MAX_TAPS);
+    const int P = (c->H + 2 * c->pad - c->R) / c->stride + 1, Q = (c->W + 2 * c->pad - c->S) / c->stride + 1;
+    CSLGAN_REQUIRE(P == c->P && Q == c->Q, "%s: output %dx%d does not match P,Q=%d,%d", who, P, Q, c->P, c->Q);
+    CSLGAN_REQUIRE((long long)c->N * c->P * c->Q * c->K < (1ll << 31) && (long long)c->N * c->H * c->W * c->C < (1ll << 31) &&
+                   (long long)c->K * c->R * c->S * c->C < (1ll << 31), "%s: tensor too large for 32-bit offsets", who);
+    return CSLGAN_OK;
+}
+
+extern "C" {
+
+int cslgan_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream) {
+    CSLGAN_REQUIRE(in && out && n >= 0, "cast_f32_bf16: bad argument");
+    CSLGAN_REQUIRE(aligned16(in) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0, "cast_f32_bf16: misaligned");
+    if (n == 0) return CSLGAN_OK;
+    hipLaunchKernelGGL(round_bf16_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, in, reinterpret_cast<unsigned short*>(out), (long long)n);
+    return check_launch("round_bf16_kernel");
+}
+
+int cslgan_cast_bf16_f32(const void* in, float* out, int64_t n, void* stream) {
+    CSLGAN_REQUIRE(in && out && n >= 0, "cast_bf16_f32: bad argument");
+    CSLGAN_REQUIRE(aligned16(out) && (reinterpret_cast<uintptr_t>(in) & 7u) == 0, "cast_bf16_f32: misaligned");
+    if (n == 0) return CSLGAN_OK;
+    hipLaunchKernelGGL(widen_bf16_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned short*>(in), out, (long long)n);
+    return check_launch("widen_bf16_kernel");
+}
+
+// y = act(conv(x, w) + bias [+ residual]) with x bf16 [N,H,W,C] (C % 8 == 0), the filter read from wb_ws = bf16(w) in KRSC order
+// (written here when repack != 0), y bf16 or fp32.
+int cslgan_conv2d_fwd_bf16s(const cslgan_conv_t* c, const void* x, const float* w, void* wb_ws, int repack, const float* bias,
+                            const void* residual, int res_bf16, int act, void* y, int y_bf16, void* stream) {
+    CSLGAN_REQUIRE(c && x && w && wb_ws && y, "conv2d_fwd_bf16s: null argument");
+    int rc = check_conv_s(c, "conv2d_fwd_bf16s");
+    if (rc) return rc;
+    CSLGAN_REQUIRE(act >= 0 && act <= 3, "conv2d_fwd_bf16s: unknown activation %d", act);
+    CSLGAN_REQUIRE(c->C % 8 == 0, "conv2d_fwd_bf16s: C=%d is not a multiple of 8", c->C);
+    hipStream_t st = (hipStream_t)stream;
+    const long long wn = (long long)c->K * c->R * c->S * c->C;
+    if (repack) {
+        CSLGAN_REQUIRE(aligned16(w) && aligned16(wb_ws), "conv2d_fwd_bf16s: filter must be 16-byte aligned");
+        hipLaunchKernelGGL(round_bf16_kernel, dim3(stream_blocks(wn / 4)), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wb_ws), wn);
+        rc = check_launch("round_bf16_kernel");
+        if (rc) return rc;
+    }
+    KsParams p{};
+    p.a = x; p.AH = c->H; p.AW = c->W; p.AC = c->C; p.VH = c->H; p.VW = c->W; p.sy = p.sx = c->stride;
+    p.w = wb_ws; p.Nn = c->K; p.out = y; p.OHf = c->P; p.OWf = c->Q; p.osy = p.osx = 1; p.ldo = c->K; p.dense_out = 1;
+    p.bias = bias; p.res = residual; p.res_bf16 = res_bf16; p.mask = nullptr; p.mask_bf16 = 0; p.act = act;
+    p.n_cls = 1;
+    KcClass& k = p.cls[0];
+    k.M = c->N * c->P * c->Q; k.OHc = c->P; k.OWc = c->Q; k.T = c->R * c->S; k.Kdim = k.T * c->C; k.w_off = 0; k.oy0 = k.ox0 = 0;
+    for (int t = 0; t < IG_MAX_TAPS; ++t) { k.ty[t] = 0; k.tx[t] = 0; }
+    for (int kh = 0; kh < c->R; ++kh)
+        for (int kw = 0; kw < c->S; ++kw) { k.ty[kh * c->S + kw] = (signed char)(kh - c->pad); k.tx[kh * c->S + kw] = (signed char)(kw - c->pad); }
+    return launch_kcs(p, y_bf16 != 0, st);
+}
+
+// gx = conv_transpose(gy, w) (* lrelu'(mask)) with gy bf16 [N,P,Q,K] (K % 8 == 0), the per-parity-class filter matrices read from
+// wt_ws (bf16, K*R*S*C elements, written here when repack != 0), gx bf16 or fp32, mask (nullable) of gx's shape and element type.
+int cslgan_conv2d_dgrad_bf16s(const cslgan_conv_t* c, const void* gy, const float* w, void* wt_ws, int repack, const void* mask,
+                              void* gx, int gx_bf16, void* stream) {
+    CSLGAN_REQUIRE(c && gy && w && wt_ws && gx, "conv2d_dgrad_bf16s: null argument");
+    int rc = check_conv_s(c, "conv2d_dgrad_bf16s");
+    if (rc) return rc;
+    CSLGAN_REQUIRE(c->stride >= 1 && c->stride <= 2, "conv2d_dgrad_bf16s: stride %d unsupported", c->stride);
+    CSLGAN_REQUIRE(c->K % 8 == 0, "conv2d_dgrad_bf16s: K=%d is not a multiple of 8", c->K);
+    const int s = c->stride;
+    hipStream_t st = (hipStream_t)stream;
+    DgradRepack ra{};
+    ra.K = c->K; ra.R = c->R; ra.S = c->S; ra.C = c->C;
+    KsParams p{};
+    p.a = gy; p.AH = c->P; p.AW = c->Q; p.AC = c->K; p.VH = c->P; p.VW = c->Q; p.sy = p.sx = 1;
+    p.w = wt_ws; p.Nn = c->C; p.out = gx; p.OHf = c->H; p.OWf = c->W; p.osy = p.osx = s; p.ldo = c->C;
+    p.dense_out = (s == 1) ? 1 : 0;
+    p.bias = nullptr; p.res = nullptr; p.mask = mask; p.mask_bf16 = gx_bf16; p.act = CSLGAN_ACT_NONE;
+    int off = 0, ncls = 0;
+    for (int py = 0; py < s; ++py)
+        for (int px = 0; px < s; ++px) {
+            const int OHc = (c->H - py + s - 1) / s, OWc = (c->W - px + s - 1) / s;
+            if (OHc <= 0 || OWc <= 0) continue;
+            const int cls = ncls++;
+            KcClass& k = p.cls[cls];
+            for (int t = 0; t < IG_MAX_TAPS; ++t) { k.ty[t] = 0; k.tx[t] = 0; }
+            int T = 0;
+            for (int kh = 0; kh < c->R; ++kh) {
+                if (((py + c->pad - kh) % s + s) % s != 0) continue;
+                for (int kw = 0; kw < c->S; ++kw) {
+                    if (((px + c->pad - kw) % s + s) % s != 0) continue;
+                    ra.kh[cls][T] = (signed char)kh; ra.kw[cls][T] = (signed char)kw;
+                    k.ty[T] = (signed char)((py + c->pad - kh) / s);
+                    k.tx[T] = (signed char)((px + c->pad - kw) / s);
+                    ++T;
+                }
+            }
+            CSLGAN_REQUIRE(T > 0, "conv2d_dgrad_bf16s: a parity class has no taps (filter smaller than stride)");
+            k.M = c->N * OHc * OWc; k.OHc = OHc; k.OWc = OWc; k.T = T; k.Kdim = T * c->K; k.w_off = off; k.oy0 = py; k.ox0 = px;
+            ra.cls_T[cls] = T; ra.cls_off[cls] = off; off += T * c->K * c->C;
+        }
+    p.n_cls = ncls; ra.n_cls = ncls;
+    if (repack) {
+        unsigned gxn = (unsigned)(((long long)c->K * c->C * c->R * c->S / (s * s) + 255) / 256);
+        gxn = gxn > 1024 ? 1024 : (gxn < 1 ? 1 : gxn);
+        hipLaunchKernelGGL(repack_dgrad_bf16_kernel, dim3(gxn, (unsigned)ncls), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wt_ws), ra);
+        rc = check_launch("repack_dgrad_bf16_kernel");
+        if (rc) return rc;
+    }
+    return launch_kcs(p, gx_bf16 != 0, st);
+}
+
+// gw[N/group][K][R][S][C] (fp32, or bf16 when gw_bf16) and / or sq[N/group] += ||alpha * gw_g||^2 from bf16 gy [N,P,Q,K] and
+// bf16 x [N,H,W,C] (K % 8 == 0, C % 8 == 0).
+int cslgan_conv2d_wgrad_grouped_bf16s(const cslgan_conv_t* c, const void* gy, const void* x, int group, float alpha, void* gw, int gw_bf16,
+                                      float* sq, void* stream) {
+    CSLGAN_REQUIRE(c && gy && x, "conv2d_wgrad_bf16s: null argument");
+    CSLGAN_REQUIRE(gw || sq, "conv2d_wgrad_bf16s: neither gw nor sq requested");
+    int rc = check_conv_s(c, "conv2d_wgrad_bf16s");
+    if (rc) return rc;
+    CSLGAN_REQUIRE(group >= 1 && c->N % group == 0, "conv2d_wgrad_bf16s: N=%d not divisible by group=%d", c->N, group);
+    CSLGAN_REQUIRE(c->K % 8 == 0 && c->C % 8 == 0 && aligned16(gy) && aligned16(x), "conv2d_wgrad_bf16s: K and C must be multiples of 8, operands 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    MsParams p{};
+    p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->P; p.Q = c->Q; p.Kc = c->K;
+    p.T = c->R * c->S; p.Ndim = p.T * c->C; p.stride = c->stride; p.group = group; p.n_groups = c->N / group;
+    p.alpha = alpha; p.gw = gw; p.sq = sq; p.out_bf16 = gw_bf16;
+    for (int t = 0; t < IG_MAX_TAPS; ++t) { p.ty[t] = 0; p.tx[t] = 0; }
+    for (int kh = 0; kh < c->R; ++kh)
+        for (int kw = 0; kw < c->S; ++kw) { p.ty[kh * c->S + kw] = (signed char)(kh - c->pad); p.tx[kh * c->S + kw] = (signed char)(kw - c->pad); }
+    p.tiles_m = (p.Kc + 127) / 128;
+    p.tiles_n = (p.Ndim + 127) / 128;
+    p.ksplit = 1;
+    {
+        const long long base = (long long)p.n_groups * p.tiles_m * p.tiles_n;
+        const int nk_all = (p.group * p.P * p.Q + MS_BK - 1) / MS_BK;
+        if (p.gw && !p.out_bf16 && base < 192 && nk_all >= 8) {
+            const long long want = (512 + base - 1) / base, cap = nk_all / 2;
+            p.ksplit = (int)(want < cap ? want : cap);
+            if (p.ksplit < 1) p.ksplit = 1;
+        }
+    }
+    if (p.ksplit > 1) {
+        rc = zero_floats(reinterpret_cast<float*>(p.gw), (size_t)p.n_groups * p.Kc * p.Ndim, st);
+        if (rc) return rc;
+    }
+    const long long nb = (long long)p.n_groups * p.tiles_m * p.tiles_n * p.ksplit;
+    CSLGAN_REQUIRE(nb <= 0x7fffffffll, "conv2d_wgrad_bf16s: grid too large");
+    note_kernel("igemm_mcs_kernel<128,128>");
+    if (c->Q % 8 == 0) hipLaunchKernelGGL(igemm_mcs_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(igemm_mcs_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, p);
+    rc = check_launch("igemm_mcs_kernel");
+    if (rc) return rc;
+    if (p.ksplit > 1 && p.sq) rc = sqnorm_rows_accumulate(reinterpret_cast<float*>(p.gw), p.n_groups, (long long)p.Kc * p.Ndim, p.sq, st);
+    return rc;
+}
+
+int cslgan_act_bwd_bf16(const void* g, const void* y, int64_t n, float slope, void* out, void* stream) {
+    CSLGAN_REQUIRE(g && y && out && n >= 0, "act_bwd_bf16: bad argument");
+    CSLGAN_REQUIRE(n % 8 == 0 && aligned16(g) && aligned16(y) && aligned16(out), "act_bwd_bf16: needs a multiple of 8 elements, 16-byte aligned");
+    if (n == 0) return CSLGAN_OK;
+    hipLaunchKernelGGL(act_bwd_bf16_kernel, dim3(stream_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint4*>(g),
+                       reinterpret_cast<const uint4*>(y), (long long)(n / 8), slope, reinterpret_cast<uint4*>(out));
+    return check_launch("act_bwd_bf16_kernel");
+}
+
+int cslgan_bias_grad_grouped_bf16(const void* gy, int N, int PQ, int K, int group, float alpha, float* gb, float* sq, void* stream) {
+    CSLGAN_REQUIRE(gy && (gb || sq), "bias_grad_bf16: null argument");
+    CSLGAN_REQUIRE(N > 0 && PQ > 0 && K > 0 && group >= 1 && N % group == 0, "bias_grad_bf16: bad sizes");
+    CSLGAN_REQUIRE(K % 8 == 0 && K <= 2048 && 256 % (K / 8) == 0 && aligned16(gy), "bias_grad_bf16: K must be a multiple of 8 with 256 %% (K/8) == 0");
+    hipLaunchKernelGGL(bias_grad_bf16_kernel, dim3((unsigned)(N / group)), dim3(256), sizeof(float) * K, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned short*>(gy), PQ, K, group, alpha, gb, sq);
+    return check_launch("bias_grad_bf16_kernel");
+}
+
+}  // extern "C"

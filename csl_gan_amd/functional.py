@@ -140,7 +140,7 @@ class BiasGrad(Function):
 
     @staticmethod
     def forward(ctx, gy):
-        ctx.shape = gy.shape
+        ctx.shape, ctx.dtype = gy.shape, gy.dtype
         N = gy.shape[0]
         group = _dense_group(N)
         part = ops.bias_grad_grouped(gy.contiguous(), group=group)
@@ -152,7 +152,7 @@ class BiasGrad(Function):
 
     @staticmethod
     def backward(ctx, ggb):
-        return ggb.reshape((1,) * (len(ctx.shape) - 1) + (-1,)).expand(ctx.shape)
+        return ggb.reshape((1,) * (len(ctx.shape) - 1) + (-1,)).expand(ctx.shape).to(ctx.dtype)
 
 
 def _dense_group(N: int, tiles: int = 1) -> int:
@@ -167,8 +167,10 @@ def _dense_group(N: int, tiles: int = 1) -> int:
 class Conv(Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, act, residual, wkey=None, alg_scale=1.0, wversion=None, bpc=None, in_mask=False,
-                out_masked=False):
-        y = ops.conv2d_fwd(x, w, b, stride=stride, pad=pad, residual=residual, act=act, wkey=wkey, alg_scale=alg_scale, wversion=wversion)
+                out_masked=False, out_dtype=None):
+        """out_dtype: torch.bfloat16 stores y as bfloat16 (ops.set_storage_dtype); None follows x's element type."""
+        y = ops.conv2d_fwd(x, w, b, stride=stride, pad=pad, residual=residual, act=act, wkey=wkey, alg_scale=alg_scale, wversion=wversion,
+                           out_dtype=out_dtype)
         ctx.set_materialize_grads(False)      # an output nobody differentiates reaches backward as None, not as a zero tensor
         ctx.in_mask, ctx.out_masked = in_mask, out_masked
         ctx.bpc = bpc              # backprop clipping (csl_gan_amd.backprop_clip): per-sample clip of the pre-activation gradient
@@ -184,7 +186,7 @@ class Conv(Function):
     @staticmethod
     def backward(ctx, gy):
         if gy is None:
-            return (None,) * 13
+            return (None,) * 14
         x, w, y = ctx.saved_tensors
         stride, pad, act = ctx.cfg
         gz = gy
@@ -202,14 +204,14 @@ class Conv(Function):
             gz = ctx.bpc.clip_grad(gz)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = Dgrad.apply(gz, w, x.shape[1], x.shape[2], stride, pad, ctx.wkey, x.detach() if ctx.in_mask else None)
+            gx = Dgrad.apply(gz, w, x.shape[1], x.shape[2], stride, pad, ctx.wkey, x.detach() if ctx.in_mask else None, x.dtype)
         if ctx.needs_input_grad[1] and not ctx.input_only:
             gw = Wgrad.apply(gz, x, w.shape[1], w.shape[2], stride, pad, ctx.in_mask)
         if ctx.needs_input_grad[2] and not ctx.input_only:
             gb = BiasGrad.apply(gz)
         # the residual is added before the activation (ResBlockUp's "o + s", DCResNet_models.py:38): its gradient is gz
         gres = gz if (ctx.has_res and ctx.needs_input_grad[6]) else None
-        return gx, gw, gb, None, None, None, gres, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, gres, None, None, None, None, None, None, None
 
 
 class DepthToSpace(Function):
@@ -285,18 +287,19 @@ class NormAct(Function):
 
 class Dgrad(Function):
     @staticmethod
-    def forward(ctx, gy, w, H, W, stride, pad, wkey=None, mask=None):
-        """mask (optional, the conv's own input when that is a LeakyReLU(0.2) output): gx *= lrelu'(mask) in the kernel's epilogue."""
+    def forward(ctx, gy, w, H, W, stride, pad, wkey=None, mask=None, out_dtype=None):
+        """mask (optional, the conv's own input when that is a LeakyReLU(0.2) output): gx *= lrelu'(mask) in the kernel's epilogue.
+        out_dtype: element type of gx = that of the conv's input x (bf16-stored activations get bf16 gradients)."""
         ctx.set_materialize_grads(False)
         ctx.cfg = (H, W, stride, pad)
         ctx.wkey = wkey
         ctx.save_for_backward(gy, w, mask)
-        return ops.conv2d_dgrad(gy, w, (H, W), stride=stride, pad=pad, wkey=wkey, mask=mask)
+        return ops.conv2d_dgrad(gy, w, (H, W), stride=stride, pad=pad, wkey=wkey, mask=mask, out_dtype=out_dtype)
 
     @staticmethod
     def backward(ctx, ggx):
         if ggx is None:
-            return (None,) * 8
+            return (None,) * 9
         gy, w, mask = ctx.saved_tensors
         H, W, stride, pad = ctx.cfg
         ggx = ggx.contiguous()
@@ -304,7 +307,7 @@ class Dgrad(Function):
             ggx = ActBwd.apply(ggx, mask, 0.2)
         g_gy = g_w = None
         if ctx.needs_input_grad[0]:
-            g_gy = Conv.apply(ggx, w, None, stride, pad, ops.ACT_NONE, None, ctx.wkey)
+            g_gy = Conv.apply(ggx, w, None, stride, pad, ops.ACT_NONE, None, ctx.wkey, 1.0, None, None, False, False, gy.dtype)
         if ctx.needs_input_grad[1]:
             ps = _PS_SINK
             param = None if ps is None else ps.by_ptr.get(w.data_ptr())
@@ -315,7 +318,7 @@ class Dgrad(Function):
                     ps.sink(param, rows.reshape(rows.shape[0], -1))
             else:
                 g_w = Wgrad.apply(gy, ggx, w.shape[1], w.shape[2], stride, pad)
-        return g_gy, g_w, None, None, None, None, None, None
+        return g_gy, g_w, None, None, None, None, None, None, None
 
 
 class Wgrad(Function):
@@ -341,9 +344,9 @@ class Wgrad(Function):
         ggw = ggw.contiguous()
         g_gy = g_x = None
         if ctx.needs_input_grad[0]:
-            g_gy = Conv.apply(x, ggw, None, stride, pad, ops.ACT_NONE, None)
+            g_gy = Conv.apply(x, ggw, None, stride, pad, ops.ACT_NONE, None, None, 1.0, None, None, False, False, gy.dtype)
         if ctx.needs_input_grad[1]:
-            g_x = Dgrad.apply(gy, ggw, x.shape[1], x.shape[2], stride, pad, None, x.detach() if ctx.in_mask else None)
+            g_x = Dgrad.apply(gy, ggw, x.shape[1], x.shape[2], stride, pad, None, x.detach() if ctx.in_mask else None, x.dtype)
         return g_gy, g_x, None, None, None, None, None
 
 
@@ -352,8 +355,9 @@ class ConvPerSample(Function):
     store (the Opacus-hook replacement, train.py:373,387) and returns only the data gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, sink, pass_idx, wkey=None, bpc=None, in_mask=False, out_masked=False):
-        y = ops.conv2d_fwd(x, w, b, stride=stride, pad=pad, act=act)
+    def forward(ctx, x, w, b, stride, pad, act, sink, pass_idx, wkey=None, bpc=None, in_mask=False, out_masked=False, out_dtype=None):
+        stored = x.dtype == torch.bfloat16 or out_dtype == torch.bfloat16       # the bf16 filter copy is cached per parameter version
+        y = ops.conv2d_fwd(x, w, b, stride=stride, pad=pad, act=act, wkey=wkey if stored else None, out_dtype=out_dtype)
         ctx.wkey, ctx.bpc = wkey, bpc
         ctx.in_mask, ctx.out_masked = in_mask, out_masked
         ctx.cfg = (stride, pad, act)
@@ -391,8 +395,8 @@ class ConvPerSample(Function):
             gx = None
             if ctx.needs_input_grad[0]:
                 gx = ops.conv2d_dgrad(gz, w, (x.shape[1], x.shape[2]), stride=stride, pad=pad, wkey=ctx.wkey,
-                                      mask=x if ctx.in_mask else None)
-        return gx, None, None, None, None, None, None, None, None, None, None, None
+                                      mask=x if ctx.in_mask else None, out_dtype=x.dtype)
+        return gx, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class RowL2Norm(Function):

@@ -89,8 +89,10 @@ class HipConv2d(nn.Conv2d, _PerSampleMixin):
         self.act = act
         self._wtoken = next(_tokens)
 
-    def forward_nhwc(self, x, residual=None, in_mask=False, out_masked=False):
+    def forward_nhwc(self, x, residual=None, in_mask=False, out_masked=False, out_dtype=None):
         """x: NHWC-contiguous device tensor -> NHWC output (+ residual before the activation).
+        out_dtype: torch.bfloat16 stores the output as bfloat16 (ops.set_storage_dtype; the model that owns the chain decides);
+        None follows x's element type.
 
         Activation-backward fusion, decided by the MODEL that owns the chain (DCResNetDiscriminator.forward):
           in_mask     x is the LeakyReLU(0.2) output of a layer that was called with out_masked: this layer multiplies the data
@@ -106,9 +108,10 @@ class HipConv2d(nn.Conv2d, _PerSampleMixin):
         if self._per_sample_active() and residual is None:
             sink = self._sink
             y = HF.ConvPerSample.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act, sink.collector(self), sink.next_pass(self),
-                                       self._wkey(w), bpc, im, om)
+                                       self._wkey(w), bpc, im, om, out_dtype)
         else:
-            y = HF.Conv.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act, residual, self._wkey(w), 1.0, None, bpc, im, om)
+            y = HF.Conv.apply(x, w, self.bias, self.stride[0], self.padding[0], self.act, residual, self._wkey(w), 1.0, None, bpc, im, om,
+                              out_dtype)
         if _shape_log is not None:
             _shape_log[self] = ((x.shape[3], x.shape[1], x.shape[2]), (y.shape[3], y.shape[1], y.shape[2]))
         return _record_mask(self, y, self.act)

@@ -71,6 +71,92 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_storage_bf16 = False
+
+
+def set_storage_dtype(name):
+    """Element type of the ACTIVATIONS and ACTIVATION GRADIENTS between the critic's conv layers in HBM (BASELINE configs[4],
+    csrc/igemm_bf16s.hip):
+      "fp32"  the default: every tensor is fp32;
+      "bf16"  the critic's conv layers write bfloat16 outputs; every conv / data-gradient / weight-gradient call whose activation
+              operands are bfloat16 runs on the bf16-stored kernels (bf16 filter copies cached per parameter version, fp32
+              accumulation, fp32 weight gradients).  Parameters, weight gradients, per-sample gradients, norms, clip, noise and
+              Adam stay fp32.  The dtype then FOLLOWS the tensors: an op handed bf16 activations answers in kind.
+    Process-wide like set_compute_dtype, set once from --storage_dtype."""
+    global _storage_bf16
+    if name not in ("fp32", "bf16"):
+        raise ValueError("storage dtype must be 'fp32' or 'bf16', got %r" % (name,))
+    _storage_bf16 = name == "bf16"
+
+
+def get_storage_dtype():
+    return "bf16" if _storage_bf16 else "fp32"
+
+
+def storage_bf16():
+    return _storage_bf16
+
+
+class storage_dtype:
+    """Context manager form of set_storage_dtype (tests)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = get_storage_dtype()
+        set_storage_dtype(self.name)
+
+    def __exit__(self, *a):
+        set_storage_dtype(self.prev)
+
+
+def cast_bf16(t):
+    """fp32 -> bfloat16 (round to nearest even), same shape and strides; one pass of cslgan_cast_f32_bf16."""
+    if t.dtype == torch.bfloat16:
+        return t
+    _chk_dense(t, "t")
+    out = torch.empty_like(t, dtype=torch.bfloat16)
+    check(_lib.lib().cslgan_cast_f32_bf16(_p(t), _p(out), t.numel(), _stream()), "cast_f32_bf16")
+    return out
+
+
+def cast_f32(t):
+    """bfloat16 -> fp32 (exact), same shape and strides."""
+    if t is None or t.dtype == torch.float32:
+        return t
+    _chk_dense(t, "t", allow_bf16=True)
+    out = torch.empty_like(t, dtype=torch.float32)
+    check(_lib.lib().cslgan_cast_bf16_f32(_p(t), _p(out), t.numel(), _stream()), "cast_bf16_f32")
+    return out
+
+
+def _chk_dense(t, name, allow_bf16=False):
+    """A device tensor whose memory is one dense block in some dimension order (casts are layout-agnostic)."""
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a device tensor (csl_gan_amd.ops has no CPU path)" % name)
+    if t.dtype != torch.float32 and not (allow_bf16 and t.dtype == torch.bfloat16):
+        raise RuntimeError("%s must be float32%s, got %s" % (name, " or bfloat16" if allow_bf16 else "", t.dtype))
+    if not (t.is_contiguous() or _dense_block(t)):
+        raise RuntimeError("%s must be dense" % name)
+    return t
+
+
+def _dense_block(t):
+    """True when t's elements fill one block of memory exactly once (any dimension order: e.g. channels-last views)."""
+    dims = sorted(((st, sz) for sz, st in zip(t.shape, t.stride()) if sz > 1))
+    run = 1
+    for st, sz in dims:
+        if st != run:
+            return False
+        run *= sz
+    return True
+
+
+def _is_bf16(t):
+    return t is not None and t.dtype == torch.bfloat16
+
+
 class _RepackCache:
     """Repacked filter matrices (data-gradient classes, stride-2 parity classes, the channel-folded filters of the
     generator's UpsampleConv layers) keyed by the filter tensor's storage and autograd version counter: any in-place
@@ -218,11 +304,56 @@ def _conv_desc(N, H, W, Cc, K, R, S, stride, pad, kind="wgrad"):
     return ConvT(N, H, W, Cc, K, R, S, stride, pad, comp, P, Q), P, Q
 
 
-def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, out=None, wkey=None, alg_scale=1.0, wversion=None):
+def _conv2d_fwd_stored(x, w, bias, stride, pad, residual, act, out, wkey, alg_scale, wversion, out_dtype):
+    """conv2d_fwd with bf16-stored activations (x and / or y bfloat16): the bf16-stored kernel when x is bf16 with C % 8 == 0,
+    otherwise the fp32 kernels between casts."""
+    _chk(x, "x", allow_bf16=True); _chk(w, "w")
+    N, H, W, Cc = x.shape
+    K, R, S, C2 = w.shape
+    if C2 != Cc:
+        raise RuntimeError("conv2d_fwd: channel mismatch x C=%d, w C=%d" % (Cc, C2))
+    P, Q = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
+    if out_dtype is None:           # follow the input: conv layers answer bf16 activations in kind; heads and 1..4-channel images stay fp32
+        out_dtype = torch.bfloat16 if (x.dtype == torch.bfloat16 and P * Q > 1 and K > 4) else torch.float32
+    y_bf16 = out_dtype == torch.bfloat16
+    if x.dtype == torch.bfloat16 and Cc % 8 == 0:
+        d = ConvT(N, H, W, Cc, K, R, S, stride, pad, COMPUTE_BF16, P, Q)
+        y = out if out is not None else torch.empty((N, P, Q, K), device=x.device, dtype=out_dtype)
+        if y.dtype != out_dtype:
+            raise RuntimeError("conv2d_fwd: out has dtype %s, expected %s" % (y.dtype, out_dtype))
+        if bias is not None:
+            _chk(bias, "bias")
+        if residual is not None:
+            _chk(residual, "residual", allow_bf16=True)
+            if tuple(residual.shape) != (N, P, Q, K):
+                raise RuntimeError("conv2d_fwd: residual shape %s, expected %s" % (tuple(residual.shape), (N, P, Q, K)))
+        ws, repack = repack_cache.get("bf16s_fwd", w, (w.numel() + 1) // 2, wkey, version=wversion)
+        flop = 2.0 * N * P * Q * K * R * S * Cc * alg_scale
+        nbytes = 2.0 * (N * H * W * Cc + K * R * S * Cc) + y.element_size() * float(N * P * Q * K)
+        _timed("conv2d_fwd", flop, nbytes, lambda: check(
+            _lib.lib().cslgan_conv2d_fwd_bf16s(C.byref(d), _p(x), _p(w), _p(ws), repack, _p(bias), _p(residual), 1 if _is_bf16(residual) else 0,
+                                               act, _p(y), 1 if y_bf16 else 0, _stream()), "conv2d_fwd_bf16s"),
+            exec_flop=2.0 * N * P * Q * K * R * S * Cc, tag=lambda: "N%d %dx%d C%d K%d R%d s%d bf16s" % (N, H, W, Cc, K, R, stride))
+        repack_cache.packed()
+        return y
+    yf = conv2d_fwd(cast_f32(x), w, bias, stride=stride, pad=pad, residual=cast_f32(residual), act=act, wkey=wkey, alg_scale=alg_scale,
+                    wversion=wversion)
+    y = cast_bf16(yf) if y_bf16 else yf
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, out=None, wkey=None, alg_scale=1.0, wversion=None,
+               out_dtype=None):
     """y[N,P,Q,K] = act(conv(x[N,H,W,C], w[K,R,S,C]) + bias [+ residual[N,P,Q,K]]).
 
     alg_scale: FLOP the reference spends on this layer / FLOP of this call (4 for an UpsampleConv's conv, which the
-    reference runs over four identical channel groups) — bench accounting only."""
+    reference runs over four identical channel groups) — bench accounting only.
+    out_dtype: torch.bfloat16 stores the output as bfloat16 (set_storage_dtype); None follows the input's element type."""
+    if x.dtype == torch.bfloat16 or out_dtype == torch.bfloat16 or _is_bf16(residual):
+        return _conv2d_fwd_stored(x, w, bias, stride, pad, residual, act, out, wkey, alg_scale, wversion, out_dtype)
     _chk(x, "x"); _chk(w, "w")
     N, H, W, Cc = x.shape
     K, R, S, C2 = w.shape
@@ -320,8 +451,44 @@ def _pad_c4(t):
     return out
 
 
-def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None, wkey=None):
-    """gx[N,H,W,C] = conv_transpose(gy[N,P,Q,K], w[K,R,S,C]) (* lrelu'(mask))."""
+def _conv2d_dgrad_stored(gy, w, in_hw, stride, pad, mask, wkey, out_dtype):
+    """conv2d_dgrad with bf16-stored activation gradients: the bf16-stored kernel when gy is bf16 with K % 8 == 0, otherwise the
+    fp32 kernels between casts."""
+    _chk(gy, "gy", allow_bf16=True); _chk(w, "w")
+    N, P, Q, K = gy.shape
+    K2, R, S, Cc = w.shape
+    H, W = in_hw
+    if out_dtype is None:
+        out_dtype = torch.bfloat16 if (gy.dtype == torch.bfloat16 and Cc > 4) else torch.float32
+    if mask is not None and mask.dtype != out_dtype:
+        mask = cast_bf16(mask) if out_dtype == torch.bfloat16 else cast_f32(mask)
+    if gy.dtype == torch.bfloat16 and K % 8 == 0 and stride in (1, 2):
+        P2, Q2 = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
+        if K2 != K or (P2, Q2) != (P, Q):
+            raise RuntimeError("conv2d_dgrad: gy shape %s inconsistent with input %dx%d" % (tuple(gy.shape), H, W))
+        d = ConvT(N, H, W, Cc, K, R, S, stride, pad, COMPUTE_BF16, P, Q)
+        gx = torch.empty((N, H, W, Cc), device=gy.device, dtype=out_dtype)
+        if mask is not None:
+            _chk(mask, "mask", allow_bf16=True)
+            if tuple(mask.shape) != tuple(gx.shape):
+                raise RuntimeError("conv2d_dgrad: mask shape mismatch")
+        ws, repack = repack_cache.get("bf16s_dgrad%d" % stride, w, (w.numel() + 1) // 2, wkey)
+        flop = 2.0 * N * P * Q * K * R * S * Cc
+        nbytes = 2.0 * (K * R * S * Cc + N * P * Q * K) + gx.element_size() * float(N * H * W * Cc)
+        _timed("conv2d_dgrad", flop, nbytes, lambda: check(
+            _lib.lib().cslgan_conv2d_dgrad_bf16s(C.byref(d), _p(gy), _p(w), _p(ws), repack, _p(mask), _p(gx),
+                                                 1 if out_dtype == torch.bfloat16 else 0, _stream()), "conv2d_dgrad_bf16s"),
+            tag=lambda: "N%d %dx%d C%d K%d R%d s%d bf16s" % (N, H, W, Cc, K, R, stride))
+        repack_cache.packed()
+        return gx
+    gx = conv2d_dgrad(cast_f32(gy), w, in_hw, stride=stride, pad=pad, mask=cast_f32(mask), wkey=wkey)
+    return cast_bf16(gx) if out_dtype == torch.bfloat16 else gx
+
+
+def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None, wkey=None, out_dtype=None):
+    """gx[N,H,W,C] = conv_transpose(gy[N,P,Q,K], w[K,R,S,C]) (* lrelu'(mask)).  out_dtype as for conv2d_fwd."""
+    if gy.dtype == torch.bfloat16 or out_dtype == torch.bfloat16 or _is_bf16(mask):
+        return _conv2d_dgrad_stored(gy, w, in_hw, stride, pad, mask, wkey, out_dtype)
     _chk(gy, "gy"); _chk(w, "w")
     N, P, Q, K = gy.shape
     K2, R, S, Cc = w.shape
@@ -407,6 +574,7 @@ _GRAM_MAX_PIX = int(os.environ.get("CSLGAN_GHOST_MAX_PIX", "64"))     # 16 resto
 
 def conv2d_wgrad_sqnorm_gram(gy, x, R, S, stride=1, pad=0, alpha=1.0, sq=None):
     """sq[N] += ||alpha * per-sample weight gradient||^2 from the two PQ x PQ Gram matrices (no gradient formed)."""
+    gy, x = cast_f32(gy), cast_f32(x)       # fp32 kernels only (ghost clipping is not combined with bf16 storage)
     _chk(gy, "gy"); _chk(x, "x")
     N, H, W, Cc = x.shape
     N2, P, Q, K = gy.shape
@@ -440,6 +608,11 @@ def conv2d_wgrad_sqnorm_gram(gy, x, R, S, stride=1, pad=0, alpha=1.0, sq=None):
 def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_gw=True, sq=None, out=None, row_scale=None):
     """gw[N/group,K,R,S,C] (per-group weight gradients) and/or sq[N/group] += ||alpha*gw_g||^2.
     row_scale [N]: gy of sample n is weighted by row_scale[n] (clip-weighted sums; fp32 output, no sq)."""
+    if gy.dtype == torch.bfloat16 or x.dtype == torch.bfloat16:
+        if (gy.dtype == x.dtype and row_scale is None and gy.shape[-1] % 8 == 0 and x.shape[-1] % 8 == 0
+                and (want_gw or sq is not None)):
+            return _conv2d_wgrad_grouped_stored(gy, x, R, S, stride, pad, group, alpha, want_gw, sq, out)
+        gy, x = cast_f32(gy), cast_f32(x)       # mixed element types / shapes the bf16-stored kernel does not take
     _chk(gy, "gy"); _chk(x, "x")
     N, H, W, Cc = x.shape
     N2, P, Q, K = gy.shape
@@ -496,6 +669,33 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
     return None if scratch else gw
 
 
+def _conv2d_wgrad_grouped_stored(gy, x, R, S, stride, pad, group, alpha, want_gw, sq, out):
+    """conv2d_wgrad_grouped on bf16 gy and bf16 x (cslgan_conv2d_wgrad_grouped_bf16s): fp32 (or bf16) gw and / or sq."""
+    _chk(gy, "gy", allow_bf16=True); _chk(x, "x", allow_bf16=True)
+    N, H, W, Cc = x.shape
+    N2, P, Q, K = gy.shape
+    P2, Q2 = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
+    if N2 != N or (P2, Q2) != (P, Q):
+        raise RuntimeError("conv2d_wgrad: gy %s inconsistent with x %s" % (tuple(gy.shape), tuple(x.shape)))
+    if N % group:
+        raise RuntimeError("conv2d_wgrad: N=%d not divisible by group=%d" % (N, group))
+    G = N // group
+    d = ConvT(N, H, W, Cc, K, R, S, stride, pad, COMPUTE_BF16, P, Q)
+    gw = None
+    if want_gw:
+        gw = out if out is not None else torch.empty((G, K, R, S, Cc), device=x.device, dtype=torch.float32)
+        _chk(gw, "gw", allow_bf16=True)
+    if sq is not None:
+        _chk(sq, "sq")
+    flop = 2.0 * N * P * Q * K * R * S * Cc
+    nbytes = 2.0 * (N * H * W * Cc + N * P * Q * K) + (float(gw.element_size()) * (G * K * R * S * Cc) if want_gw else 0.0)
+    _timed("conv2d_wgrad_grouped" + ("" if want_gw else "_normonly"), flop, nbytes, lambda: check(
+        _lib.lib().cslgan_conv2d_wgrad_grouped_bf16s(C.byref(d), _p(gy), _p(x), group, float(alpha), _p(gw),
+                                                     1 if _is_bf16(gw) else 0, _p(sq), _stream()), "conv2d_wgrad_grouped_bf16s"),
+        tag=lambda: "N%d %dx%d C%d K%d R%d s%d g%d bf16s" % (N, H, W, Cc, K, R, stride, group))
+    return gw
+
+
 def wgrad_blocks_eligible(gy_shape, x_shape, R, S, stride):
     """Shapes cslgan_conv2d_wgrad_blocks_f32 takes (the LDS-resident fp32 kernel): mirrors wgh_eligible in csrc/igemm_wgh.hip."""
     _, P, Q, K = gy_shape
@@ -539,6 +739,9 @@ def conv2d_wgrad_blocks(gy, x, R, S, stride, pad, alpha, blocks):
 def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, alpha=1.0, row_scale=None, out=None):
     """The summed weight gradient [K,R,S,C] of a batch: slabs of the grouped MFMA kernel + a column sum, or the
     vector-ALU kernel for 1..4 output channels.  out (optional, flat fp32 [K*R*S*C]): destination of the sum."""
+    if (gy.dtype == torch.bfloat16 or x.dtype == torch.bfloat16) and not (
+            gy.dtype == x.dtype and row_scale is None and gy.shape[-1] % 8 == 0 and x.shape[-1] % 8 == 0):
+        gy, x = cast_f32(gy), cast_f32(x)
     N, H, W, Cc = x.shape
     _, P, Q, K = gy.shape
     if (K <= 4 and Cc == 64 and stride == 1 and R * S <= 9 and P % 8 == 0 and Q % 8 == 0 and row_scale is None):
@@ -587,12 +790,18 @@ def norm_act_bwd(x, dy, y, gamma, stats, rows_per_stat, groups, eps, relu):
 
 
 def bias_grad_grouped(gy, group=1, alpha=1.0, want_gb=True, sq=None, out=None):
-    _chk(gy, "gy")
     N, K = gy.shape[0], gy.shape[-1]
     PQ = gy.numel() // (N * K)
     gb = None
     if want_gb:
         gb = out if out is not None else torch.empty((N // group, K), device=gy.device, dtype=torch.float32)
+    if gy.dtype == torch.bfloat16:
+        if K % 8 == 0 and K <= 2048 and 256 % (K // 8) == 0:
+            _chk(gy, "gy", allow_bf16=True)
+            check(_lib.lib().cslgan_bias_grad_grouped_bf16(_p(gy), N, PQ, K, group, float(alpha), _p(gb), _p(sq), _stream()), "bias_grad_bf16")
+            return gb
+        gy = cast_f32(gy)
+    _chk(gy, "gy")
     check(_lib.lib().cslgan_bias_grad_grouped_f32(_p(gy), N, PQ, K, group, float(alpha), _p(gb), _p(sq), _stream()), "bias_grad")
     return gb
 
@@ -757,6 +966,14 @@ def row_l2norm_bwd(t2d, norm, gnorm):
 
 
 def act_bwd(g, y, slope):
+    if g.dtype == torch.bfloat16 or y.dtype == torch.bfloat16:
+        if g.dtype == y.dtype and g.numel() % 8 == 0:
+            _chk(g, "g", allow_bf16=True); _chk(y, "y", allow_bf16=True)
+            out = torch.empty_like(g)
+            check(_lib.lib().cslgan_act_bwd_bf16(_p(g), _p(y), g.numel(), float(slope), _p(out), _stream()), "act_bwd_bf16")
+            return out
+        out = act_bwd(cast_f32(g), cast_f32(y), slope)
+        return cast_bf16(out) if g.dtype == torch.bfloat16 else out
     _chk(g, "g"); _chk(y, "y")
     out = torch.empty_like(g)
     check(_lib.lib().cslgan_act_bwd_f32(_p(g), _p(y), g.numel(), float(slope), _p(out), _stream()), "act_bwd")

@@ -16,6 +16,9 @@ Additions of this build (all optional, none changes a reference default):
                        kernels, fp32 accumulate; BASELINE.json configs[4]).  With bf16
                        the per-sample norms must be norms of the gradients that are actually summed, so ghost clipping (whose
                        Gram norms are computed in fp32) is replaced by --materialize private
+  --storage_dtype T    element type of the critic's activations and activation gradients in HBM: fp32 (default) or bf16 (needs
+                       --compute_dtype bf16: bf16-stored kernels of csrc/igemm_bf16s.hip, bf16 filter copies, fp32 accumulation,
+                       fp32 weight gradients / norms / clip / noise / Adam; BASELINE.json configs[4])
   --hip_graph B        (default True) record the DP D-step (dp_mode=gc, full batches, one process) once in a HIP graph and replay it
                        (trainer.GraphedDStep): no per-launch host work, and the step's second stream (gradient-penalty branch)
                        overlaps by dependency instead of by host timing; partial batches and every other mode run eagerly
@@ -167,6 +170,7 @@ _ARGS = [
     (("--moving_avg_beta",), dict(type=float, default=None)),
     (("--hip_graph",), dict(type=str2bool, default=True)),
     (("--compute_dtype",), dict(type=str, choices=["fp32", "bf16", "bf16x3", "fp32_auto"], default="fp32")),
+    (("--storage_dtype",), dict(type=str, choices=["fp32", "bf16"], default="fp32")),
 ]
 ALWAYS_KEEP = ["g_device", "d_device", "num_workers", "resume_path", "resume_epochs"]
 
@@ -235,6 +239,10 @@ def finalize(opt, make_dirs=True):
     if getattr(opt, "compute_dtype", "fp32") == "bf16" and opt.materialize == "ghost":
         print("compute_dtype=bf16: using --materialize private (ghost clipping's Gram norms are fp32 norms of unrounded products)")
         opt.materialize = "private"
+    if getattr(opt, "storage_dtype", "fp32") == "bf16" and getattr(opt, "compute_dtype", "fp32") != "bf16":
+        raise Exception("--storage_dtype bf16 needs --compute_dtype bf16 (bf16-stored activations are multiplied on the bf16 matrix cores)")
+    if getattr(opt, "storage_dtype", "fp32") == "bf16" and getattr(opt, "backprop_clip", False):
+        raise Exception("--storage_dtype bf16 is not combined with --backprop_clip")
 
     if not opt.output_dir:
         stamp = datetime.now().strftime("output/%m-%d-%H:%M-")

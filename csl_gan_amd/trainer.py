@@ -33,6 +33,7 @@ class Trainer:
         if any(p.is_cuda for p in D.parameters()):
             from . import ops
             ops.set_compute_dtype(getattr(opt, "compute_dtype", "fp32"))     # process-wide: one process drives one run
+            ops.set_storage_dtype(getattr(opt, "storage_dtype", "fp32"))
         self.dataset, self.public_dataloader, self.public_dataset = dataset, public_dataloader, public_dataset
         self.mean_sampler = mean_sampler
         self.world_size, self.rank, self.grad_reducer = world_size, rank, grad_reducer

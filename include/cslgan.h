@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CSLGAN_ABI_VERSION 3
+#define CSLGAN_ABI_VERSION 4
 
 typedef enum {
     CSLGAN_OK = 0,
@@ -226,6 +226,37 @@ int cslgan_conv2d_wgrad_grouped_bf16out_f32(const cslgan_conv_t* p, const float*
 /* Per-group bias gradient gb[g][k] = alpha * sum_{n in g, p, q} gy[n,p,q,k]; sq as above. */
 int cslgan_bias_grad_grouped_f32(const float* gy, int N, int PQ, int K, int group, float alpha,
                                  float* gb, float* sq, void* stream);
+
+/* ---- bf16 STORAGE (BASELINE.json configs[4]; csrc/igemm_bf16s.hip) -------------------------------------------------
+ * The entries above read fp32 tensors whatever cslgan_conv_t.compute says.  These read and write ACTIVATIONS and ACTIVATION
+ * GRADIENTS stored as bfloat16 in HBM (NHWC, the same index maps), with a bfloat16 copy of the fp32 master filter; sums are
+ * fp32 (v_mfma_f32_32x32x16_bf16), weight gradients / norms are fp32.  `*_bf16` flags give the element type of the tensor
+ * named before them (0 = float, 1 = bfloat16).  Replaces the same reference calls as the fp32 entries: nn.Conv2d / nn.Linear
+ * forward and data gradient (DCResNet_models.py:131-132,145), per-sample weight gradients (train.py:373,387). */
+
+/* y = act(conv(x, w) + bias [+ residual]); x bf16 [N,H,W,C] with C % 8 == 0; w the fp32 KRSC filter, wb_ws a caller-owned
+ * bf16 workspace of K*R*S*C elements holding bf16(w) (written here when repack != 0: once per parameter version);
+ * residual (nullable) and y are bf16 or fp32 as flagged. */
+int cslgan_conv2d_fwd_bf16s(const cslgan_conv_t* p, const void* x, const float* w, void* wb_ws, int repack, const float* bias,
+                            const void* residual, int res_bf16, int act, void* y, int y_bf16, void* stream);
+
+/* gx = conv_transpose(gy, w) (* lrelu'(mask)); gy bf16 [N,P,Q,K] with K % 8 == 0; wt_ws: bf16 workspace of K*R*S*C elements for
+ * the per-parity-class filter matrices (written when repack != 0); mask (nullable) has gx's shape AND element type. */
+int cslgan_conv2d_dgrad_bf16s(const cslgan_conv_t* p, const void* gy, const float* w, void* wt_ws, int repack, const void* mask,
+                              void* gx, int gx_bf16, void* stream);
+
+/* cslgan_conv2d_wgrad_grouped_f32 on bf16 gy [N,P,Q,K] and bf16 x [N,H,W,C] (K % 8 == 0, C % 8 == 0): gw fp32 (bf16 when
+ * gw_bf16; nullable) and / or sq[N/group] += ||alpha gw_g||^2. */
+int cslgan_conv2d_wgrad_grouped_bf16s(const cslgan_conv_t* p, const void* gy, const void* x, int group, float alpha, void* gw,
+                                      int gw_bf16, float* sq, void* stream);
+
+/* Element-type conversions at the edges of the bf16-stored chain (round-to-nearest-even / exact widening). */
+int cslgan_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, void* stream);
+int cslgan_cast_bf16_f32(const void* in_bf16, float* out, int64_t n, void* stream);
+
+/* cslgan_act_bwd_f32 / cslgan_bias_grad_grouped_f32 on bf16 tensors (fp32 sums; n % 8 == 0; K % 8 == 0, 256 % (K/8) == 0). */
+int cslgan_act_bwd_bf16(const void* g, const void* y, int64_t n, float slope, void* out, void* stream);
+int cslgan_bias_grad_grouped_bf16(const void* gy, int N, int PQ, int K, int group, float alpha, float* gb, float* sq, void* stream);
 
 /* ---- pointwise / normalisation ------------------------------------------------------------- */
 

@@ -37,3 +37,4 @@ def _reset_compute_dtype():
     ops = sys.modules.get("csl_gan_amd.ops")
     if ops is not None:
         ops.set_compute_dtype("fp32")
+        ops.set_storage_dtype("fp32")

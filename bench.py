@@ -352,7 +352,7 @@ def main():
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
         "config": {"workload": "CelebA DCResNet D-step: %s -nms %d, WGAN-GP on mean samples, 3x%dx%d" % (mode, opt.num_mean_samples, opt.im_size, opt.im_size),
-                   "compute_dtype": getattr(opt, "compute_dtype", "fp32"),
+                   "compute_dtype": getattr(opt, "compute_dtype", "fp32"), "storage_dtype": getattr(opt, "storage_dtype", "fp32"),
                    "launch": launch_mode, "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                    "materialize": getattr(opt, "materialize", "all"), "grad_sample_dtype": getattr(opt, "grad_sample_dtype", "fp32"),
                    "fuse_passes": bool(getattr(opt, "fuse_passes", False)),

@@ -505,6 +505,202 @@ __global__ __launch_bounds__(256, 2) void igemm_mcs_kernel(const MsParams p) {
     }
 }
 
+// Same contraction with NO register transpose: the [pixel][channel] tiles go to LDS as they are loaded (row-major, 256-byte rows,
+// 16-byte chunks XOR-swizzled by the row so that both the row writes and the transposed reads are conflict-free) and the MFMA
+// operands come back through ds_read_b64_tr_b16, gfx950's transposing LDS read: per 16-lane group a block of 4 rows (pixels) x 16
+// columns (channels) is delivered column-major, i.e. each lane receives 4 consecutive k of ITS channel; two such reads are one
+// operand of v_mfma_f32_32x32x16_bf16.  The register transpose above costs ~100 vector instructions per thread and K tile beside
+// 16 MFMAs per wave (measured 176-208 TF); here a K tile is 8 global loads, 8 ds_write_b128 and 32 transposed reads per thread.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+template <bool Q8>
+__global__ __launch_bounds__(256, 2) void igemm_mcs_tr_kernel(const MsParams p) {
+    constexpr int OPB = 64 * 256;                           // bytes of one operand tile: 64 pixels x 128 channels x 2 B
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * OPB];     // [buffer][operand]
+    __shared__ float s_red[4];
+
+    const int tid = threadIdx.x;
+    const int per_g = p.tiles_m * p.tiles_n;
+    const int split = p.ksplit > 1 ? blockIdx.x % p.ksplit : 0;
+    const int bid = p.ksplit > 1 ? blockIdx.x / p.ksplit : blockIdx.x;
+    const int g = bid / per_g;
+    const int tl = bid - g * per_g;
+    const int tile_m = tl / p.tiles_n, tile_n = tl - tile_m * p.tiles_n;
+    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const int PQ = p.P * p.Q;
+    const int Ktot = p.group * PQ;
+    const long long pix_base = (long long)g * p.group * PQ;
+
+    const bool is_a = tid < 128;
+    const int lt = tid & 127;
+    const int c16 = lt & 15;             // this thread's 16-byte chunk (8 channels) of a pixel row: 16 lanes cover its 256 bytes
+    const int c8 = c16 * 8;
+    const int kg = lt >> 4;              // its group of 8 pixels within the 64-pixel tile
+    const int nb = n0 + c8;
+    const bool b_ok = nb < p.Ndim;
+    const int b_t = b_ok ? nb / p.C : 0;
+    const int b_c = nb - b_t * p.C;
+    const int b_ty = p.ty[b_t], b_tx = p.tx[b_t];
+    const bool a_ok = m0 + c8 < p.Kc;
+    const unsigned short* __restrict__ gyh = reinterpret_cast<const unsigned short*>(p.gy);
+    const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(p.x);
+
+    uint4 rv[8];
+    auto load_tile = [&](int kt) {
+        const int kk0 = kt * MS_BK + kg * 8;
+        if (is_a) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (a_ok && kk0 + j < Ktot) v = *reinterpret_cast<const uint4*>(gyh + (pix_base + kk0 + j) * p.Kc + m0 + c8);
+                rv[j] = v;
+            }
+        } else if (Q8) {
+            const int il = kk0 / PQ;
+            const int pix = kk0 - il * PQ;
+            const int oy = pix / p.Q, ox0 = pix - oy * p.Q;
+            const long long img = (long long)g * p.group + il;
+            const int iy = oy * p.stride + b_ty;
+            const bool row_ok = b_ok && kk0 < Ktot && iy >= 0 && iy < p.H;
+            const unsigned short* src = xh + ((img * p.H + iy) * p.W) * p.C + b_c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ix = (ox0 + j) * p.stride + b_tx;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (row_ok && ix >= 0 && ix < p.W) v = *reinterpret_cast<const uint4*>(src + (long long)ix * p.C);
+                rv[j] = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kk = kk0 + j;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (b_ok && kk < Ktot) {
+                    const int il = kk / PQ;
+                    const int pix = kk - il * PQ;
+                    const int oy = pix / p.Q, ox = pix - oy * p.Q;
+                    const long long img = (long long)g * p.group + il;
+                    const int iy = oy * p.stride + b_ty, ix = ox * p.stride + b_tx;
+                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = *reinterpret_cast<const uint4*>(xh + ((img * p.H + iy) * p.W + ix) * p.C + b_c);
+                }
+                rv[j] = v;
+            }
+        }
+    };
+    // row (pixel) kr of a tile, 16-byte chunk ch: byte offset 256*kr + 16*(ch ^ (((kr & 3) << 2) | ((kr >> 2) & 3)))
+    auto store_tile = [&](int buf) {
+        unsigned char* dst = smem + (buf * 2 + (is_a ? 0 : 1)) * OPB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kr = kg * 8 + j;
+            const int sw = ((j & 3) << 2) | ((kr >> 2) & 3);
+            *reinterpret_cast<uint4*>(dst + 256 * kr + 16 * (c16 ^ sw)) = rv[j];
+        }
+    };
+
+    const int lane = tid & 63, wid = tid >> 6;
+    const int h = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+    // transposed-read addresses (bytes within an operand tile) of this lane for k-step 0: [4-row half u][32-row tile i]
+    const int gq = (lane >> 2) & 3, gp = lane & 3, ghalf = (lane >> 4) & 1;       // row q and column quad p within the 16-lane group; which 16 of the 32 rows
+    int a_tr[2][2], b_tr[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kr = 8 * h + 4 * u + gq;
+            const int sw = (gq << 2) | ((2 * h + u) & 3);
+            const int cha = (wm * 64 + i * 32) / 8 + 2 * ghalf + (gp >> 1), chb = (wn * 64 + i * 32) / 8 + 2 * ghalf + (gp >> 1);
+            a_tr[u][i] = 256 * kr + 16 * (cha ^ sw) + 8 * (gp & 1);
+            b_tr[u][i] = 256 * kr + 16 * (chb ^ sw) + 8 * (gp & 1);
+        }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    const int nk_all = (Ktot + MS_BK - 1) / MS_BK;
+    int kt0 = 0, nk = nk_all;
+    if (p.ksplit > 1) {
+        const int per = (nk_all + p.ksplit - 1) / p.ksplit;
+        kt0 = split * per;
+        nk = kt0 + per < nk_all ? kt0 + per : nk_all;
+        if (kt0 >= nk) return;      // uniform across the workgroup
+    }
+    load_tile(kt0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const unsigned char* As = smem + (buf * 2) * OPB;
+        const unsigned char* Bs = As + OPB;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {       // 16 pixels per step: rows 16 s .. 16 s + 15 = +4096 bytes per step
+            bf16x8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(As + a_tr[0][i] + 4096 * s));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(As + a_tr[1][i] + 4096 * s));
+                const uint4 w = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y, __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
+                af[i] = __builtin_bit_cast(bf16x8, w);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Bs + b_tr[0][j] + 4096 * s));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Bs + b_tr[1][j] + 4096 * s));
+                const uint4 w = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y, __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
+                bf[j] = __builtin_bit_cast(bf16x8, w);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: scale, store, per-group sum of squares (as igemm_mc) ------------------------
+    const int r = lane & 31;
+    float ss = 0.f;
+    float* __restrict__ outg = (p.gw && !p.out_bf16) ? reinterpret_cast<float*>(p.gw) + (long long)g * p.Kc * p.Ndim : nullptr;
+    unsigned short* __restrict__ outh = (p.gw && p.out_bf16) ? reinterpret_cast<unsigned short*>(p.gw) + (long long)g * p.Kc * p.Ndim : nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + r;
+        if (n >= p.Ndim) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (m >= p.Kc) continue;
+                float val = p.alpha * acc[i][j][v];
+                if (p.out_bf16) {
+                    const unsigned short u = f2bf(val);
+                    if (outh) outh[(long long)m * p.Ndim + n] = u;
+                    val = bf2f(u);
+                }
+                ss = fmaf(val, val, ss);
+                if (outg) {
+                    if (p.ksplit > 1) atomicAdd(&outg[(long long)m * p.Ndim + n], val);
+                    else outg[(long long)m * p.Ndim + n] = val;
+                }
+            }
+        }
+    }
+    if (p.sq && p.ksplit <= 1) {
+        const float tot = block_sum_256(ss, s_red);
+        if (tid == 0) atomicAdd(p.sq + g, tot);
+    }
+}
+
 int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, float* sq_accum, hipStream_t st);   // clip_kernels.hip
 
 // ---- pointwise kernels on bf16 tensors -----------------------------------------------------------------------------------------
@@ -573,6 +769,91 @@ __global__ __launch_bounds__(256) void bias_grad_bf16_kernel(const unsigned shor
     }
 }
 
+// ---- the critic's head on bf16 features (nn.Linear(C, 1), DCResNet_models.py:145) as streams -------------------------------------
+// y[n] = act(<x[n,:], bf16(w)> + b): one workgroup per row (as linear_k1.hip, x bfloat16)
+__global__ __launch_bounds__(256) void linear_k1s_fwd_kernel(const unsigned short* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                             long long C, int act, float* __restrict__ y) {
+    __shared__ float s_red[4];
+    const long long n = blockIdx.x;
+    const uint4* xr = reinterpret_cast<const uint4*>(x + n * C);
+    float acc = 0.f;
+    for (long long i = threadIdx.x; i < (C >> 3); i += 256) {
+        const uint4 a = xr[i];
+        const float4 b0 = reinterpret_cast<const float4*>(w)[2 * i], b1 = reinterpret_cast<const float4*>(w)[2 * i + 1];
+        acc = fmaf(__uint_as_float(a.x << 16), bf2f(f2bf(b0.x)), acc); acc = fmaf(__uint_as_float(a.x & 0xffff0000u), bf2f(f2bf(b0.y)), acc);
+        acc = fmaf(__uint_as_float(a.y << 16), bf2f(f2bf(b0.z)), acc); acc = fmaf(__uint_as_float(a.y & 0xffff0000u), bf2f(f2bf(b0.w)), acc);
+        acc = fmaf(__uint_as_float(a.z << 16), bf2f(f2bf(b1.x)), acc); acc = fmaf(__uint_as_float(a.z & 0xffff0000u), bf2f(f2bf(b1.y)), acc);
+        acc = fmaf(__uint_as_float(a.w << 16), bf2f(f2bf(b1.z)), acc); acc = fmaf(__uint_as_float(a.w & 0xffff0000u), bf2f(f2bf(b1.w)), acc);
+    }
+    const float tot = block_sum_256(acc, s_red);
+    if (threadIdx.x == 0) {
+        float val = tot + (bias ? bias[0] : 0.f);
+        if (act == CSLGAN_ACT_LRELU02) val = val > 0.f ? val : 0.2f * val;
+        else if (act == CSLGAN_ACT_RELU) val = val > 0.f ? val : 0.f;
+        else if (act == CSLGAN_ACT_TANH) val = tanhf(val);
+        y[n] = val;
+    }
+}
+
+// gx[n,:] = bf16( gy[n] * bf16(w) (* lrelu'(mask[n,:])) ), 8 channels per lane
+__global__ __launch_bounds__(256) void linear_k1s_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w, const unsigned short* __restrict__ mask,
+                                                               long long C8, unsigned short* __restrict__ gx) {
+    const long long n = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= C8) return;
+    const float g = gy[n];
+    const float4 b0 = reinterpret_cast<const float4*>(w)[2 * i], b1 = reinterpret_cast<const float4*>(w)[2 * i + 1];
+    float o[8] = {g * bf2f(f2bf(b0.x)), g * bf2f(f2bf(b0.y)), g * bf2f(f2bf(b0.z)), g * bf2f(f2bf(b0.w)),
+                  g * bf2f(f2bf(b1.x)), g * bf2f(f2bf(b1.y)), g * bf2f(f2bf(b1.z)), g * bf2f(f2bf(b1.w))};
+    if (mask) {
+        const uint4 m = reinterpret_cast<const uint4*>(mask + n * C8 * 8)[i];
+        const unsigned md[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            o[2 * q] *= __uint_as_float(md[q] << 16) > 0.f ? 1.f : 0.2f;
+            o[2 * q + 1] *= __uint_as_float(md[q] & 0xffff0000u) > 0.f ? 1.f : 0.2f;
+        }
+    }
+    reinterpret_cast<uint4*>(gx + n * C8 * 8)[i] = make_uint4(f2bf_pk(o[0], o[1]), f2bf_pk(o[2], o[3]), f2bf_pk(o[4], o[5]), f2bf_pk(o[6], o[7]));
+}
+
+// gw[g,:] = alpha * sum_{n in group g} gy[n] * x[n,:] (fp32), sq[g] += ||gw[g,:]||^2: the head's per-sample / grouped weight gradient
+// is a scaled copy (a short weighted sum) of bf16 feature rows
+__global__ __launch_bounds__(256) void linear_k1s_wgrad_kernel(const float* __restrict__ gy, const unsigned short* __restrict__ x, long long C8, int group,
+                                                               float alpha, float* __restrict__ gw, float* __restrict__ sq) {
+    __shared__ float s_red[4];
+    const long long g = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    if (i < C8) {
+        for (int r = 0; r < group; ++r) {
+            const long long n = g * group + r;
+            const float s = gy[n];
+            const uint4 a = reinterpret_cast<const uint4*>(x + n * C8 * 8)[i];
+            const unsigned d[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[2 * q] = fmaf(s, __uint_as_float(d[q] << 16), acc[2 * q]);
+                acc[2 * q + 1] = fmaf(s, __uint_as_float(d[q] & 0xffff0000u), acc[2 * q + 1]);
+            }
+        }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { acc[q] *= alpha; ss = fmaf(acc[q], acc[q], ss); }
+    if (gw && i < C8) {
+        float4* o = reinterpret_cast<float4*>(gw + g * C8 * 8) + 2 * i;
+        o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+    if (sq) {
+        const float tot = block_sum_256(ss, s_red);
+        if (threadIdx.x == 0) atomicAdd(sq + g, tot);
+    }
+}
+
 }  // namespace cslgan
 
 using namespace cslgan;
@@ -616,6 +897,13 @@ int cslgan_conv2d_fwd_bf16s(const cslgan_conv_t* c, const void* x, const float* 
     CSLGAN_REQUIRE(act >= 0 && act <= 3, "conv2d_fwd_bf16s: unknown activation %d", act);
     CSLGAN_REQUIRE(c->C % 8 == 0, "conv2d_fwd_bf16s: C=%d is not a multiple of 8", c->C);
     hipStream_t st = (hipStream_t)stream;
+    if (c->K == 1 && c->H == 1 && c->W == 1 && c->R == 1 && c->S == 1 && c->stride == 1 && c->pad == 0 && !residual && !y_bf16 && c->N <= 65535 &&
+        aligned16(x) && aligned16(w)) {       // the critic's head: a dot product per row
+        note_kernel("linear_k1s_fwd_kernel");
+        hipLaunchKernelGGL(linear_k1s_fwd_kernel, dim3((unsigned)c->N), dim3(256), 0, st, reinterpret_cast<const unsigned short*>(x), w, bias,
+                           (long long)c->C, act, reinterpret_cast<float*>(y));
+        return check_launch("linear_k1s_fwd_kernel");
+    }
     const long long wn = (long long)c->K * c->R * c->S * c->C;
     if (repack) {
         CSLGAN_REQUIRE(aligned16(w) && aligned16(wb_ws), "conv2d_fwd_bf16s: filter must be 16-byte aligned");
@@ -724,13 +1012,45 @@ int cslgan_conv2d_wgrad_grouped_bf16s(const cslgan_conv_t* c, const void* gy, co
     }
     const long long nb = (long long)p.n_groups * p.tiles_m * p.tiles_n * p.ksplit;
     CSLGAN_REQUIRE(nb <= 0x7fffffffll, "conv2d_wgrad_bf16s: grid too large");
-    note_kernel("igemm_mcs_kernel<128,128>");
-    if (c->Q % 8 == 0) hipLaunchKernelGGL(igemm_mcs_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(igemm_mcs_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, p);
+    static const int tr_env = [] { const char* e = getenv("CSLGAN_MCS_TR"); return e ? atoi(e) : 1; }();
+    if (tr_env) {
+        note_kernel("igemm_mcs_tr_kernel<128,128>");
+        if (c->Q % 8 == 0) hipLaunchKernelGGL(igemm_mcs_tr_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(igemm_mcs_tr_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, p);
+    } else {
+        note_kernel("igemm_mcs_kernel<128,128>");
+        if (c->Q % 8 == 0) hipLaunchKernelGGL(igemm_mcs_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(igemm_mcs_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, p);
+    }
     rc = check_launch("igemm_mcs_kernel");
     if (rc) return rc;
     if (p.ksplit > 1 && p.sq) rc = sqnorm_rows_accumulate(reinterpret_cast<float*>(p.gw), p.n_groups, (long long)p.Kc * p.Ndim, p.sq, st);
     return rc;
+}
+
+// The head nn.Linear(C, 1) on bf16 features x [N, C] (C % 8 == 0): data gradient gx[n,:] = bf16(gy[n] * bf16(w) (* lrelu'(mask)))
+// with fp32 gy [N] and bf16 mask / gx [N, C] ...
+int cslgan_linear_k1_dgrad_bf16s(const float* gy, const float* w, const void* mask, int N, int64_t C, void* gx, void* stream) {
+    CSLGAN_REQUIRE(gy && w && gx && N > 0 && N <= 65535 && C > 0 && C % 8 == 0, "linear_k1_dgrad_bf16s: bad argument");
+    CSLGAN_REQUIRE(aligned16(w) && aligned16(gx) && (!mask || aligned16(mask)), "linear_k1_dgrad_bf16s: misaligned");
+    const long long C8 = C / 8;
+    note_kernel("linear_k1s_dgrad_kernel");
+    hipLaunchKernelGGL(linear_k1s_dgrad_kernel, dim3((unsigned)((C8 + 255) / 256), (unsigned)N), dim3(256), 0, (hipStream_t)stream, gy, w,
+                       reinterpret_cast<const unsigned short*>(mask), C8, reinterpret_cast<unsigned short*>(gx));
+    return check_launch("linear_k1s_dgrad_kernel");
+}
+
+// ... and its grouped weight gradient gw[N/group, C] = alpha * sum_{n in g} gy[n] x[n,:] (fp32; nullable) and / or
+// sq[N/group] += ||gw_g||^2.
+int cslgan_linear_k1_wgrad_bf16s(const float* gy, const void* x, int N, int64_t C, int group, float alpha, float* gw, float* sq, void* stream) {
+    CSLGAN_REQUIRE(gy && x && (gw || sq) && N > 0 && C > 0 && C % 8 == 0 && group >= 1 && N % group == 0 && N / group <= 65535,
+                   "linear_k1_wgrad_bf16s: bad argument");
+    CSLGAN_REQUIRE(aligned16(x) && (!gw || aligned16(gw)), "linear_k1_wgrad_bf16s: misaligned");
+    const long long C8 = C / 8;
+    note_kernel("linear_k1s_wgrad_kernel");
+    hipLaunchKernelGGL(linear_k1s_wgrad_kernel, dim3((unsigned)((C8 + 255) / 256), (unsigned)(N / group)), dim3(256), 0, (hipStream_t)stream, gy,
+                       reinterpret_cast<const unsigned short*>(x), C8, group, alpha, gw, sq);
+    return check_launch("linear_k1s_wgrad_kernel");
 }
 
 int cslgan_act_bwd_bf16(const void* g, const void* y, int64_t n, float slope, void* out, void* stream) {

@@ -462,6 +462,16 @@ def _conv2d_dgrad_stored(gy, w, in_hw, stride, pad, mask, wkey, out_dtype):
         out_dtype = torch.bfloat16 if (gy.dtype == torch.bfloat16 and Cc > 4) else torch.float32
     if mask is not None and mask.dtype != out_dtype:
         mask = cast_bf16(mask) if out_dtype == torch.bfloat16 else cast_f32(mask)
+    if (gy.dtype == torch.float32 and out_dtype == torch.bfloat16 and K == 1 and (P, Q, R, S, H, W) == (1, 1, 1, 1, 1, 1) and Cc % 8 == 0
+            and N <= 65535 and stride == 1 and pad == 0):
+        # the critic's head: fp32 loss cotangent, bf16 features
+        gx = torch.empty((N, 1, 1, Cc), device=gy.device, dtype=torch.bfloat16)
+        if mask is not None:
+            _chk(mask, "mask", allow_bf16=True)
+        _timed("conv2d_dgrad", 2.0 * N * Cc, 2.0 * N * Cc * (2 if mask is not None else 1) + 4.0 * Cc, lambda: check(
+            _lib.lib().cslgan_linear_k1_dgrad_bf16s(_p(gy), _p(w), _p(mask), N, Cc, _p(gx), _stream()), "linear_k1_dgrad_bf16s"),
+            tag=lambda: "N%d 1x1 C%d K1 R1 s1 bf16s" % (N, Cc))
+        return gx
     if gy.dtype == torch.bfloat16 and K % 8 == 0 and stride in (1, 2):
         P2, Q2 = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
         if K2 != K or (P2, Q2) != (P, Q):
@@ -612,6 +622,22 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
         if (gy.dtype == x.dtype and row_scale is None and gy.shape[-1] % 8 == 0 and x.shape[-1] % 8 == 0
                 and (want_gw or sq is not None)):
             return _conv2d_wgrad_grouped_stored(gy, x, R, S, stride, pad, group, alpha, want_gw, sq, out)
+        if (gy.dtype == torch.float32 and x.dtype == torch.bfloat16 and row_scale is None and gy.shape[-1] == 1 and R == 1 and S == 1
+                and tuple(x.shape[1:3]) == (1, 1) and x.shape[-1] % 8 == 0 and (out is None or out.dtype == torch.float32)
+                and x.shape[0] % group == 0 and x.shape[0] // group <= 65535):
+            # the critic's head: fp32 loss cotangent times bf16 feature rows
+            N, Cc = x.shape[0], x.shape[-1]
+            _chk(gy, "gy"); _chk(x, "x", allow_bf16=True)
+            gw = None
+            if want_gw:
+                gw = out if out is not None else torch.empty((N // group, 1, 1, 1, Cc), device=x.device, dtype=torch.float32)
+                _chk(gw, "gw")
+            if sq is not None:
+                _chk(sq, "sq")
+            _timed("conv2d_wgrad_grouped" + ("" if want_gw else "_normonly"), 2.0 * N * Cc, 2.0 * N * Cc + (4.0 * (N // group) * Cc if want_gw else 0.0),
+                   lambda: check(_lib.lib().cslgan_linear_k1_wgrad_bf16s(_p(gy), _p(x), N, Cc, group, float(alpha), _p(gw), _p(sq), _stream()),
+                                 "linear_k1_wgrad_bf16s"), tag=lambda: "N%d 1x1 C%d K1 R1 s1 g%d bf16s" % (N, Cc, group))
+            return gw
         gy, x = cast_f32(gy), cast_f32(x)       # mixed element types / shapes the bf16-stored kernel does not take
     _chk(gy, "gy"); _chk(x, "x")
     N, H, W, Cc = x.shape
@@ -739,6 +765,14 @@ def conv2d_wgrad_blocks(gy, x, R, S, stride, pad, alpha, blocks):
 def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, alpha=1.0, row_scale=None, out=None):
     """The summed weight gradient [K,R,S,C] of a batch: slabs of the grouped MFMA kernel + a column sum, or the
     vector-ALU kernel for 1..4 output channels.  out (optional, flat fp32 [K*R*S*C]): destination of the sum."""
+    if (gy.dtype == torch.float32 and x.dtype == torch.bfloat16 and row_scale is None and gy.shape[-1] == 1 and R == 1 and S == 1
+            and tuple(x.shape[1:3]) == (1, 1) and x.shape[-1] % 8 == 0):
+        # the critic's head on bf16 features: weighted sums of feature rows in slabs of 8 samples + a column sum
+        N = x.shape[0]
+        slabs = conv2d_wgrad_grouped(gy, x, 1, 1, group=8 if N % 8 == 0 else 1, alpha=alpha)
+        res = torch.empty(x.shape[-1], device=x.device, dtype=torch.float32) if out is None else out
+        clip_accum_noise([slabs.reshape(slabs.shape[0], -1)], [res.view(-1)])
+        return res.view(1, 1, 1, -1)
     if (gy.dtype == torch.bfloat16 or x.dtype == torch.bfloat16) and not (
             gy.dtype == x.dtype and row_scale is None and gy.shape[-1] % 8 == 0 and x.shape[-1] % 8 == 0):
         gy, x = cast_f32(gy), cast_f32(x)

@@ -250,6 +250,14 @@ int cslgan_conv2d_dgrad_bf16s(const cslgan_conv_t* p, const void* gy, const floa
 int cslgan_conv2d_wgrad_grouped_bf16s(const cslgan_conv_t* p, const void* gy, const void* x, int group, float alpha, void* gw,
                                       int gw_bf16, float* sq, void* stream);
 
+/* The critic's head nn.Linear(C, 1) (DCResNet_models.py:145) on bf16 features x [N, C], C % 8 == 0 (its forward is
+ * cslgan_conv2d_fwd_bf16s with K == 1): data gradient gx[n,:] = bf16(gy[n] * bf16(w) (* lrelu'(mask[n,:]))) from fp32 gy [N], with
+ * bf16 mask / gx [N, C]; grouped weight gradient gw[N/group, C] = alpha * sum_{n in g} gy[n] x[n,:] (fp32, nullable) and / or
+ * sq[N/group] += ||gw_g||^2. */
+int cslgan_linear_k1_dgrad_bf16s(const float* gy, const float* w, const void* mask_bf16, int N, int64_t C, void* gx_bf16, void* stream);
+int cslgan_linear_k1_wgrad_bf16s(const float* gy, const void* x_bf16, int N, int64_t C, int group, float alpha, float* gw, float* sq,
+                                 void* stream);
+
 /* Element-type conversions at the edges of the bf16-stored chain (round-to-nearest-even / exact widening). */
 int cslgan_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, void* stream);
 int cslgan_cast_bf16_f32(const void* in_bf16, float* out, int64_t n, void* stream);

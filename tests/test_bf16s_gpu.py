@@ -186,6 +186,21 @@ def test_mixed_element_types_fall_back_to_the_fp32_kernels():
     gy = torch.randn(6, 1, 1, 1, generator=g)
     gw = ops.conv2d_wgrad_grouped(_nhwc(gy), _nhwc16(x), 1, 1, group=1, alpha=2.0)
     _close(gw.reshape(6, 512), 2.0 * gy.reshape(6, 1) * x.reshape(6, 512), what="linear head per-sample gradient")
+    x8 = _bf(torch.randn(16, 4096, 1, 1, generator=g))
+    gy8 = torch.randn(16, 1, 1, 1, generator=g)
+    sq = torch.zeros(8, device="cuda")
+    gw2 = ops.conv2d_wgrad_grouped(_nhwc(gy8), _nhwc16(x8), 1, 1, group=2, alpha=0.5, sq=sq)
+    ref2 = 0.5 * (gy8.reshape(16, 1) * x8.reshape(16, 4096)).reshape(8, 2, 4096).sum(1)
+    _close(gw2.reshape(8, 4096), ref2, what="linear head grouped gradient")
+    _close(sq, ref2.pow(2).sum(1), rtol=2e-4, what="linear head grouped sq")
+    dense = ops.conv2d_wgrad_dense(_nhwc(gy8), _nhwc16(x8), 1, 1, alpha=0.5)
+    _close(dense.reshape(-1), ref2.sum(0), rtol=2e-4, what="linear head dense gradient")
+    w8 = torch.randn(1, 4096, 1, 1, generator=g)
+    m8 = torch.randn(16, 4096, 1, 1, generator=g)
+    gx8 = ops.conv2d_dgrad(_nhwc(gy8), _krsc(w8), (1, 1), mask=_nhwc16(m8), out_dtype=torch.bfloat16)
+    assert gx8.dtype == torch.bfloat16
+    _close(gx8.reshape(16, 4096), gy8.reshape(16, 1) * _bf(w8).reshape(1, 4096) * torch.where(m8.reshape(16, 4096) > 0, 1.0, 0.2), ulps=0.51,
+           what="linear head data gradient to bf16 features")
     img = torch.randn(3, 3, 32, 32, generator=g)
     gy1 = _bf(torch.randn(3, 64, 16, 16, generator=g))
     wz = torch.zeros(64, 3, 5, 5, requires_grad=True)

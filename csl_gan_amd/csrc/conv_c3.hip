@@ -34,6 +34,8 @@ struct C3Params {
     float* gw;           // [N][64][75] or null (wgrad)
     float* sq;           // [N] or null (wgrad): += ||alpha * gw_n||^2
     int N, H, W, P, Q, act;
+    int y_bf16;          // fwd: y is stored as bfloat16 (round to nearest even) — csrc/igemm_bf16s.hip's storage mode
+    int gy_bf16;         // wgrad: gy is bfloat16
     float alpha;
     int tiles_x, tiles_per_img, n_tiles;     // fwd
     int rows_per_strip, strips, pitch;        // wgrad
@@ -120,7 +122,14 @@ __global__ __launch_bounds__(256) void c3_fwd_kernel(const C3Params p) {
                 if (p.act == CSLGAN_ACT_LRELU02) val = val > 0.f ? val : 0.2f * val;
                 else if (p.act == CSLGAN_ACT_RELU) val = val > 0.f ? val : 0.f;
                 else if (p.act == CSLGAN_ACT_TANH) val = tanhf(val);
-                p.y[(((long long)img * p.P + oy) * p.Q + ox) * C3_K + n] = val;
+                const long long o = (((long long)img * p.P + oy) * p.Q + ox) * C3_K + n;
+                if (p.y_bf16) {
+                    unsigned u = __float_as_uint(val);
+                    u += 0x7FFFu + ((u >> 16) & 1u);
+                    reinterpret_cast<unsigned short*>(p.y)[o] = (unsigned short)(u >> 16);
+                } else {
+                    p.y[o] = val;
+                }
             }
         }
     }
@@ -135,8 +144,16 @@ struct C3wStage { float4 g0, g1; float x[C3W_XREG]; };
 
 __device__ __forceinline__ void c3w_fetch(const C3Params& p, C3wStage& st, int s, int img, int m0, int tid, int pitch, int x_total) {
     const long long g0 = ((long long)img * p.P * p.Q + (long long)s * C3W_STRIP) * C3_K + m0;
-    st.g0 = *reinterpret_cast<const float4*>(p.gy + g0 + (long long)(tid >> 3) * C3_K + (tid & 7) * 4);
-    st.g1 = *reinterpret_cast<const float4*>(p.gy + g0 + (long long)((tid + 512) >> 3) * C3_K + (tid & 7) * 4);
+    if (p.gy_bf16) {
+        const unsigned short* gh = reinterpret_cast<const unsigned short*>(p.gy);
+        const uint2 a = *reinterpret_cast<const uint2*>(gh + g0 + (long long)(tid >> 3) * C3_K + (tid & 7) * 4);
+        const uint2 b = *reinterpret_cast<const uint2*>(gh + g0 + (long long)((tid + 512) >> 3) * C3_K + (tid & 7) * 4);
+        st.g0 = make_float4(__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u));
+        st.g1 = make_float4(__uint_as_float(b.x << 16), __uint_as_float(b.x & 0xffff0000u), __uint_as_float(b.y << 16), __uint_as_float(b.y & 0xffff0000u));
+    } else {
+        st.g0 = *reinterpret_cast<const float4*>(p.gy + g0 + (long long)(tid >> 3) * C3_K + (tid & 7) * 4);
+        st.g1 = *reinterpret_cast<const float4*>(p.gy + g0 + (long long)((tid + 512) >> 3) * C3_K + (tid & 7) * 4);
+    }
     const int iy0 = 2 * s * p.rows_per_strip - 2;
     const long long row_f = (long long)p.W * 3;
 #pragma unroll
@@ -267,9 +284,9 @@ bool c3_fwd_eligible(const cslgan_conv_t* c, const float* residual) {
     return c3_shape(c) && residual == nullptr && (c->P & 7) == 0 && (c->Q & 15) == 0;
 }
 
-int launch_c3_fwd(const cslgan_conv_t* c, const float* x, const float* w, const float* bias, int act, float* y, hipStream_t st) {
+int launch_c3_fwd(const cslgan_conv_t* c, const float* x, const float* w, const float* bias, int act, float* y, hipStream_t st, int y_bf16) {
     C3Params p{};
-    p.x = x; p.w = w; p.bias = bias; p.y = y; p.act = act;
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.act = act; p.y_bf16 = y_bf16;
     p.N = c->N; p.H = c->H; p.W = c->W; p.P = c->P; p.Q = c->Q;
     p.tiles_x = c->Q / 16; p.tiles_per_img = (c->P / 8) * p.tiles_x;
     const long long nt = (long long)c->N * p.tiles_per_img;
@@ -289,9 +306,9 @@ bool c3_wgrad_eligible(const cslgan_conv_t* c, int group, int out_bf16, const vo
     return c->P % rows == 0 && (2 * rows + 3) * ((c->W + 4) * 3 + 3) <= C3W_MAXX;
 }
 
-int launch_c3_wgrad(const cslgan_conv_t* c, const float* gy, const float* x, float alpha, float* gw, float* sq, hipStream_t st) {
+int launch_c3_wgrad(const cslgan_conv_t* c, const float* gy, const float* x, float alpha, float* gw, float* sq, hipStream_t st, int gy_bf16) {
     C3Params p{};
-    p.x = x; p.gy = gy; p.gw = gw; p.sq = sq; p.alpha = alpha;
+    p.x = x; p.gy = gy; p.gw = gw; p.sq = sq; p.alpha = alpha; p.gy_bf16 = gy_bf16;
     p.N = c->N; p.H = c->H; p.W = c->W; p.P = c->P; p.Q = c->Q;
     p.rows_per_strip = C3W_STRIP / c->Q; p.strips = c->P / p.rows_per_strip;
     p.pitch = (c->W + 4) * 3 + 3;             // = 15 (mod 32) for W = 32, 64, 128: the 75 columns of a step spread over the banks
@@ -301,3 +318,24 @@ int launch_c3_wgrad(const cslgan_conv_t* c, const float* gy, const float* x, flo
 }
 
 }  // namespace cslgan
+
+using namespace cslgan;
+
+extern "C" {
+
+// The RGB first layer with a bfloat16-STORED output / output gradient (the bf16 storage mode of csrc/igemm_bf16s.hip); fp32 image,
+// fp32 arithmetic, fp32 weight gradients as in the fp32 entries.  Shapes: exactly those of c3_fwd_eligible / c3_wgrad_eligible.
+int cslgan_conv2d_c3_fwd_bf16out(const cslgan_conv_t* c, const float* x, const float* w, const float* bias, int act, void* y_bf16, void* stream) {
+    CSLGAN_REQUIRE(c && x && w && y_bf16, "conv2d_c3_fwd_bf16out: null argument");
+    CSLGAN_REQUIRE(act >= 0 && act <= 3, "conv2d_c3_fwd_bf16out: unknown activation %d", act);
+    CSLGAN_REQUIRE(c3_fwd_eligible(c, nullptr), "conv2d_c3_fwd_bf16out: not the 3 -> 64 channel 5x5 stride-2 first layer on a 16x32-tileable image");
+    return launch_c3_fwd(c, x, w, bias, act, reinterpret_cast<float*>(y_bf16), (hipStream_t)stream, 1);
+}
+
+int cslgan_conv2d_c3_wgrad_bf16gy(const cslgan_conv_t* c, const void* gy_bf16, const float* x, float alpha, float* gw, float* sq, void* stream) {
+    CSLGAN_REQUIRE(c && gy_bf16 && x && (gw || sq), "conv2d_c3_wgrad_bf16gy: null argument");
+    CSLGAN_REQUIRE(c3_wgrad_eligible(c, 1, 0, gy_bf16), "conv2d_c3_wgrad_bf16gy: shape not taken by the first-layer kernel");
+    return launch_c3_wgrad(c, reinterpret_cast<const float*>(gy_bf16), x, alpha, gw, sq, (hipStream_t)stream, 1);
+}
+
+}  // extern "C"

@@ -134,9 +134,9 @@ struct McParams {
 
 // conv_c3.hip: the 3 -> 64 channel 5x5 stride-2 first layer on unpadded RGB input
 bool c3_fwd_eligible(const cslgan_conv_t* c, const float* residual);
-int launch_c3_fwd(const cslgan_conv_t* c, const float* x, const float* w, const float* bias, int act, float* y, hipStream_t st);
+int launch_c3_fwd(const cslgan_conv_t* c, const float* x, const float* w, const float* bias, int act, float* y, hipStream_t st, int y_bf16 = 0);
 bool c3_wgrad_eligible(const cslgan_conv_t* c, int group, int out_bf16, const void* gy);
-int launch_c3_wgrad(const cslgan_conv_t* c, const float* gy, const float* x, float alpha, float* gw, float* sq, hipStream_t st);
+int launch_c3_wgrad(const cslgan_conv_t* c, const float* gy, const float* x, float alpha, float* gw, float* sq, hipStream_t st, int gy_bf16 = 0);
 
 // linear_k1.hip: linear layers with one output unit as streams
 bool linear_k1_shape(const cslgan_conv_t* c);

@@ -63,6 +63,7 @@ struct KsParams {
     int mask_bf16;
     int act;
     int n_cls, tiles_m, tiles_n;
+    const void* w3;              // igemm_halos: the filter as bf16 in step-major order [chunk * T + tap][n][16 k] (split_filter_x3_kernel<1>)
     KcClass cls[IG_MAX_CLS];
 };
 
@@ -115,8 +116,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kcs_kernel(const KsParams p) {
     }
     __syncthreads();
 
-    u32x4 ra[A_PASS], rb[B_PASS];
-    auto load_tile = [&](int kt) {
+    // Two register sets: the loads of K tile t+2 are issued before the MFMAs of tile t and written to LDS after the MFMAs of tile
+    // t+1 — two tiles of matrix work (>= 2 x 512 MFMA cycles per wave) to cover the L2 / HBM latency of a gathered load.  With one
+    // set (loads one tile ahead) the kernel waited on its loads every iteration: 390-500 TF.
+    u32x4 ra0[A_PASS], rb0[B_PASS], ra1[A_PASS], rb1[B_PASS];
+    auto load_tile = [&](int kt, u32x4 (&ra)[A_PASS], u32x4 (&rb)[B_PASS]) {
         const int kb = kt * KS_BK + e * 8;
         const bool kin = kb < Kdim;
         const int t = kin ? (int)__umulhi((unsigned)kb, p.ac_recip) : 0;
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kcs_kernel(const KsParams p) {
         for (int i = 0; i < B_PASS; ++i)
             rb[i] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)((b_off[i] == S_OOB16 || kofs == S_OOB16) ? S_OOB16 : b_off[i] + kofs), 0, 0);
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const u32x4 (&ra)[A_PASS], const u32x4 (&rb)[B_PASS]) {
 #pragma unroll
         for (int i = 0; i < A_PASS; ++i) As[buf][e * A_ES + lrow + 32 * i] = __builtin_bit_cast(uint4, ra[i]);
 #pragma unroll
@@ -154,13 +158,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kcs_kernel(const KsParams p) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-    const int nk = (Kdim + KS_BK - 1) / KS_BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        load_tile(kt + 1);       // past the last tile every offset is out of range -> zeros, never read
+    auto mma_tile = [&](int buf) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             bf16x8 af[TM], bf[TN];
@@ -173,7 +171,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kcs_kernel(const KsParams p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        store_tile(buf ^ 1);
+    };
+
+    const int nk = (Kdim + KS_BK - 1) / KS_BK;
+    load_tile(0, ra0, rb0);
+    load_tile(1, ra1, rb1);          // past the last tile every offset is out of range -> zeros, never multiplied
+    store_tile(0, ra0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        load_tile(kt + 2, ra0, rb0);
+        mma_tile(0);
+        store_tile(1, ra1, rb1);     // tile kt + 1
+        __syncthreads();
+        if (kt + 1 >= nk) break;     // uniform
+        load_tile(kt + 3, ra1, rb1);
+        mma_tile(1);
+        store_tile(0, ra0, rb0);     // tile kt + 2
         __syncthreads();
     }
 
@@ -222,6 +235,247 @@ __global__ __launch_bounds__(256, 2) void igemm_kcs_kernel(const KsParams p) {
             }
         }
     }
+}
+
+// ---- stride-1 convs with an LDS-resident input halo (the generator's 5x5 / 3x3 convs on bf16 activations) ---------------------
+// igemm_halo_x3_kernel<BN, 1> (igemm_bf16.hip) with bfloat16 activations in HBM: a workgroup owns two 8x8 output patches x BN
+// channels; per 16-channel chunk the (8+R-1) x (8+S-1) halo of each patch is staged in LDS ONCE (a pixel's 16 channels are two
+// 16-byte loads, stored as loaded — no conversion) and every tap reads its A fragments from that image at a per-tap offset; the
+// filter never touches LDS: it is streamed pre-rounded in step-major order straight into a 4-deep register ring.  Against the
+// gather form above the input is read from L2 / HBM once per chunk instead of once per tap.
+constexpr int HS_MAX = 12 * 12;        // pixels per patch halo (8+4 squared: up to 5x5 taps)
+
+template <int BN, bool OUT_BF16>
+__global__ __launch_bounds__(256, 2) void igemm_halos_kernel(const KsParams p) {
+    constexpr int RING = 4;
+    constexpr int BM = 128, TM = 2, TN = BN / 64;            // waves 2 (M: one patch each) x 2 (N)
+    __shared__ __attribute__((aligned(16))) uint2 Hs[2 * HS_MAX * 4];     // [patch][pixel][4 x (4 ch bf16)]
+    __shared__ int s_tapoff[IG_MAX_TAPS];
+    __shared__ int s_off[BM];
+
+    const int tid = threadIdx.x;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int tile_mg = wg / p.tiles_n, tile_n = wg - tile_mg * p.tiles_n;
+    const KcClass& kc = p.cls[0];
+    const int M = kc.M, OHc = kc.OHc, OWc = kc.OWc, T = kc.T;
+    const int m0 = tile_mg * BM, n0 = tile_n * BN;
+    const int HW_ = kc.halo_w, hpix = kc.halo_h * kc.halo_w;
+    const int img_stride = p.AH * p.AW * p.AC;
+
+    // tap offset in uint2 units; bit 0 = parity of the tap's halo-row offset (selects the swizzled base)
+    if (tid < IG_MAX_TAPS) s_tapoff[tid] = ((((int)kc.ty[tid] - kc.ty_min) * HW_ + ((int)kc.tx[tid] - kc.tx_min)) * 4) | (((int)kc.ty[tid] - kc.ty_min) & 1);
+
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, p.a_bytes, 0x00020000);
+    int p_img[2], p_y0[2], p_x0[2];
+    bool p_ok[2];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        const int m = m0 + 64 * pp;
+        p_ok[pp] = m < M;
+        const RowCoord rc = kc_decode_row(p_ok[pp] ? m : 0, OHc, OWc, 1);     // first row of the patch = its top-left pixel
+        p_img[pp] = rc.img * img_stride;
+        p_y0[pp] = rc.oy + kc.ty_min;
+        p_x0[pp] = rc.ox + kc.tx_min;
+    }
+    const int lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;                   // wm = patch index
+    // filter: lane (r, h), tile j reads 8 consecutive k of filter row n0 + wn*TN*32 + j*32 + r of one step = one 16-byte load
+    const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w3), 0, 2u * (unsigned)p.Nn * (unsigned)kc.Kdim, 0x00020000);
+    const unsigned step_bytes = 32u * (unsigned)p.Nn;
+    unsigned b_off[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + r;
+        b_off[j] = n < p.Nn ? 32u * (unsigned)n + 16u * (unsigned)h : S_OOB16;
+    }
+    u32x4 rb[RING][TN];
+    const int n_steps = (p.AC >> 4) * T;
+    auto load_b = [&](int step, int slot) {                 // filter slice of `step` (= chunk * T + tap); zeros past the end
+        const unsigned kb = (unsigned)step * step_bytes;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const unsigned o = (step >= n_steps || b_off[j] == S_OOB16) ? S_OOB16 : b_off[j] + kb;
+            rb[slot][j] = __builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, (int)o, 0, 0);
+        }
+    };
+    // halo staging: 2 patches x hpix pixels x 2 halves of 8 channels; <= 2*144*2/256 = 2.25 16-byte loads per thread
+    constexpr int HREG = (2 * HS_MAX * 2 + 255) / 256;
+    u32x4 rh[HREG];
+    const int h_total = 2 * hpix * 2;
+    auto fetch_halo = [&](int cc) {
+#pragma unroll
+        for (int j = 0; j < HREG; ++j) {
+            const int idx = tid + 256 * j;
+            const int half = idx & 1, pixg = idx >> 1;
+            const int pp = pixg >= hpix ? 1 : 0;
+            const int pix = pixg - pp * hpix;
+            const int hy = pix / HW_, hx = pix - hy * HW_;
+            const int iy = p_y0[pp] + hy, ix = p_x0[pp] + hx;
+            const bool ok = idx < h_total && p_ok[pp] && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
+            rh[j] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(ok ? 2u * (unsigned)(p_img[pp] + (iy * p.AW + ix) * p.AC + cc * 16 + half * 8) : S_OOB16), 0, 0);
+        }
+    };
+    auto commit_halo = [&]() {
+#pragma unroll
+        for (int j = 0; j < HREG; ++j) {
+            const int idx = tid + 256 * j;
+            if (idx < h_total) {
+                const int half = idx & 1, pixg = idx >> 1;
+                const int pp = pixg >= hpix ? 1 : 0;
+                const int pix = pixg - pp * hpix;
+                // the two 16-byte halves of a pixel are swapped on odd halo rows (the two patch rows a 16-lane ds_read_b128 group
+                // covers then hit disjoint banks)
+                const int at = (pp * HS_MAX + pix) * 4 + 2 * (half ^ ((pix / HW_) & 1));
+                *reinterpret_cast<uint4*>(&Hs[at]) = __builtin_bit_cast(uint4, rh[j]);
+            }
+        }
+    };
+
+    int a_base[2][TM];                                       // uint2 offset of this lane's pixel (tap 0,0 corner) per MFMA tile,
+#pragma unroll                                               // for taps landing on an even / odd halo row (half-swap swizzle)
+    for (int i = 0; i < TM; ++i) {
+        const int qq = i * 32 + r;                           // row within the patch
+        const int pix = (wm * HS_MAX + (qq >> 3) * HW_ + (qq & 7)) * 4;
+        a_base[0][i] = pix + ((h ^ ((qq >> 3) & 1)) << 1);
+        a_base[1][i] = pix + ((h ^ (((qq >> 3) + 1) & 1)) << 1);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    fetch_halo(0);
+#pragma unroll
+    for (int q = 0; q < RING; ++q) load_b(q, q);
+    commit_halo();
+    __syncthreads();
+
+    bf16x8 af_n[TM];
+    auto read_a = [&](int t) {
+        const int tw = s_tapoff[t], toff = tw & ~1, odd = tw & 1;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af_n[i] = *reinterpret_cast<const bf16x8*>(&Hs[(odd ? a_base[1][i] : a_base[0][i]) + toff]);
+    };
+    read_a(0);
+
+    auto k_step = [&](int s, int SL) {
+        const int cc = s / T, t = s - cc * T;
+        const int t_fetch = T > 3 ? T - 3 : 0;
+        const bool last_chunk = (cc + 1) * 16 >= p.AC;
+        if (t == t_fetch && !last_chunk) fetch_halo(cc + 1);
+        bf16x8 bf[TN], af[TM];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = __builtin_bit_cast(bf16x8, rb[SL][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = af_n[i];
+        load_b(s + RING, SL);
+        const bool boundary = t == T - 1;
+        if (!boundary) read_a(t + 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        if (boundary) {
+            if (!last_chunk) {                 // the halo image is the only shared state: one barrier pair per CHUNK, none per tap
+                __syncthreads();
+                commit_halo();
+                __syncthreads();
+            }
+            if (s + 1 < n_steps) read_a(0);
+        }
+    };
+    for (int s = 0; s < n_steps; s += RING) {
+        k_step(s, 0);
+        if (s + 1 < n_steps) k_step(s + 1, 1);
+        if (s + 2 < n_steps) k_step(s + 2, 2);
+        if (s + 3 < n_steps) k_step(s + 3, 3);
+    }
+    __syncthreads();
+
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int off = -1;
+        if (m < M) {
+            const RowCoord rc = kc_decode_row(m, OHc, OWc, 1);
+            off = ((rc.img * p.OHf + rc.oy * p.osy + kc.oy0) * p.OWf + rc.ox * p.osx + kc.ox0) * p.ldo;
+        }
+        s_off[tid] = off;
+    }
+    __syncthreads();
+    const unsigned short* __restrict__ res_h = reinterpret_cast<const unsigned short*>(p.res);
+    const float* __restrict__ res_f = reinterpret_cast<const float*>(p.res);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + r;
+        if (n >= p.Nn) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                const int off = s_off[row];
+                if (off < 0) continue;
+                float val = acc[i][j][v] + bv;
+                if (p.res) val += p.res_bf16 ? bf2f(res_h[off + n]) : res_f[off + n];
+                if (p.act == CSLGAN_ACT_LRELU02) val = val > 0.f ? val : 0.2f * val;
+                else if (p.act == CSLGAN_ACT_RELU) val = val > 0.f ? val : 0.f;
+                else if (p.act == CSLGAN_ACT_TANH) val = tanhf(val);
+                if (OUT_BF16) reinterpret_cast<unsigned short*>(p.out)[off + n] = f2bf(val);
+                else reinterpret_cast<float*>(p.out)[off + n] = val;
+            }
+        }
+    }
+}
+
+int split_filter_x3(const float* w, int Nn, int T, int C, void* w3, hipStream_t st, int pieces);      // igemm_bf16.hip
+
+// one class, stride 1, an 8x8-patchable grid of at least 16x16, channels a multiple of 16, 2..25 taps within a 12x12 halo, >= 64 filters
+static bool halos_eligible(const KsParams& p) {
+    static const int env = [] { const char* e = getenv("CSLGAN_HALOS"); return e ? atoi(e) : 1; }();
+    if (!env || p.n_cls != 1 || p.sy != 1 || p.sx != 1 || (p.AC & 15) || p.Nn < 64 || p.mask || !aligned16(p.a)) return false;
+    const KcClass& k = p.cls[0];
+    if (k.T < 2 || (k.M & 63) || (k.OHc & 7) || (k.OWc & 7) || k.OHc < 16 || k.OWc < 16 || k.oy0 || k.ox0 || p.osy != 1 || p.osx != 1) return false;
+    int ymin = 127, ymax = -128, xmin = 127, xmax = -128;
+    for (int t = 0; t < k.T; ++t) {
+        ymin = k.ty[t] < ymin ? k.ty[t] : ymin; ymax = k.ty[t] > ymax ? k.ty[t] : ymax;
+        xmin = k.tx[t] < xmin ? k.tx[t] : xmin; xmax = k.tx[t] > xmax ? k.tx[t] : xmax;
+    }
+    return ymax - ymin <= 4 && xmax - xmin <= 4;
+}
+
+static int launch_halos(KsParams& p, bool out_bf16, hipStream_t st) {
+    KcClass& k = p.cls[0];
+    int ymin = 127, ymax = -128, xmin = 127, xmax = -128;
+    for (int t = 0; t < k.T; ++t) {
+        ymin = k.ty[t] < ymin ? k.ty[t] : ymin; ymax = k.ty[t] > ymax ? k.ty[t] : ymax;
+        xmin = k.tx[t] < xmin ? k.tx[t] : xmin; xmax = k.tx[t] > xmax ? k.tx[t] : xmax;
+    }
+    k.ty_min = ymin; k.tx_min = xmin; k.halo_h = 8 + ymax - ymin; k.halo_w = 8 + xmax - xmin;
+    k.patch = 1; k.tile0 = 0;
+    const long long n_img = k.M / ((long long)k.OHc * k.OWc);
+    const long long a_b = 2ll * n_img * p.AH * p.AW * p.AC;
+    CSLGAN_REQUIRE(a_b < 0xFFFFFFF0ll && 2ll * p.Nn * k.Kdim < 0xFFFFFFF0ll, "igemm_halos: operand larger than 4 GB");
+    p.a_bytes = (unsigned)a_b;
+    p.tiles_m = (k.M + 127) / 128;
+    const bool wide = p.Nn > 64;
+    p.tiles_n = wide ? (p.Nn + 127) / 128 : 1;
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);
+    note_kernel("igemm_halos_kernel<%d>", wide ? 128 : 64);
+    if (wide) {
+        if (out_bf16) hipLaunchKernelGGL((igemm_halos_kernel<128, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((igemm_halos_kernel<128, false>), grid, block, 0, st, p);
+    } else {
+        if (out_bf16) hipLaunchKernelGGL((igemm_halos_kernel<64, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((igemm_halos_kernel<64, false>), grid, block, 0, st, p);
+    }
+    return check_launch("igemm_halos_kernel");
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -546,8 +800,9 @@ __global__ __launch_bounds__(256, 2) void igemm_mcs_tr_kernel(const MsParams p) 
     const unsigned short* __restrict__ gyh = reinterpret_cast<const unsigned short*>(p.gy);
     const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(p.x);
 
-    uint4 rv[8];
-    auto load_tile = [&](int kt) {
+    // two register sets: tile t+2 is loaded under the MFMAs of tile t and written to LDS after those of tile t+1 (see igemm_kcs_kernel)
+    uint4 rv0[8], rv1[8];
+    auto load_tile = [&](int kt, uint4 (&rv)[8]) {
         const int kk0 = kt * MS_BK + kg * 8;
         if (is_a) {
 #pragma unroll
@@ -589,7 +844,7 @@ __global__ __launch_bounds__(256, 2) void igemm_mcs_tr_kernel(const MsParams p) 
         }
     };
     // row (pixel) kr of a tile, 16-byte chunk ch: byte offset 256*kr + 16*(ch ^ (((kr & 3) << 2) | ((kr >> 2) & 3)))
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const uint4 (&rv)[8]) {
         unsigned char* dst = smem + (buf * 2 + (is_a ? 0 : 1)) * OPB;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -632,12 +887,7 @@ __global__ __launch_bounds__(256, 2) void igemm_mcs_tr_kernel(const MsParams p) 
         nk = kt0 + per < nk_all ? kt0 + per : nk_all;
         if (kt0 >= nk) return;      // uniform across the workgroup
     }
-    load_tile(kt0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = kt0; kt < nk; ++kt) {
-        const int buf = (kt - kt0) & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+    auto mma_tile = [&](int buf) {
         const unsigned char* As = smem + (buf * 2) * OPB;
         const unsigned char* Bs = As + OPB;
 #pragma unroll
@@ -662,7 +912,20 @@ __global__ __launch_bounds__(256, 2) void igemm_mcs_tr_kernel(const MsParams p) 
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+    };
+    load_tile(kt0, rv0);
+    load_tile(kt0 + 1, rv1);         // past the group's pixels every lane loads zeros (kk >= Ktot)
+    store_tile(0, rv0);
+    __syncthreads();
+    for (int kt = kt0; kt < nk; kt += 2) {
+        load_tile(kt + 2, rv0);
+        mma_tile(0);
+        store_tile(1, rv1);          // tile kt + 1
+        __syncthreads();
+        if (kt + 1 >= nk) break;     // uniform
+        load_tile(kt + 3, rv1);
+        mma_tile(1);
+        store_tile(0, rv0);          // tile kt + 2
         __syncthreads();
     }
 
@@ -905,12 +1168,6 @@ int cslgan_conv2d_fwd_bf16s(const cslgan_conv_t* c, const void* x, const float* 
         return check_launch("linear_k1s_fwd_kernel");
     }
     const long long wn = (long long)c->K * c->R * c->S * c->C;
-    if (repack) {
-        CSLGAN_REQUIRE(aligned16(w) && aligned16(wb_ws), "conv2d_fwd_bf16s: filter must be 16-byte aligned");
-        hipLaunchKernelGGL(round_bf16_kernel, dim3(stream_blocks(wn / 4)), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wb_ws), wn);
-        rc = check_launch("round_bf16_kernel");
-        if (rc) return rc;
-    }
     KsParams p{};
     p.a = x; p.AH = c->H; p.AW = c->W; p.AC = c->C; p.VH = c->H; p.VW = c->W; p.sy = p.sx = c->stride;
     p.w = wb_ws; p.Nn = c->K; p.out = y; p.OHf = c->P; p.OWf = c->Q; p.osy = p.osx = 1; p.ldo = c->K; p.dense_out = 1;
@@ -921,6 +1178,23 @@ int cslgan_conv2d_fwd_bf16s(const cslgan_conv_t* c, const void* x, const float* 
     for (int t = 0; t < IG_MAX_TAPS; ++t) { k.ty[t] = 0; k.tx[t] = 0; }
     for (int kh = 0; kh < c->R; ++kh)
         for (int kw = 0; kw < c->S; ++kw) { k.ty[kh * c->S + kw] = (signed char)(kh - c->pad); k.tx[kh * c->S + kw] = (signed char)(kw - c->pad); }
+    // the layout of the bf16 filter copy follows the kernel, and the kernel follows the SHAPE alone (a layer always takes the same
+    // route, so a cached copy is always in the layout its reader expects): step-major for the LDS-halo form, plain KRSC otherwise
+    const bool halo = halos_eligible(p) && aligned16(w) && aligned16(wb_ws) && wn % 4 == 0;
+    if (repack) {
+        CSLGAN_REQUIRE(aligned16(w) && aligned16(wb_ws), "conv2d_fwd_bf16s: filter must be 16-byte aligned");
+        if (halo) {
+            rc = split_filter_x3(w, c->K, c->R * c->S, c->C, wb_ws, st, 1);
+        } else {
+            hipLaunchKernelGGL(round_bf16_kernel, dim3(stream_blocks(wn / 4)), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wb_ws), wn);
+            rc = check_launch("round_bf16_kernel");
+        }
+        if (rc) return rc;
+    }
+    if (halo) {
+        p.w3 = wb_ws;
+        return launch_halos(p, y_bf16 != 0, st);
+    }
     return launch_kcs(p, y_bf16 != 0, st);
 }
 

@@ -46,8 +46,30 @@ constexpr int NS_ROWS_MIN = 64;   // rows per block, lower bound (the launch pic
 // squares) pairs in `final_stats` and leaves scratch and ticket zeroed for the next launch — no memset before and no finalize
 // launch after (two 4-us dispatches per normalisation layer).  The ticket is per row group on purpose: ONE ticket for the whole
 // grid serialises ~1000 same-address atomics in L2 (measured: 30 -> 146 us on the 64x64 layer).
-template <bool VEC, bool FUSED>
-__global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x, long long rows_per_stat, int C, int cpg,
+// Element access for the normalisation kernels: fp32 tensors, or bfloat16-stored activations (csrc/igemm_bf16s.hip's storage mode;
+// statistics and arithmetic are fp32 either way, a bf16 output is rounded to nearest even).
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float ldf(const float* p, long long i) { return p[i]; }
+__device__ __forceinline__ float ldf(const bf16_t* p, long long i) { return __uint_as_float((unsigned)p[i] << 16); }
+__device__ __forceinline__ float4 ld4(const float* p, long long i) { return *reinterpret_cast<const float4*>(p + i); }
+__device__ __forceinline__ float4 ld4(const bf16_t* p, long long i) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p + i);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned rne_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void st1(float* p, long long i, float v) { p[i] = v; }
+__device__ __forceinline__ void st1(bf16_t* p, long long i, float v) { p[i] = (bf16_t)rne_bf16(v); }
+__device__ __forceinline__ void st4(float* p, long long i, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p + i) = make_float4(a, b, c, d); }
+__device__ __forceinline__ void st4(bf16_t* p, long long i, float a, float b, float c, float d) {
+    *reinterpret_cast<uint2*>(p + i) = make_uint2(rne_bf16(a) | (rne_bf16(b) << 16), rne_bf16(c) | (rne_bf16(d) << 16));
+}
+
+template <bool VEC, bool FUSED, typename TX>
+__global__ __launch_bounds__(256) void norm_stats_kernel(const TX* __restrict__ x, long long rows_per_stat, int C, int cpg,
                                                          int n_groups, int rows_per_block, float* __restrict__ stats,
                                                          float* __restrict__ final_stats, long long n_stats) {
     extern __shared__ float s_acc[];   // [2*C]: S1, S2 per channel
@@ -65,13 +87,13 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
         const int c4 = tid % c4n, rl = tid / c4n, rstep = 256 / c4n;
         float k[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) k[e] = x[row_first * C + ((4 * c4 + e) / cpg) * cpg];
+        for (int e = 0; e < 4; ++e) k[e] = ldf(x, row_first * C + ((4 * c4 + e) / cpg) * cpg);
         float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
         long long r = r0 + rl;
         for (; r + 3 * rstep < r1; r += 4 * rstep) {      // four independent 16-byte loads in flight
             float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + (r + u * rstep) * C + 4 * c4);
+            for (int u = 0; u < 4; ++u) v[u] = ld4(x, (r + u * rstep) * C + 4 * c4);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float d[4] = {v[u].x - k[0], v[u].y - k[1], v[u].z - k[2], v[u].w - k[3]};
@@ -80,7 +102,7 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
             }
         }
         for (; r < r1; r += rstep) {
-            const float4 v = *reinterpret_cast<const float4*>(x + r * C + 4 * c4);
+            const float4 v = ld4(x, r * C + 4 * c4);
             const float d[4] = {v.x - k[0], v.y - k[1], v.z - k[2], v.w - k[3]};
 #pragma unroll
             for (int e = 0; e < 4; ++e) { a1[e] += d[e]; a2[e] = fmaf(d[e], d[e], a2[e]); }
@@ -94,7 +116,7 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
         const long long n = (r1 - r0) * C;
         for (long long i = tid; i < n; i += 256) {
             const int c = (int)(i % C);
-            const float d = x[r0 * C + i] - x[row_first * C + (c / cpg) * cpg];
+            const float d = ldf(x, r0 * C + i) - ldf(x, row_first * C + (c / cpg) * cpg);
             atomicAdd(&s_acc[2 * c], d);
             atomicAdd(&s_acc[2 * c + 1], d * d);
         }
@@ -120,7 +142,7 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
     for (long long s = sr * n_groups + tid; s < (sr + 1) * n_groups; s += 256) {
         const long long srow = sr;
         const int g = (int)(s - srow * n_groups);
-        const float k = x[srow * rows_per_stat * C + g * cpg];
+        const float k = ldf(x, srow * rows_per_stat * C + g * cpg);
         const float S1 = __hip_atomic_load(stats + 2 * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float S2 = __hip_atomic_load(stats + 2 * s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         stats[2 * s] = 0.f;
@@ -135,13 +157,14 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
 }
 
 // (S1, S2) about the shift k  ->  (sum x, sum (x-mean)^2)
-__global__ void norm_stats_finalize_kernel(const float* __restrict__ x, long long rows_per_stat, int C, int cpg, int n_groups,
+template <typename TX>
+__global__ void norm_stats_finalize_kernel(const TX* __restrict__ x, long long rows_per_stat, int C, int cpg, int n_groups,
                                            long long n_stats, float* __restrict__ stats) {
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_stats) return;
     const long long sr = s / n_groups;
     const int g = (int)(s - sr * n_groups);
-    const float k = x[sr * rows_per_stat * C + g * cpg];
+    const float k = ldf(x, sr * rows_per_stat * C + g * cpg);
     const float cnt = (float)rows_per_stat * (float)cpg;
     const float S1 = stats[2 * s], S2 = stats[2 * s + 1];
     const float m1 = S1 / cnt;
@@ -166,10 +189,10 @@ __device__ __forceinline__ long long d2s_offset(long long r, int p, int H, int W
 
 // y = act((x - mean_s) * rstd_s * gamma[c] + beta[c])
 // D2S: y (and xs, the raw input, when given) are written in the depth-to-space layout [N][2H][2W][C/4].
-template <bool VEC, bool D2S>
-__global__ void norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+template <bool VEC, bool D2S, typename TX, typename TY>
+__global__ void norm_apply_kernel(const TX* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                   const float* __restrict__ stats, long long total, long long rows_per_stat, int C, int cpg,
-                                  int n_groups, float eps, int relu, float* __restrict__ y, int H, int W, float* __restrict__ xs) {
+                                  int n_groups, float eps, int relu, TY* __restrict__ y, int H, int W, TY* __restrict__ xs) {
     const float inv_cnt = 1.f / ((float)rows_per_stat * (float)cpg);
     const long long per_stat_elems = rows_per_stat * C;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -179,7 +202,7 @@ __global__ void norm_apply_kernel(const float* __restrict__ x, const float* __re
             const long long e0 = i << 2;
             const int c = (int)(e0 % C);
             const long long sr = e0 / per_stat_elems;
-            const float4 v = reinterpret_cast<const float4*>(x)[i];
+            const float4 v = ld4(x, e0);
             float in[4] = {v.x, v.y, v.z, v.w}, o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -195,11 +218,11 @@ __global__ void norm_apply_kernel(const float* __restrict__ x, const float* __re
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {          // lanes hold consecutive c': each of the four stores is coalesced
                     const long long off = d2s_offset(r, e, H, W, Cq) + cq;
-                    y[off] = o[e];
-                    if (xs) xs[off] = in[e];
+                    st1(y, off, o[e]);
+                    if (xs) st1(xs, off, in[e]);
                 }
             } else {
-                reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+                st4(y, e0, o[0], o[1], o[2], o[3]);
             }
         }
     } else {
@@ -208,14 +231,15 @@ __global__ void norm_apply_kernel(const float* __restrict__ x, const float* __re
             const long long s = (i / per_stat_elems) * n_groups + c / cpg;
             const float mean = stats[2 * s] * inv_cnt;
             const float rstd = rsqrtf(stats[2 * s + 1] * inv_cnt + eps);
-            float t = (x[i] - mean) * rstd * gamma[c] + beta[c];
+            const float xi = ldf(x, i);
+            float t = (xi - mean) * rstd * gamma[c] + beta[c];
             t = (relu && t < 0.f) ? 0.f : t;
             if (D2S) {
                 const long long off = d2s_offset(i / C, c & 3, H, W, C >> 2) + (c >> 2);
-                y[off] = t;
-                if (xs) xs[off] = x[i];
+                st1(y, off, t);
+                if (xs) st1(xs, off, xi);
             } else {
-                y[i] = t;
+                st1(y, i, t);
             }
         }
     }
@@ -393,30 +417,32 @@ __global__ void bn_running_kernel(const float* __restrict__ stats, int C, float 
     rv[c] = (1.f - momentum) * rv[c] + momentum * var_unb;
 }
 
-static int launch_norm_apply(const float* x, const float* gamma, const float* beta, long long R, long long rows_per_stat, int C,
-                             int cpg, int n_groups, float eps, int relu, const float* stats, float* y, int d2s_H, int d2s_W,
-                             float* xs, bool vec, hipStream_t st) {
+template <typename TX, typename TY>
+static int launch_norm_apply(const TX* x, const float* gamma, const float* beta, long long R, long long rows_per_stat, int C,
+                             int cpg, int n_groups, float eps, int relu, const float* stats, TY* y, int d2s_H, int d2s_W,
+                             TY* xs, bool vec, hipStream_t st) {
     const long long total = R * C;
     long long nb = (total / 4 + 255) / 256;
     nb = nb > 4096 ? 4096 : (nb < 1 ? 1 : nb);
     const dim3 g((unsigned)nb), b(256);
     if (d2s_W > 0) {
-        if (vec) hipLaunchKernelGGL((norm_apply_kernel<true, true>), g, b, 0, st, x, gamma, beta, stats, total, rows_per_stat, C, cpg, n_groups, eps, relu, y, d2s_H, d2s_W, xs);
-        else hipLaunchKernelGGL((norm_apply_kernel<false, true>), g, b, 0, st, x, gamma, beta, stats, total, rows_per_stat, C, cpg, n_groups, eps, relu, y, d2s_H, d2s_W, xs);
+        if (vec) hipLaunchKernelGGL((norm_apply_kernel<true, true, TX, TY>), g, b, 0, st, x, gamma, beta, stats, total, rows_per_stat, C, cpg, n_groups, eps, relu, y, d2s_H, d2s_W, xs);
+        else hipLaunchKernelGGL((norm_apply_kernel<false, true, TX, TY>), g, b, 0, st, x, gamma, beta, stats, total, rows_per_stat, C, cpg, n_groups, eps, relu, y, d2s_H, d2s_W, xs);
     } else {
-        if (vec) hipLaunchKernelGGL((norm_apply_kernel<true, false>), g, b, 0, st, x, gamma, beta, stats, total, rows_per_stat, C, cpg, n_groups, eps, relu, y, 0, 0, (float*)nullptr);
-        else hipLaunchKernelGGL((norm_apply_kernel<false, false>), g, b, 0, st, x, gamma, beta, stats, total, rows_per_stat, C, cpg, n_groups, eps, relu, y, 0, 0, (float*)nullptr);
+        if (vec) hipLaunchKernelGGL((norm_apply_kernel<true, false, TX, TY>), g, b, 0, st, x, gamma, beta, stats, total, rows_per_stat, C, cpg, n_groups, eps, relu, y, 0, 0, (TY*)nullptr);
+        else hipLaunchKernelGGL((norm_apply_kernel<false, false, TX, TY>), g, b, 0, st, x, gamma, beta, stats, total, rows_per_stat, C, cpg, n_groups, eps, relu, y, 0, 0, (TY*)nullptr);
     }
     return check_launch("norm_apply_kernel");
 }
 
-static bool norm_vec_ok(const float* x, const float* y, const float* xs, int C, int cpg) {
+static bool norm_vec_ok(const void* x, const void* y, const void* xs, int C, int cpg) {
     return (C % 4 == 0) && ((C / 4) <= 256) && (256 % (C / 4) == 0) && (cpg % 4 == 0 || 4 % cpg == 0) && aligned16(x) && aligned16(y) &&
            (!xs || aligned16(xs));
 }
 
-static int launch_norm(const float* x, const float* gamma, const float* beta, long long R, long long rows_per_stat, int C, int cpg,
-                       int n_groups, float eps, int relu, float* stats, float* y, int d2s_H, int d2s_W, float* xs, hipStream_t st,
+template <typename TX, typename TY>
+static int launch_norm(const TX* x, const float* gamma, const float* beta, long long R, long long rows_per_stat, int C, int cpg,
+                       int n_groups, float eps, int relu, float* stats, TY* y, int d2s_H, int d2s_W, TY* xs, hipStream_t st,
                        float* scratch = nullptr) {
     const long long n_row_groups = R / rows_per_stat;
     const long long n_stats = n_row_groups * n_groups;
@@ -430,17 +456,17 @@ static int launch_norm(const float* x, const float* gamma, const float* beta, lo
     }
     const size_t lds = sizeof(float) * C;
     if (scratch && grid.x <= 64) {         // few workgroups per row group share a ticket (BatchNorm's single row group: classic path)
-        if (vec) hipLaunchKernelGGL((norm_stats_kernel<true, true>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, scratch, stats, n_stats);
-        else hipLaunchKernelGGL((norm_stats_kernel<false, true>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, scratch, stats, n_stats);
+        if (vec) hipLaunchKernelGGL((norm_stats_kernel<true, true, TX>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, scratch, stats, n_stats);
+        else hipLaunchKernelGGL((norm_stats_kernel<false, true, TX>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, scratch, stats, n_stats);
         const int rc1 = check_launch("norm_stats_kernel");
         if (rc1) return rc1;
         return launch_norm_apply(x, gamma, beta, R, rows_per_stat, C, cpg, n_groups, eps, relu, stats, y, d2s_H, d2s_W, xs, vec, st);
     }
-    if (vec) hipLaunchKernelGGL((norm_stats_kernel<true, false>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, stats, (float*)nullptr, n_stats);
-    else hipLaunchKernelGGL((norm_stats_kernel<false, false>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, stats, (float*)nullptr, n_stats);
+    if (vec) hipLaunchKernelGGL((norm_stats_kernel<true, false, TX>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, stats, (float*)nullptr, n_stats);
+    else hipLaunchKernelGGL((norm_stats_kernel<false, false, TX>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, stats, (float*)nullptr, n_stats);
     int rc = check_launch("norm_stats_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(norm_stats_finalize_kernel, dim3((unsigned)((n_stats + 127) / 128)), dim3(128), 0, st, x, rows_per_stat, C, cpg,
+    hipLaunchKernelGGL(norm_stats_finalize_kernel<TX>, dim3((unsigned)((n_stats + 127) / 128)), dim3(128), 0, st, x, rows_per_stat, C, cpg,
                        n_groups, n_stats, stats);
     rc = check_launch("norm_stats_finalize_kernel");
     if (rc) return rc;
@@ -448,7 +474,7 @@ static int launch_norm(const float* x, const float* gamma, const float* beta, lo
 }
 
 // d2s_W > 0 asks for the depth-to-space output layout: rows are (n, h, w) with w fastest, H = rows_per_image / d2s_W
-static int check_d2s(long long rows_per_image, int C, int d2s_W, const float* xs, int* H_out) {
+static int check_d2s(long long rows_per_image, int C, int d2s_W, const void* xs, int* H_out) {
     *H_out = 0;
     if (d2s_W <= 0) {
         CSLGAN_REQUIRE(d2s_W == 0 && !xs, "norm: x_shuffled needs d2s_W > 0");
@@ -524,6 +550,25 @@ int cslgan_groupnorm_act_f32(const float* x, const float* gamma, const float* be
     if (rc) return rc;
     return launch_norm(x, gamma, beta, (long long)N * HW, HW, C, C / groups, groups, eps, relu, stats_ws, y, H, d2s_W, x_shuffled,
                        (hipStream_t)stream, scratch);
+}
+
+// GroupNorm (+ReLU) at the head of the bf16-stored chain (csrc/igemm_bf16s.hip): x fp32 or bfloat16, y (and x_shuffled) bfloat16;
+// statistics and arithmetic in fp32 exactly as cslgan_groupnorm_act_f32.
+int cslgan_groupnorm_act_bf16s(const void* x, int x_bf16, const float* gamma, const float* beta, int N, int HW, int C, int groups,
+                               float eps, int relu, float* stats_ws, void* y_bf16, int d2s_W, void* x_shuffled_bf16, void* stream) {
+    CSLGAN_REQUIRE(x && gamma && beta && stats_ws && y_bf16, "groupnorm_bf16s: null argument");
+    CSLGAN_REQUIRE(N > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, "groupnorm_bf16s: C=%d not divisible by groups=%d", C, groups);
+    CSLGAN_REQUIRE(N <= 65535 && C <= 8192, "groupnorm_bf16s: N or C too large");
+    int H = 0;
+    int rc = check_d2s(HW, C, d2s_W, x_shuffled_bf16, &H);
+    if (rc) return rc;
+    bf16_t* y = reinterpret_cast<bf16_t*>(y_bf16);
+    bf16_t* xs = reinterpret_cast<bf16_t*>(x_shuffled_bf16);
+    if (x_bf16)
+        return launch_norm(reinterpret_cast<const bf16_t*>(x), gamma, beta, (long long)N * HW, HW, C, C / groups, groups, eps, relu, stats_ws, y, H,
+                           d2s_W, xs, (hipStream_t)stream);
+    return launch_norm(reinterpret_cast<const float*>(x), gamma, beta, (long long)N * HW, HW, C, C / groups, groups, eps, relu, stats_ws, y, H, d2s_W,
+                       xs, (hipStream_t)stream);
 }
 
 int cslgan_batchnorm_act_f32(const float* x, const float* gamma, const float* beta, int64_t rows, int C, float eps, int relu,

@@ -316,7 +316,7 @@ def _conv2d_fwd_stored(x, w, bias, stride, pad, residual, act, out, wkey, alg_sc
     if out_dtype is None:           # follow the input: conv layers answer bf16 activations in kind; heads and 1..4-channel images stay fp32
         out_dtype = torch.bfloat16 if (x.dtype == torch.bfloat16 and P * Q > 1 and K > 4) else torch.float32
     y_bf16 = out_dtype == torch.bfloat16
-    if x.dtype == torch.bfloat16 and Cc % 8 == 0:
+    if x.dtype == torch.bfloat16 and Cc % 8 == 0 and (K > 4 or P * Q == 1):      # 1..4 output channels of an image: the fp32 vector-ALU kernel below
         d = ConvT(N, H, W, Cc, K, R, S, stride, pad, COMPUTE_BF16, P, Q)
         y = out if out is not None else torch.empty((N, P, Q, K), device=x.device, dtype=out_dtype)
         if y.dtype != out_dtype:
@@ -335,6 +335,17 @@ def _conv2d_fwd_stored(x, w, bias, stride, pad, residual, act, out, wkey, alg_sc
                                                act, _p(y), 1 if y_bf16 else 0, _stream()), "conv2d_fwd_bf16s"),
             exec_flop=2.0 * N * P * Q * K * R * S * Cc, tag=lambda: "N%d %dx%d C%d K%d R%d s%d bf16s" % (N, H, W, Cc, K, R, stride))
         repack_cache.packed()
+        return y
+    if (x.dtype == torch.float32 and y_bf16 and residual is None and out is None
+            and Cc == 3 and _c3_layer(H, W, K, R, S, stride, pad, H % 16 == 0 and W % 32 == 0)):
+        # the RGB first layer: fp32 image in, bf16-stored activations out of the same kernel (no cast pass)
+        d = ConvT(N, H, W, Cc, K, R, S, stride, pad, COMPUTE_F32, P, Q)
+        y = torch.empty((N, P, Q, K), device=x.device, dtype=torch.bfloat16)
+        if bias is not None:
+            _chk(bias, "bias")
+        _timed("conv2d_fwd", 2.0 * N * P * Q * K * R * S * Cc, 4.0 * N * H * W * Cc + 2.0 * N * P * Q * K, lambda: check(
+            _lib.lib().cslgan_conv2d_c3_fwd_bf16out(C.byref(d), _p(x), _p(w), _p(bias), act, _p(y), _stream()), "conv2d_c3_fwd_bf16out"),
+            tag=lambda: "N%d %dx%d C%d K%d R%d s%d bf16out" % (N, H, W, Cc, K, R, stride))
         return y
     yf = conv2d_fwd(cast_f32(x), w, bias, stride=stride, pad=pad, residual=cast_f32(residual), act=act, wkey=wkey, alg_scale=alg_scale,
                     wversion=wversion)
@@ -400,6 +411,8 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, ou
 def depth_to_space(x, inverse=False):
     """UpsampleConv's data movement (DCResNet_models.py:13-15) on NHWC data: [N,H,W,C] -> [N,2H,2W,C/4] with
     out[n,2h+i,2w+j,c'] = x[n,h,w,4c'+2i+j]; inverse=True maps [N,2H,2W,C/4] back to [N,H,W,C] (its gradient)."""
+    if x.dtype == torch.bfloat16:          # parity-test route only (the product path shuffles inside the normalisation kernel)
+        return cast_bf16(depth_to_space(cast_f32(x), inverse=inverse))
     _chk(x, "x")
     if inverse:
         N, H2, W2, Cq = x.shape
@@ -638,6 +651,24 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
                    lambda: check(_lib.lib().cslgan_linear_k1_wgrad_bf16s(_p(gy), _p(x), N, Cc, group, float(alpha), _p(gw), _p(sq), _stream()),
                                  "linear_k1_wgrad_bf16s"), tag=lambda: "N%d 1x1 C%d K1 R1 s1 g%d bf16s" % (N, Cc, group))
             return gw
+        if (gy.dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[-1] == 3 and group == 1 and row_scale is None
+                and (out is None or out.dtype == torch.float32) and (want_gw or sq is not None)
+                and _c3_layer(x.shape[1], x.shape[2], gy.shape[-1], R, S, stride, pad, gy.shape[2] in (16, 32, 64) and gy.shape[1] % (128 // gy.shape[2]) == 0)):
+            # the RGB first layer: bf16-stored output gradient, fp32 image, the first-layer kernel reads gy as stored
+            N, H, W, Cc = x.shape
+            _, P, Q, K = gy.shape
+            _chk(gy, "gy", allow_bf16=True); _chk(x, "x")
+            d = ConvT(N, H, W, Cc, K, R, S, stride, pad, COMPUTE_F32, P, Q)
+            gw = None
+            if want_gw:
+                gw = out if out is not None else torch.empty((N, K, R, S, Cc), device=x.device, dtype=torch.float32)
+                _chk(gw, "gw")
+            if sq is not None:
+                _chk(sq, "sq")
+            _timed("conv2d_wgrad_grouped" + ("" if want_gw else "_normonly"), 2.0 * N * P * Q * K * R * S * Cc, 4.0 * N * H * W * Cc + 2.0 * N * P * Q * K,
+                   lambda: check(_lib.lib().cslgan_conv2d_c3_wgrad_bf16gy(C.byref(d), _p(gy), _p(x), float(alpha), _p(gw), _p(sq), _stream()),
+                                 "conv2d_c3_wgrad_bf16gy"), tag=lambda: "N%d %dx%d C%d K%d R%d s%d g1 bf16gy" % (N, H, W, Cc, K, R, stride))
+            return gw
         gy, x = cast_f32(gy), cast_f32(x)       # mixed element types / shapes the bf16-stored kernel does not take
     _chk(gy, "gy"); _chk(x, "x")
     N, H, W, Cc = x.shape
@@ -773,7 +804,9 @@ def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, alpha=1.0, row_scale=None, 
         res = torch.empty(x.shape[-1], device=x.device, dtype=torch.float32) if out is None else out
         clip_accum_noise([slabs.reshape(slabs.shape[0], -1)], [res.view(-1)])
         return res.view(1, 1, 1, -1)
-    if (gy.dtype == torch.bfloat16 or x.dtype == torch.bfloat16) and not (
+    c3_mixed = (gy.dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[-1] == 3 and row_scale is None
+                and _c3_layer(x.shape[1], x.shape[2], gy.shape[-1], R, S, stride, pad, gy.shape[2] in (16, 32, 64) and gy.shape[1] % (128 // gy.shape[2]) == 0))
+    if (gy.dtype == torch.bfloat16 or x.dtype == torch.bfloat16) and not c3_mixed and not (
             gy.dtype == x.dtype and row_scale is None and gy.shape[-1] % 8 == 0 and x.shape[-1] % 8 == 0):
         gy, x = cast_f32(gy), cast_f32(x)
     N, H, W, Cc = x.shape
@@ -1014,17 +1047,17 @@ def act_bwd(g, y, slope):
     return out
 
 
-def _d2s_out(x, d2s, want_raw):
+def _d2s_out(x, d2s, want_raw, dtype=torch.float32):
     N, H, W, Cc = x.shape
     if not d2s:
         if want_raw:
             raise RuntimeError("want_raw needs d2s=True")
-        return torch.empty_like(x), None, 0
+        return torch.empty_like(x, dtype=dtype), None, 0
     if Cc % 4:
         raise RuntimeError("depth-to-space output needs C %% 4 == 0 (C=%d)" % Cc)
     shp = (N, 2 * H, 2 * W, Cc // 4)
-    y = torch.empty(shp, device=x.device, dtype=torch.float32)
-    return y, (torch.empty(shp, device=x.device, dtype=torch.float32) if want_raw else None), W
+    y = torch.empty(shp, device=x.device, dtype=dtype)
+    return y, (torch.empty(shp, device=x.device, dtype=dtype) if want_raw else None), W
 
 
 _norm_scratch = {}
@@ -1050,9 +1083,19 @@ def _scratch(dev, n_floats):
     return t
 
 
-def groupnorm_act(x, gamma, beta, groups, eps=1e-5, relu=True, return_stats=False, d2s=False, want_raw=False):
+def groupnorm_act(x, gamma, beta, groups, eps=1e-5, relu=True, return_stats=False, d2s=False, want_raw=False, out_dtype=None):
     """GroupNorm(+ReLU).  d2s=True: the output is written depth-to-space shuffled ([N,2H,2W,C/4], see depth_to_space);
-    want_raw=True additionally returns the raw x in that layout (one read of x feeds ResBlockUp's convUp and shortcut)."""
+    want_raw=True additionally returns the raw x in that layout (one read of x feeds ResBlockUp's convUp and shortcut).
+    out_dtype torch.bfloat16 (or a bfloat16 x): bf16-stored outputs (set_storage_dtype), fp32 statistics and arithmetic."""
+    if x.dtype == torch.bfloat16 or out_dtype == torch.bfloat16:
+        _chk(x, "x", allow_bf16=True); _chk(gamma, "gamma"); _chk(beta, "beta")
+        N, H, W, Cc = x.shape
+        y, xs, dW = _d2s_out(x, d2s, want_raw, torch.bfloat16)
+        ws = torch.empty(2 * N * groups, device=x.device, dtype=torch.float32)
+        check(_lib.lib().cslgan_groupnorm_act_bf16s(_p(x), 1 if x.dtype == torch.bfloat16 else 0, _p(gamma), _p(beta), N, H * W, Cc, groups,
+                                                    float(eps), 1 if relu else 0, _p(ws), _p(y), dW, _p(xs), _stream()), "groupnorm_act_bf16s")
+        out = (y, xs) if want_raw else y
+        return (out, ws) if return_stats else out
     _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
     N, H, W, Cc = x.shape
     y, xs, dW = _d2s_out(x, d2s, want_raw)

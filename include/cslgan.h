@@ -258,6 +258,20 @@ int cslgan_linear_k1_dgrad_bf16s(const float* gy, const float* w, const void* ma
 int cslgan_linear_k1_wgrad_bf16s(const float* gy, const void* x_bf16, int N, int64_t C, int group, float alpha, float* gw, float* sq,
                                  void* stream);
 
+/* The critic's RGB first layer (3 -> 64 channels, 5x5, stride 2; csrc/conv_c3.hip) at the edge of the bf16-stored chain: fp32 image
+ * and fp32 arithmetic as in cslgan_conv2d_fwd_f32 / cslgan_conv2d_wgrad_grouped_f32(group = 1), with the OUTPUT stored as bfloat16 /
+ * the output gradient read as bfloat16.  Only the shapes the first-layer kernels take (even image, P % 8 == 0, Q % 16 == 0 forward;
+ * Q in {16, 32, 64} with whole-row strips for the weight gradient); anything else is an error. */
+int cslgan_conv2d_c3_fwd_bf16out(const cslgan_conv_t* p, const float* x, const float* w, const float* bias, int act, void* y_bf16,
+                                 void* stream);
+int cslgan_conv2d_c3_wgrad_bf16gy(const cslgan_conv_t* p, const void* gy_bf16, const float* x, float alpha, float* gw, float* sq,
+                                  void* stream);
+
+/* nn.GroupNorm(groups, C) + ReLU (DCResNet_models.py:55-57) writing bf16-stored activations: x fp32 or bfloat16 (x_bf16), y and
+ * x_shuffled bfloat16; everything else as cslgan_groupnorm_act_f32 (fp32 statistics, d2s_W > 0 = depth-to-space output layout). */
+int cslgan_groupnorm_act_bf16s(const void* x, int x_bf16, const float* gamma, const float* beta, int N, int HW, int C, int groups,
+                               float eps, int relu, float* stats_ws, void* y_bf16, int d2s_W, void* x_shuffled_bf16, void* stream);
+
 /* Element-type conversions at the edges of the bf16-stored chain (round-to-nearest-even / exact widening). */
 int cslgan_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, void* stream);
 int cslgan_cast_bf16_f32(const void* in_bf16, float* out, int64_t n, void* stream);

@@ -207,6 +207,11 @@ def test_mixed_element_types_fall_back_to_the_fp32_kernels():
     ref = torch.stack([torch.autograd.grad(F.conv2d(img[i:i + 1], wz, None, stride=2, padding=2), wz, gy1[i:i + 1])[0] for i in range(3)])
     gw1 = ops.conv2d_wgrad_grouped(_nhwc16(gy1), _nhwc(img), 5, 5, stride=2, pad=2, group=1)
     _close(gw1.permute(0, 1, 4, 2, 3), ref, what="first-layer per-sample gradient from a bf16 output gradient")
+    dense1 = ops.conv2d_wgrad_dense(_nhwc16(gy1), _nhwc(img), 5, 5, stride=2, pad=2)
+    _close(dense1.permute(0, 3, 1, 2), ref.sum(0), rtol=2e-4, what="first-layer dense gradient from a bf16 output gradient")
+    sq1 = torch.zeros(3, device="cuda")
+    assert ops.conv2d_wgrad_grouped(_nhwc16(gy1), _nhwc(img), 5, 5, stride=2, pad=2, group=1, want_gw=False, sq=sq1) is None
+    _close(sq1, ref.reshape(3, -1).pow(2).sum(1), rtol=2e-4, what="first-layer per-sample norms from a bf16 output gradient")
     w = torch.randn(64, 3, 5, 5, generator=g) * 0.1
     y = ops.conv2d_fwd(_nhwc(img), _krsc(w), None, stride=2, pad=2, act=1, out_dtype=torch.bfloat16)
     assert y.dtype == torch.bfloat16
@@ -227,6 +232,48 @@ def test_act_bwd_and_bias_grad_bf16():
         ref = 1.5 * gy.reshape(6 // grp, -1, 128).sum(1)
         _close(gb, ref, what="bias grad bf16 g%d" % grp)
         _close(sq, ref.pow(2).sum(1), rtol=2e-4, what="bias grad sq")
+
+
+@pytest.mark.parametrize("case", [(4, 16, 16, 64, True, True), (3, 8, 8, 128, False, False), (2, 32, 32, 32, True, False), (2, 4, 4, 512, False, True)])
+def test_groupnorm_act_bf16_stored(case):
+    """GroupNorm(32) + ReLU writing bf16-stored activations from an fp32 or a bf16 input, plain and depth-to-space shuffled
+    (with the raw input beside it), against torch in fp32 on the input as stored."""
+    ops = _ops()
+    N, H, W, C, in16, d2s = case
+    g = torch.Generator().manual_seed(_seed(case))
+    x = torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3
+    if in16:
+        x = _bf(x)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    ref = F.relu(F.group_norm(x, 32, gamma, beta, eps=1e-5))
+    xd = _nhwc16(x) if in16 else _nhwc(x)
+    if d2s:
+        y, xs = ops.groupnorm_act(xd, gamma.cuda(), beta.cuda(), 32, d2s=True, want_raw=True, out_dtype=torch.bfloat16)
+        assert y.dtype == torch.bfloat16 and xs.dtype == torch.bfloat16
+        shuf = lambda t: F.pixel_shuffle(t, 2)          # [N, 4c'+2i+j, h, w] -> [N, c', 2h+i, 2w+j]: the plain depth-to-space map
+        _close(y.permute(0, 3, 1, 2), shuf(ref), ulps=0.51, what="groupnorm bf16 d2s %s" % (case,))
+        _close(xs.permute(0, 3, 1, 2), shuf(x), ulps=0.51, rtol=1e-6, what="raw input, shuffled %s" % (case,))
+    else:
+        y = ops.groupnorm_act(xd, gamma.cuda(), beta.cuda(), 32, out_dtype=torch.bfloat16)
+        assert y.dtype == torch.bfloat16
+        _close(y.permute(0, 3, 1, 2), ref, ulps=0.51, what="groupnorm bf16 %s" % (case,))
+
+
+def test_generator_forward_bf16_stored_matches_fp32():
+    """The frozen generator of a D-step with --storage_dtype bf16 (GroupNorm writes bf16, the convs answer in kind, the output conv
+    returns the fp32 image) against the same generator on the fp32 kernels: 13 convs deep, 4e-2 of scale per pixel."""
+    ops = _ops()
+    from csl_gan_amd import init_util, options
+    import tempfile
+    opt = options.parse(["CelebA", "-dpm", "gc", "-nms", "4", "-bs", "4", "-gd", "cuda:0", "-dd", "cuda:0", "-o", tempfile.mkdtemp(), "--manual_seed", "3"])
+    G, D = init_util.init_models(opt)
+    z = torch.randn(4, 128, generator=torch.Generator().manual_seed(4)).cuda()
+    with torch.no_grad():
+        ref = G(z)
+        with ops.compute_dtype("bf16"), ops.storage_dtype("bf16"):
+            got = G(z)
+    assert got.dtype == torch.float32 and got.shape == ref.shape
+    _close(got, ref, rtol=4e-2, what="generator forward, bf16 storage vs fp32")
 
 
 def test_conv_autograd_closed_under_bf16_storage():

@@ -305,7 +305,9 @@ def main():
         # a bf16x3 kernel issues SIX bf16 MFMAs per logical fp32 multiply-add step: its executed matrix FLOP are 6x the logical
         mfma_mult = 6.0 if "bf16x3" in dom["name"] else 1.0
         ach = mfma_mult * dom["exec_flop"] / (dom["ms"] * 1e-3) / 1e12
-        peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom["name"] else PEAK_FP32_MFMA_TFLOPS
+        # bf16 matrix-core kernels: the fp32-tensor family of csrc/igemm_bf16.hip and the bf16-stored family of csrc/igemm_bf16s.hip
+        on_bf16 = "bf16" in dom["name"] or any(t in dom["name"] for t in ("igemm_kcs_kernel", "igemm_mcs_kernel", "igemm_mcs_tr_kernel", "igemm_halos_kernel"))
+        peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
         worst = sorted((v for k, v in timed_shapes.items() if k.startswith(dom["name"])), key=lambda v: -v["ms"])
         roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_from": traffic_src,
@@ -367,6 +369,7 @@ def main():
         "roofline_hbm": roof_hbm,
         "secondary": loop,
         "variants": variant,
+        "graph_error": graph_err,
         "tables_from": "%d launch-by-launch instrumented warm-up step(s) run on ONE stream (isolated kernel times); roofline from the "
                        "eagerly launched timed region; both timed regions run the step's two streams" % n_pr,
         "entries_ms_per_step": {k: round(v["ms"] / n_pr, 3) for k, v in sorted(entries.items(), key=lambda kv: -kv[1]["ms"])},

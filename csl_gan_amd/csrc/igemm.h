@@ -62,6 +62,7 @@ struct KcParams {
     int bf16;               // 0: exact fp32 MFMA; 1: operands rounded to bfloat16, v_mfma_f32_32x32x16_bf16 (igemm_bf16.hip);
                             // 3: fp32 emulated from three bfloat16 pieces per operand, six bf16 MFMAs per step
     const void* w3;         // igemm_halo_x3: the filter pre-split into three bfloat16 pieces, [3][Nn][Kdim] (same k order as w), or null
+    int a_bf16;             // igemm_skinny only: the input tensor a is stored as bfloat16 (bf16 storage mode, csrc/igemm_bf16s.hip)
     int acc_classes;        // igemm_halo: 1 = every workgroup runs ALL classes on its m-tile into ONE accumulator (the classes are
                             // partial sums of the same output: a stride-2 conv as four stride-1 convs over parity sub-images)
     KcClass cls[IG_MAX_CLS];

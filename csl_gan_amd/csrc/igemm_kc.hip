@@ -388,7 +388,7 @@ int launch_kc(KcParams& p, hipStream_t st, long long out_elems) {
     if (rows <= 0 || p.Nn <= 0) return CSLGAN_OK;
     {
         const long long n_img = p.cls[0].M / ((long long)p.cls[0].OHc * p.cls[0].OWc);
-        const long long a_b = 4ll * n_img * p.AH * p.AW * p.AC;
+        const long long a_b = (p.a_bf16 ? 2ll : 4ll) * n_img * p.AH * p.AW * p.AC;
         long long w_end = 0;
         for (int c = 0; c < p.n_cls; ++c) {
             const long long e = (long long)p.cls[c].w_off + (long long)p.Nn * p.cls[c].Kdim;
@@ -413,6 +413,7 @@ int launch_kc(KcParams& p, hipStream_t st, long long out_elems) {
     // 1..4 output channels: vector-ALU kernel, fp32 in every compute mode (a 32-wide MFMA tile would be 29/32 padding)
     static const int skinny_env = [] { const char* e = getenv("CSLGAN_KC_SKINNY"); return e ? atoi(e) : 1; }();
     if (skinny_env && !p.acc_classes && skinny_eligible(p)) return launch_skinny(p, st);
+    if (p.a_bf16) { set_error("igemm_kc: a bfloat16-stored input is only taken by the 1..4-output-channel kernel (64 input channels, stride 1)"); return CSLGAN_ERR_INVALID_ARG; }
     if (p.bf16) {
         if (p.acc_classes) { set_error("igemm_kc: accumulated classes have no bf16 form"); return CSLGAN_ERR_INVALID_ARG; }
         return launch_kc_bf16(p, st, out_elems);
@@ -467,7 +468,13 @@ using namespace cslgan;
 extern "C" {
 
 static int conv2d_fwd_impl(const cslgan_conv_t* c, const float* x, const float* w, const void* w3, const float* bias,
-                           const float* residual, int act, float* y, void* stream);
+                           const float* residual, int act, float* y, void* stream, int x_bf16 = 0);
+
+// cslgan_conv2d_fwd_f32 for a conv with 1..4 output channels (the generator's output conv, DCResNet_models.py:85) whose INPUT is
+// stored as bfloat16 (bf16 storage mode): fp32 filter, fp32 arithmetic, fp32 output; only shapes the vector-ALU kernel takes.
+int cslgan_conv2d_fwd_skinny_bf16in(const cslgan_conv_t* c, const void* x_bf16, const float* w, const float* bias, int act, float* y, void* stream) {
+    return conv2d_fwd_impl(c, reinterpret_cast<const float*>(x_bf16), w, nullptr, bias, nullptr, act, y, stream, 1);
+}
 
 int cslgan_conv2d_fwd_f32(const cslgan_conv_t* c, const float* x, const float* w, const float* bias,
                           const float* residual, int act, float* y, void* stream) {
@@ -488,12 +495,15 @@ int cslgan_conv2d_fwd_x3_f32(const cslgan_conv_t* c, const float* x, const float
 }
 
 static int conv2d_fwd_impl(const cslgan_conv_t* c, const float* x, const float* w, const void* w3, const float* bias,
-                           const float* residual, int act, float* y, void* stream) {
+                           const float* residual, int act, float* y, void* stream, int x_bf16) {
     CSLGAN_REQUIRE(c && x && w && y, "conv2d_fwd: null argument");
     int rc = check_conv(c, "conv2d_fwd");
     if (rc) return rc;
     CSLGAN_REQUIRE(act >= 0 && act <= 3, "conv2d_fwd: unknown activation %d", act);
     static const int c3_env = [] { const char* e = getenv("CSLGAN_C3"); return e ? atoi(e) : 1; }();
+    if (x_bf16) {
+        CSLGAN_REQUIRE(c->K <= 4 && c->C == 64 && c->stride == 1 && !residual, "conv2d_fwd_skinny_bf16in: needs 1..4 output channels, 64 input channels, stride 1");
+    } else
     if (c3_env && c3_fwd_eligible(c, residual))          // the critic's RGB first layer (conv_c3.hip), exact fp32 in every compute mode
         return launch_c3_fwd(c, x, w, bias, act, y, (hipStream_t)stream);
     if (conv1x1_eligible(c, x, w, residual))                     // the generator's shortcut convs (conv1x1.hip)
@@ -506,6 +516,7 @@ static int conv2d_fwd_impl(const cslgan_conv_t* c, const float* x, const float* 
     p.sy = p.sx = c->stride;
     p.w = w; p.w3 = w3; p.Nn = c->K; p.out = y; p.OHf = c->P; p.OWf = c->Q; p.osy = p.osx = 1; p.ldo = c->K; p.dense_out = 1;
     p.bias = bias; p.res = residual; p.mask = nullptr; p.act = act; p.bf16 = c->compute == CSLGAN_COMPUTE_BF16 ? 1 : (c->compute == CSLGAN_COMPUTE_BF16X3 ? 3 : 0);
+    p.a_bf16 = x_bf16;
     p.n_cls = 1;
     KcClass& k = p.cls[0];
     k.M = c->N * c->P * c->Q; k.OHc = c->P; k.OWc = c->Q; k.T = c->R * c->S; k.Kdim = k.T * c->C; k.w_off = 0; k.oy0 = k.ox0 = 0;
@@ -577,13 +588,28 @@ int cslgan_conv2d_s2_fwd_f32(const cslgan_conv_t* c, const float* x, const float
     return launch_kc(p, st, 0);
 }
 
+static int conv2d_dgrad_impl(const cslgan_conv_t* c, const float* gy, const float* w, float* wt_ws, int repack,
+                             const float* mask, float* gx, void* stream, int gy_bf16);
+
 int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* c, const float* gy, const float* w, float* wt_ws, int repack,
                             const float* mask, float* gx, void* stream) {
+    return conv2d_dgrad_impl(c, gy, w, wt_ws, repack, mask, gx, stream, 0);
+}
+
+// cslgan_conv2d_dgrad_f32 for a conv with 1..4 INPUT channels (the critic's RGB first layer: the gradient of the image,
+// gradient_penalty.py:48-50) whose output gradient gy is stored as bfloat16: fp32 filter classes, fp32 arithmetic, fp32 gx.
+int cslgan_conv2d_dgrad_skinny_bf16in(const cslgan_conv_t* c, const void* gy_bf16, const float* w, float* wt_ws, int repack, float* gx, void* stream) {
+    CSLGAN_REQUIRE(c && c->C <= 4 && c->K == 64, "conv2d_dgrad_skinny_bf16in: needs 1..4 input channels and 64 output channels");
+    return conv2d_dgrad_impl(c, reinterpret_cast<const float*>(gy_bf16), w, wt_ws, repack, nullptr, gx, stream, 1);
+}
+
+static int conv2d_dgrad_impl(const cslgan_conv_t* c, const float* gy, const float* w, float* wt_ws, int repack,
+                             const float* mask, float* gx, void* stream, int gy_bf16) {
     CSLGAN_REQUIRE(c && gy && w && wt_ws && gx, "conv2d_dgrad: null argument");
     int rc = check_conv(c, "conv2d_dgrad");
     if (rc) return rc;
     CSLGAN_REQUIRE(c->stride >= 1 && c->stride <= 2, "conv2d_dgrad: stride %d unsupported", c->stride);
-    if (linear_k1_shape(c) && aligned16(w) && aligned16(gx) && (!mask || aligned16(mask)))      // gx[n,:] = gy[n] * w: no repack needed
+    if (!gy_bf16 && linear_k1_shape(c) && aligned16(w) && aligned16(gx) && (!mask || aligned16(mask)))      // gx[n,:] = gy[n] * w: no repack needed
         return launch_linear_k1_dgrad(c, gy, w, mask, gx, (hipStream_t)stream);
     const int s = c->stride;
     hipStream_t st = (hipStream_t)stream;
@@ -594,6 +620,7 @@ int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* c, const float* gy, const float
     p.w = wt_ws; p.Nn = c->C; p.out = gx; p.OHf = c->H; p.OWf = c->W; p.osy = p.osx = s; p.ldo = c->C;
     p.dense_out = (s == 1) ? 1 : 0;
     p.bias = nullptr; p.res = nullptr; p.mask = mask; p.act = CSLGAN_ACT_NONE; p.bf16 = c->compute == CSLGAN_COMPUTE_BF16 ? 1 : (c->compute == CSLGAN_COMPUTE_BF16X3 ? 3 : 0);
+    p.a_bf16 = gy_bf16;
     int off = 0, ncls = 0;
     for (int py = 0; py < s; ++py)
         for (int px = 0; px < s; ++px) {

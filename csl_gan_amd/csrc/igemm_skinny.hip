@@ -55,7 +55,13 @@ __global__ __launch_bounds__(256) void igemm_skinny_kernel(const KcParams p) {
         const int hy = pix / HW_, hx = pix - hy * HW_;
         const int iy = y0 + hy, ix = x0 + hx;
         const bool ok = pix < hpix && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
-        rh[j] = sbuf_load4(a_rsrc, ok ? 4u * (unsigned)(img_base + (iy * p.AW + ix) * SK_C + c4 * 4) : SOOB);
+        if (p.a_bf16) {        // bf16-stored input: 4 channels = 8 bytes, widened here (the arithmetic stays fp32)
+            const unsigned o = ok ? 2u * (unsigned)(img_base + (iy * p.AW + ix) * SK_C + c4 * 4) : SOOB;
+            const unsigned lo = __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, (int)o, 0, 0), hi = __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, (int)(o == SOOB ? SOOB : o + 4u), 0, 0);
+            rh[j] = make_float4(__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u));
+        } else {
+            rh[j] = sbuf_load4(a_rsrc, ok ? 4u * (unsigned)(img_base + (iy * p.AW + ix) * SK_C + c4 * 4) : SOOB);
+        }
     }
     const int cl = tid & 15;
 #pragma unroll

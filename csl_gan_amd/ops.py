@@ -336,6 +336,17 @@ def _conv2d_fwd_stored(x, w, bias, stride, pad, residual, act, out, wkey, alg_sc
             exec_flop=2.0 * N * P * Q * K * R * S * Cc, tag=lambda: "N%d %dx%d C%d K%d R%d s%d bf16s" % (N, H, W, Cc, K, R, stride))
         repack_cache.packed()
         return y
+    if (x.dtype == torch.bfloat16 and not y_bf16 and K <= 4 and Cc == 64 and stride == 1 and R * S <= 9 and P % 8 == 0 and Q % 8 == 0
+            and residual is None and out is None):
+        # the generator's output conv (64 -> 3 channels): the vector-ALU kernel reads the bf16-stored input as it is
+        d = ConvT(N, H, W, Cc, K, R, S, stride, pad, COMPUTE_F32, P, Q)
+        y = torch.empty((N, P, Q, K), device=x.device, dtype=torch.float32)
+        if bias is not None:
+            _chk(bias, "bias")
+        _timed("conv2d_fwd", 2.0 * N * P * Q * K * R * S * Cc, 2.0 * N * H * W * Cc + 4.0 * N * P * Q * K, lambda: check(
+            _lib.lib().cslgan_conv2d_fwd_skinny_bf16in(C.byref(d), _p(x), _p(w), _p(bias), act, _p(y), _stream()), "conv2d_fwd_skinny_bf16in"),
+            tag=lambda: "N%d %dx%d C%d K%d R%d s%d bf16in" % (N, H, W, Cc, K, R, stride))
+        return y
     if (x.dtype == torch.float32 and y_bf16 and residual is None and out is None
             and Cc == 3 and _c3_layer(H, W, K, R, S, stride, pad, H % 16 == 0 and W % 32 == 0)):
         # the RGB first layer: fp32 image in, bf16-stored activations out of the same kernel (no cast pass)
@@ -485,7 +496,7 @@ def _conv2d_dgrad_stored(gy, w, in_hw, stride, pad, mask, wkey, out_dtype):
             _lib.lib().cslgan_linear_k1_dgrad_bf16s(_p(gy), _p(w), _p(mask), N, Cc, _p(gx), _stream()), "linear_k1_dgrad_bf16s"),
             tag=lambda: "N%d 1x1 C%d K1 R1 s1 bf16s" % (N, Cc))
         return gx
-    if gy.dtype == torch.bfloat16 and K % 8 == 0 and stride in (1, 2):
+    if gy.dtype == torch.bfloat16 and K % 8 == 0 and stride in (1, 2) and Cc > 4:
         P2, Q2 = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
         if K2 != K or (P2, Q2) != (P, Q):
             raise RuntimeError("conv2d_dgrad: gy shape %s inconsistent with input %dx%d" % (tuple(gy.shape), H, W))
@@ -502,6 +513,17 @@ def _conv2d_dgrad_stored(gy, w, in_hw, stride, pad, mask, wkey, out_dtype):
             _lib.lib().cslgan_conv2d_dgrad_bf16s(C.byref(d), _p(gy), _p(w), _p(ws), repack, _p(mask), _p(gx),
                                                  1 if out_dtype == torch.bfloat16 else 0, _stream()), "conv2d_dgrad_bf16s"),
             tag=lambda: "N%d %dx%d C%d K%d R%d s%d bf16s" % (N, H, W, Cc, K, R, stride))
+        repack_cache.packed()
+        return gx
+    if (gy.dtype == torch.bfloat16 and out_dtype == torch.float32 and mask is None and Cc <= 4 and K == 64 and stride in (1, 2) and R * S <= 25
+            and H % stride == 0 and W % stride == 0 and (H // stride) % 8 == 0 and (W // stride) % 8 == 0 and (R <= 3 or stride == 2)):
+        # the critic's first layer: the image gradient from a bf16-stored output gradient on the vector-ALU kernel
+        d = ConvT(N, H, W, Cc, K, R, S, stride, pad, COMPUTE_F32, P, Q)
+        gx = torch.empty((N, H, W, Cc), device=gy.device, dtype=torch.float32)
+        ws, repack = repack_cache.get("dgrad%d" % stride, w, w.numel(), wkey)
+        _timed("conv2d_dgrad", 2.0 * N * P * Q * K * R * S * Cc, 2.0 * N * P * Q * K + 4.0 * N * H * W * Cc, lambda: check(
+            _lib.lib().cslgan_conv2d_dgrad_skinny_bf16in(C.byref(d), _p(gy), _p(w), _p(ws), repack, _p(gx), _stream()), "conv2d_dgrad_skinny_bf16in"),
+            tag=lambda: "N%d %dx%d C%d K%d R%d s%d bf16in" % (N, H, W, Cc, K, R, stride))
         repack_cache.packed()
         return gx
     gx = conv2d_dgrad(cast_f32(gy), w, in_hw, stride=stride, pad=pad, mask=cast_f32(mask), wkey=wkey)
@@ -901,6 +923,14 @@ def _segs(ins: Sequence[torch.Tensor], outs=None, noises=None):
     return s, n_rows
 
 
+def _take_rows(t, idx):
+    """t[idx] for a list of row indices WITHOUT building an index tensor on the host (that is a host-to-device copy, which a HIP-graph
+    capture refuses): a slice when the indices are consecutive, a stack of row views otherwise."""
+    if all(b - a == 1 for a, b in zip(idx, idx[1:])):
+        return t[idx[0]:idx[-1] + 1].contiguous()
+    return torch.stack([t[j] for j in idx])
+
+
 def _by_dtype(mats):
     """Index lists of the fp32 and the bf16 segments (a launch handles one element type)."""
     parts = {}
@@ -925,7 +955,8 @@ def sample_sqnorm(mats: Sequence[torch.Tensor]) -> torch.Tensor:
             _timed("sample_sqnorm", 0.0, nbytes, lambda: check(fn(C.byref(s), n_rows, _p(o), _stream()), "sample_sqnorm"))
             if len(sub) == len(mats):
                 return o
-            out[torch.tensor(sub, device=out.device)] = o
+            for k, j in enumerate(sub):
+                out[j].copy_(o[k])
     return out
 
 
@@ -966,12 +997,12 @@ def clip_accum_noise(mats, outs, factors=None, noise_std=None, noises=None, seed
             if factors is not None:
                 if factors.dim() == 2:
                     per_seg = 1
-                    f = factors if whole else factors[torch.tensor(sub, device=factors.device)].contiguous()
+                    f = factors if whole else _take_rows(factors, sub)
                 else:
                     f = factors
             ns = None
             if noise_std is not None:
-                ns = noise_std if whole else noise_std[torch.tensor(sub, device=noise_std.device)].contiguous()
+                ns = noise_std if whole else _take_rows(noise_std, sub)
             nbytes = float(sum(n_rows * mats[j].shape[1] * mats[j].element_size() + 4 * mats[j].shape[1] for j in sub))
             # the Philox stream is keyed by (offset, segment index within the launch): make it unique per launch
             _timed("clip_accum_noise", 0.0, nbytes, lambda: check(

@@ -272,6 +272,15 @@ int cslgan_conv2d_c3_wgrad_bf16gy(const cslgan_conv_t* p, const void* gy_bf16, c
 int cslgan_groupnorm_act_bf16s(const void* x, int x_bf16, const float* gamma, const float* beta, int N, int HW, int C, int groups,
                                float eps, int relu, float* stats_ws, void* y_bf16, int d2s_W, void* x_shuffled_bf16, void* stream);
 
+/* The two 1..4-channel ends of the bf16-stored chain on the vector-ALU kernel (csrc/igemm_skinny.hip), reading bfloat16, computing and
+ * writing fp32: the generator's output conv (64 -> 3 channels, stride 1; DCResNet_models.py:85) on a bf16 input, and the data gradient
+ * of the critic's RGB first layer (the image gradient of gradient_penalty.py:48-50) from a bf16 output gradient.  Shapes the
+ * vector-ALU kernel does not take are an error. */
+int cslgan_conv2d_fwd_skinny_bf16in(const cslgan_conv_t* p, const void* x_bf16, const float* w, const float* bias, int act, float* y,
+                                    void* stream);
+int cslgan_conv2d_dgrad_skinny_bf16in(const cslgan_conv_t* p, const void* gy_bf16, const float* w, float* wt_ws, int repack, float* gx,
+                                      void* stream);
+
 /* Element-type conversions at the edges of the bf16-stored chain (round-to-nearest-even / exact widening). */
 int cslgan_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, void* stream);
 int cslgan_cast_bf16_f32(const void* in_bf16, float* out, int64_t n, void* stream);

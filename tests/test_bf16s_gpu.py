@@ -76,6 +76,10 @@ FWD_CASES = [
     (130, 1, 1, 8192, 1, 1, 1, 0, False, 0, None, False),         # the critic's head on bf16 features
     (6, 1, 1, 512, 10, 1, 1, 0, True, 0, None, False),            # auxiliary head
     (128, 8, 8, 512, 512, 5, 1, 2, False, 0, None, True),         # > 256 tiles of 128x128
+    (4, 32, 32, 64, 3, 3, 1, 1, True, 3, None, False),            # the generator's output conv: bf16 in, tanh, fp32 image out
+    (2, 64, 64, 32, 64, 5, 1, 2, False, 0, None, True),           # LDS-halo form, 64 filters
+    (2, 16, 16, 128, 256, 5, 1, 2, True, 2, "bf16", True),        # LDS-halo form, 128-wide filter tiles, bf16 residual
+    (2, 32, 32, 16, 64, 5, 1, 2, False, 0, "f32", False),         # LDS-halo form on one 16-channel chunk, fp32 residual / output
 ]
 
 
@@ -87,7 +91,7 @@ def test_conv2d_fwd_bf16_stored(case):
     x = _bf(torch.randn(N, C, H, W, generator=g))
     w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
     b = torch.randn(K, generator=g) if has_b else None
-    y0 = F.conv2d(x, _bf(w), b, stride=s, padding=p)
+    y0 = F.conv2d(x, w if (K <= 4 and H * W > 1) else _bf(w), b, stride=s, padding=p)      # 1..4 output channels of an image: fp32 filter, vector ALU
     rs = None
     if res is not None:
         rs = torch.randn(y0.shape, generator=g)
@@ -122,7 +126,8 @@ def test_conv2d_dgrad_bf16_stored(case):
     w = torch.randn(K, C, R, R, generator=g) / (K * R * R) ** 0.5
     P, Q = (H + 2 * p - R) // s + 1, (W + 2 * p - R) // s + 1
     gy = _bf(torch.randn(N, K, P, Q, generator=g))
-    ref = F.conv_transpose2d(gy, _bf(w), None, stride=s, padding=p, output_padding=(H + 2 * p - R - (P - 1) * s, W + 2 * p - R - (Q - 1) * s))
+    wr = w if C <= 4 else _bf(w)        # 1..4 image channels: the vector-ALU kernel keeps the fp32 filter and fp32 arithmetic
+    ref = F.conv_transpose2d(gy, wr, None, stride=s, padding=p, output_padding=(H + 2 * p - R - (P - 1) * s, W + 2 * p - R - (Q - 1) * s))
     mask = None
     if use_mask:
         mask = torch.randn(N, C, H, W, generator=g)

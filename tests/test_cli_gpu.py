@@ -57,3 +57,29 @@ def test_cli_checkpoint_and_resume_with_graph_replay(tmp_path):
     # test_graph_gpu.py::test_capturable_adam_checkpoint_roundtrip)
     assert all(st["step"] == steps1 for st in tr2.d_optimizer.state.values())
     assert all(torch.isfinite(p).all() for p in tr2.D.parameters())
+
+
+@pytest.mark.parametrize("extra", [["--im_size", "128"], ["--conditional"], ["-dpm", "is"]])
+def test_cli_bf16_storage(tmp_path, extra):
+    """BASELINE configs[4] from the command line: --compute_dtype bf16 --storage_dtype bf16 (bf16-stored activations of the critic and of
+    the frozen generator, eager generator steps differentiating through them) — the 128x128 extension, the conditional (ACGAN) critic
+    whose first layer sees label planes, and the immediate-sensitivity engine's double backward."""
+    bs, iters = 16, 7
+    argv = ["CelebA", "-tss", "1000", "-nms", "1", "--mean_sample_size", "10", "-bs", str(bs), "--max_iters", str(iters), "--log_every", str(bs * 3),
+            "--compute_dtype", "bf16", "--storage_dtype", "bf16"]
+    if "-dpm" not in extra:
+        argv += ["-dpm", "gc"]
+    tr = _run(tmp_path, argv + extra)
+    torch.cuda.synchronize()
+    from csl_gan_amd import ops
+    assert ops.get_storage_dtype() == "bf16" and tr.privacy_engine.steps == iters
+    for p in list(tr.D.parameters()) + list(tr.G.parameters()):
+        assert torch.isfinite(p).all()
+    rows = open(os.path.join(str(tmp_path), "log.csv")).read().strip().splitlines()
+    assert len(rows) >= 3 and "nan" not in rows[-1].lower()
+
+
+def test_storage_dtype_needs_bf16_compute(tmp_path):
+    from csl_gan_amd import options
+    with pytest.raises(Exception, match="needs --compute_dtype bf16"):
+        options.parse(["CelebA", "-dpm", "gc", "-nms", "1", "-bs", "4", "-gd", "cuda:0", "-dd", "cuda:0", "-o", str(tmp_path), "--storage_dtype", "bf16"])

@@ -121,6 +121,10 @@ def test_graph_replay_equals_eager_steps(tmp_path, name, argv, B, shape, cond, s
     ("celeba_nd2", ["CelebA", "-dpm", "gc", "-gcm", "adaptive-pl", "-nms", "8", "--sigma", "0.5", "--n_d_steps", "2"], 8, (3, 64, 64), False, 128),
     ("celeba_auto", ["CelebA", "-dpm", "gc", "-gcm", "adaptive-pl", "-nms", "8", "--sigma", "0.5", "--n_d_steps", "2", "--compute_dtype",
                      "fp32_auto"], 8, (3, 64, 64), False, 128),
+    # bf16 storage (BASELINE configs[4]): the bf16 filter copies of G and D are re-rounded after every Adam step, train_G differentiates
+    # through the critic's bf16-stored activations; tolerances at the bf16 level (tests/test_bf16s_gpu.py states the error model)
+    ("celeba_bf16s", ["CelebA", "-dpm", "gc", "-gcm", "adaptive-pl", "-nms", "8", "--sigma", "0.5", "--n_d_steps", "2", "--compute_dtype",
+                      "bf16", "--storage_dtype", "bf16"], 8, (3, 64, 64), False, 128),
 ])
 def test_graph_replay_interleaved_with_generator_steps(tmp_path, name, argv, B, shape, cond, latent):
     """train() interleaves eager generator steps with replayed D-steps.  After such a sequence (a) the generator
@@ -161,7 +165,8 @@ def test_graph_replay_interleaved_with_generator_steps(tmp_path, name, argv, B, 
     with torch.no_grad():
         want = Go(z)
     got = tr.last["fake_img"].detach().cpu()
-    assert (got - want).abs().max().item() <= 1e-3 * want.abs().max().item(), "the replay ran a stale generator: %.3e" % (got - want).abs().max().item()
+    tol = 4e-2 if name.endswith("bf16s") else 1e-3
+    assert (got - want).abs().max().item() <= tol * want.abs().max().item(), "the replay ran a stale generator: %.3e" % (got - want).abs().max().item()
     # (b) eager forward + data gradient of the critic after the replays
     Do.load_state_dict({k: v.detach().cpu() for k, v in D.state_dict().items()})
     x = (torch.rand((B,) + shape, generator=g) * 2 - 1)
@@ -171,11 +176,11 @@ def test_graph_replay_interleaved_with_generator_steps(tmp_path, name, argv, B, 
     xd = x.cuda().requires_grad_(True)
     od, _ = D(xd)
     gd, = torch.autograd.grad(od.sum(), xd)
-    assert (od.detach().cpu() - oo.detach()).abs().max().item() <= 1e-3 * oo.detach().abs().max().item(), "eager D forward uses stale re-packed filters"
+    assert (od.detach().cpu() - oo.detach()).abs().max().item() <= tol * oo.detach().abs().max().item(), "eager D forward uses stale re-packed filters"
     # a gradient through LeakyReLU units: a unit within rounding of zero may take the other slope on the device and moves that sample's
     # gradient by a per cent or two — relative L2 (measured 1e-3 .. 2e-2 of max |g| per entry in the flip case), decisive against O(1)
     l2 = ((gd.cpu() - go).norm() / go.norm()).item()
-    assert l2 <= 3e-2, "eager D data gradient uses stale re-packed filters: relative L2 error %.3e" % l2
+    assert l2 <= (1.5e-1 if name.endswith("bf16s") else 3e-2), "eager D data gradient uses stale re-packed filters: relative L2 error %.3e" % l2
 
 
 def test_capturable_adam_checkpoint_roundtrip():

@@ -26,6 +26,11 @@ rm -rf $OUT/fetch $OUT/write $OUT/stats
 # 4. the other BASELINE configurations on the same harness
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --loop-steps 0 --no-variants --opt "-dpm is -ispp True" > $OUT/bench_is.json 2> /dev/null || true
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --loop-steps 0 --no-variants --opt "--compute_dtype bf16 --im_size 128" > $OUT/bench_bf16_128.json 2> /dev/null || true
+# BASELINE configs[4] as built in round 3: bf16 STORAGE (csrc/igemm_bf16s.hip) — bench line + launch table, then the kernel statistics of the same command
+python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --loop-steps 0 --no-variants --dump-shapes $OUT/launch_shapes_bf16s_128.txt --opt "--compute_dtype bf16 --storage_dtype bf16 --im_size 128" > $OUT/bench_bf16s_128.json 2> /dev/null || true
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats16 -o stats -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-variants --loop-steps 0 --opt "--compute_dtype bf16 --storage_dtype bf16 --im_size 128" > $OUT/stats_bench_bf16s.json 2> /dev/null) || true
+cp $(ls $OUT/stats16/*kernel_stats.csv | head -1) $OUT/kernel_stats_bf16s_128.csv || true
+rm -rf $OUT/stats16
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --loop-steps 0 --no-variants --opt "--im_size 128" > $OUT/bench_fp32_128.json 2> /dev/null || true
 python3 scripts/mnist_step_time.py > $OUT/mnist_eager.txt 2> /dev/null || true
 python3 scripts/mnist_step_time.py --graph > $OUT/mnist_graph.txt 2> /dev/null || true

@@ -68,6 +68,37 @@ def test_invalid_arguments_fail_loudly_without_gpu(built_lib):
     assert rc == -1 and b"not taken by the LDS-resident kernel" in L.cslgan_last_error()
 
 
+def test_bf16_storage_entries_validate_their_arguments(built_lib):
+    """csrc/igemm_bf16s.hip and the bf16 forms of the first-layer / vector-ALU / normalisation kernels (round 3): shapes they do not
+    take are refused on the host, before any launch."""
+    from csl_gan_amd import _lib
+    L = _lib.lib()
+    err = lambda: L.cslgan_last_error()
+    d = _lib.ConvT(2, 16, 16, 12, 64, 5, 5, 2, 2, 1, 8, 8)               # 12 channels: not a multiple of 8
+    assert L.cslgan_conv2d_fwd_bf16s(ctypes.byref(d), 16, 16, 16, 0, None, None, 0, 0, 16, 1, None) == -1 and b"multiple of 8" in err()
+    assert L.cslgan_conv2d_fwd_bf16s(ctypes.byref(d), None, 16, 16, 0, None, None, 0, 0, 16, 1, None) == -1 and b"null" in err()
+    d = _lib.ConvT(2, 16, 16, 64, 12, 5, 5, 2, 2, 1, 8, 8)               # 12 output channels: the data gradient's reduction
+    assert L.cslgan_conv2d_dgrad_bf16s(ctypes.byref(d), 16, 16, 16, 0, None, 16, 1, None) == -1 and b"multiple of 8" in err()
+    d = _lib.ConvT(2, 16, 16, 64, 128, 5, 5, 3, 2, 1, 6, 6)
+    assert L.cslgan_conv2d_dgrad_bf16s(ctypes.byref(d), 16, 16, 16, 0, None, 16, 1, None) == -1 and b"stride" in err()
+    d = _lib.ConvT(6, 16, 16, 64, 128, 5, 5, 2, 2, 1, 8, 8)
+    assert L.cslgan_conv2d_wgrad_grouped_bf16s(ctypes.byref(d), 16, 16, 4, 1.0, 16, 0, None, None) == -1 and b"not divisible" in err()
+    assert L.cslgan_conv2d_wgrad_grouped_bf16s(ctypes.byref(d), 16, 16, 1, 1.0, None, 0, None, None) == -1 and b"neither" in err()
+    assert L.cslgan_cast_f32_bf16(16, 20, 64, None) == -1 and b"misaligned" in err()
+    assert L.cslgan_act_bwd_bf16(16, 16, 12, 0.2, 16, None) == -1 and b"multiple of 8" in err()
+    assert L.cslgan_bias_grad_grouped_bf16(16, 4, 16, 24, 1, 1.0, 16, None, None) == -1 and b"multiple of 8" in err()
+    assert L.cslgan_linear_k1_dgrad_bf16s(16, 16, None, 4, 100, 16, None) == -1 and b"bad argument" in err()
+    assert L.cslgan_linear_k1_wgrad_bf16s(16, 16, 6, 64, 4, 1.0, 16, None, None) == -1 and b"bad argument" in err()
+    d = _lib.ConvT(2, 30, 30, 3, 64, 5, 5, 2, 2, 0, 15, 15)              # not a 16x32-tileable image
+    assert L.cslgan_conv2d_c3_fwd_bf16out(ctypes.byref(d), 16, 16, None, 1, 16, None) == -1 and b"first layer" in err()
+    assert L.cslgan_conv2d_c3_wgrad_bf16gy(ctypes.byref(d), 16, 16, 1.0, 16, None, None) == -1 and b"first-layer kernel" in err()
+    d = _lib.ConvT(2, 16, 16, 32, 3, 3, 3, 1, 1, 0, 16, 16)              # 32 input channels: the vector-ALU kernel takes 64
+    assert L.cslgan_conv2d_fwd_skinny_bf16in(ctypes.byref(d), 16, 16, None, 3, 16, None) == -1 and b"64 input channels" in err()
+    d = _lib.ConvT(2, 16, 16, 8, 64, 5, 5, 2, 2, 0, 8, 8)
+    assert L.cslgan_conv2d_dgrad_skinny_bf16in(ctypes.byref(d), 16, 16, 16, 0, 16, None) == -1 and b"1..4 input channels" in err()
+    assert L.cslgan_groupnorm_act_bf16s(16, 1, 16, 16, 2, 64, 48, 32, 1e-5, 1, 16, 16, 0, None, None) == -1 and b"not divisible" in err()
+
+
 def test_ops_refuse_cpu_tensors(built_lib):
     import torch
     from csl_gan_amd import ops

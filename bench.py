@@ -221,11 +221,14 @@ def main():
     # roofline keeps region A's event times (same kernels, same shapes; rocprofv3 of this command covers both regions).
     dt, launch_mode, graph_err = dt_eager, "eager", None
     gs = getattr(tr, "graphed", None)
-    if gs is not None and world == 1:
+    if gs is not None:              # N > 1: every rank records the same step, RCCL all-reduce included (trainer.setup_privacy_engine)
         try:
             for _ in range(gs.warmup + 2):
                 gs(img, None)
-            dt, launch_mode = time_region(lambda: gs(img, None), a.steps), "hip_graph"
+            if gs.graph is not None:
+                dt, launch_mode = time_region(lambda: gs(img, None), a.steps), "hip_graph"
+            else:
+                graph_err = gs.capture_error or "not captured"
         except Exception as e:      # a failed capture must not cost the line: the eager region stands
             graph_err = repr(e)[:200]
     variant = None

@@ -44,15 +44,17 @@ class FlatGradReducer:
     """all-reduce(SUM) of one flat gradient bucket.  The engine hands over the flat fp32 buffer its
     per-parameter .grad tensors alias, already scaled by 1/(B_local*R)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, always=False):
+        """always: issue the collective on a one-rank group too (tests: the RCCL call as it is recorded into a HIP graph)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.always = bool(always) and dist.is_initialized()
         self.bytes_reduced = 0
 
     def __call__(self, flat: torch.Tensor):
-        if self.world > 1:
+        if self.world > 1 or self.always:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.bytes_reduced += flat.numel() * flat.element_size()
+            self.bytes_reduced += flat.numel() * flat.element_size()      # (host counter: counts recorded calls, not replays)
         return flat
 
 
@@ -63,6 +65,15 @@ def average_across_ranks(t: torch.Tensor, use_max=False, group=None):
         if not use_max:
             t /= dist.get_world_size(group)
     return t
+
+
+def collectives_capturable():
+    """True when the step's collectives can be recorded into a HIP graph: a single process, or RCCL (backend "nccl" — its
+    all-reduce is a stream-ordered kernel launch that torch registers with the capture; scripts/rccl_capture_probe.py).  gloo
+    stages through the host and cannot be captured."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return True
+    return dist.get_backend() == "nccl" and os.environ.get("CSLGAN_GRAPH_DIST", "1") == "1"
 
 
 def broadcast_object(obj, src=0):

@@ -104,7 +104,11 @@ class Trainer:
         # gc, and immediate sensitivity (no host read inside the step since round 3).  The IS replays were wrong until the library
         # stopped using hipMemsetAsync: as a memset node of a captured graph a 128-byte fill (the accumulator of the per-sample
         # input-gradient norms, B >= 24) replayed with a stale dword per 16 bytes — csrc/common.h zero_floats.
-        if (getattr(o, "hip_graph", False) and self.world_size == 1 and not o.backprop_clip
+        # N > 1 ranks over RCCL (round 3): the step's collectives — the flat gradient all-reduce, the 9-float adaptive statistics, the
+        # immediate-sensitivity maxima — are stream-ordered RCCL launches and are RECORDED with the step (every rank records and replays
+        # the same sequence); gloo (CPU rehearsals) stages through the host and keeps the eager step.  CSLGAN_GRAPH_DIST=0: eager.
+        from .distributed import collectives_capturable
+        if (getattr(o, "hip_graph", False) and (self.world_size == 1 or collectives_capturable()) and not o.backprop_clip
                 and (o.dp_mode == "gc" or (o.dp_mode == "is" and o.imm_sens_scaling_mode != "moving-avg-pl"))):
             self.graphed = GraphedDStep(self)
         return pe
@@ -814,7 +818,7 @@ class GraphedDStep:
         if not (o.use_dp and o.dp_mode in ("gc", "is")) or (o.dp_mode == "is" and o.imm_sens_scaling_mode == "moving-avg-pl"):
             raise NotImplementedError("GraphedDStep covers the DP D-steps whose host never reads the device inside the step: dp_mode=gc "
                                       "and dp_mode=is (not the moving-average scaling mode, which reads gradient norms on the host)")
-        self.graph, self.bufs = None, None
+        self.graph, self.bufs, self.capture_error = None, None, None
         self._prev = (trainer.d_optimizer.capturable, trainer.explicit)
         trainer.d_optimizer.capturable = True
 
@@ -885,9 +889,29 @@ class GraphedDStep:
             # has moved the parameters
             ops.repack_cache.clear()
             torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self._eager()                    # RECORDED, not executed; its host-side bookkeeping ran once
+            steps0, calls0 = pe.steps, pe._noise_calls
+            adam0 = {id(st): st["step"] for st in tr.d_optimizer.state.values()}
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    self._eager()                # RECORDED, not executed; its host-side bookkeeping ran once
+            except Exception as e:               # e.g. a collective this backend cannot record: the run goes on eagerly
+                import warnings
+                warnings.warn("HIP-graph capture of the D-step failed (%s: %s); stepping eagerly from here on" % (type(e).__name__, str(e)[:200]))
+                torch.cuda.synchronize()
+                ops.repack_cache.clear()
+                # nothing of the recorded step ran on the device: put the host-side bookkeeping back and drop the half-built
+                # per-sample state, then run this step eagerly
+                pe.steps, pe._noise_calls = steps0, calls0
+                for st in tr.d_optimizer.state.values():
+                    st["step"] = adam0.get(id(st), st["step"])
+                pe._reset_samples()
+                for p in pe.params:
+                    if hasattr(p, "summed_grad"):
+                        del p.summed_grad
+                self.use_graph, self.capture_error = False, repr(e)[:300]
+                return self._eager()
+            self.graph = graph
             ops.repack_cache.clear()             # entries made during capture point into the graph's private pool
             self.graph.replay()                  # the step itself
             tr.d_optimizer.bump_versions()

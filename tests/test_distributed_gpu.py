@@ -121,3 +121,60 @@ def test_two_rank_immediate_sensitivity_takes_the_maximum_over_all_ranks(tmp_pat
         local.append(np.asarray(pe.batch_sensitivity, dtype=np.float64))
     assert _rel(r0["sens"], np.maximum(local[0], local[1])) <= 1e-3
     assert (np.abs(local[0] - local[1]) > 1e-3 * np.abs(local[0]).max()).any(), "shards should differ for the test to mean anything"
+
+
+def _graph_rank(port, out, q):
+    """ONE rank over RCCL (backend nccl), the reducer forced to issue its all-reduce: the D-step is recorded into a HIP graph WITH the
+    collective in it (trainer.setup_privacy_engine, N > 1 path) and replayed; an eager twin runs the same inputs."""
+    import torch.distributed as dist
+    from csl_gan_amd.distributed import FlatGradReducer, collectives_capturable
+    from csl_gan_amd.trainer import GraphedDStep
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        assert collectives_capturable()
+        res = {}
+        for use_graph in (False, True):
+            torch.manual_seed(11); torch.cuda.manual_seed(11)
+            red = FlatGradReducer(always=True)
+            from csl_gan_amd import init_util, options
+            from csl_gan_amd.mean_sampler import MeanSampler
+            from csl_gan_amd.trainer import Trainer
+            o = os.path.join(out, "g%d" % use_graph)
+            opt = options.parse(["MNIST", "--model", "DeepConvResNet", "-dpm", "gc", "-gcm", "adaptive-pl", "-nms", "4", "-bs", "8", "-gd", "cuda:0",
+                                 "-dd", "cuda:0", "-o", o, "--manual_seed", "1", "--g_latent_dim", str(LATENT), "--sigma", "0.8", "--penalty", "WGAN-GP"])
+            G, D = init_util.init_models(opt)
+            ms = MeanSampler(num_samples=4, mean_size=10, device="cuda:0", res=28, ch=1)
+            ms.mean_samples = (torch.randn((1, 4, 1, 28, 28), generator=torch.Generator().manual_seed(9)) * 0.2).cuda()
+            tr = Trainer(opt, G, D, mean_sampler=ms, log_to=os.path.join(o, "log.csv"), world_size=1, rank=0, grad_reducer=red)
+            pe = tr.setup_privacy_engine()
+            step = GraphedDStep(tr, use_graph=use_graph, warmup=1)
+            g = torch.Generator().manual_seed(5)
+            for i in range(4):
+                step(torch.rand(8, 1, 28, 28, generator=g).cuda(), None)
+            torch.cuda.synchronize()
+            assert (step.graph is not None) == use_graph, step.capture_error
+            res[use_graph] = ([p.detach().cpu().clone() for p in D.parameters()], red.bytes_reduced, pe.steps)
+        q.put(("ok", res))
+    except Exception as e:               # noqa: BLE001 — reported to the parent
+        import traceback
+        q.put(("err", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_graph_replay_records_the_rccl_all_reduce(tmp_path):
+    """With RCCL the multi-GPU D-step replays from a HIP graph like the single-GPU one: the all-reduce of the flat gradient bucket
+    and of the adaptive statistics are stream-ordered RCCL launches recorded with the step.  One rank on the box's one GPU, the
+    collective forced: four steps recorded-and-replayed equal four eager steps (same seeds; weights after Adam at lr level)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_graph_rank, args=(_free_port(), str(tmp_path), q))
+    p.start()
+    status, res = q.get(timeout=300)
+    p.join(60)
+    assert status == "ok", res
+    (we, be, se), (wg, bg, sg) = res[False], res[True]
+    assert se == sg == 4 and be > 0 and bg > 0          # the eager twin reduced 4 buckets; the recorded one issued the call while recording
+    for a, b in zip(we, wg):
+        assert (a - b).abs().max().item() <= 2.5 * 1e-4 * 4 * 0.5 + 1e-7, (a - b).abs().max().item()   # d_lr 2e-4 (MNIST): a fraction of the 4 Adam steps

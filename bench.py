@@ -216,11 +216,135 @@ def main():
     ops.set_launch_timer(timer)
     dt_eager = time_region(step, a.steps)
     ops.set_launch_timer(None)
+    def finish(dt, launch_mode, graph_err, variant, loop, with_cpu=True):
+        """Assemble and print the ONE JSON line (rank 0) from the instrumented / eager regions plus whatever came after them."""
+        if rank != 0:
+            return
+        ips = world * B * a.steps / dt
+        n_pr = max(n_probe, 1)
+        entries = probe.summary()                                   # per-kernel tables: the instrumented warm-up steps
+        kernels = probe.summary(by_kernel=True)
+        shapes = probe.summary(by_kernel=True, by_shape=True)
+        timed = timer.summary(by_kernel=True)                       # the dominant kernel, inside the timed region
+        timed_shapes = timer.summary(by_kernel=True, by_shape=True)
+        # roofline: the dominant device KERNEL by summed HIP-event time (names as rocprofv3 lists them)
+        dom = timed.get(dom_name) if dom_name else None
+        roof = None
+        if dom:
+            traffic, traffic_src = None, None
+            try:        # fabric bytes per launch of that kernel from the newest committed rocprofv3 PMC passes (scripts/collect_profiles.sh)
+                import glob
+                src = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+                with open(src) as f:
+                    pk = {k.replace(" ", ""): v for k, v in json.load(f)["per_kernel"].items()}
+                v = pk.get(dom["name"].replace(" ", ""))
+                traffic = None if v is None else round((v["fetch_MB_per_launch"] + v["write_MB_per_launch"]) * 1e6)
+                traffic_src = "profiles/" + os.path.basename(src) + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"
+            except Exception:
+                traffic = None
+            # a bf16x3 kernel issues SIX bf16 MFMAs per logical fp32 multiply-add step: its executed matrix FLOP are 6x the logical
+            mfma_mult = 6.0 if "bf16x3" in dom["name"] else 1.0
+            ach = mfma_mult * dom["exec_flop"] / (dom["ms"] * 1e-3) / 1e12
+            # bf16 matrix-core kernels: the fp32-tensor family of csrc/igemm_bf16.hip and the bf16-stored family of csrc/igemm_bf16s.hip
+            on_bf16 = "bf16" in dom["name"] or any(t in dom["name"] for t in ("igemm_kcs_kernel", "igemm_mcs_kernel", "igemm_mcs_tr_kernel", "igemm_halos_kernel"))
+            peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
+            worst = sorted((v for k, v in timed_shapes.items() if k.startswith(dom["name"])), key=lambda v: -v["ms"])
+            roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_from": traffic_src,
+                    "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]),
+                    "flop_per_launch_executed": round(mfma_mult * dom["exec_flop"] / dom["n"]),
+                    "logical_fp32_tflops": round(dom["exec_flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
+                    "reference_algorithmic_tflops": round(dom["flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
+                    "note": "achieved = FLOP the kernel executes / its summed HIP-event time; reference_algorithmic_tflops charges the "
+                            "UpsampleConv layers at the reference's 4x redundant channel count and is NOT a roofline fraction",
+                    "launches_per_step": dom["n"] / a.steps, "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
+                    "share_of_step": round(dom["ms"] / (dt_eager * 1e3), 3),
+                    "measured_in": "HIP events around this kernel's launches over the %d eagerly launched timed steps (%.3f ms/step)%s" % (
+                        a.steps, dt_eager / a.steps * 1e3,
+                        "; the headline region replays the same launches from a HIP graph, where events cannot be placed" if launch_mode == "hip_graph" else ""),
+                    "launch_shapes": {v["name"][len(dom["name"]) + 1:]: {"n_per_step": v["n"] / a.steps, "avg_ms": round(v["ms"] / v["n"], 4),
+                                                                         "tflops": round(v["exec_flop"] / (v["ms"] * 1e-3) / 1e12, 1)}
+                                      for v in worst[:8]}}
+        # the HBM group (SURVEY.md §8d): clip_accum_noise over the materialised per-sample gradients / slabs, from the instrumented steps
+        roof_hbm = None
+        ck = kernels.get("clip_accum_noise_kernel<float>")
+        if ck and ck["ms"] > 0:
+            gbs = ck["bytes"] / (ck["ms"] * 1e-3) / 1e9
+            roof_hbm = {"bound": "hbm", "kernel": "clip_accum_noise_kernel<float>", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": round(gbs / PEAK_HBM_GBPS, 4), "launches_per_step": ck["n"] / n_pr, "MB_per_step": round(ck["bytes"] / n_pr / 1e6, 1),
+                        "avg_launch_us": round(ck["ms"] / ck["n"] * 1e3, 2),
+                        "note": "algorithmic bytes of each launch (rows x row length read once + one output row) / HIP-event time, instrumented "
+                                "warm-up steps; SURVEY §8d's materialised-path figure is 34.5 MB/img/clipped pass — ghost clipping materialises only "
+                                "conv1 + conv2 (5 %% of the parameters), so the kernel moves %.1f MB per step instead of 4.4 GB and is launch-latency "
+                                "sized" % (ck["bytes"] / n_pr / 1e6)}
+        exec_flop_step = sum(v["exec_flop"] for v in kernels.values()) / n_pr
+        if a.dump_shapes:
+            with open(a.dump_shapes, "w") as f:
+                for k, v in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"]):
+                    f.write("%-78s n/step %5.1f  avg_ms %8.4f  ms/step %7.3f  %s\n" % (
+                        k, v["n"] / n_pr, v["ms"] / v["n"], v["ms"] / n_pr,
+                        ("%6.1f TF" % (v["exec_flop"] / (v["ms"] * 1e-3) / 1e12)) if v["exec_flop"] else ("%7.1f GB/s" % (v["bytes"] / (v["ms"] * 1e-3) / 1e9))))
+        bf16 = getattr(opt, "compute_dtype", "fp32") == "bf16"
+        step_peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+        mode = ("dp_mode=gc -gcm %s" % opt.grad_clip_mode) if opt.dp_mode == "gc" else ("dp_mode=is -ispp %s" % bool(opt.imm_sens_per_param))
+        line = {
+            # the BASELINE.json metric for the default command; with --opt the line names what was actually run
+            "metric": "images/sec/GPU CelebA DCResNet dp_mode=%s bs=%d at 1/2/4/8 MI355X" % (opt.dp_mode, B),
+            "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "config": {"workload": "CelebA DCResNet D-step: %s -nms %d, WGAN-GP on mean samples, 3x%dx%d" % (mode, opt.num_mean_samples, opt.im_size, opt.im_size),
+                       "compute_dtype": getattr(opt, "compute_dtype", "fp32"), "storage_dtype": getattr(opt, "storage_dtype", "fp32"),
+                       "launch": launch_mode, "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "materialize": getattr(opt, "materialize", "all"), "grad_sample_dtype": getattr(opt, "grad_sample_dtype", "fp32"),
+                       "fuse_passes": bool(getattr(opt, "fuse_passes", False)),
+                       "step": ("train_D (adaptive pass + G fwd + 2 D passes + per-sample grads + clip + GP + noise + Adam)" if opt.dp_mode == "gc" else
+                                "train_D (G fwd + D passes + create_graph gradients + one double-backward sweep per sensitivity + GP + noise + Adam)")},
+            "per_gpu": round(ips / world, 2),
+            "step_gflop_executed_per_image": round(exec_flop_step / B / 1e9, 3),
+            "step_tflops_executed": round(exec_flop_step / (dt / a.steps) / 1e12, 2),
+            ("step_frac_of_bf16_mfma_peak" if bf16 else "step_frac_of_fp32_mfma_peak"): round(exec_flop_step / (dt / a.steps) / 1e12 / step_peak, 4),
+            "step_tflops_reference_algorithmic": None if a.opt else round(FLOP_PER_IMG_STEP * ips / world / 1e12, 2),
+            "roofline": roof,
+            "roofline_hbm": roof_hbm,
+            "secondary": loop,
+            "variants": variant,
+            "graph_error": graph_err,
+            "tables_from": "%d launch-by-launch instrumented warm-up step(s) run on ONE stream (isolated kernel times); roofline from the "
+                           "eagerly launched timed region; both timed regions run the step's two streams" % n_pr,
+            "entries_ms_per_step": {k: round(v["ms"] / n_pr, 3) for k, v in sorted(entries.items(), key=lambda kv: -kv[1]["ms"])},
+            "kernels_ms_per_step": {k: {"ms": round(v["ms"] / n_pr, 3), "n": v["n"] / n_pr,
+                                        "tflops": round(v["exec_flop"] / (v["ms"] * 1e-3) / 1e12, 1) if v["exec_flop"] else None,
+                                        "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if not v["exec_flop"] else None}
+                                    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},
+        }
+        if world == 1 and not a.no_cpu_baseline and with_cpu:
+            line["cpu_baseline"] = cpu_baseline()
+            line["gpu_over_cpu"] = round(ips / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line))
+
     # Region B — the same step as the framework runs it by default on one GPU (--hip_graph True): recorded once in a HIP graph
     # (both streams of the step) and replayed.  This is the headline when it exists; events cannot be placed inside a replay, so the
     # roofline keeps region A's event times (same kernels, same shapes; rocprofv3 of this command covers both regions).
     dt, launch_mode, graph_err = dt_eager, "eager", None
     gs = getattr(tr, "graphed", None)
+    bail = None
+    if gs is not None and world > 1:
+        # A multi-rank capture has never run on the pool this was built on (one GPU per box): if recording or replaying the step with
+        # its RCCL collectives does not come back, every rank keeps the eager measurement — rank 0 prints the line, labelled — and ends.
+        import threading
+        limit = float(os.environ.get("CSLGAN_GRAPH_REGION_LIMIT_S", "240"))
+
+        def _bail():
+            try:
+                finish(dt_eager, "eager", "the HIP-graph region did not finish within %.0f s on %d ranks; the eager region is reported" % (limit, world),
+                       None, None, with_cpu=False)
+                sys.stdout.flush()
+            finally:
+                os._exit(0)
+        bail = threading.Timer(limit, _bail)
+        bail.daemon = True
+        bail.start()
     if gs is not None:              # N > 1: every rank records the same step, RCCL all-reduce included (trainer.setup_privacy_engine)
         try:
             for _ in range(gs.warmup + 2):
@@ -231,6 +355,8 @@ def main():
                 graph_err = gs.capture_error or "not captured"
         except Exception as e:      # a failed capture must not cost the line: the eager region stands
             graph_err = repr(e)[:200]
+    if bail is not None:
+        bail.cancel()
     variant = None
     if not a.opt and world == 1 and not a.no_variants:
         variant = {}
@@ -281,110 +407,8 @@ def main():
         dl = time_region(lambda it=iter(range(10 ** 9)): tr.train(0, next(it), img, lbl, use_dp=True), a.loop_steps)
         loop = {"metric": "full train() loop, G step every %d iterations" % opt.n_d_steps, "value": round(world * B * a.loop_steps / dl, 2),
                 "unit": "images/sec", "iterations": a.loop_steps, "ms_per_iteration": round(dl / a.loop_steps * 1e3, 3)}
-    if rank != 0:
-        return
-    ips = world * B * a.steps / dt
-    n_pr = max(n_probe, 1)
-    entries = probe.summary()                                   # per-kernel tables: the instrumented warm-up steps
-    kernels = probe.summary(by_kernel=True)
-    shapes = probe.summary(by_kernel=True, by_shape=True)
-    timed = timer.summary(by_kernel=True)                       # the dominant kernel, inside the timed region
-    timed_shapes = timer.summary(by_kernel=True, by_shape=True)
-    # roofline: the dominant device KERNEL by summed HIP-event time (names as rocprofv3 lists them)
-    dom = timed.get(dom_name) if dom_name else None
-    roof = None
-    if dom:
-        traffic, traffic_src = None, None
-        try:        # fabric bytes per launch of that kernel from the newest committed rocprofv3 PMC passes (scripts/collect_profiles.sh)
-            import glob
-            src = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
-            with open(src) as f:
-                pk = {k.replace(" ", ""): v for k, v in json.load(f)["per_kernel"].items()}
-            v = pk.get(dom["name"].replace(" ", ""))
-            traffic = None if v is None else round((v["fetch_MB_per_launch"] + v["write_MB_per_launch"]) * 1e6)
-            traffic_src = "profiles/" + os.path.basename(src) + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"
-        except Exception:
-            traffic = None
-        # a bf16x3 kernel issues SIX bf16 MFMAs per logical fp32 multiply-add step: its executed matrix FLOP are 6x the logical
-        mfma_mult = 6.0 if "bf16x3" in dom["name"] else 1.0
-        ach = mfma_mult * dom["exec_flop"] / (dom["ms"] * 1e-3) / 1e12
-        # bf16 matrix-core kernels: the fp32-tensor family of csrc/igemm_bf16.hip and the bf16-stored family of csrc/igemm_bf16s.hip
-        on_bf16 = "bf16" in dom["name"] or any(t in dom["name"] for t in ("igemm_kcs_kernel", "igemm_mcs_kernel", "igemm_mcs_tr_kernel", "igemm_halos_kernel"))
-        peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
-        worst = sorted((v for k, v in timed_shapes.items() if k.startswith(dom["name"])), key=lambda v: -v["ms"])
-        roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_from": traffic_src,
-                "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]),
-                "flop_per_launch_executed": round(mfma_mult * dom["exec_flop"] / dom["n"]),
-                "logical_fp32_tflops": round(dom["exec_flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
-                "reference_algorithmic_tflops": round(dom["flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
-                "note": "achieved = FLOP the kernel executes / its summed HIP-event time; reference_algorithmic_tflops charges the "
-                        "UpsampleConv layers at the reference's 4x redundant channel count and is NOT a roofline fraction",
-                "launches_per_step": dom["n"] / a.steps, "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
-                "share_of_step": round(dom["ms"] / (dt_eager * 1e3), 3),
-                "measured_in": "HIP events around this kernel's launches over the %d eagerly launched timed steps (%.3f ms/step)%s" % (
-                    a.steps, dt_eager / a.steps * 1e3,
-                    "; the headline region replays the same launches from a HIP graph, where events cannot be placed" if launch_mode == "hip_graph" else ""),
-                "launch_shapes": {v["name"][len(dom["name"]) + 1:]: {"n_per_step": v["n"] / a.steps, "avg_ms": round(v["ms"] / v["n"], 4),
-                                                                     "tflops": round(v["exec_flop"] / (v["ms"] * 1e-3) / 1e12, 1)}
-                                  for v in worst[:8]}}
-    # the HBM group: clip_accum_noise over the materialised per-sample gradients / slabs, from the instrumented steps
-    roof_hbm = None
-    ck = kernels.get("clip_accum_noise_kernel<float>")
-    if ck and ck["ms"] > 0:
-        gbs = ck["bytes"] / (ck["ms"] * 1e-3) / 1e9
-        roof_hbm = {"bound": "hbm", "kernel": "clip_accum_noise_kernel<float>", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                    "frac": round(gbs / PEAK_HBM_GBPS, 4), "launches_per_step": ck["n"] / n_pr, "MB_per_step": round(ck["bytes"] / n_pr / 1e6, 1),
-                    "avg_launch_us": round(ck["ms"] / ck["n"] * 1e3, 2),
-                    "note": "algorithmic bytes of each launch (rows x row length read once + one output row) / HIP-event time, instrumented "
-                            "warm-up steps; SURVEY §8d's materialised-path figure is 34.5 MB/img/clipped pass — ghost clipping materialises only "
-                            "conv1 + conv2 (5 %% of the parameters), so the kernel moves %.1f MB per step instead of 4.4 GB and is launch-latency "
-                            "sized" % (ck["bytes"] / n_pr / 1e6)}
-    exec_flop_step = sum(v["exec_flop"] for v in kernels.values()) / n_pr
-    if a.dump_shapes:
-        with open(a.dump_shapes, "w") as f:
-            for k, v in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"]):
-                f.write("%-78s n/step %5.1f  avg_ms %8.4f  ms/step %7.3f  %s\n" % (
-                    k, v["n"] / n_pr, v["ms"] / v["n"], v["ms"] / n_pr,
-                    ("%6.1f TF" % (v["exec_flop"] / (v["ms"] * 1e-3) / 1e12)) if v["exec_flop"] else ("%7.1f GB/s" % (v["bytes"] / (v["ms"] * 1e-3) / 1e9))))
-    bf16 = getattr(opt, "compute_dtype", "fp32") == "bf16"
-    step_peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-    mode = ("dp_mode=gc -gcm %s" % opt.grad_clip_mode) if opt.dp_mode == "gc" else ("dp_mode=is -ispp %s" % bool(opt.imm_sens_per_param))
-    line = {
-        # the BASELINE.json metric for the default command; with --opt the line names what was actually run
-        "metric": "images/sec/GPU CelebA DCResNet dp_mode=%s bs=%d at 1/2/4/8 MI355X" % (opt.dp_mode, B),
-        "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-        "config": {"workload": "CelebA DCResNet D-step: %s -nms %d, WGAN-GP on mean samples, 3x%dx%d" % (mode, opt.num_mean_samples, opt.im_size, opt.im_size),
-                   "compute_dtype": getattr(opt, "compute_dtype", "fp32"), "storage_dtype": getattr(opt, "storage_dtype", "fp32"),
-                   "launch": launch_mode, "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                   "materialize": getattr(opt, "materialize", "all"), "grad_sample_dtype": getattr(opt, "grad_sample_dtype", "fp32"),
-                   "fuse_passes": bool(getattr(opt, "fuse_passes", False)),
-                   "step": ("train_D (adaptive pass + G fwd + 2 D passes + per-sample grads + clip + GP + noise + Adam)" if opt.dp_mode == "gc" else
-                            "train_D (G fwd + D passes + create_graph gradients + one double-backward sweep per sensitivity + GP + noise + Adam)")},
-        "per_gpu": round(ips / world, 2),
-        "step_gflop_executed_per_image": round(exec_flop_step / B / 1e9, 3),
-        "step_tflops_executed": round(exec_flop_step / (dt / a.steps) / 1e12, 2),
-        ("step_frac_of_bf16_mfma_peak" if bf16 else "step_frac_of_fp32_mfma_peak"): round(exec_flop_step / (dt / a.steps) / 1e12 / step_peak, 4),
-        "step_tflops_reference_algorithmic": None if a.opt else round(FLOP_PER_IMG_STEP * ips / world / 1e12, 2),
-        "roofline": roof,
-        "roofline_hbm": roof_hbm,
-        "secondary": loop,
-        "variants": variant,
-        "graph_error": graph_err,
-        "tables_from": "%d launch-by-launch instrumented warm-up step(s) run on ONE stream (isolated kernel times); roofline from the "
-                       "eagerly launched timed region; both timed regions run the step's two streams" % n_pr,
-        "entries_ms_per_step": {k: round(v["ms"] / n_pr, 3) for k, v in sorted(entries.items(), key=lambda kv: -kv[1]["ms"])},
-        "kernels_ms_per_step": {k: {"ms": round(v["ms"] / n_pr, 3), "n": v["n"] / n_pr,
-                                    "tflops": round(v["exec_flop"] / (v["ms"] * 1e-3) / 1e12, 1) if v["exec_flop"] else None,
-                                    "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if not v["exec_flop"] else None}
-                                for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},
-    }
-    if world == 1 and not a.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline()
-        line["gpu_over_cpu"] = round(ips / line["cpu_baseline"]["value"], 1)
-    print(json.dumps(line))
+
+    finish(dt, launch_mode, graph_err, variant, loop)
 
 
 if __name__ == "__main__":

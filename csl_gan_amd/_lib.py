@@ -37,7 +37,7 @@ class SegsT(C.Structure):
     _fields_ = [
         ("n_seg", C.c_int32), ("_pad", C.c_int32),
         ("inp", C.c_void_p * MAX_SEGS), ("out", C.c_void_p * MAX_SEGS), ("noise", C.c_void_p * MAX_SEGS),
-        ("len", C.c_int64 * MAX_SEGS), ("row_stride", C.c_int64 * MAX_SEGS), ("call_counter", C.c_void_p),
+        ("len", C.c_int64 * MAX_SEGS), ("row_stride", C.c_int64 * MAX_SEGS), ("rows", C.c_int64 * MAX_SEGS), ("call_counter", C.c_void_p),
     ]
 
 

@@ -228,6 +228,7 @@ struct CaArgs {
     const float* noise[CSLGAN_MAX_SEGS];
     long long len[CSLGAN_MAX_SEGS];
     long long row_stride[CSLGAN_MAX_SEGS];
+    int rows[CSLGAN_MAX_SEGS];                // > 0: the segment's own row count (ragged column sums), 0: n_rows
     int tile_prefix[CSLGAN_MAX_SEGS + 1];
     int vec_ok[CSLGAN_MAX_SEGS];
     const unsigned long long* call_counter;   // nullable: the Philox offset advances by 64 x *call_counter (graph replays)
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(CA_THREADS) void clip_accum_noise_kernel(CaArgs a, 
     int s = 0;
 #pragma unroll 1
     while (s + 1 < a.n_seg && bx >= a.tile_prefix[s + 1]) ++s;
+    if (a.rows[s] > 0) n_rows = a.rows[s];
     const long long j0 = (long long)(bx - a.tile_prefix[s]) * CA_COLS + (long long)threadIdx.x * 4;
     const long long len = a.len[s];
     if (j0 >= len) return;
@@ -455,13 +457,14 @@ static int clip_accum_noise_impl(const cslgan_segs_t* segs, int64_t n_rows, cons
             CSLGAN_REQUIRE(segs->out[s] || segs->len[s] == 0, "clip_accum_noise: out[%d] is null", s);
             CSLGAN_REQUIRE((segs->in[s] || n_rows == 0 || segs->len[s] == 0), "clip_accum_noise: in[%d] is null", s);
             CSLGAN_REQUIRE(segs->len[s] >= 0 && (n_rows == 0 || segs->row_stride[s] >= segs->len[s]), "clip_accum_noise: bad len/stride in segment %d", s);
+            CSLGAN_REQUIRE(segs->rows[s] >= 0 && segs->rows[s] < (1ll << 31) && (segs->rows[s] == 0 || !factors), "clip_accum_noise: per-segment row counts need factors == NULL (segment %d)", s);
             a.in[s] = segs->in[s]; a.out[s] = segs->out[s]; a.noise[s] = segs->noise[s];
-            a.len[s] = segs->len[s]; a.row_stride[s] = segs->row_stride[s];
+            a.len[s] = segs->len[s]; a.row_stride[s] = segs->row_stride[s]; a.rows[s] = (int)segs->rows[s];
             a.vec_ok[s] = aligned_to(segs->in[s], bf16 ? 8 : 16) && (segs->row_stride[s] % 4 == 0);
             a.tile_prefix[s] = tot;
             tot += (int)((segs->len[s] + CA_COLS - 1) / CA_COLS);
         } else {
-            a.in[s] = nullptr; a.out[s] = nullptr; a.noise[s] = nullptr; a.len[s] = 0; a.row_stride[s] = 0; a.vec_ok[s] = 0;
+            a.in[s] = nullptr; a.out[s] = nullptr; a.noise[s] = nullptr; a.len[s] = 0; a.row_stride[s] = 0; a.vec_ok[s] = 0; a.rows[s] = 0;
             a.tile_prefix[s] = tot;
         }
     }

@@ -218,7 +218,7 @@ class _LayerCollector:
             # a pass that is never clipped (generated data in split mode): only its SUM is needed
             e._add_dense(w, _dense_wgrad(gz, x, R, S, stride, pad, scale))
             if has_bias:
-                e._add_dense(layer.bias, _dense_bgrad(gz, scale))
+                e._add_dense_rows(layer.bias, _dense_bgrad(gz, scale))
             return
         if e.lean:
             pass_idx, n_pass = pass_idx - (n_pass - n_private), n_private
@@ -277,15 +277,16 @@ def _ghost_rows(self, pass_idx, n_pass, gz, x, R, S, stride, pad, scale, has_bia
 _LayerCollector._ghost_rows = _ghost_rows
 
 
-def _dense_wgrad(gz, x, R, S, stride, pad, scale, row_scale=None, out=None):
-    return ops.conv2d_wgrad_dense(gz, x, R, S, stride=stride, pad=pad, alpha=scale, row_scale=row_scale, out=out).reshape(-1)
+def _dense_wgrad(gz, x, R, S, stride, pad, scale, row_scale=None, out=None, rows=False):
+    """rows: the un-summed slabs [n, numel] (for PrivacyEngine._add_dense_rows) where the layer's dense gradient is made of slabs."""
+    r = ops.conv2d_wgrad_dense(gz, x, R, S, stride=stride, pad=pad, alpha=scale, row_scale=row_scale, out=out, want_rows=rows)
+    return r if (rows and r.dim() == 2 and r.shape[0] > 1) else r.reshape(-1)
 
 
 def _dense_bgrad(gz, scale):
-    part = ops.bias_grad_grouped(gz, group=1, alpha=scale)
-    out = torch.empty(part.shape[1], device=gz.device, dtype=torch.float32)
-    ops.clip_accum_noise([part], [out])
-    return out
+    """Per-sample bias gradients [N, K] of a never-clipped row block: their column sum is taken by the launch that folds the dense
+    sums into summed_grad (PrivacyEngine._add_dense_rows), not by a launch of its own."""
+    return ops.bias_grad_grouped(gz, group=1, alpha=scale)
 
 
 def _collect_roles(self, gz, x, R, S, stride, pad, has_bias):
@@ -327,9 +328,10 @@ def _collect_roles(self, gz, x, R, S, stride, pad, has_bias):
             elif blocks is not None:
                 blocks.append((n, torch.empty((n, K * R * S * Cc), device=gz.device, dtype=torch.float32), None, "dense"))
             else:
-                e._add_dense(w, _dense_wgrad(g_, x_, R, S, stride, pad, scale))
+                r = _dense_wgrad(g_, x_, R, S, stride, pad, scale, rows=True)
+                (e._add_dense_rows if r.dim() == 2 else e._add_dense)(w, r)
             if has_bias:
-                e._add_dense(layer.bias, _dense_bgrad(g_, scale))
+                e._add_dense_rows(layer.bias, _dense_bgrad(g_, scale))
         elif ghost:
             joint = None
             if held is not None and held[0] + held[1] == row0:
@@ -360,10 +362,8 @@ def _collect_roles(self, gz, x, R, S, stride, pad, has_bias):
         n = blocks[0][0]
         ops.conv2d_wgrad_blocks(gz, x, R, S, stride, pad, float(n) if e.loss_reduction == "mean" else 1.0, [(bl[0], bl[1], bl[2]) for bl in blocks])
         for _, slabs, _, kind in blocks:
-            if kind == "dense":              # the block's sum: one column sum over its per-sample slabs
-                tot = torch.empty(slabs.shape[1], device=slabs.device, dtype=torch.float32)
-                ops.clip_accum_noise([slabs], [tot])
-                e._add_dense(w, tot)
+            if kind == "dense":              # the block's sum: its per-sample slabs are column-summed by the launch that folds the dense sums
+                e._add_dense_rows(w, slabs)
 
 
 _LayerCollector._collect_roles = _collect_roles
@@ -474,7 +474,21 @@ class PrivacyEngine(PerSampleSink):
 
     def _add_dense(self, p, flat):
         cur = self._dense.get(id(p))
+        if cur is not None and cur.dim() == 2:          # un-reduced rows queued earlier: reduce them now
+            tot = torch.empty(cur.shape[1], device=cur.device, dtype=torch.float32)
+            ops.clip_accum_noise([cur], [tot])
+            cur = tot
         self._dense[id(p)] = flat if cur is None else cur.add_(flat)
+
+    def _add_dense_rows(self, p, rows):
+        """A never-clipped contribution handed over as UN-REDUCED rows [n, numel(p)] (per-sample slabs, per-sample bias gradients):
+        clip() column-sums them in the same launch that adds the dense sums into summed_grad (segments of different heights), so the
+        five to six per-layer column sums of a step are not launches of their own."""
+        if id(p) in self._dense:
+            tot = torch.empty(rows.shape[1], device=rows.device, dtype=torch.float32)
+            ops.clip_accum_noise([rows], [tot])
+            return self._add_dense(p, tot)
+        self._dense[id(p)] = rows
 
     def norms_rows_sqnorms(self) -> torch.Tensor:
         """[n_params, n] squared norms of the "norms" row block of a fused pass."""
@@ -619,7 +633,8 @@ class PrivacyEngine(PerSampleSink):
                 cur.wait_stream(self._clip_side)
         if self._dense:       # sums of the never-clipped passes (lean modes)
             idx = [i for i, p in enumerate(ps) if id(p) in self._dense]
-            ops.clip_accum_noise([self._dense[id(ps[i])].view(1, -1) for i in idx], [outs[i] for i in idx], beta=1.0)
+            segs = [self._dense[id(ps[i])] for i in idx]
+            ops.clip_accum_noise([t if t.dim() == 2 else t.view(1, -1) for t in segs], [outs[i] for i in idx], beta=1.0, ragged=True)
         self._accumulated = False
 
     def _clip_ghost_layer(self, i, p, stash, f, per_layer, n_pass, B, outs):

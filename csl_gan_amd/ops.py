@@ -815,16 +815,18 @@ def conv2d_wgrad_blocks(gy, x, R, S, stride, pad, alpha, blocks):
         "conv2d_wgrad_blocks"), tag=lambda: "N%d %dx%d C%d K%d R%d s%d g1 blocks%d" % (N, H, W, Cc, K, R, stride, nb))
 
 
-def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, alpha=1.0, row_scale=None, out=None):
+def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, alpha=1.0, row_scale=None, out=None, want_rows=False):
     """The summed weight gradient [K,R,S,C] of a batch: slabs of the grouped MFMA kernel + a column sum, or the
-    vector-ALU kernel for 1..4 output channels.  out (optional, flat fp32 [K*R*S*C]): destination of the sum."""
+    vector-ALU kernel for 1..4 output channels.  out (optional, flat fp32 [K*R*S*C]): destination of the sum.
+    want_rows: return the UN-SUMMED slabs [n_slabs, K*R*S*C] instead (the caller column-sums them together with other
+    contributions in one launch: PrivacyEngine._add_dense_rows)."""
     if (gy.dtype == torch.float32 and x.dtype == torch.bfloat16 and row_scale is None and gy.shape[-1] == 1 and R == 1 and S == 1
             and tuple(x.shape[1:3]) == (1, 1) and x.shape[-1] % 8 == 0):
         # the critic's head on bf16 features: weighted sums of feature rows in slabs of 8 samples + a column sum
         N = x.shape[0]
         slabs = conv2d_wgrad_grouped(gy, x, 1, 1, group=8 if N % 8 == 0 else 1, alpha=alpha)
         res = torch.empty(x.shape[-1], device=x.device, dtype=torch.float32) if out is None else out
-        clip_accum_noise([slabs.reshape(slabs.shape[0], -1)], [res.view(-1)])
+        sum_rows(slabs.reshape(slabs.shape[0], -1), res.view(-1))
         return res.view(1, 1, 1, -1)
     c3_mixed = (gy.dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[-1] == 3 and row_scale is None
                 and _c3_layer(x.shape[1], x.shape[2], gy.shape[-1], R, S, stride, pad, gy.shape[2] in (16, 32, 64) and gy.shape[1] % (128 // gy.shape[2]) == 0))
@@ -845,20 +847,22 @@ def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, alpha=1.0, row_scale=None, 
             _lib.lib().cslgan_conv2d_wgrad_skinny_f32(C.byref(d), _p(gy), _p(x), float(alpha), _p(partial), nb, _stream()),
             "conv2d_wgrad_skinny"), tag=lambda: "N%d %dx%d C%d K%d R%d skinny" % (N, H, W, Cc, K, R))
         out = torch.empty(K * R * S * Cc, device=x.device, dtype=torch.float32) if out is None else out
-        clip_accum_noise([partial], [out])
+        sum_rows(partial, out)
         return out.view(K, R, S, Cc)
     if Cc == 3 and row_scale is None and _c3_layer(H, W, K, R, S, stride, pad, Q in (16, 32, 64) and P % (128 // Q) == 0):
         group = 1            # first-layer kernel: per-image gradients (19 KB each), summed below
     else:
         group = dense_wgrad_group(N, K, Cc, R, S, P * Q, stride=stride, out_hw=(P, Q))
     slabs = conv2d_wgrad_grouped(gy, x, R, S, stride=stride, pad=pad, group=group, alpha=alpha, row_scale=row_scale)
+    if want_rows and out is None:
+        return slabs.reshape(slabs.shape[0], -1)
     if slabs.shape[0] == 1:
         if out is not None:
             out.copy_(slabs[0].reshape(-1))
             return out.view(slabs.shape[1:])
         return slabs[0]
     out = torch.empty(slabs[0].numel(), device=x.device, dtype=torch.float32) if out is None else out
-    clip_accum_noise([slabs.reshape(slabs.shape[0], -1)], [out.view(-1)])
+    sum_rows(slabs.reshape(slabs.shape[0], -1), out.view(-1))
     return out.view(slabs.shape[1:])
 
 
@@ -895,18 +899,23 @@ def bias_grad_grouped(gy, group=1, alpha=1.0, want_gb=True, sq=None, out=None):
     return gb
 
 
-def _segs(ins: Sequence[torch.Tensor], outs=None, noises=None):
+def _segs(ins: Sequence[torch.Tensor], outs=None, noises=None, ragged=False):
+    """ragged: the segments may have different row counts (column sums only: cslgan_segs_t.rows)."""
     s = SegsT()
     if len(ins) > _lib.MAX_SEGS:
         raise RuntimeError("at most %d segments per launch" % _lib.MAX_SEGS)
     s.n_seg = len(ins)
     n_rows = ins[0].shape[0] if len(ins) else 0
+    if ragged:
+        n_rows = max(t.shape[0] for t in ins)
     for i, t in enumerate(ins):
         _chk(t, "segment %d" % i, allow_bf16=True)
         if t.dtype != ins[0].dtype:
             raise RuntimeError("segments of one launch must share a dtype")
-        if t.dim() != 2 or t.shape[0] != n_rows:
+        if t.dim() != 2 or (t.shape[0] != n_rows and not ragged):
             raise RuntimeError("segments must be 2-D [n_rows, len] with equal n_rows")
+        if ragged:
+            s.rows[i] = t.shape[0]
         s.inp[i] = t.data_ptr()
         s.len[i] = t.shape[1]
         s.row_stride[i] = t.shape[1]
@@ -974,10 +983,51 @@ def clip_factors(sq, max_norm, flat, eps=1e-6, first_private_row=0, want_norms=F
     return (f, nrm) if want_norms else f
 
 
-def clip_accum_noise(mats, outs, factors=None, noise_std=None, noises=None, seed=0, offset=0, scale=1.0, beta=0.0, call_counter=None):
+class deferred_sums:
+    """Inside this context the column sums requested through sum_rows() are only queued; they run as ONE multi-segment launch
+    (segments of different heights: cslgan_segs_t.rows) at exit.  For callers that take several dense weight gradients and read
+    none of them before the block ends — the parameter gradients of the gradient penalty (train.py:427), which were nine
+    latency-sized launches per step.  A queued destination holds garbage until the flush: never use this around code that consumes
+    a sum inside the block (autograd accumulating two contributions into one parameter, a double backward)."""
+
+    def __enter__(self):
+        global _pending_sums
+        self._prev, _pending_sums = _pending_sums, []
+        return self
+
+    def __exit__(self, *exc):
+        global _pending_sums
+        pend, _pending_sums = _pending_sums, self._prev
+        if exc[0] is None:
+            flush_sums(pend)
+
+
+_pending_sums = None
+
+
+def flush_sums(pend):
+    for i in range(0, len(pend), _lib.MAX_SEGS):
+        chunk = pend[i:i + _lib.MAX_SEGS]
+        clip_accum_noise([m for m, _ in chunk], [o for _, o in chunk], ragged=True)
+
+
+def sum_rows(slabs, out):
+    """out[len] = sum over the rows of slabs [n, len] (fp32) — queued when a deferred_sums block is open."""
+    if _pending_sums is not None and slabs.dtype == torch.float32:
+        _pending_sums.append((slabs, out))
+        return out
+    clip_accum_noise([slabs], [out])
+    return out
+
+
+def clip_accum_noise(mats, outs, factors=None, noise_std=None, noises=None, seed=0, offset=0, scale=1.0, beta=0.0, call_counter=None,
+                     ragged=False):
     """outs[i] = beta*outs[i] + scale*(sum_r f_r * mats[i][r] + noise_std[i]*z_i).  mats may mix fp32 and bf16
     segments (one launch per element type, fp32 accumulation either way).  call_counter: device int64 [1] whose value is
-    added to `offset` inside the kernel (graph-captured steps: the counter lives in HBM, not in the launch arguments)."""
+    added to `offset` inside the kernel (graph-captured steps: the counter lives in HBM, not in the launch arguments).
+    ragged: the segments may have different row counts (plain column sums: no factors)."""
+    if ragged and factors is not None:
+        raise RuntimeError("clip_accum_noise: ragged segments take no clip factors")
     L = _lib.lib()
     if factors is not None:
         _chk(factors, "factors")
@@ -988,7 +1038,7 @@ def clip_accum_noise(mats, outs, factors=None, noise_std=None, noises=None, seed
         for i in range(0, len(idx), _lib.MAX_SEGS):
             sub = idx[i:i + _lib.MAX_SEGS]
             whole = len(sub) == len(mats)
-            s, n_rows = _segs([mats[j] for j in sub], [outs[j] for j in sub], None if noises is None else [noises[j] for j in sub])
+            s, n_rows = _segs([mats[j] for j in sub], [outs[j] for j in sub], None if noises is None else [noises[j] for j in sub], ragged=ragged)
             if call_counter is not None:
                 if call_counter.dtype != torch.int64 or not call_counter.is_cuda:
                     raise RuntimeError("call_counter must be a device int64 tensor")
@@ -1003,7 +1053,7 @@ def clip_accum_noise(mats, outs, factors=None, noise_std=None, noises=None, seed
             ns = None
             if noise_std is not None:
                 ns = noise_std if whole else _take_rows(noise_std, sub)
-            nbytes = float(sum(n_rows * mats[j].shape[1] * mats[j].element_size() + 4 * mats[j].shape[1] for j in sub))
+            nbytes = float(sum(mats[j].shape[0] * mats[j].shape[1] * mats[j].element_size() + 4 * mats[j].shape[1] for j in sub))
             # the Philox stream is keyed by (offset, segment index within the launch): make it unique per launch
             _timed("clip_accum_noise", 0.0, nbytes, lambda: check(
                 fn(C.byref(s), n_rows, _p(f), per_seg, _p(ns), int(seed), int(offset) * 64 + sub[0], float(scale), float(beta),

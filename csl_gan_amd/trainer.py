@@ -350,11 +350,25 @@ class Trainer:
                 pen_real, pen_labels = self.get_penalty_data(img, labels)
                 penalty = calc_penalty(D, o.penalty, pen_real, pen_labels, fake_img, y, device=o.d_device, aux_penalty=o.aux_penalty,
                                        alpha=self.explicit.get("alpha"))
-                grads = autograd.grad(penalty, list(D.parameters()), create_graph=False, retain_graph=False, allow_unused=True)
+                grads = self._penalty_param_grads(penalty)
         finally:
             if was_enabled:
                 pe.enable_hooks()
         self._pending_penalty = (penalty, grads)
+
+    def _penalty_param_grads(self, penalty):
+        """autograd.grad(penalty, D.parameters()) (train.py:427).  With ONE penalty term every critic weight receives exactly one
+        dense second-order weight gradient and nothing reads it before this call returns, so the column sums over the gradients'
+        slabs are queued and run as one multi-segment launch (ops.deferred_sums; they were five latency-sized launches).  Several
+        terms (an auxiliary-logit penalty, two penalty types) make autograd ADD contributions inside the call: those run undeferred."""
+        from . import ops
+        o, D = self.opt, self.D
+        params = list(D.parameters())
+        single_term = len(o.penalty) == 1 and not (o.aux_penalty and hasattr(D, "linOutAux"))
+        if single_term and penalty.is_cuda:
+            with ops.deferred_sums():
+                return autograd.grad(penalty, params, create_graph=False, retain_graph=False, allow_unused=True)
+        return autograd.grad(penalty, params, create_graph=False, retain_graph=False, allow_unused=True)
 
     def _fused_passes(self, img, labels, z, y, on_fake=None):
         """[adaptive mean-sample pass] + generated pass + real pass as ONE discriminator forward/backward over the
@@ -496,7 +510,7 @@ class Trainer:
                     if use_grad_clip:
                         pe.accumulate_batch()
                     penalty = calc_penalty(D, o.penalty, pen_real, pen_labels, fake_img, y, **kw)
-                    penalty_grad = autograd.grad(penalty, list(D.parameters()), create_graph=False, retain_graph=False, allow_unused=True)
+                    penalty_grad = self._penalty_param_grads(penalty)
                 with torch.no_grad():
                     pairs = [(p.summed_grad, g) for p, g in zip(D.parameters(), penalty_grad) if g is not None]
                     if pairs:      # summed_grad is a sum, not a mean (train.py:431); one multi-tensor launch

@@ -51,6 +51,8 @@ typedef struct {
     const float* noise[CSLGAN_MAX_SEGS];   /* device, [len] pre-drawn N(0,1) or NULL -> Philox  */
     int64_t len[CSLGAN_MAX_SEGS];
     int64_t row_stride[CSLGAN_MAX_SEGS];   /* in elements */
+    int64_t rows[CSLGAN_MAX_SEGS];         /* clip_accum only: > 0 = this segment has its OWN row count (column sums of slab sets of
+                                            * different heights in one launch; needs factors == NULL), 0 = the call's n_rows */
     const uint64_t* call_counter;          /* device, nullable (clip_accum only): the Philox offset used is
                                             * offset + 64 * *call_counter — a step captured in a HIP graph passes its
                                             * noise-call counter here instead of by value, so every replay draws new noise */

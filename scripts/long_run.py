@@ -6,8 +6,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+EXTRA = sys.argv[2].split() if len(sys.argv) > 2 else []        # e.g. "--compute_dtype bf16 --storage_dtype bf16 --im_size 128"
 with contextlib.redirect_stdout(sys.stderr):
-    opt, tr, img = bench.build_trainer(0, 1, 0)
+    opt, tr, img = bench.build_trainer(0, 1, 0, extra=EXTRA)
 B = img.shape[0]
 lab = torch.zeros(B, dtype=torch.long)
 mem = []

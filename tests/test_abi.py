@@ -97,6 +97,9 @@ def test_bf16_storage_entries_validate_their_arguments(built_lib):
     d = _lib.ConvT(2, 16, 16, 8, 64, 5, 5, 2, 2, 0, 8, 8)
     assert L.cslgan_conv2d_dgrad_skinny_bf16in(ctypes.byref(d), 16, 16, 16, 0, 16, None) == -1 and b"1..4 input channels" in err()
     assert L.cslgan_groupnorm_act_bf16s(16, 1, 16, 16, 2, 64, 48, 32, 1e-5, 1, 16, 16, 0, None, None) == -1 and b"not divisible" in err()
+    segs = _lib.SegsT()                                                  # per-segment row counts are for plain column sums
+    segs.n_seg = 1; segs.inp[0] = 16; segs.out[0] = 16; segs.len[0] = 8; segs.row_stride[0] = 8; segs.rows[0] = 4
+    assert L.cslgan_clip_accum_noise_f32(ctypes.byref(segs), 4, 16, 0, None, 0, 0, 1.0, 0.0, None) == -1 and b"factors == NULL" in err()
 
 
 def test_ops_refuse_cpu_tensors(built_lib):

@@ -1053,3 +1053,28 @@ def test_zeroed_accumulators_replay_correctly_in_a_captured_graph():
         _close(outs[1], torch.stack([(t.double() ** 2).sum(1) for t in seg]).float(), rtol=1e-5, what="per-sample squared norms, replay %d" % k)
         _close(outs[2].permute(0, 3, 1, 2), F.group_norm(xg.permute(0, 3, 1, 2), 32, gam, bet), what="groupnorm, replay %d" % k)
         _close(outs[3].permute(0, 3, 1, 2), F.conv2d(xc.permute(0, 3, 1, 2), wc.permute(0, 3, 1, 2), padding=2), rtol=2e-3, what="split-K conv, replay %d" % k)
+
+
+def test_ragged_column_sums_and_deferred_sums():
+    """cslgan_segs_t.rows: one clip_accum_noise launch sums slab sets of DIFFERENT heights (beta accumulates into the destination),
+    and ops.deferred_sums queues sum_rows() requests into one such launch at the end of the block."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    mats = [torch.randn(n, ln, generator=g) for n, ln in ((128, 4800), (16, 1000), (1, 77), (8, 3_276_800 // 64))]
+    outs = [torch.randn(m.shape[1], generator=g) for m in mats]
+    dev_outs = [o.clone().cuda() for o in outs]
+    ops.clip_accum_noise([m.cuda() for m in mats], dev_outs, beta=1.0, ragged=True)
+    for m, o, d in zip(mats, outs, dev_outs):
+        _close(d, o + m.double().sum(0).float(), rtol=1e-5, what="ragged column sum, %d rows" % m.shape[0])
+    with pytest.raises(RuntimeError, match="ragged"):
+        ops.clip_accum_noise([m.cuda() for m in mats], dev_outs, factors=torch.ones(128, device="cuda"), ragged=True)
+    res = [torch.full((m.shape[1],), float("nan"), device="cuda") for m in mats]
+    with ops.deferred_sums():
+        for m, r in zip(mats, res):
+            assert ops.sum_rows(m.cuda(), r) is r
+        assert all(torch.isnan(r).all() for r in res), "queued, not run"
+    for m, r in zip(mats, res):
+        _close(r, m.double().sum(0).float(), rtol=1e-5, what="deferred column sum, %d rows" % m.shape[0])
+    r2 = torch.empty(mats[1].shape[1], device="cuda")
+    ops.sum_rows(mats[1].cuda(), r2)             # outside a block: immediate
+    _close(r2, mats[1].double().sum(0).float(), rtol=1e-5, what="immediate column sum")

@@ -397,6 +397,34 @@ def main():
                                 "what": "--compute_dtype fp32_auto: large forward / data-gradient launches run fp32 emulated "
                                         "from three bfloat16 pieces per operand (six bf16 MFMAs per product step; error vs fp64 <= the "
                                         "exact-fp32 kernels', tests/test_kernels_gpu.py::test_bf16x3_*), everything else the exact fp32 MFMA kernels"}
+        # BASELINE.json configs[4] beside the headline (its own trainer: 128x128 extension, bf16 matrix cores, bf16-STORED activations —
+        # csrc/igemm_bf16s.hip), so that the driver's run carries a measurement of it too; never the headline value
+        try:
+            with contextlib.redirect_stdout(sys.stderr):
+                opt16, tr16, img16 = build_trainer(rank, world, local, extra=["--compute_dtype", "bf16", "--storage_dtype", "bf16", "--im_size", "128"])
+            for _ in range(2):
+                tr16.train_D(img16, None, tr16.gen_z(B), None, use_dp=True)
+            d16 = time_region(lambda: tr16.train_D(img16, None, tr16.gen_z(B), None, use_dp=True), max(a.steps // 2, 5))
+            n16, mode16 = max(a.steps // 2, 5), "eager"
+            g16 = getattr(tr16, "graphed", None)
+            if g16 is not None:
+                for _ in range(g16.warmup + 2):
+                    g16(img16, None)
+                if g16.graph is not None:
+                    d16, mode16 = time_region(lambda: g16(img16, None), n16), "hip_graph"
+            variant["bf16_storage_128x128"] = {
+                "value": round(world * B * n16 / d16, 2), "unit": "images/sec", "ms_per_step": round(d16 / n16 * 1e3, 3), "dtype": "bf16", "launch": mode16,
+                "what": "BASELINE configs[4]: the same D-step at 3x128x128, bs=%d per GPU, --compute_dtype bf16 --storage_dtype bf16 (bfloat16 "
+                        "activations / activation gradients / filter copies in HBM, fp32 accumulate, fp32 weight gradients, norms, clip, noise, Adam); "
+                        "per-kernel figures: python bench.py --opt \"--compute_dtype bf16 --storage_dtype bf16 --im_size 128\"" % B}
+            del tr16, img16, g16
+        except Exception as e:      # the variant must not cost the headline line
+            variant["bf16_storage_128x128"] = {"error": repr(e)[:200]}
+        finally:
+            ops.set_compute_dtype(getattr(opt, "compute_dtype", "fp32"))
+            ops.set_storage_dtype(getattr(opt, "storage_dtype", "fp32"))
+            ops.repack_cache.clear()
+            torch.cuda.empty_cache()
     # secondary metric: the full train() loop, a G step forced on every n_d_steps-th iteration
     loop = None
     if a.loop_steps > 0:

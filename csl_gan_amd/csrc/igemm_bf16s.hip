@@ -64,6 +64,7 @@ struct KsParams {
     int act;
     int n_cls, tiles_m, tiles_n;
     const void* w3;              // igemm_halos: the filter as bf16 in step-major order [chunk * T + tap][n][16 k] (split_filter_x3_kernel<1>)
+    int w3_off[IG_MAX_CLS];      // igemm_halos: element offset of each class's step-major matrix in w3 (data-gradient parity classes)
     KcClass cls[IG_MAX_CLS];
 };
 
@@ -257,9 +258,12 @@ __global__ __launch_bounds__(256, 2) void igemm_halos_kernel(const KsParams p) {
     const int nwg = p.tiles_m * p.tiles_n;
     const int wg = xcd_remap(blockIdx.x, nwg);
     const int tile_mg = wg / p.tiles_n, tile_n = wg - tile_mg * p.tiles_n;
-    const KcClass& kc = p.cls[0];
+    int ci = 0;
+#pragma unroll 1
+    while (ci + 1 < p.n_cls && tile_mg >= p.cls[ci + 1].tile0) ++ci;      // data gradient: one class per output parity, each its own tiles
+    const KcClass& kc = p.cls[ci];
     const int M = kc.M, OHc = kc.OHc, OWc = kc.OWc, T = kc.T;
-    const int m0 = tile_mg * BM, n0 = tile_n * BN;
+    const int m0 = (tile_mg - kc.tile0) * BM, n0 = tile_n * BN;
     const int HW_ = kc.halo_w, hpix = kc.halo_h * kc.halo_w;
     const int img_stride = p.AH * p.AW * p.AC;
 
@@ -282,7 +286,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halos_kernel(const KsParams p) {
     const int r = lane & 31, h = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;                   // wm = patch index
     // filter: lane (r, h), tile j reads 8 consecutive k of filter row n0 + wn*TN*32 + j*32 + r of one step = one 16-byte load
-    const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w3), 0, 2u * (unsigned)p.Nn * (unsigned)kc.Kdim, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(p.w3) + p.w3_off[ci]), 0, 2u * (unsigned)p.Nn * (unsigned)kc.Kdim, 0x00020000);
     const unsigned step_bytes = 32u * (unsigned)p.Nn;
     unsigned b_off[TN];
 #pragma unroll
@@ -427,6 +432,10 @@ __global__ __launch_bounds__(256, 2) void igemm_halos_kernel(const KsParams p) {
                 if (p.act == CSLGAN_ACT_LRELU02) val = val > 0.f ? val : 0.2f * val;
                 else if (p.act == CSLGAN_ACT_RELU) val = val > 0.f ? val : 0.f;
                 else if (p.act == CSLGAN_ACT_TANH) val = tanhf(val);
+                if (p.mask) {
+                    const float mv = p.mask_bf16 ? bf2f(reinterpret_cast<const unsigned short*>(p.mask)[off + n]) : reinterpret_cast<const float*>(p.mask)[off + n];
+                    val *= (mv > 0.f ? 1.f : 0.2f);
+                }
                 if (OUT_BF16) reinterpret_cast<unsigned short*>(p.out)[off + n] = f2bf(val);
                 else reinterpret_cast<float*>(p.out)[off + n] = val;
             }
@@ -436,34 +445,46 @@ __global__ __launch_bounds__(256, 2) void igemm_halos_kernel(const KsParams p) {
 
 int split_filter_x3(const float* w, int Nn, int T, int C, void* w3, hipStream_t st, int pieces);      // igemm_bf16.hip
 
-// one class, stride 1, an 8x8-patchable grid of at least 16x16, channels a multiple of 16, 2..25 taps within a 12x12 halo, >= 64 filters
+// stride-1 classes (one for a forward conv; the output-parity classes of a strided data gradient), each on an 8x8-patchable grid of at
+// least 16x16, channels a multiple of 16, 2..25 taps within a 12x12 halo, >= 64 filters
 static bool halos_eligible(const KsParams& p) {
     static const int env = [] { const char* e = getenv("CSLGAN_HALOS"); return e ? atoi(e) : 1; }();
-    if (!env || p.n_cls != 1 || p.sy != 1 || p.sx != 1 || (p.AC & 15) || p.Nn < 64 || p.mask || !aligned16(p.a)) return false;
-    const KcClass& k = p.cls[0];
-    if (k.T < 2 || (k.M & 63) || (k.OHc & 7) || (k.OWc & 7) || k.OHc < 16 || k.OWc < 16 || k.oy0 || k.ox0 || p.osy != 1 || p.osx != 1) return false;
-    int ymin = 127, ymax = -128, xmin = 127, xmax = -128;
-    for (int t = 0; t < k.T; ++t) {
-        ymin = k.ty[t] < ymin ? k.ty[t] : ymin; ymax = k.ty[t] > ymax ? k.ty[t] : ymax;
-        xmin = k.tx[t] < xmin ? k.tx[t] : xmin; xmax = k.tx[t] > xmax ? k.tx[t] : xmax;
+    if (!env || p.n_cls < 1 || p.sy != 1 || p.sx != 1 || (p.AC & 15) || p.Nn < 64 || !aligned16(p.a)) return false;
+    for (int c = 0; c < p.n_cls; ++c) {
+        const KcClass& k = p.cls[c];
+        if (k.T < 2 || (k.M & 63) || (k.OHc & 7) || (k.OWc & 7) || k.OHc < 16 || k.OWc < 16) return false;
+        int ymin = 127, ymax = -128, xmin = 127, xmax = -128;
+        for (int t = 0; t < k.T; ++t) {
+            ymin = k.ty[t] < ymin ? k.ty[t] : ymin; ymax = k.ty[t] > ymax ? k.ty[t] : ymax;
+            xmin = k.tx[t] < xmin ? k.tx[t] : xmin; xmax = k.tx[t] > xmax ? k.tx[t] : xmax;
+        }
+        if (ymax - ymin > 4 || xmax - xmin > 4) return false;
     }
-    return ymax - ymin <= 4 && xmax - xmin <= 4;
+    return true;
 }
 
 static int launch_halos(KsParams& p, bool out_bf16, hipStream_t st) {
-    KcClass& k = p.cls[0];
-    int ymin = 127, ymax = -128, xmin = 127, xmax = -128;
-    for (int t = 0; t < k.T; ++t) {
-        ymin = k.ty[t] < ymin ? k.ty[t] : ymin; ymax = k.ty[t] > ymax ? k.ty[t] : ymax;
-        xmin = k.tx[t] < xmin ? k.tx[t] : xmin; xmax = k.tx[t] > xmax ? k.tx[t] : xmax;
+    int tm = 0;
+    long long w_el = 0;
+    for (int c = 0; c < p.n_cls; ++c) {
+        KcClass& k = p.cls[c];
+        int ymin = 127, ymax = -128, xmin = 127, xmax = -128;
+        for (int t = 0; t < k.T; ++t) {
+            ymin = k.ty[t] < ymin ? k.ty[t] : ymin; ymax = k.ty[t] > ymax ? k.ty[t] : ymax;
+            xmin = k.tx[t] < xmin ? k.tx[t] : xmin; xmax = k.tx[t] > xmax ? k.tx[t] : xmax;
+        }
+        k.ty_min = ymin; k.tx_min = xmin; k.halo_h = 8 + ymax - ymin; k.halo_w = 8 + xmax - xmin;
+        k.patch = 1; k.tile0 = tm;
+        tm += (k.M + 127) / 128;
+        p.w3_off[c] = k.w_off;              // a class's step-major matrix has the size of its plain one: same offsets
+        w_el += (long long)p.Nn * k.Kdim;
     }
-    k.ty_min = ymin; k.tx_min = xmin; k.halo_h = 8 + ymax - ymin; k.halo_w = 8 + xmax - xmin;
-    k.patch = 1; k.tile0 = 0;
-    const long long n_img = k.M / ((long long)k.OHc * k.OWc);
+    const KcClass& k0 = p.cls[0];
+    const long long n_img = k0.M / ((long long)k0.OHc * k0.OWc);
     const long long a_b = 2ll * n_img * p.AH * p.AW * p.AC;
-    CSLGAN_REQUIRE(a_b < 0xFFFFFFF0ll && 2ll * p.Nn * k.Kdim < 0xFFFFFFF0ll, "igemm_halos: operand larger than 4 GB");
+    CSLGAN_REQUIRE(a_b < 0xFFFFFFF0ll && 2ll * w_el < 0xFFFFFFF0ll, "igemm_halos: operand larger than 4 GB");
     p.a_bytes = (unsigned)a_b;
-    p.tiles_m = (k.M + 127) / 128;
+    p.tiles_m = tm;
     const bool wide = p.Nn > 64;
     p.tiles_n = wide ? (p.Nn + 127) / 128 : 1;
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);
@@ -552,6 +573,7 @@ static unsigned stream_blocks(long long n_items) {
 // data-gradient classes: wt[off_cls + (c*Tc + t)*K + k] = bf16(w[((k*R + kh)*S + kw)*C + c]) for the (kh, kw) of the class's tap t
 struct DgradRepack {
     int K, R, S, C, n_cls;
+    int step_major;      // 1: igemm_halos' layout [(k/16) * Tc + t][c][k % 16] per class instead of the plain [c][t][k]
     int cls_off[IG_MAX_CLS], cls_T[IG_MAX_CLS];
     signed char kh[IG_MAX_CLS][IG_MAX_TAPS], kw[IG_MAX_CLS][IG_MAX_TAPS];
 };
@@ -564,7 +586,8 @@ __global__ void repack_dgrad_bf16_kernel(const float* __restrict__ w, unsigned s
         const int k = (int)(i % a.K);
         const long long rest = i / a.K;
         const int t = (int)(rest % Tc), c = (int)(rest / Tc);
-        wt[a.cls_off[cls] + i] = f2bf(w[(((long long)k * a.R + a.kh[cls][t]) * a.S + a.kw[cls][t]) * a.C + c]);
+        const long long dst = a.step_major ? ((((long long)(k >> 4) * Tc + t) * a.C + c) << 4) + (k & 15) : i;
+        wt[a.cls_off[cls] + dst] = f2bf(w[(((long long)k * a.R + a.kh[cls][t]) * a.S + a.kw[cls][t]) * a.C + c]);
     }
 }
 
@@ -1240,12 +1263,24 @@ int cslgan_conv2d_dgrad_bf16s(const cslgan_conv_t* c, const void* gy, const floa
             ra.cls_T[cls] = T; ra.cls_off[cls] = off; off += T * c->K * c->C;
         }
     p.n_cls = ncls; ra.n_cls = ncls;
+    // the LDS-halo form reads step-major class matrices; like the forward entry, the route (and with it the layout of the cached bf16
+    // copy) follows the SHAPE alone
+    // Measured (128x128, same run, gather vs halo): conv2's data gradient into 64 channels 0.652 vs 0.682 ms at 384 rows (247 / 236 TF),
+    // conv3's into 128 channels 0.386 vs 0.473 ms (417 / 340 TF): with 4-9 taps per class the halo's reuse does not pay for its
+    // one-MFMA-tile-per-wave steps, so the data gradient stays on the gather form (CSLGAN_HALOS_DGRAD=1 routes it to the halo form).
+    static const int halo_dgrad_env = [] { const char* e = getenv("CSLGAN_HALOS_DGRAD"); return e ? atoi(e) : 0; }();
+    const bool halo = halo_dgrad_env && c->K % 16 == 0 && halos_eligible(p) && aligned16(wt_ws);
+    ra.step_major = halo ? 1 : 0;
     if (repack) {
         unsigned gxn = (unsigned)(((long long)c->K * c->C * c->R * c->S / (s * s) + 255) / 256);
         gxn = gxn > 1024 ? 1024 : (gxn < 1 ? 1 : gxn);
         hipLaunchKernelGGL(repack_dgrad_bf16_kernel, dim3(gxn, (unsigned)ncls), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wt_ws), ra);
         rc = check_launch("repack_dgrad_bf16_kernel");
         if (rc) return rc;
+    }
+    if (halo) {
+        p.w3 = wt_ws;
+        return launch_halos(p, gx_bf16 != 0, st);
     }
     return launch_kcs(p, gx_bf16 != 0, st);
 }

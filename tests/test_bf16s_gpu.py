@@ -115,6 +115,8 @@ DGRAD_CASES = [
     (2, 16, 16, 64, 64, 5, 1, 2, False, True),             # stride 1 (the generator's convs under train_G)
     (2, 9, 7, 16, 24, 3, 1, 1, True, True),
     (5, 15, 15, 8, 16, 5, 2, 2, True, True),               # odd image: ragged parity classes
+    (2, 64, 64, 128, 256, 5, 2, 2, True, True),            # parity classes on 32x32 grids, 128 output channels: LDS-halo form, wide tiles
+    (3, 32, 32, 64, 64, 3, 2, 1, False, False),            # 3x3 stride 2: a class with a single tap keeps the launch on the gather form
 ]
 
 

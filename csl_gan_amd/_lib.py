@@ -29,7 +29,7 @@ EXPORTS = [
     "cslgan_conv2d_fwd_bf16s", "cslgan_conv2d_dgrad_bf16s", "cslgan_conv2d_wgrad_grouped_bf16s", "cslgan_cast_f32_bf16", "cslgan_cast_bf16_f32",
     "cslgan_act_bwd_bf16", "cslgan_bias_grad_grouped_bf16", "cslgan_linear_k1_dgrad_bf16s", "cslgan_linear_k1_wgrad_bf16s",
     "cslgan_conv2d_c3_fwd_bf16out", "cslgan_conv2d_c3_wgrad_bf16gy", "cslgan_groupnorm_act_bf16s",
-    "cslgan_conv2d_fwd_skinny_bf16in", "cslgan_conv2d_dgrad_skinny_bf16in",
+    "cslgan_conv2d_fwd_skinny_bf16in", "cslgan_conv2d_dgrad_skinny_bf16in", "cslgan_conv2d_wgrad_scaled_bf16s",
 ]
 
 
@@ -118,7 +118,8 @@ def lib():
         "cslgan_act_bwd_bf16": [vp, vp, i64, f32, vp, vp],
         "cslgan_bias_grad_grouped_bf16": [vp, i32, i32, i32, i32, f32, vp, vp, vp],
         "cslgan_linear_k1_dgrad_bf16s": [vp, vp, vp, i32, i64, vp, vp],
-        "cslgan_linear_k1_wgrad_bf16s": [vp, vp, i32, i64, i32, f32, vp, vp, vp],
+        "cslgan_linear_k1_wgrad_bf16s": [vp, vp, vp, i32, i64, i32, f32, vp, vp, vp],
+        "cslgan_conv2d_wgrad_scaled_bf16s": [C.POINTER(ConvT), vp, vp, vp, i32, f32, vp, vp],
         "cslgan_conv2d_c3_fwd_bf16out": [C.POINTER(ConvT), vp, vp, vp, i32, vp, vp],
         "cslgan_conv2d_c3_wgrad_bf16gy": [C.POINTER(ConvT), vp, vp, f32, vp, vp, vp],
         "cslgan_groupnorm_act_bf16s": [vp, i32, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, i32, vp, vp],

@@ -602,6 +602,8 @@ struct MsParams {
     int out_bf16;
     float* sq;           // [n_groups] or null
     int tiles_m, tiles_n, ksplit;
+    const float* row_scale;   // igemm_mcs_tr_kernel<., true>: [N] fp32 weight of each sample's WHOLE gradient, applied in fp32 to the sample's
+                              // accumulated product (clip-weighted sums: sum_b f_b g_b with every g_b exactly the bf16-MFMA gradient)
     signed char ty[IG_MAX_TAPS], tx[IG_MAX_TAPS];
 };
 
@@ -791,7 +793,12 @@ __global__ __launch_bounds__(256, 2) void igemm_mcs_kernel(const MsParams p) {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-template <bool Q8>
+// SCALED (clip-weighted sums for ghost clipping): P*Q is a multiple of the 64-pixel K tile, so every K tile lies
+// in ONE sample; when a sample's last tile has been multiplied its accumulated product is folded into a second accumulator with the
+// sample's fp32 weight (acc_sum += f_b * acc; acc = 0).  The weight never touches a bfloat16 operand: the summed contribution of
+// sample b is f_b times exactly the gradient the unscaled kernel materialises, so the clipped sum keeps the sensitivity bound to fp32
+// rounding (scaling gy by f_b before the matrix core would round f_b * gy to bfloat16: a 2^-8 relative slack on that bound).
+template <bool Q8, bool SCALED = false>
 __global__ __launch_bounds__(256, 2) void igemm_mcs_tr_kernel(const MsParams p) {
     constexpr int OPB = 64 * 256;                           // bytes of one operand tile: 64 pixels x 128 channels x 2 B
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * OPB];     // [buffer][operand]
@@ -936,6 +943,42 @@ __global__ __launch_bounds__(256, 2) void igemm_mcs_tr_kernel(const MsParams p) 
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     };
+    if (SCALED) {
+        // one register set (the second accumulator needs the registers); a sample = tiles_per_sample consecutive K tiles
+        f32x16 acc_sum[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc_sum[i][j][v] = 0.f;
+        const int tps = PQ / MS_BK;
+        load_tile(kt0, rv0);
+        store_tile(0, rv0);
+        __syncthreads();
+        int in_sample = 0;
+        for (int kt = kt0; kt < nk; ++kt) {
+            const int buf = (kt - kt0) & 1;
+            if (kt + 1 < nk) load_tile(kt + 1, rv0);
+            mma_tile(buf);
+            if (++in_sample == tps) {            // uniform: the sample's product is complete
+                in_sample = 0;
+                const float f = p.row_scale[(long long)g * p.group + kt / tps];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) { acc_sum[i][j][v] = fmaf(f, acc[i][j][v], acc_sum[i][j][v]); acc[i][j][v] = 0.f; }
+            }
+            if (kt + 1 < nk) store_tile(buf ^ 1, rv0);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = acc_sum[i][j];
+    } else {
     load_tile(kt0, rv0);
     load_tile(kt0 + 1, rv1);         // past the group's pixels every lane loads zeros (kk >= Ktot)
     store_tile(0, rv0);
@@ -950,6 +993,7 @@ __global__ __launch_bounds__(256, 2) void igemm_mcs_tr_kernel(const MsParams p) 
         mma_tile(1);
         store_tile(0, rv0);          // tile kt + 2
         __syncthreads();
+    }
     }
 
     // ---- epilogue: scale, store, per-group sum of squares (as igemm_mc) ------------------------
@@ -1106,7 +1150,7 @@ __global__ __launch_bounds__(256) void linear_k1s_dgrad_kernel(const float* __re
 // gw[g,:] = alpha * sum_{n in group g} gy[n] * x[n,:] (fp32), sq[g] += ||gw[g,:]||^2: the head's per-sample / grouped weight gradient
 // is a scaled copy (a short weighted sum) of bf16 feature rows
 __global__ __launch_bounds__(256) void linear_k1s_wgrad_kernel(const float* __restrict__ gy, const unsigned short* __restrict__ x, long long C8, int group,
-                                                               float alpha, float* __restrict__ gw, float* __restrict__ sq) {
+                                                               float alpha, float* __restrict__ gw, float* __restrict__ sq, const float* __restrict__ row_scale) {
     __shared__ float s_red[4];
     const long long g = blockIdx.y;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1116,7 +1160,7 @@ __global__ __launch_bounds__(256) void linear_k1s_wgrad_kernel(const float* __re
     if (i < C8) {
         for (int r = 0; r < group; ++r) {
             const long long n = g * group + r;
-            const float s = gy[n];
+            const float s = row_scale ? gy[n] * row_scale[n] : gy[n];        // clip-weighted sums: the weight meets the fp32 cotangent
             const uint4 a = reinterpret_cast<const uint4*>(x + n * C8 * 8)[i];
             const unsigned d[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
@@ -1337,6 +1381,35 @@ int cslgan_conv2d_wgrad_grouped_bf16s(const cslgan_conv_t* c, const void* gy, co
     return rc;
 }
 
+// gw[N/group][K][R][S][C] (fp32) = alpha * sum_{n in group} row_scale[n] * (per-sample weight gradient of sample n), from bf16 gy and
+// bf16 x: clip() + accumulate for ghost-clipped layers (train.py:399-402) in the bf16 storage mode.  row_scale [N] fp32 is applied in
+// fp32 to each sample's accumulated product (igemm_mcs_tr_kernel<., true>), never to a bfloat16 operand.  Needs P*Q % 64 == 0.
+int cslgan_conv2d_wgrad_scaled_bf16s(const cslgan_conv_t* c, const void* gy, const void* x, const float* row_scale, int group, float alpha,
+                                     float* gw, void* stream) {
+    CSLGAN_REQUIRE(c && gy && x && row_scale && gw, "conv2d_wgrad_scaled_bf16s: null argument");
+    int rc = check_conv_s(c, "conv2d_wgrad_scaled_bf16s");
+    if (rc) return rc;
+    CSLGAN_REQUIRE(group >= 1 && c->N % group == 0, "conv2d_wgrad_scaled_bf16s: N=%d not divisible by group=%d", c->N, group);
+    CSLGAN_REQUIRE(c->K % 8 == 0 && c->C % 8 == 0 && aligned16(gy) && aligned16(x), "conv2d_wgrad_scaled_bf16s: K and C must be multiples of 8, operands 16-byte aligned");
+    CSLGAN_REQUIRE((c->P * c->Q) % MS_BK == 0, "conv2d_wgrad_scaled_bf16s: P*Q=%d is not a multiple of %d (a K tile must lie in one sample)", c->P * c->Q, MS_BK);
+    hipStream_t st = (hipStream_t)stream;
+    MsParams p{};
+    p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->P; p.Q = c->Q; p.Kc = c->K;
+    p.T = c->R * c->S; p.Ndim = p.T * c->C; p.stride = c->stride; p.group = group; p.n_groups = c->N / group;
+    p.alpha = alpha; p.gw = gw; p.sq = nullptr; p.out_bf16 = 0; p.row_scale = row_scale; p.ksplit = 1;
+    for (int t = 0; t < IG_MAX_TAPS; ++t) { p.ty[t] = 0; p.tx[t] = 0; }
+    for (int kh = 0; kh < c->R; ++kh)
+        for (int kw = 0; kw < c->S; ++kw) { p.ty[kh * c->S + kw] = (signed char)(kh - c->pad); p.tx[kh * c->S + kw] = (signed char)(kw - c->pad); }
+    p.tiles_m = (p.Kc + 127) / 128;
+    p.tiles_n = (p.Ndim + 127) / 128;
+    const long long nb = (long long)p.n_groups * p.tiles_m * p.tiles_n;
+    CSLGAN_REQUIRE(nb <= 0x7fffffffll, "conv2d_wgrad_scaled_bf16s: grid too large");
+    note_kernel("igemm_mcs_tr_kernel<128,128,scaled>");
+    if (c->Q % 8 == 0) hipLaunchKernelGGL((igemm_mcs_tr_kernel<true, true>), dim3((unsigned)nb), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((igemm_mcs_tr_kernel<false, true>), dim3((unsigned)nb), dim3(256), 0, st, p);
+    return check_launch("igemm_mcs_tr_kernel");
+}
+
 // The head nn.Linear(C, 1) on bf16 features x [N, C] (C % 8 == 0): data gradient gx[n,:] = bf16(gy[n] * bf16(w) (* lrelu'(mask)))
 // with fp32 gy [N] and bf16 mask / gx [N, C] ...
 int cslgan_linear_k1_dgrad_bf16s(const float* gy, const float* w, const void* mask, int N, int64_t C, void* gx, void* stream) {
@@ -1351,14 +1424,15 @@ int cslgan_linear_k1_dgrad_bf16s(const float* gy, const float* w, const void* ma
 
 // ... and its grouped weight gradient gw[N/group, C] = alpha * sum_{n in g} gy[n] x[n,:] (fp32; nullable) and / or
 // sq[N/group] += ||gw_g||^2.
-int cslgan_linear_k1_wgrad_bf16s(const float* gy, const void* x, int N, int64_t C, int group, float alpha, float* gw, float* sq, void* stream) {
+int cslgan_linear_k1_wgrad_bf16s(const float* gy, const void* x, const float* row_scale, int N, int64_t C, int group, float alpha, float* gw, float* sq,
+                                 void* stream) {
     CSLGAN_REQUIRE(gy && x && (gw || sq) && N > 0 && C > 0 && C % 8 == 0 && group >= 1 && N % group == 0 && N / group <= 65535,
                    "linear_k1_wgrad_bf16s: bad argument");
     CSLGAN_REQUIRE(aligned16(x) && (!gw || aligned16(gw)), "linear_k1_wgrad_bf16s: misaligned");
     const long long C8 = C / 8;
     note_kernel("linear_k1s_wgrad_kernel");
     hipLaunchKernelGGL(linear_k1s_wgrad_kernel, dim3((unsigned)((C8 + 255) / 256), (unsigned)(N / group)), dim3(256), 0, (hipStream_t)stream, gy,
-                       reinterpret_cast<const unsigned short*>(x), C8, group, alpha, gw, sq);
+                       reinterpret_cast<const unsigned short*>(x), C8, group, alpha, gw, sq, row_scale);
     return check_launch("linear_k1s_wgrad_kernel");
 }
 

@@ -654,12 +654,12 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
     """gw[N/group,K,R,S,C] (per-group weight gradients) and/or sq[N/group] += ||alpha*gw_g||^2.
     row_scale [N]: gy of sample n is weighted by row_scale[n] (clip-weighted sums; fp32 output, no sq)."""
     if gy.dtype == torch.bfloat16 or x.dtype == torch.bfloat16:
-        if (gy.dtype == x.dtype and row_scale is None and gy.shape[-1] % 8 == 0 and x.shape[-1] % 8 == 0
-                and (want_gw or sq is not None)):
-            return _conv2d_wgrad_grouped_stored(gy, x, R, S, stride, pad, group, alpha, want_gw, sq, out)
-        if (gy.dtype == torch.float32 and x.dtype == torch.bfloat16 and row_scale is None and gy.shape[-1] == 1 and R == 1 and S == 1
+        if (gy.dtype == x.dtype and gy.shape[-1] % 8 == 0 and x.shape[-1] % 8 == 0 and (want_gw or sq is not None)
+                and (row_scale is None or _scaled_stored_ok(gy, sq, want_gw, out))):
+            return _conv2d_wgrad_grouped_stored(gy, x, R, S, stride, pad, group, alpha, want_gw, sq, out, row_scale)
+        if (gy.dtype == torch.float32 and x.dtype == torch.bfloat16 and gy.shape[-1] == 1 and R == 1 and S == 1
                 and tuple(x.shape[1:3]) == (1, 1) and x.shape[-1] % 8 == 0 and (out is None or out.dtype == torch.float32)
-                and x.shape[0] % group == 0 and x.shape[0] // group <= 65535):
+                and x.shape[0] % group == 0 and x.shape[0] // group <= 65535 and (row_scale is None or (sq is None and want_gw))):
             # the critic's head: fp32 loss cotangent times bf16 feature rows
             N, Cc = x.shape[0], x.shape[-1]
             _chk(gy, "gy"); _chk(x, "x", allow_bf16=True)
@@ -669,9 +669,13 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
                 _chk(gw, "gw")
             if sq is not None:
                 _chk(sq, "sq")
+            if row_scale is not None:
+                _chk(row_scale, "row_scale")
+                if row_scale.numel() != N:
+                    raise RuntimeError("conv2d_wgrad: row_scale needs [N] factors")
             _timed("conv2d_wgrad_grouped" + ("" if want_gw else "_normonly"), 2.0 * N * Cc, 2.0 * N * Cc + (4.0 * (N // group) * Cc if want_gw else 0.0),
-                   lambda: check(_lib.lib().cslgan_linear_k1_wgrad_bf16s(_p(gy), _p(x), N, Cc, group, float(alpha), _p(gw), _p(sq), _stream()),
-                                 "linear_k1_wgrad_bf16s"), tag=lambda: "N%d 1x1 C%d K1 R1 s1 g%d bf16s" % (N, Cc, group))
+                   lambda: check(_lib.lib().cslgan_linear_k1_wgrad_bf16s(_p(gy), _p(x), _p(row_scale), N, Cc, group, float(alpha), _p(gw), _p(sq), _stream()),
+                                 "linear_k1_wgrad_bf16s"), tag=lambda: "N%d 1x1 C%d K1 R1 s1 g%d bf16s%s" % (N, Cc, group, " scaled" if row_scale is not None else ""))
             return gw
         if (gy.dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[-1] == 3 and group == 1 and row_scale is None
                 and (out is None or out.dtype == torch.float32) and (want_gw or sq is not None)
@@ -748,8 +752,14 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
     return None if scratch else gw
 
 
-def _conv2d_wgrad_grouped_stored(gy, x, R, S, stride, pad, group, alpha, want_gw, sq, out):
-    """conv2d_wgrad_grouped on bf16 gy and bf16 x (cslgan_conv2d_wgrad_grouped_bf16s): fp32 (or bf16) gw and / or sq."""
+def _scaled_stored_ok(gy, sq, want_gw, out):
+    """Shapes cslgan_conv2d_wgrad_scaled_bf16s takes: a K tile (64 pixels) must lie inside one sample, fp32 gradient out, no norms."""
+    return (gy.shape[1] * gy.shape[2]) % 64 == 0 and sq is None and want_gw and (out is None or out.dtype == torch.float32)
+
+
+def _conv2d_wgrad_grouped_stored(gy, x, R, S, stride, pad, group, alpha, want_gw, sq, out, row_scale=None):
+    """conv2d_wgrad_grouped on bf16 gy and bf16 x (cslgan_conv2d_wgrad_grouped_bf16s): fp32 (or bf16) gw and / or sq.
+    row_scale [N] (clip-weighted sums): cslgan_conv2d_wgrad_scaled_bf16s — the fp32 weight meets each sample's accumulated product."""
     _chk(gy, "gy", allow_bf16=True); _chk(x, "x", allow_bf16=True)
     N, H, W, Cc = x.shape
     N2, P, Q, K = gy.shape
@@ -768,6 +778,14 @@ def _conv2d_wgrad_grouped_stored(gy, x, R, S, stride, pad, group, alpha, want_gw
         _chk(sq, "sq")
     flop = 2.0 * N * P * Q * K * R * S * Cc
     nbytes = 2.0 * (N * H * W * Cc + N * P * Q * K) + (float(gw.element_size()) * (G * K * R * S * Cc) if want_gw else 0.0)
+    if row_scale is not None:
+        _chk(row_scale, "row_scale")
+        if row_scale.numel() != N:
+            raise RuntimeError("conv2d_wgrad: row_scale needs [N] factors")
+        _timed("conv2d_wgrad_grouped", flop, nbytes, lambda: check(
+            _lib.lib().cslgan_conv2d_wgrad_scaled_bf16s(C.byref(d), _p(gy), _p(x), _p(row_scale), group, float(alpha), _p(gw), _stream()),
+            "conv2d_wgrad_scaled_bf16s"), tag=lambda: "N%d %dx%d C%d K%d R%d s%d g%d bf16s scaled" % (N, H, W, Cc, K, R, stride, group))
+        return gw
     _timed("conv2d_wgrad_grouped" + ("" if want_gw else "_normonly"), flop, nbytes, lambda: check(
         _lib.lib().cslgan_conv2d_wgrad_grouped_bf16s(C.byref(d), _p(gy), _p(x), group, float(alpha), _p(gw),
                                                      1 if _is_bf16(gw) else 0, _p(sq), _stream()), "conv2d_wgrad_grouped_bf16s"),
@@ -820,18 +838,19 @@ def conv2d_wgrad_dense(gy, x, R, S, stride=1, pad=0, alpha=1.0, row_scale=None, 
     vector-ALU kernel for 1..4 output channels.  out (optional, flat fp32 [K*R*S*C]): destination of the sum.
     want_rows: return the UN-SUMMED slabs [n_slabs, K*R*S*C] instead (the caller column-sums them together with other
     contributions in one launch: PrivacyEngine._add_dense_rows)."""
-    if (gy.dtype == torch.float32 and x.dtype == torch.bfloat16 and row_scale is None and gy.shape[-1] == 1 and R == 1 and S == 1
+    if (gy.dtype == torch.float32 and x.dtype == torch.bfloat16 and gy.shape[-1] == 1 and R == 1 and S == 1
             and tuple(x.shape[1:3]) == (1, 1) and x.shape[-1] % 8 == 0):
         # the critic's head on bf16 features: weighted sums of feature rows in slabs of 8 samples + a column sum
         N = x.shape[0]
-        slabs = conv2d_wgrad_grouped(gy, x, 1, 1, group=8 if N % 8 == 0 else 1, alpha=alpha)
+        slabs = conv2d_wgrad_grouped(gy, x, 1, 1, group=8 if N % 8 == 0 else 1, alpha=alpha, row_scale=row_scale)
         res = torch.empty(x.shape[-1], device=x.device, dtype=torch.float32) if out is None else out
         sum_rows(slabs.reshape(slabs.shape[0], -1), res.view(-1))
         return res.view(1, 1, 1, -1)
     c3_mixed = (gy.dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[-1] == 3 and row_scale is None
                 and _c3_layer(x.shape[1], x.shape[2], gy.shape[-1], R, S, stride, pad, gy.shape[2] in (16, 32, 64) and gy.shape[1] % (128 // gy.shape[2]) == 0))
     if (gy.dtype == torch.bfloat16 or x.dtype == torch.bfloat16) and not c3_mixed and not (
-            gy.dtype == x.dtype and row_scale is None and gy.shape[-1] % 8 == 0 and x.shape[-1] % 8 == 0):
+            gy.dtype == x.dtype and gy.shape[-1] % 8 == 0 and x.shape[-1] % 8 == 0
+            and (row_scale is None or (gy.shape[1] * gy.shape[2]) % 64 == 0)):
         gy, x = cast_f32(gy), cast_f32(x)
     N, H, W, Cc = x.shape
     _, P, Q, K = gy.shape

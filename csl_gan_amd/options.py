@@ -236,7 +236,10 @@ def finalize(opt, make_dirs=True):
         print("penalty_use_public_data=False: using --materialize all (the per-sample penalty gradients are added to p.grad_sample of "
               "every parameter, train.py:447)")
         opt.materialize = "all"
-    if getattr(opt, "compute_dtype", "fp32") == "bf16" and opt.materialize == "ghost":
+    if getattr(opt, "compute_dtype", "fp32") == "bf16" and opt.materialize == "ghost" and getattr(opt, "storage_dtype", "fp32") != "bf16":
+        # with bf16 STORAGE the operands are already the rounded values: the Gram norms (fp32 sums of exact products of the stored
+        # values) ARE the norms of the gradients the bf16 matrix core sums, and the clip weights are applied in fp32 to each sample's
+        # accumulated product (cslgan_conv2d_wgrad_scaled_bf16s) — ghost clipping stays on in that mode
         print("compute_dtype=bf16: using --materialize private (ghost clipping's Gram norms are fp32 norms of unrounded products)")
         opt.materialize = "private"
     if getattr(opt, "storage_dtype", "fp32") == "bf16" and getattr(opt, "compute_dtype", "fp32") != "bf16":

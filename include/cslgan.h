@@ -257,8 +257,8 @@ int cslgan_conv2d_wgrad_grouped_bf16s(const cslgan_conv_t* p, const void* gy, co
  * bf16 mask / gx [N, C]; grouped weight gradient gw[N/group, C] = alpha * sum_{n in g} gy[n] x[n,:] (fp32, nullable) and / or
  * sq[N/group] += ||gw_g||^2. */
 int cslgan_linear_k1_dgrad_bf16s(const float* gy, const float* w, const void* mask_bf16, int N, int64_t C, void* gx_bf16, void* stream);
-int cslgan_linear_k1_wgrad_bf16s(const float* gy, const void* x_bf16, int N, int64_t C, int group, float alpha, float* gw, float* sq,
-                                 void* stream);
+int cslgan_linear_k1_wgrad_bf16s(const float* gy, const void* x_bf16, const float* row_scale, int N, int64_t C, int group, float alpha,
+                                 float* gw, float* sq, void* stream);   /* row_scale (nullable, [N]): gy[n] is weighted by row_scale[n] */
 
 /* The critic's RGB first layer (3 -> 64 channels, 5x5, stride 2; csrc/conv_c3.hip) at the edge of the bf16-stored chain: fp32 image
  * and fp32 arithmetic as in cslgan_conv2d_fwd_f32 / cslgan_conv2d_wgrad_grouped_f32(group = 1), with the OUTPUT stored as bfloat16 /
@@ -282,6 +282,13 @@ int cslgan_conv2d_fwd_skinny_bf16in(const cslgan_conv_t* p, const void* x_bf16, 
                                     void* stream);
 int cslgan_conv2d_dgrad_skinny_bf16in(const cslgan_conv_t* p, const void* gy_bf16, const float* w, float* wt_ws, int repack, float* gx,
                                       void* stream);
+
+/* cslgan_conv2d_wgrad_scaled_f32 on bf16 gy / x: gw[N/group] = alpha * sum_{n in g} row_scale[n] * (weight gradient of sample n) —
+ * clip() + accumulate of ghost-clipped layers (train.py:399-402).  The fp32 weight is applied to each sample's ACCUMULATED product,
+ * never to a bfloat16 operand, so every summed contribution is row_scale[n] times exactly the gradient
+ * cslgan_conv2d_wgrad_grouped_bf16s(group = 1) would store.  Needs P*Q % 64 == 0. */
+int cslgan_conv2d_wgrad_scaled_bf16s(const cslgan_conv_t* p, const void* gy, const void* x, const float* row_scale, int group, float alpha,
+                                     float* gw, void* stream);
 
 /* Element-type conversions at the edges of the bf16-stored chain (round-to-nearest-even / exact widening). */
 int cslgan_cast_f32_bf16(const float* in, void* out_bf16, int64_t n, void* stream);

@@ -88,7 +88,9 @@ def test_bf16_storage_entries_validate_their_arguments(built_lib):
     assert L.cslgan_act_bwd_bf16(16, 16, 12, 0.2, 16, None) == -1 and b"multiple of 8" in err()
     assert L.cslgan_bias_grad_grouped_bf16(16, 4, 16, 24, 1, 1.0, 16, None, None) == -1 and b"multiple of 8" in err()
     assert L.cslgan_linear_k1_dgrad_bf16s(16, 16, None, 4, 100, 16, None) == -1 and b"bad argument" in err()
-    assert L.cslgan_linear_k1_wgrad_bf16s(16, 16, 6, 64, 4, 1.0, 16, None, None) == -1 and b"bad argument" in err()
+    assert L.cslgan_linear_k1_wgrad_bf16s(16, 16, None, 6, 64, 4, 1.0, 16, None, None) == -1 and b"bad argument" in err()
+    d = _lib.ConvT(4, 8, 8, 64, 128, 5, 5, 2, 2, 1, 4, 4)               # 16 output pixels per sample: a 64-pixel K tile would span samples
+    assert L.cslgan_conv2d_wgrad_scaled_bf16s(ctypes.byref(d), 16, 16, 16, 2, 1.0, 16, None) == -1 and b"one sample" in err()
     d = _lib.ConvT(2, 30, 30, 3, 64, 5, 5, 2, 2, 0, 15, 15)              # not a 16x32-tileable image
     assert L.cslgan_conv2d_c3_fwd_bf16out(ctypes.byref(d), 16, 16, None, 1, 16, None) == -1 and b"first layer" in err()
     assert L.cslgan_conv2d_c3_wgrad_bf16gy(ctypes.byref(d), 16, 16, 1.0, 16, None, None) == -1 and b"first-layer kernel" in err()

@@ -184,6 +184,32 @@ def test_conv2d_wgrad_grouped_bf16_stored(case, group):
     _close(dense.permute(0, 3, 1, 2), ref.sum(0), rtol=2e-4, what="bf16-stored dense wgrad %s" % (case,))
 
 
+@pytest.mark.parametrize("case", [(8, 16, 16, 256, 512, 5, 2, 2, 4), (6, 32, 32, 64, 128, 5, 2, 2, 2), (4, 8, 8, 64, 64, 3, 1, 1, 4), (6, 16, 16, 128, 256, 5, 2, 2, 6)])
+def test_conv2d_wgrad_clip_weighted_bf16_stored(case):
+    """Clip-weighted sums of ghost-clipped layers from bf16 gy / x: sum_b f_b g_b with the fp32 weight applied to each sample's
+    ACCUMULATED product — equal to weighting the materialised per-sample gradients (fp32 math on the stored values) at 1e-4, i.e. no
+    bfloat16 rounding of f_b * gy anywhere."""
+    ops = _ops()
+    N, H, W, C, K, R, s, p, grp = case
+    g = torch.Generator().manual_seed(_seed(case))
+    x = _bf(torch.randn(N, C, H, W, generator=g))
+    P, Q = (H + 2 * p - R) // s + 1, (W + 2 * p - R) // s + 1
+    assert (P * Q) % 64 == 0
+    gy = _bf(torch.randn(N, K, P, Q, generator=g))
+    f = torch.rand(N, generator=g) * 0.9 + 0.1
+    wz = torch.zeros(K, C, R, R, requires_grad=True)
+    per = torch.stack([torch.autograd.grad(F.conv2d(x[i:i + 1], wz, None, stride=s, padding=p), wz, gy[i:i + 1])[0] for i in range(N)])
+    ref = (per * f.view(N, 1, 1, 1, 1)).reshape(N // grp, grp, K, C, R, R).sum(1) * 1.5
+    got = ops.conv2d_wgrad_grouped(_nhwc16(gy), _nhwc16(x), R, R, stride=s, pad=p, group=grp, alpha=1.5, row_scale=f.cuda())
+    assert got.dtype == torch.float32
+    _close(got.permute(0, 1, 4, 2, 3), ref, rtol=1e-4, what="clip-weighted bf16-stored wgrad %s" % (case,))
+    dense = ops.conv2d_wgrad_dense(_nhwc16(gy), _nhwc16(x), R, R, stride=s, pad=p, alpha=1.5, row_scale=f.cuda())
+    _close(dense.permute(0, 3, 1, 2), ref.sum(0), rtol=2e-4, what="clip-weighted dense sum %s" % (case,))
+    # the weight really is exact: weighting gy in bfloat16 first would differ at the 2^-9 level
+    rounded = torch.stack([torch.autograd.grad(F.conv2d(x[i:i + 1], wz, None, stride=s, padding=p), wz, _bf(gy[i:i + 1] * f[i]))[0] for i in range(N)])
+    assert ((rounded.sum(0) * 1.5 - ref.sum(0)).abs().max() > 3e-4 * ref.sum(0).abs().max()).item()
+
+
 def test_mixed_element_types_fall_back_to_the_fp32_kernels():
     """fp32 gy with bf16 x (the critic's head: fp32 loss cotangent, bf16 features) and the RGB first layer (fp32 image, bf16
     output gradient) run on the fp32 kernels between casts — same numbers as fp32 math on the values as stored."""
@@ -202,6 +228,9 @@ def test_mixed_element_types_fall_back_to_the_fp32_kernels():
     _close(sq, ref2.pow(2).sum(1), rtol=2e-4, what="linear head grouped sq")
     dense = ops.conv2d_wgrad_dense(_nhwc(gy8), _nhwc16(x8), 1, 1, alpha=0.5)
     _close(dense.reshape(-1), ref2.sum(0), rtol=2e-4, what="linear head dense gradient")
+    f8 = torch.rand(16, generator=g) + 0.1
+    densef = ops.conv2d_wgrad_dense(_nhwc(gy8), _nhwc16(x8), 1, 1, alpha=0.5, row_scale=f8.cuda())
+    _close(densef.reshape(-1), 0.5 * ((gy8.reshape(16, 1) * f8.reshape(16, 1)) * x8.reshape(16, 4096)).sum(0), rtol=2e-4, what="linear head clip-weighted sum")
     w8 = torch.randn(1, 4096, 1, 1, generator=g)
     m8 = torch.randn(16, 4096, 1, 1, generator=g)
     gx8 = ops.conv2d_dgrad(_nhwc(gy8), _krsc(w8), (1, 1), mask=_nhwc16(m8), out_dtype=torch.bfloat16)
@@ -323,6 +352,11 @@ def test_conv_autograd_closed_under_bf16_storage():
 
 STEP_CASES = [
     ("CelebA", ["--im_size", "128", "-gcm", "adaptive-pl"], 4, 128),          # BASELINE configs[4] geometry (extension): 128x128
+    # ghost clipping in the bf16 storage mode (the benchmarked configuration): Gram norms of the stored values, clip weights applied in
+    # fp32 to each sample's accumulated product (conv4 + head at 128x128; conv3 on the scaled kernel, conv4 on the fp32 fallback at 64x64)
+    ("CelebA", ["--im_size", "128", "-gcm", "adaptive-pl", "--materialize", "ghost"], 4, 128),
+    ("CelebA", ["-gcm", "adaptive-pl", "--materialize", "ghost"], 8, 128),
+    ("CelebA", ["-c", "2.0", "--materialize", "ghost"], 8, 128),              # flat clipping
     ("CelebA", ["-gcm", "adaptive-pl"], 8, 128),
     ("CelebA", ["-gcm", "adaptive-pl", "--grad_sample_dtype", "bf16", "--materialize", "private"], 8, 128),
 ]
@@ -379,7 +413,7 @@ def test_train_D_bf16_storage_matches_fp32_oracle(tmp_path, dataset, extra, B, l
     replays the device's masks (csl_gan_amd.nn.ActivationMaskRecorder -> oracle.nets.MaskPlayer) as the fp32 parity tests do."""
     opt, tr, oracle, Do, rec, (img, z, ms_a, ms_p, alpha), modes = _run_step(
         tmp_path, dataset, extra + ["--compute_dtype", "bf16", "--storage_dtype", "bf16"], B, latent)
-    assert modes == ("bf16", "bf16") and opt.materialize in ("all", "private")
+    assert modes == ("bf16", "bf16") and opt.materialize == (extra[extra.index("--materialize") + 1] if "--materialize" in extra else "all")
     last = tr.last
     oracle.cfg.sigma = 0.0
     from test_dstep_gpu import _close as close, _masked_oracle

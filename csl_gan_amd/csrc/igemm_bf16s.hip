@@ -443,6 +443,94 @@ __global__ __launch_bounds__(256, 2) void igemm_halos_kernel(const KsParams p) {
     }
 }
 
+// ---- 1x1 convs with 16 / 32 / 64 input channels (the generator's shortcut convs on the shuffled C/4 channels, DCResNet_models.py:22) ----
+// A stream over the pixels: the whole reduction is 1-4 MFMA k-steps, so the gather kernel's 64-k tile was mostly padding (C = 16: a
+// quarter of it) and its LDS round trip pure overhead — 0.26 ms for a layer whose traffic (67 MB in, 268 MB out at 128x128) is 0.08 ms.
+// Here a wavefront owns 32 pixels: its A operand is one 16-byte load per k-step straight from the bf16 rows (a pixel's channels are
+// contiguous, 32 pixels = 512-2048 contiguous bytes), the filter lives in registers for the whole kernel, no LDS, no barriers.
+template <int CK, int TN, bool OUT_BF16>
+__global__ __launch_bounds__(256) void conv1x1s_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ wb, const float* __restrict__ bias,
+                                                       long long M, int K, int act, void* __restrict__ y) {
+    constexpr int C = CK * 16;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    bf16x8 bw[TN][CK];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int s = 0; s < CK; ++s) {
+            const int n = 32 * j + r;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (n < K) v = *reinterpret_cast<const uint4*>(wb + (long long)n * C + 16 * s + 8 * h);
+            bw[j][s] = __builtin_bit_cast(bf16x8, v);
+        }
+    float bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = (bias && 32 * j + r < K) ? bias[32 * j + r] : 0.f;
+    const long long n_tiles = (M + 31) / 32;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * 4;
+    for (long long t = wave0; t < n_tiles; t += n_waves) {
+        const long long m = 32 * t + r;
+        f32x16 acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+#pragma unroll
+        for (int s = 0; s < CK; ++s) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (m < M) v = *reinterpret_cast<const uint4*>(x + m * C + 16 * s + 8 * h);
+            const bf16x8 a = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[j][s], acc[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = 32 * j + r;
+            if (n >= K) continue;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const long long row = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (row >= M) continue;
+                float val = acc[j][v] + bv[j];
+                if (act == CSLGAN_ACT_LRELU02) val = val > 0.f ? val : 0.2f * val;
+                else if (act == CSLGAN_ACT_RELU) val = val > 0.f ? val : 0.f;
+                else if (act == CSLGAN_ACT_TANH) val = tanhf(val);
+                if (OUT_BF16) reinterpret_cast<unsigned short*>(y)[row * K + n] = f2bf(val);
+                else reinterpret_cast<float*>(y)[row * K + n] = val;
+            }
+        }
+    }
+}
+
+static bool conv1x1s_eligible(const cslgan_conv_t* c, const void* residual) {
+    static const int env = [] { const char* e = getenv("CSLGAN_CONV1X1S"); return e ? atoi(e) : 1; }();
+    return env && !residual && c->R == 1 && c->S == 1 && c->stride == 1 && c->pad == 0 && (c->C == 16 || c->C == 32 || c->C == 64) &&
+           c->K % 32 == 0 && c->K >= 32 && c->K <= 128 && (long long)c->N * c->H * c->W >= 65536;
+}
+
+template <int CK>
+static int launch_conv1x1s_ck(const cslgan_conv_t* c, const void* x, const void* wb, const float* bias, int act, void* y, int y_bf16, hipStream_t st) {
+    const long long M = (long long)c->N * c->H * c->W;
+    long long nb = (M / 32 + 3) / 4;
+    nb = nb > 2048 ? 2048 : (nb < 1 ? 1 : nb);
+    const dim3 grid((unsigned)nb), block(256);
+    const unsigned short* xh = reinterpret_cast<const unsigned short*>(x);
+    const unsigned short* wh = reinterpret_cast<const unsigned short*>(wb);
+    note_kernel("conv1x1s_kernel<%d>", CK * 16);
+#define CSL_C1S(TN)                                                                                                          \
+    do {                                                                                                                     \
+        if (y_bf16) hipLaunchKernelGGL((conv1x1s_kernel<CK, TN, true>), grid, block, 0, st, xh, wh, bias, M, c->K, act, y);   \
+        else hipLaunchKernelGGL((conv1x1s_kernel<CK, TN, false>), grid, block, 0, st, xh, wh, bias, M, c->K, act, y);         \
+    } while (0)
+    const int tn = c->K / 32;
+    if (tn == 1) CSL_C1S(1);
+    else if (tn == 2) CSL_C1S(2);
+    else if (tn == 3) CSL_C1S(3);
+    else CSL_C1S(4);
+#undef CSL_C1S
+    return check_launch("conv1x1s_kernel");
+}
+
 int split_filter_x3(const float* w, int Nn, int T, int C, void* w3, hipStream_t st, int pieces);      // igemm_bf16.hip
 
 // stride-1 classes (one for a forward conv; the output-parity classes of a strided data gradient), each on an 8x8-patchable grid of at
@@ -1235,6 +1323,16 @@ int cslgan_conv2d_fwd_bf16s(const cslgan_conv_t* c, const void* x, const float* 
         return check_launch("linear_k1s_fwd_kernel");
     }
     const long long wn = (long long)c->K * c->R * c->S * c->C;
+    if (conv1x1s_eligible(c, residual) && aligned16(x) && aligned16(w) && aligned16(wb_ws)) {      // the generator's shortcut convs: a stream over pixels
+        if (repack) {
+            hipLaunchKernelGGL(round_bf16_kernel, dim3(stream_blocks(wn / 4)), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(wb_ws), wn);
+            rc = check_launch("round_bf16_kernel");
+            if (rc) return rc;
+        }
+        if (c->C == 16) return launch_conv1x1s_ck<1>(c, x, wb_ws, bias, act, y, y_bf16, st);
+        if (c->C == 32) return launch_conv1x1s_ck<2>(c, x, wb_ws, bias, act, y, y_bf16, st);
+        return launch_conv1x1s_ck<4>(c, x, wb_ws, bias, act, y, y_bf16, st);
+    }
     KsParams p{};
     p.a = x; p.AH = c->H; p.AW = c->W; p.AC = c->C; p.VH = c->H; p.VW = c->W; p.sy = p.sx = c->stride;
     p.w = wb_ws; p.Nn = c->K; p.out = y; p.OHf = c->P; p.OWf = c->Q; p.osy = p.osx = 1; p.ldo = c->K; p.dense_out = 1;

@@ -46,28 +46,49 @@ __global__ __launch_bounds__(256) void igemm_skinny_kernel(const KcParams p) {
 
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
     // ---- halo: hpix pixels x 16 float4 ------------------------------------------------------------------
-    constexpr int HREG = (SK_HALO * 16 + 255) / 256;
-    float4 rh[HREG];
+    const int cl = tid & 15;
+    if (p.a_bf16) {
+        // bf16-stored input (csrc/igemm_bf16s.hip's storage mode): a 16-byte load is 8 channels, widened to two float4 of the fp32 LDS
+        // image (the arithmetic stays fp32).  Two 4-byte loads per lane ran the 64 -> 3 output conv at 0.45 ms against 0.34 ms for the
+        // fp32 input: the kernel is bound by its load instructions, so the bf16 form must not issue more of them than the fp32 one.
+        constexpr int HREG8 = (SK_HALO * 8 + 255) / 256;
+        uint4 r8[HREG8];
 #pragma unroll
-    for (int j = 0; j < HREG; ++j) {
-        const int idx = tid + 256 * j;
-        const int c4 = idx & 15, pix = idx >> 4;
-        const int hy = pix / HW_, hx = pix - hy * HW_;
-        const int iy = y0 + hy, ix = x0 + hx;
-        const bool ok = pix < hpix && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
-        if (p.a_bf16) {        // bf16-stored input: 4 channels = 8 bytes, widened here (the arithmetic stays fp32)
-            const unsigned o = ok ? 2u * (unsigned)(img_base + (iy * p.AW + ix) * SK_C + c4 * 4) : SOOB;
-            const unsigned lo = __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, (int)o, 0, 0), hi = __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, (int)(o == SOOB ? SOOB : o + 4u), 0, 0);
-            rh[j] = make_float4(__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u));
-        } else {
+        for (int j = 0; j < HREG8; ++j) {
+            const int idx = tid + 256 * j;
+            const int c8 = idx & 7, pix = idx >> 3;
+            const int hy = pix / HW_, hx = pix - hy * HW_;
+            const int iy = y0 + hy, ix = x0 + hx;
+            const bool ok = pix < hpix && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(ok ? 2u * (unsigned)(img_base + (iy * p.AW + ix) * SK_C + c8 * 8) : SOOB), 0, 0);
+            r8[j] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < HREG8; ++j) {
+            const int idx = tid + 256 * j;
+            if ((idx >> 3) < hpix) {
+                const uint4 v = r8[j];
+                Hs[2 * idx] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+                Hs[2 * idx + 1] = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u));
+            }
+        }
+    } else {
+        constexpr int HREG = (SK_HALO * 16 + 255) / 256;
+        float4 rh[HREG];
+#pragma unroll
+        for (int j = 0; j < HREG; ++j) {
+            const int idx = tid + 256 * j;
+            const int c4 = idx & 15, pix = idx >> 4;
+            const int hy = pix / HW_, hx = pix - hy * HW_;
+            const int iy = y0 + hy, ix = x0 + hx;
+            const bool ok = pix < hpix && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
             rh[j] = sbuf_load4(a_rsrc, ok ? 4u * (unsigned)(img_base + (iy * p.AW + ix) * SK_C + c4 * 4) : SOOB);
         }
-    }
-    const int cl = tid & 15;
 #pragma unroll
-    for (int j = 0; j < HREG; ++j) {
-        const int idx = tid + 256 * j;
-        if ((idx >> 4) < hpix) Hs[idx] = rh[j];
+        for (int j = 0; j < HREG; ++j) {
+            const int idx = tid + 256 * j;
+            if ((idx >> 4) < hpix) Hs[idx] = rh[j];
+        }
     }
     __syncthreads();
 

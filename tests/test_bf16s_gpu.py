@@ -80,6 +80,9 @@ FWD_CASES = [
     (2, 64, 64, 32, 64, 5, 1, 2, False, 0, None, True),           # LDS-halo form, 64 filters
     (2, 16, 16, 128, 256, 5, 1, 2, True, 2, "bf16", True),        # LDS-halo form, 128-wide filter tiles, bf16 residual
     (2, 32, 32, 16, 64, 5, 1, 2, False, 0, "f32", False),         # LDS-halo form on one 16-channel chunk, fp32 residual / output
+    (128, 32, 32, 64, 128, 1, 1, 0, True, 0, None, True),         # 1x1 stream kernel (the generator's shortcut convs): 64 -> 128
+    (64, 64, 64, 16, 64, 1, 1, 0, False, 0, None, True),          # ... 16 -> 64: the whole reduction is one MFMA k-step
+    (70, 31, 31, 32, 96, 1, 1, 0, True, 2, None, False),          # ... ragged pixel count, three filter tiles, ReLU, fp32 output
 ]
 
 

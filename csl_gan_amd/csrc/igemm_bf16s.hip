@@ -249,8 +249,9 @@ constexpr int HS_MAX = 12 * 12;        // pixels per patch halo (8+4 squared: up
 template <int BN, bool OUT_BF16>
 __global__ __launch_bounds__(256, 2) void igemm_halos_kernel(const KsParams p) {
     constexpr int RING = 4;
-    constexpr int BM = 128, TM = 2, TN = BN / 64;            // waves 2 (M: one patch each) x 2 (N)
-    __shared__ __attribute__((aligned(16))) uint2 Hs[2 * HS_MAX * 4];     // [patch][pixel][4 x (4 ch bf16)]
+    constexpr int PATCHES = 2, WN = 2;                       // waves 2 (M: one 8x8 patch each) x 2 (N halves)
+    constexpr int BM = 64 * PATCHES, TM = 2, TN = BN / (32 * WN);
+    __shared__ __attribute__((aligned(16))) uint2 Hs[PATCHES * HS_MAX * 4];     // [patch][pixel][4 x (4 ch bf16)]
     __shared__ int s_tapoff[IG_MAX_TAPS];
     __shared__ int s_off[BM];
 
@@ -271,10 +272,10 @@ __global__ __launch_bounds__(256, 2) void igemm_halos_kernel(const KsParams p) {
     if (tid < IG_MAX_TAPS) s_tapoff[tid] = ((((int)kc.ty[tid] - kc.ty_min) * HW_ + ((int)kc.tx[tid] - kc.tx_min)) * 4) | (((int)kc.ty[tid] - kc.ty_min) & 1);
 
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, p.a_bytes, 0x00020000);
-    int p_img[2], p_y0[2], p_x0[2];
-    bool p_ok[2];
+    int p_img[PATCHES], p_y0[PATCHES], p_x0[PATCHES];
+    bool p_ok[PATCHES];
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
+    for (int pp = 0; pp < PATCHES; ++pp) {
         const int m = m0 + 64 * pp;
         p_ok[pp] = m < M;
         const RowCoord rc = kc_decode_row(p_ok[pp] ? m : 0, OHc, OWc, 1);     // first row of the patch = its top-left pixel
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halos_kernel(const KsParams p) {
     }
     const int lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int wm = wid >> 1, wn = wid & 1;                   // wm = patch index
+    const int wm = wid / WN, wn = wid - wm * WN;             // wm = patch index
     // filter: lane (r, h), tile j reads 8 consecutive k of filter row n0 + wn*TN*32 + j*32 + r of one step = one 16-byte load
     const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(p.w3) + p.w3_off[ci]), 0, 2u * (unsigned)p.Nn * (unsigned)kc.Kdim, 0x00020000);
@@ -305,21 +306,28 @@ __global__ __launch_bounds__(256, 2) void igemm_halos_kernel(const KsParams p) {
             rb[slot][j] = __builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, (int)o, 0, 0);
         }
     };
-    // halo staging: 2 patches x hpix pixels x 2 halves of 8 channels; <= 2*144*2/256 = 2.25 16-byte loads per thread
-    constexpr int HREG = (2 * HS_MAX * 2 + 255) / 256;
+    // halo staging: PATCHES x hpix pixels x 2 halves of 8 channels; <= PATCHES*144*2/256 = 2.25 / 4.5 16-byte loads per thread
+    constexpr int HREG = (PATCHES * HS_MAX * 2 + 255) / 256;
     u32x4 rh[HREG];
-    const int h_total = 2 * hpix * 2;
+    const int h_total = PATCHES * hpix * 2;
     auto fetch_halo = [&](int cc) {
 #pragma unroll
         for (int j = 0; j < HREG; ++j) {
             const int idx = tid + 256 * j;
             const int half = idx & 1, pixg = idx >> 1;
-            const int pp = pixg >= hpix ? 1 : 0;
+            const int pp = idx < h_total ? pixg / hpix : 0;
             const int pix = pixg - pp * hpix;
             const int hy = pix / HW_, hx = pix - hy * HW_;
-            const int iy = p_y0[pp] + hy, ix = p_x0[pp] + hx;
-            const bool ok = idx < h_total && p_ok[pp] && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
-            rh[j] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(ok ? 2u * (unsigned)(p_img[pp] + (iy * p.AW + ix) * p.AC + cc * 16 + half * 8) : S_OOB16), 0, 0);
+            // (select chains, not p_y0[pp]: a dynamically indexed register array goes to scratch)
+            int sy0 = p_y0[0], sx0 = p_x0[0], simg = p_img[0];
+            bool sok = p_ok[0];
+#pragma unroll
+            for (int q = 1; q < PATCHES; ++q) {
+                sy0 = pp == q ? p_y0[q] : sy0; sx0 = pp == q ? p_x0[q] : sx0; simg = pp == q ? p_img[q] : simg; sok = pp == q ? p_ok[q] : sok;
+            }
+            const int iy = sy0 + hy, ix = sx0 + hx;
+            const bool ok = idx < h_total && sok && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
+            rh[j] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(ok ? 2u * (unsigned)(simg + (iy * p.AW + ix) * p.AC + cc * 16 + half * 8) : S_OOB16), 0, 0);
         }
     };
     auto commit_halo = [&]() {
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halos_kernel(const KsParams p) {
             const int idx = tid + 256 * j;
             if (idx < h_total) {
                 const int half = idx & 1, pixg = idx >> 1;
-                const int pp = pixg >= hpix ? 1 : 0;
+                const int pp = pixg / hpix;
                 const int pix = pixg - pp * hpix;
                 // the two 16-byte halves of a pixel are swapped on odd halo rows (the two patch rows a 16-lane ds_read_b128 group
                 // covers then hit disjoint banks)
@@ -338,13 +346,14 @@ __global__ __launch_bounds__(256, 2) void igemm_halos_kernel(const KsParams p) {
         }
     };
 
-    int a_base[2][TM];                                       // uint2 offset of this lane's pixel (tap 0,0 corner) per MFMA tile,
-#pragma unroll                                               // for taps landing on an even / odd halo row (half-swap swizzle)
+    // uint2 offset of this lane's pixel (tap 0,0 corner) per MFMA tile; a tap landing on an odd halo row reads the other 16-byte half
+    // of the pixel (half-swap swizzle): a_pix + (a_half ^ (odd << 1)) — arithmetic, not a [2][TM] table (that went to scratch)
+    int a_pix[TM], a_half[TM];
+#pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int qq = i * 32 + r;                           // row within the patch
-        const int pix = (wm * HS_MAX + (qq >> 3) * HW_ + (qq & 7)) * 4;
-        a_base[0][i] = pix + ((h ^ ((qq >> 3) & 1)) << 1);
-        a_base[1][i] = pix + ((h ^ (((qq >> 3) + 1) & 1)) << 1);
+        a_pix[i] = (wm * HS_MAX + (qq >> 3) * HW_ + (qq & 7)) * 4;
+        a_half[i] = (h ^ ((qq >> 3) & 1)) << 1;
     }
 
     f32x16 acc[TM][TN];
@@ -365,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halos_kernel(const KsParams p) {
     auto read_a = [&](int t) {
         const int tw = s_tapoff[t], toff = tw & ~1, odd = tw & 1;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af_n[i] = *reinterpret_cast<const bf16x8*>(&Hs[(odd ? a_base[1][i] : a_base[0][i]) + toff]);
+        for (int i = 0; i < TM; ++i) af_n[i] = *reinterpret_cast<const bf16x8*>(&Hs[a_pix[i] + (a_half[i] ^ (odd << 1)) + toff]);
     };
     read_a(0);
 
@@ -572,8 +581,11 @@ static int launch_halos(KsParams& p, bool out_bf16, hipStream_t st) {
     const long long a_b = 2ll * n_img * p.AH * p.AW * p.AC;
     CSLGAN_REQUIRE(a_b < 0xFFFFFFF0ll && 2ll * w_el < 0xFFFFFFF0ll, "igemm_halos: operand larger than 4 GB");
     p.a_bytes = (unsigned)a_b;
-    p.tiles_m = tm;
     const bool wide = p.Nn > 64;
+    // (A four-patch form for the 64-filter layers — one patch per wave, each wave all 64 filters, four MFMAs per step instead of two —
+    // was built and measured same-box: 312 vs 396 TF on the 128x128x64 layer, 257 vs 324 and 309 vs 363 on the others.  The steps are
+    // paced by the filter slices every wave streams from L1 / L2, not by MFMAs per operand load; it was removed again.)
+    p.tiles_m = tm;
     p.tiles_n = wide ? (p.Nn + 127) / 128 : 1;
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);
     note_kernel("igemm_halos_kernel<%d>", wide ? 128 : 64);

@@ -201,6 +201,10 @@ def main():
     saved_env = {k: os.environ.get(k) for k in ("CSLGAN_GP_STREAM", "CSLGAN_CLIP_STREAM")}
     os.environ.update({k: "0" for k in saved_env})
     for _ in range(n_probe):
+        # A few milliseconds of head start for the host: an event pair brackets the launch CALL, so on an idle GPU the pair also times the
+        # host's way from the first record to the launch (the generator's first small kernels read 0.3-0.6 ms for 10-30 us of work).
+        # With the queue ahead of the device every pair times its kernel.
+        torch.cuda._sleep(int(6e-3 * 2.1e9))
         step()
     torch.cuda.synchronize()
     for k, v in saved_env.items():
@@ -280,6 +284,10 @@ def main():
         exec_flop_step = sum(v["exec_flop"] for v in kernels.values()) / n_pr
         if a.dump_shapes:
             with open(a.dump_shapes, "w") as f:
+                f.write("# HIP-event times of the launch-by-launch instrumented steps (eager, one stream, %d step(s)).  An event pair brackets the launch\n"
+                        "# CALL: for a few short launches at the head of the generator (its first linear layer, the first 1x1 / 5x5 convs after a\n"
+                        "# normalisation) the pair reads 0.2-0.6 ms where rocprofv3 --kernel-trace of the same command shows 10-250 us\n"
+                        "# (profiles/*kernel_stats*.csv, authoritative for kernel durations; the headline region replays a HIP graph).\n" % n_pr)
                 for k, v in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"]):
                     f.write("%-78s n/step %5.1f  avg_ms %8.4f  ms/step %7.3f  %s\n" % (
                         k, v["n"] / n_pr, v["ms"] / v["n"], v["ms"] / n_pr,

@@ -15,7 +15,8 @@ Additions of this build (all optional, none changes a reference default):
                        fp32_auto (per launch the faster of those two) or bf16 (operands rounded to bfloat16 inside the
                        kernels, fp32 accumulate; BASELINE.json configs[4]).  With bf16
                        the per-sample norms must be norms of the gradients that are actually summed, so ghost clipping (whose
-                       Gram norms are computed in fp32) is replaced by --materialize private
+                       Gram norms are computed in fp32) is replaced by --materialize private — unless the activations are also STORED as
+                       bfloat16 (--storage_dtype bf16), where the Gram norms are the norms of the stored values' gradients
   --storage_dtype T    element type of the critic's activations and activation gradients in HBM: fp32 (default) or bf16 (needs
                        --compute_dtype bf16: bf16-stored kernels of csrc/igemm_bf16s.hip, bf16 filter copies, fp32 accumulation,
                        fp32 weight gradients / norms / clip / noise / Adam; BASELINE.json configs[4])

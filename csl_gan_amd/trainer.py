@@ -364,7 +364,7 @@ class Trainer:
         from . import ops
         o, D = self.opt, self.D
         params = list(D.parameters())
-        single_term = len(o.penalty) == 1 and not (o.aux_penalty and hasattr(D, "linOutAux"))
+        single_term = len(o.penalty) == 1 and not (o.aux_penalty and getattr(D, "linOutAux", None) is not None)
         if single_term and penalty.is_cuda:
             with ops.deferred_sums():
                 return autograd.grad(penalty, params, create_graph=False, retain_graph=False, allow_unused=True)

@@ -179,12 +179,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kcs_kernel(const KsParams p) {
     load_tile(1, ra1, rb1);          // past the last tile every offset is out of range -> zeros, never multiplied
     store_tile(0, ra0, rb0);
     __syncthreads();
+    // ONE loop exit: with a break between the halves the epilogue had two live-in states for the accumulators and the register
+    // allocator copied all 64 of them (32 v_mov_b64) plus the staging registers between the halves of every iteration — 107 moves per
+    // 16 MFMAs, most of the "8 vector instructions per MFMA" the PMC counters showed.  An odd tile count multiplies one all-zero tile.
     for (int kt = 0; kt < nk; kt += 2) {
         load_tile(kt + 2, ra0, rb0);
         mma_tile(0);
-        store_tile(1, ra1, rb1);     // tile kt + 1
+        store_tile(1, ra1, rb1);     // tile kt + 1 (zeros past the end)
         __syncthreads();
-        if (kt + 1 >= nk) break;     // uniform
         load_tile(kt + 3, ra1, rb1);
         mma_tile(1);
         store_tile(0, ra0, rb0);     // tile kt + 2
@@ -932,13 +934,14 @@ __global__ __launch_bounds__(256, 2) void igemm_mcs_tr_kernel(const MsParams p) 
 
     // two register sets: tile t+2 is loaded under the MFMAs of tile t and written to LDS after those of tile t+1 (see igemm_kcs_kernel)
     uint4 rv0[8], rv1[8];
+    int k_lim = Ktot;            // pixels this workgroup may read (its K range when the reduction is split): past it every load is zero
     auto load_tile = [&](int kt, uint4 (&rv)[8]) {
         const int kk0 = kt * MS_BK + kg * 8;
         if (is_a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (a_ok && kk0 + j < Ktot) v = *reinterpret_cast<const uint4*>(gyh + (pix_base + kk0 + j) * p.Kc + m0 + c8);
+                if (a_ok && kk0 + j < k_lim) v = *reinterpret_cast<const uint4*>(gyh + (pix_base + kk0 + j) * p.Kc + m0 + c8);
                 rv[j] = v;
             }
         } else if (Q8) {
@@ -947,7 +950,7 @@ __global__ __launch_bounds__(256, 2) void igemm_mcs_tr_kernel(const MsParams p) 
             const int oy = pix / p.Q, ox0 = pix - oy * p.Q;
             const long long img = (long long)g * p.group + il;
             const int iy = oy * p.stride + b_ty;
-            const bool row_ok = b_ok && kk0 < Ktot && iy >= 0 && iy < p.H;
+            const bool row_ok = b_ok && kk0 < k_lim && iy >= 0 && iy < p.H;
             const unsigned short* src = xh + ((img * p.H + iy) * p.W) * p.C + b_c;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -961,7 +964,7 @@ __global__ __launch_bounds__(256, 2) void igemm_mcs_tr_kernel(const MsParams p) 
             for (int j = 0; j < 8; ++j) {
                 const int kk = kk0 + j;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (b_ok && kk < Ktot) {
+                if (b_ok && kk < k_lim) {
                     const int il = kk / PQ;
                     const int pix = kk - il * PQ;
                     const int oy = pix / p.Q, ox = pix - oy * p.Q;
@@ -1017,6 +1020,7 @@ __global__ __launch_bounds__(256, 2) void igemm_mcs_tr_kernel(const MsParams p) 
         nk = kt0 + per < nk_all ? kt0 + per : nk_all;
         if (kt0 >= nk) return;      // uniform across the workgroup
     }
+    k_lim = nk * MS_BK < Ktot ? nk * MS_BK : Ktot;
     auto mma_tile = [&](int buf) {
         const unsigned char* As = smem + (buf * 2) * OPB;
         const unsigned char* Bs = As + OPB;
@@ -1083,12 +1087,11 @@ __global__ __launch_bounds__(256, 2) void igemm_mcs_tr_kernel(const MsParams p) 
     load_tile(kt0 + 1, rv1);         // past the group's pixels every lane loads zeros (kk >= Ktot)
     store_tile(0, rv0);
     __syncthreads();
-    for (int kt = kt0; kt < nk; kt += 2) {
+    for (int kt = kt0; kt < nk; kt += 2) {      // one loop exit (see igemm_kcs_kernel): an odd tile count multiplies one all-zero tile
         load_tile(kt + 2, rv0);
         mma_tile(0);
-        store_tile(1, rv1);          // tile kt + 1
+        store_tile(1, rv1);          // tile kt + 1 (zeros past k_lim)
         __syncthreads();
-        if (kt + 1 >= nk) break;     // uniform
         load_tile(kt + 3, rv1);
         mma_tile(1);
         store_tile(0, rv0);          // tile kt + 2

@@ -122,22 +122,25 @@ __global__ __launch_bounds__(256, 2) void igemm_kcs_kernel(const KsParams p) {
     // set (loads one tile ahead) the kernel waited on its loads every iteration: 390-500 TF.
     u32x4 ra0[A_PASS], rb0[B_PASS], ra1[A_PASS], rb1[B_PASS];
     auto load_tile = [&](int kt, u32x4 (&ra)[A_PASS], u32x4 (&rb)[B_PASS]) {
+        // Branch-free offsets: an invalid element ORs 0xFFFFFFF0 into its (always computed) offset, which the buffer descriptor's range
+        // check turns into a zero load.  Written as `ok ? offset : OOB` the compiler put every load into its own exec-masked block
+        // (nine s_and_saveexec per half iteration), which also kept it from issuing the eight loads back to back.
         const int kb = kt * KS_BK + e * 8;
         const bool kin = kb < Kdim;
-        const int t = kin ? (int)__umulhi((unsigned)kb, p.ac_recip) : 0;
-        const int c = kb - t * p.AC;
+        const int t = (int)__umulhi((unsigned)(kin ? kb : 0), p.ac_recip);
+        const int c = (kin ? kb : 0) - t * p.AC;
         const int tap = s_tap[t];
         const int ty = tap >> 16, tx = (int)(short)(tap & 0xffff);
+        const unsigned kbad = kin ? 0u : S_OOB16;
 #pragma unroll
         for (int i = 0; i < A_PASS; ++i) {
             const int iy = a_iy[i] + ty, ix = a_ix[i] + tx;
-            const bool ok = kin && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(ok ? 2u * (unsigned)(a_img[i] + (iy * p.AW + ix) * p.AC + c) : S_OOB16), 0, 0);
+            const unsigned bad = ((unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW) ? kbad : S_OOB16;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)((2u * (unsigned)(a_img[i] + (iy * p.AW + ix) * p.AC + c)) | bad), 0, 0);
         }
-        const unsigned kofs = kin ? 2u * (unsigned)kb : S_OOB16;
 #pragma unroll
         for (int i = 0; i < B_PASS; ++i)
-            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)((b_off[i] == S_OOB16 || kofs == S_OOB16) ? S_OOB16 : b_off[i] + kofs), 0, 0);
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)((b_off[i] + 2u * (unsigned)kb) | kbad | (b_off[i] == S_OOB16 ? S_OOB16 : 0u)), 0, 0);
     };
     auto store_tile = [&](int buf, const u32x4 (&ra)[A_PASS], const u32x4 (&rb)[B_PASS]) {
 #pragma unroll

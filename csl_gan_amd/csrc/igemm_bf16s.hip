@@ -307,8 +307,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halos_kernel(const KsParams p) {
         const unsigned kb = (unsigned)step * step_bytes;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const unsigned o = (step >= n_steps || b_off[j] == S_OOB16) ? S_OOB16 : b_off[j] + kb;
-            rb[slot][j] = __builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, (int)o, 0, 0);
+            rb[slot][j] = __builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, (int)((b_off[j] + kb) | ((step >= n_steps || b_off[j] == S_OOB16) ? S_OOB16 : 0u)), 0, 0);
         }
     };
     // halo staging: PATCHES x hpix pixels x 2 halves of 8 channels; <= PATCHES*144*2/256 = 2.25 / 4.5 16-byte loads per thread
@@ -332,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halos_kernel(const KsParams p) {
             }
             const int iy = sy0 + hy, ix = sx0 + hx;
             const bool ok = idx < h_total && sok && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
-            rh[j] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(ok ? 2u * (unsigned)(simg + (iy * p.AW + ix) * p.AC + cc * 16 + half * 8) : S_OOB16), 0, 0);
+            rh[j] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)((2u * (unsigned)(simg + (iy * p.AW + ix) * p.AC + cc * 16 + half * 8)) | (ok ? 0u : S_OOB16)), 0, 0);
         }
     };
     auto commit_halo = [&]() {
@@ -932,8 +931,14 @@ __global__ __launch_bounds__(256, 2) void igemm_mcs_tr_kernel(const MsParams p) 
     const int b_c = nb - b_t * p.C;
     const int b_ty = p.ty[b_t], b_tx = p.tx[b_t];
     const bool a_ok = m0 + c8 < p.Kc;
-    const unsigned short* __restrict__ gyh = reinterpret_cast<const unsigned short*>(p.gy);
-    const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(p.x);
+    // buffer loads with branch-free offsets (an invalid element ORs 0xFFFFFFF0 into its offset -> the range check returns zeros): see
+    // igemm_kcs_kernel — as `if (valid) v = *ptr` every load sat in its own exec-masked block
+    const __amdgpu_buffer_rsrc_t gy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.gy), 0, (unsigned)(2ll * p.N * PQ * p.Kc), 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (unsigned)(2ll * p.N * p.H * p.W * p.C), 0x00020000);
+    auto bld = [](__amdgpu_buffer_rsrc_t r, unsigned off) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+        return make_uint4(v[0], v[1], v[2], v[3]);
+    };
 
     // two register sets: tile t+2 is loaded under the MFMAs of tile t and written to LDS after those of tile t+1 (see igemm_kcs_kernel)
     uint4 rv0[8], rv1[8];
@@ -942,40 +947,33 @@ __global__ __launch_bounds__(256, 2) void igemm_mcs_tr_kernel(const MsParams p) 
         const int kk0 = kt * MS_BK + kg * 8;
         if (is_a) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (a_ok && kk0 + j < k_lim) v = *reinterpret_cast<const uint4*>(gyh + (pix_base + kk0 + j) * p.Kc + m0 + c8);
-                rv[j] = v;
-            }
+            for (int j = 0; j < 8; ++j)
+                rv[j] = bld(gy_rsrc, (2u * (((unsigned)pix_base + (unsigned)(kk0 + j)) * (unsigned)p.Kc + (unsigned)(m0 + c8))) | ((a_ok && kk0 + j < k_lim) ? 0u : S_OOB16));
         } else if (Q8) {
             const int il = kk0 / PQ;
             const int pix = kk0 - il * PQ;
             const int oy = pix / p.Q, ox0 = pix - oy * p.Q;
-            const long long img = (long long)g * p.group + il;
+            const int img = g * p.group + il;           // (32-bit: the entry checks that both operands are below 4 GB)
             const int iy = oy * p.stride + b_ty;
-            const bool row_ok = b_ok && kk0 < k_lim && iy >= 0 && iy < p.H;
-            const unsigned short* src = xh + ((img * p.H + iy) * p.W) * p.C + b_c;
+            const unsigned row_bad = (b_ok && kk0 < k_lim && iy >= 0 && iy < p.H) ? 0u : S_OOB16;
+            const unsigned src = 2u * (unsigned)(((img * p.H + iy) * p.W) * p.C + b_c);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int ix = (ox0 + j) * p.stride + b_tx;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (row_ok && ix >= 0 && ix < p.W) v = *reinterpret_cast<const uint4*>(src + (long long)ix * p.C);
-                rv[j] = v;
+                rv[j] = bld(x_rsrc, (src + 2u * (unsigned)(ix * p.C)) | row_bad | ((unsigned)ix < (unsigned)p.W ? 0u : S_OOB16));
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int kk = kk0 + j;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (b_ok && kk < k_lim) {
-                    const int il = kk / PQ;
-                    const int pix = kk - il * PQ;
-                    const int oy = pix / p.Q, ox = pix - oy * p.Q;
-                    const long long img = (long long)g * p.group + il;
-                    const int iy = oy * p.stride + b_ty, ix = ox * p.stride + b_tx;
-                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = *reinterpret_cast<const uint4*>(xh + ((img * p.H + iy) * p.W + ix) * p.C + b_c);
-                }
-                rv[j] = v;
+                const int kc2 = kk < k_lim ? kk : 0;
+                const int il = kc2 / PQ;
+                const int pix = kc2 - il * PQ;
+                const int oy = pix / p.Q, ox = pix - oy * p.Q;
+                const int img = g * p.group + il;
+                const int iy = oy * p.stride + b_ty, ix = ox * p.stride + b_tx;
+                const bool ok = b_ok && kk < k_lim && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                rv[j] = bld(x_rsrc, (2u * (unsigned)(((img * p.H + iy) * p.W + ix) * p.C + b_c)) | (ok ? 0u : S_OOB16));
             }
         }
     };
@@ -1455,6 +1453,7 @@ int cslgan_conv2d_wgrad_grouped_bf16s(const cslgan_conv_t* c, const void* gy, co
     if (rc) return rc;
     CSLGAN_REQUIRE(group >= 1 && c->N % group == 0, "conv2d_wgrad_bf16s: N=%d not divisible by group=%d", c->N, group);
     CSLGAN_REQUIRE(c->K % 8 == 0 && c->C % 8 == 0 && aligned16(gy) && aligned16(x), "conv2d_wgrad_bf16s: K and C must be multiples of 8, operands 16-byte aligned");
+    CSLGAN_REQUIRE(2ll * c->N * c->P * c->Q * c->K < 0xFFFFFFF0ll && 2ll * c->N * c->H * c->W * c->C < 0xFFFFFFF0ll, "conv2d_wgrad_bf16s: operand larger than 4 GB");
     hipStream_t st = (hipStream_t)stream;
     MsParams p{};
     p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->P; p.Q = c->Q; p.Kc = c->K;
@@ -1507,6 +1506,7 @@ int cslgan_conv2d_wgrad_scaled_bf16s(const cslgan_conv_t* c, const void* gy, con
     if (rc) return rc;
     CSLGAN_REQUIRE(group >= 1 && c->N % group == 0, "conv2d_wgrad_scaled_bf16s: N=%d not divisible by group=%d", c->N, group);
     CSLGAN_REQUIRE(c->K % 8 == 0 && c->C % 8 == 0 && aligned16(gy) && aligned16(x), "conv2d_wgrad_scaled_bf16s: K and C must be multiples of 8, operands 16-byte aligned");
+    CSLGAN_REQUIRE(2ll * c->N * c->P * c->Q * c->K < 0xFFFFFFF0ll && 2ll * c->N * c->H * c->W * c->C < 0xFFFFFFF0ll, "conv2d_wgrad_scaled_bf16s: operand larger than 4 GB");
     CSLGAN_REQUIRE((c->P * c->Q) % MS_BK == 0, "conv2d_wgrad_scaled_bf16s: P*Q=%d is not a multiple of %d (a K tile must lie in one sample)", c->P * c->Q, MS_BK);
     hipStream_t st = (hipStream_t)stream;
     MsParams p{};

@@ -127,7 +127,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kc_bf16_kernel(const KcParams p)
     auto a_offset = [&](int i, int ty, int tx, int c, bool kin) -> unsigned {
         const int iy = a_iy[i] + ty, ix = a_ix[i] + tx;
         const bool ok = kin && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
-        return ok ? 4u * (unsigned)(a_img[i] + (iy * p.AW + ix) * p.AC + c) : OOB16;
+        // branch-free: an invalid element ORs 0xFFFFFFF0 into its (always computed) offset -> the descriptor's range check returns zeros;
+        // as `ok ? offset : OOB16` every load sat in its own exec-masked block (found in csrc/igemm_bf16s.hip: +7-10 % there)
+        return (4u * (unsigned)(a_img[i] + (iy * p.AW + ix) * p.AC + c)) | (ok ? 0u : OOB16);
     };
     auto load_tile = [&](int kt) {
         const int kb = kt * IG_BK + q * 4;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kc_bf16_kernel(const KcParams p)
         if (VEC_B) {
             const unsigned kofs = kb < k_end ? 4u * (unsigned)kb : OOB16;
 #pragma unroll
-            for (int i = 0; i < B_PASS; ++i) rb[i] = bload4(w_rsrc, (b_off[i] == OOB16 || kofs == OOB16) ? OOB16 : b_off[i] + kofs);
+            for (int i = 0; i < B_PASS; ++i) rb[i] = bload4(w_rsrc, (b_off[i] + 4u * (unsigned)kb) | ((b_off[i] == OOB16 || kofs == OOB16) ? OOB16 : 0u));
         } else {
 #pragma unroll
             for (int i = 0; i < B_PASS; ++i) {
@@ -676,10 +678,10 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_x3_kernel(const KcParams p)
         const unsigned kb = (unsigned)step * step_bytes;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const unsigned o = (step >= n_steps || b_off[j] == OOB16) ? OOB16 : b_off[j] + kb;
+            const unsigned bad = (step >= n_steps || b_off[j] == OOB16) ? OOB16 : 0u;
 #pragma unroll
             for (int c = 0; c < NP; ++c)
-                rb[slot][c][j] = __builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, (int)(o == OOB16 ? OOB16 : o + c * piece_bytes), 0, 0);
+                rb[slot][c][j] = __builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, (int)((b_off[j] + kb + c * piece_bytes) | bad), 0, 0);
         }
     };
     // ---- halo staging: 2 patches x hpix pixels x 4 groups of 4 channels; <= 2*144*4/256 = 4.5 float4 per thread -----------
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_x3_kernel(const KcParams p)
             const int hy = pix / HW_, hx = pix - hy * HW_;
             const int iy = p_y0[pp] + hy, ix = p_x0[pp] + hx;
             const bool ok = idx < h_total && p_ok[pp] && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
-            rh[j] = bload4(a_rsrc, ok ? 4u * (unsigned)(p_img[pp] + (iy * p.AW + ix) * p.AC + cc * 16 + ch * 4) : OOB16);
+            rh[j] = bload4(a_rsrc, (4u * (unsigned)(p_img[pp] + (iy * p.AW + ix) * p.AC + cc * 16 + ch * 4)) | (ok ? 0u : OOB16));
         }
     };
     auto commit_halo = [&]() {

@@ -245,6 +245,65 @@ __global__ void norm_apply_kernel(const TX* __restrict__ x, const float* __restr
     }
 }
 
+// The vector path of norm_apply_kernel with the index arithmetic taken out of the loop.  grid = (slices, statistic row groups): a
+// workgroup walks a slice of ONE row group (an image for GroupNorm), and since 256 % (C/4) == 0 a thread keeps the same four
+// channels for the whole walk — mean, rstd, gamma and beta are loop constants and an element costs a load, four fused operations
+// and a store.  norm_apply_kernel<true, ...> spent two 64-bit divisions, four 32-bit ones, eight statistic loads and four rsqrt per
+// four elements: 206 us for the generator's 128x128x64 bfloat16 tensors (537 MB, 2.6 TB/s) — arithmetic, not memory.
+template <bool D2S, typename TX, typename TY>
+__global__ __launch_bounds__(256) void norm_apply_rows_kernel(const TX* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ stats, long long rows_per_stat, int C, int cpg, int n_groups,
+                                                              float eps, int relu, TY* __restrict__ y, int H, int W, TY* __restrict__ xs) {
+    const int c4n = C >> 2;                           // a power of two (256 % c4n == 0)
+    const int lg = __ffs(c4n) - 1;
+    const int c = (threadIdx.x & (c4n - 1)) << 2;
+    const long long sr = blockIdx.y;
+    const float inv_cnt = 1.f / ((float)rows_per_stat * (float)cpg);
+    float mean[4], rstd[4], ga[4], be[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const long long s = sr * n_groups + (c + e) / cpg;
+        mean[e] = stats[2 * s] * inv_cnt;
+        rstd[e] = rsqrtf(stats[2 * s + 1] * inv_cnt + eps);
+        ga[e] = gamma[c + e];
+        be[e] = beta[c + e];
+    }
+    const long long base = sr * rows_per_stat * C;
+    const unsigned n4 = (unsigned)((rows_per_stat * C) >> 2);          // launcher: rows_per_stat * C < 2^32
+    const bool per_image = rows_per_stat == (long long)H * W;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+        const long long e0 = base + ((long long)i << 2);
+        const float4 v = ld4(x, e0);
+        const float in[4] = {v.x, v.y, v.z, v.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = (in[e] - mean[e]) * rstd[e] * ga[e] + be[e];
+            o[e] = (relu && t < 0.f) ? 0.f : t;
+        }
+        if (D2S) {
+            const unsigned rl = i >> lg;              // row within the group
+            const int Cq = C >> 2, cq = c >> 2;
+            long long off[4];
+            if (per_image) {
+                const unsigned h = rl / (unsigned)W, w = rl - h * (unsigned)W;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) off[e] = (((sr * 2 * H + 2 * h + (e >> 1)) * 2 * W + 2 * w + (e & 1)) * Cq) + cq;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) off[e] = d2s_offset(sr * rows_per_stat + rl, e, H, W, Cq) + cq;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {             // lanes hold consecutive c': each of the four stores is coalesced
+                st1(y, off[e], o[e]);
+                if (xs) st1(xs, off[e], in[e]);
+            }
+        } else {
+            st4(y, e0, o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // ps[n][2h+i][2w+j][c'] = x[n][h][w][4c'+2i+j]  (INVERSE: x from ps — the backward of the forward and vice versa)
 template <bool INVERSE>
 __global__ void depth_to_space_kernel(const float* __restrict__ in, long long rows, int H, int W, int C, float* __restrict__ out) {
@@ -422,6 +481,17 @@ static int launch_norm_apply(const TX* x, const float* gamma, const float* beta,
                              int cpg, int n_groups, float eps, int relu, const float* stats, TY* y, int d2s_H, int d2s_W,
                              TY* xs, bool vec, hipStream_t st) {
     const long long total = R * C;
+    static const int rows_env = [] { const char* e = getenv("CSLGAN_NORM_ROWS"); return e ? atoi(e) : 1; }();
+    const long long n_rg = R / rows_per_stat;
+    if (vec && rows_env && rows_per_stat * C < (1ll << 32) && n_rg <= 65535) {
+        long long bx = (rows_per_stat * C / 4 + 255) / 256;
+        const long long cap = (4096 + n_rg - 1) / n_rg;                 // about 4096 workgroups in all
+        bx = bx > cap ? cap : (bx < 1 ? 1 : bx);
+        const dim3 g2((unsigned)bx, (unsigned)n_rg), b2(256);
+        if (d2s_W > 0) hipLaunchKernelGGL((norm_apply_rows_kernel<true, TX, TY>), g2, b2, 0, st, x, gamma, beta, stats, rows_per_stat, C, cpg, n_groups, eps, relu, y, d2s_H, d2s_W, xs);
+        else hipLaunchKernelGGL((norm_apply_rows_kernel<false, TX, TY>), g2, b2, 0, st, x, gamma, beta, stats, rows_per_stat, C, cpg, n_groups, eps, relu, y, 0, 0, (TY*)nullptr);
+        return check_launch("norm_apply_rows_kernel");
+    }
     long long nb = (total / 4 + 255) / 256;
     nb = nb > 4096 ? 4096 : (nb < 1 ? 1 : nb);
     const dim3 g((unsigned)nb), b(256);

@@ -83,6 +83,9 @@ FWD_CASES = [
     (128, 32, 32, 64, 128, 1, 1, 0, True, 0, None, True),         # 1x1 stream kernel (the generator's shortcut convs): 64 -> 128
     (64, 64, 64, 16, 64, 1, 1, 0, False, 0, None, True),          # ... 16 -> 64: the whole reduction is one MFMA k-step
     (70, 31, 31, 32, 96, 1, 1, 0, True, 2, None, False),          # ... ragged pixel count, three filter tiles, ReLU, fp32 output
+    (2, 8, 8, 16, 6, 3, 1, 1, True, 1, "bf16", True),             # 6 filters: the epilogue's element-wise path (channel count not a multiple of 4)
+    (2, 8, 8, 16, 20, 3, 1, 1, True, 2, "f32", True),             # 20 filters: 4-channel vector groups, the last 32-wide tile partly filled
+    (3, 8, 8, 16, 36, 3, 1, 1, True, 1, "bf16", False),           # ... fp32 output with a bf16 residual
 ]
 
 
@@ -120,6 +123,8 @@ DGRAD_CASES = [
     (5, 15, 15, 8, 16, 5, 2, 2, True, True),               # odd image: ragged parity classes
     (2, 64, 64, 128, 256, 5, 2, 2, True, True),            # parity classes on 32x32 grids, 128 output channels: LDS-halo form, wide tiles
     (3, 32, 32, 64, 64, 3, 2, 1, False, False),            # 3x3 stride 2: a class with a single tap keeps the launch on the gather form
+    (2, 12, 12, 20, 16, 3, 1, 1, True, False),             # 20 input channels, fp32 mask and fp32 gradient: vector groups, partly filled tile
+    (2, 10, 10, 6, 16, 5, 2, 2, True, False),              # 6 input channels: element-wise epilogue with an fp32 mask
 ]
 
 

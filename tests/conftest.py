@@ -38,3 +38,17 @@ def _reset_compute_dtype():
     if ops is not None:
         ops.set_compute_dtype("fp32")
         ops.set_storage_dtype("fp32")
+
+
+@pytest.fixture(autouse=True)
+def _collect_garbage_between_tests():
+    """A test's Trainer / GraphedDStep (HIP graph, its private memory pool, side streams, double-backward autograd graphs) dies as
+    cyclic garbage.  Collect it HERE, on the main thread with the device idle, instead of whenever the next test's allocation count
+    trips the collector — which can be inside an autograd worker thread in the middle of a backward."""
+    yield
+    import gc
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available():
+        torch.cuda.synchronize()
+    gc.collect()

@@ -906,10 +906,27 @@ class GraphedDStep:
             steps0, calls0 = pe.steps, pe._noise_calls
             adam0 = {id(st): st["step"] for st in tr.d_optimizer.state.values()}
             graph = torch.cuda.CUDAGraph()
+            # No cyclic garbage collection while the stream is capturing.  A dead cycle that owns device resources — an earlier
+            # GraphedDStep's graph and its private pool, most of all — is finalised wherever the collector happens to run, which can
+            # be an autograd worker thread in the middle of this recording; releasing a pool calls hipFree, which is not permitted
+            # during a (global-mode) capture, and the failure surfaces inside a destructor: the process aborts.  (torch 2.10 no longer
+            # collects in torch.cuda.graph.__enter__.)  So: collect now, on this thread, then keep the collector off until the
+            # capture has ended.  The double backward of an is-mode step makes enough cycles to trip it within one recording.
+            import gc
+            gc.collect()
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            err = None
             try:
                 with torch.cuda.graph(graph):
                     self._eager()                # RECORDED, not executed; its host-side bookkeeping ran once
             except Exception as e:               # e.g. a collective this backend cannot record: the run goes on eagerly
+                err = e
+            finally:
+                if gc_was_on:
+                    gc.enable()
+            if err is not None:
+                e = err
                 import warnings
                 warnings.warn("HIP-graph capture of the D-step failed (%s: %s); stepping eagerly from here on" % (type(e).__name__, str(e)[:200]))
                 torch.cuda.synchronize()

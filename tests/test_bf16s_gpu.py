@@ -367,6 +367,8 @@ STEP_CASES = [
     ("CelebA", ["-c", "2.0", "--materialize", "ghost"], 8, 128),              # flat clipping
     ("CelebA", ["-gcm", "adaptive-pl"], 8, 128),
     ("CelebA", ["-gcm", "adaptive-pl", "--grad_sample_dtype", "bf16", "--materialize", "private"], 8, 128),
+    # every pass written out per sample (the reference route of tests/test_fullsize_gpu.py's route comparison)
+    ("CelebA", ["--im_size", "128", "-gcm", "adaptive-pl", "--materialize", "all", "--fuse_passes", "False"], 4, 128),
 ]
 
 

@@ -154,7 +154,8 @@ def _bench_like_step(tmp_path, tag, extra, B, dataset="CelebA", conditional=Fals
     last = tr.last
     res = dict(C=last["clip_params"].cpu().double(), norms=last["norms"].cpu().double(), factors=last["clip_factors"].cpu().double(),
                summed=[t.cpu().double() for t in last["summed_grad"]], grad=[p.grad.detach().cpu().double() for p in D.parameters()],
-               names=[n for n, _ in D.named_parameters()], d_real=last["d_real"].cpu().double(), d_fake=last["d_fake"].cpu().double())
+               names=[n for n, _ in D.named_parameters()], d_real=last["d_real"].cpu().double(), d_fake=last["d_fake"].cpu().double(),
+               fake_img=last["fake_img"].float().cpu().double())
     del tr, pe, G, D
     torch.cuda.empty_cache()
     return res
@@ -206,11 +207,15 @@ def test_config4_bf16_storage_128x128_bs128_routes_agree(tmp_path):
     property the fp32 configurations use: the benchmarked route (ghost clipping for the last conv + head, fused 384-row critic pass,
     clip-weighted two-accumulator sum) against `--materialize all --fuse_passes False` (every per-sample gradient written out, norms
     from the weight-gradient epilogue, one critic pass per batch).  Tolerances follow tests/test_bf16s_gpu.py's error model instead of
-    the fp32 ones: the two routes sum the same products in different orders, and an activation whose fp32 value sits at a bfloat16
-    rounding boundary is STORED one spacing (2^-8) apart in the two — outputs are held to 2 spacings, norms / factors to 5e-3
-    (measured 3e-7: the private pass is the same computation in both), the gradient tensors to 4e-2 in relative L2: each route is
-    held to 2e-2 per tensor against the mask-shared oracle (test_bf16s_gpu.py), so two routes may be twice that apart (measured
-    5e-4..1.2e-2 on the weights, 1.3e-2..1.9e-2 on the bias gradients, whose sums over pixels cancel)."""
+    the fp32 ones.  The private pass is the same computation in both routes (critic outputs on the real rows bit-identical, per-sample
+    norms 3e-7, clip factors identical).  The GENERATED rows are not: the generator's GroupNorm statistics are summed with float
+    atomics, a last-bit difference in a statistic moves some activations across a bfloat16 rounding boundary, and runs that
+    share the generator's code path entirely (`--materialize ghost` / `private`, fused or not) already produce generated images that
+    differ from one another by a bf16 spacing in a few places (max 1.4e-2..1.7e-2 of the image range against this reference route,
+    a different figure for each; critic outputs on them 5e-3..7e-3) — in fp32 storage the same atomics give 1e-7.  The unclipped gradient of the generated pass
+    inherits that: weights 5e-4..1.5e-2, bias gradients (sums over pixels that cancel) 1.3e-2..2.2e-2 between two runs.  Held to 4e-2
+    per tensor in relative L2 = twice the per-route bound against the mask-shared oracle (tests/test_bf16s_gpu.py); the kernels
+    themselves agree to 1e-6 at this size (per-sample sum vs dense vs grouped vs clip-weighted, checked on the three strided layers)."""
     base = ["--im_size", "128", "--compute_dtype", "bf16", "--storage_dtype", "bf16", "-gcm", "adaptive-pl"]
     ref = _bench_like_step(tmp_path, "all", base + ["--materialize", "all", "--fuse_passes", "False"], 128)
     got = _bench_like_step(tmp_path, "ghost", base + ["--materialize", "ghost", "--fuse_passes", "True"], 128)
@@ -221,7 +226,8 @@ def test_config4_bf16_storage_128x128_bs128_routes_agree(tmp_path):
 
     def rel_l2(x, y):
         return ((x - y).norm() / (y.norm() + 1e-30)).item()
-    assert rel(got["d_real"], ref["d_real"]) <= 2 * 2 ** -8 and rel(got["d_fake"], ref["d_fake"]) <= 2 * 2 ** -8
+    assert rel(got["d_real"], ref["d_real"]) <= 1e-6, "the critic has no atomics: its outputs on the real rows are reproducible"
+    assert rel(got["d_fake"], ref["d_fake"]) <= 4 * 2 ** -8 and (got["fake_img"] - ref["fake_img"]).abs().max().item() <= 8 * 2 ** -8
     assert rel(got["C"], ref["C"]) <= 5e-3, "adaptive clip norms: %.3e" % rel(got["C"], ref["C"])
     n_all = ref["norms"].reshape(ref["norms"].shape[0], -1)
     n_b = got["norms"].reshape(got["norms"].shape[0], -1)

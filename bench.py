@@ -70,10 +70,24 @@ def build_trainer(rank, world, local, batch=B_PER_GPU, outdir=None, extra=()):
 def cpu_baseline():
     """The oracle's D-step (same step definition, hook-based unfold+einsum per-sample gradients —
     the algorithm family the reference's Opacus dependency uses) on the host cores."""
+    from oracle import dp_engine as E
     from oracle.dstep import OracleDStep, StepConfig
     from oracle.nets import build_models
     threads = min(16, os.cpu_count() or 1)      # the GPU box gives one GPU a 16-core CPU share
     torch.set_num_threads(threads)
+    # ONE fixed algorithm from round 4 on: the hook-based fp32 unfold+einsum step with fp32 norm reductions (what the reference's
+    # dependency executes).  The checker's float64 norm reductions (a 4.4 GB copy per pass at bs=128) are switched off for the timed
+    # steps — they are test hygiene and made this baseline drift 24.6 -> 22.1 -> 14.9 images/s over rounds 1-3.
+    E.set_norm_dtype(torch.float32)
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     G, Dm = build_models(weights_seed=42, manual_seed=1234)
     st = OracleDStep(G, Dm, StepConfig(grad_clip_mode="adaptive-pl", clipping_param_per_layer=[1.0] * 9, sigma=0.5))
     g = torch.Generator().manual_seed(1234)
@@ -84,12 +98,16 @@ def cpu_baseline():
         t0 = time.perf_counter()
         st.step(img, None, torch.randn(B, 128, generator=g), None, ms_adapt=ms, pen_real=ms, alpha=torch.rand(B, generator=g), noise_gen=g)
         return time.perf_counter() - t0
-    one(8)                       # warm-up (allocator, thread pool)
-    n_steps, dt = 0, 0.0
-    while dt < 15.0 and n_steps < 5:          # about 15-25 s of host work
-        dt += one(B_PER_GPU)
-        n_steps += 1
-    return {"value": round(n_steps * B_PER_GPU / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+    try:
+        one(8)                       # warm-up (allocator, thread pool)
+        n_steps, dt = 0, 0.0
+        while dt < 15.0 and n_steps < 5:          # about 15-25 s of host work
+            dt += one(B_PER_GPU)
+            n_steps += 1
+    finally:
+        E.set_norm_dtype(torch.float64)
+    return {"value": round(n_steps * B_PER_GPU / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "cpu_model": cpu_model,
+            "host_cpus": os.cpu_count(), "kind": "port", "algorithm": "hook-based fp32 unfold+einsum per-sample gradients, fp32 norm reductions",
             "sample": "%d oracle D-step(s) (config 3) at bs=128 after a bs=8 warm-up, %.1f s" % (n_steps, dt)}
 
 
@@ -338,8 +356,9 @@ def main():
     gs = getattr(tr, "graphed", None)
     bail = None
     if gs is not None and world > 1:
-        # A multi-rank capture has never run on the pool this was built on (one GPU per box): if recording or replaying the step with
-        # its RCCL collectives does not come back, every rank keeps the eager measurement — rank 0 prints the line, labelled — and ends.
+        # Only with CSLGAN_GRAPH_DIST=1 (multi-rank capture is opt-in: csl_gan_amd.distributed.collectives_capturable).  If recording or
+        # replaying the step with its RCCL collectives does not come back, rank 0 still prints the eager measurement, labelled — and the
+        # process ends with a NON-ZERO status (3): a hang is a failure of the run, not a result.
         import threading
         limit = float(os.environ.get("CSLGAN_GRAPH_REGION_LIMIT_S", "240"))
 
@@ -349,7 +368,7 @@ def main():
                        None, None, with_cpu=False)
                 sys.stdout.flush()
             finally:
-                os._exit(0)
+                os._exit(3)
         bail = threading.Timer(limit, _bail)
         bail.daemon = True
         bail.start()

@@ -68,12 +68,14 @@ def average_across_ranks(t: torch.Tensor, use_max=False, group=None):
 
 
 def collectives_capturable():
-    """True when the step's collectives can be recorded into a HIP graph: a single process, or RCCL (backend "nccl" — its
-    all-reduce is a stream-ordered kernel launch that torch registers with the capture; scripts/rccl_capture_probe.py).  gloo
-    stages through the host and cannot be captured."""
+    """True when the step's collectives may be recorded into a HIP graph: always in a single process; with several ranks only
+    over RCCL (backend "nccl" — its all-reduce is a stream-ordered kernel launch that torch registers with the capture;
+    scripts/rccl_capture_probe.py; gloo stages through the host and cannot be captured) AND only when asked for with
+    CSLGAN_GRAPH_DIST=1.  Multi-rank capture is OPT-IN: it has been verified on a one-rank RCCL group only (the pool this was
+    built on has one GPU per box), so until a multi-GPU run has shown it working the default N > 1 step is launched eagerly."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return True
-    return dist.get_backend() == "nccl" and os.environ.get("CSLGAN_GRAPH_DIST", "1") == "1"
+    return dist.get_backend() == "nccl" and os.environ.get("CSLGAN_GRAPH_DIST", "0") == "1"
 
 
 def broadcast_object(obj, src=0):

@@ -106,7 +106,8 @@ class Trainer:
         # input-gradient norms, B >= 24) replayed with a stale dword per 16 bytes — csrc/common.h zero_floats.
         # N > 1 ranks over RCCL (round 3): the step's collectives — the flat gradient all-reduce, the 9-float adaptive statistics, the
         # immediate-sensitivity maxima — are stream-ordered RCCL launches and are RECORDED with the step (every rank records and replays
-        # the same sequence); gloo (CPU rehearsals) stages through the host and keeps the eager step.  CSLGAN_GRAPH_DIST=0: eager.
+        # the same sequence) — OPT-IN with CSLGAN_GRAPH_DIST=1 (round 4: verified on a one-rank RCCL group only, so N > 1 defaults to the
+        # eager step); gloo (CPU rehearsals) stages through the host and keeps the eager step.
         from .distributed import collectives_capturable
         if (getattr(o, "hip_graph", False) and (self.world_size == 1 or collectives_capturable()) and not o.backprop_clip
                 and (o.dp_mode == "gc" or (o.dp_mode == "is" and o.imm_sens_scaling_mode != "moving-avg-pl"))):

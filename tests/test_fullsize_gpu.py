@@ -255,8 +255,12 @@ def test_config1_mnist_conditional_bs600_routes_agree(tmp_path):
     _assert_routes_agree(ref, got)
 
 
-def test_benchmarked_config_matches_mask_shared_oracle_at_bs128(tmp_path):
-    """BASELINE configs[2] as bench.py runs it (B=128, adaptive-pl, ghost clipping, fused passes, WGAN-GP on mean samples)
+@pytest.mark.parametrize("compute", ["fp32", "fp32_auto"])
+def test_benchmarked_config_matches_mask_shared_oracle_at_bs128(tmp_path, compute):
+    """`compute`: "fp32" = the exact fp32 MFMA kernels; "fp32_auto" = bench.py's headline arithmetic (fp32 from three bfloat16 pieces
+    on the bf16 matrix cores wherever a launch is large enough, csrc/igemm_bf16.hip / igemm_x3.hip) — the same 1e-3 per entry.
+
+    BASELINE configs[2] as bench.py runs it (B=128, adaptive-pl, ghost clipping, fused passes, WGAN-GP on mean samples)
     against the CPU oracle at the SAME size, with the HIP run's activation masks replayed by the oracle (so a unit at zero
     cannot take different slopes): losses, adaptive clip norms, per-sample norms, clip factors, the clipped sum, the penalty
     gradients and the final summed gradient, per entry at 1e-3 of each tensor's scale.  (~10 s and ~10 GB on the host: the
@@ -267,10 +271,12 @@ def test_benchmarked_config_matches_mask_shared_oracle_at_bs128(tmp_path):
     from oracle.dstep import OracleDStep, StepConfig
     from oracle.nets import build_models
     opt = options.parse(["CelebA", "-dpm", "gc", "-gcm", "adaptive-pl", "-nms", "32", "-bs", str(B), "-gd", "cuda:0", "-dd", "cuda:0",
-                         "-o", str(tmp_path), "--manual_seed", "1", "--sigma", "0"])
+                         "-o", str(tmp_path), "--manual_seed", "1", "--sigma", "0", "--compute_dtype", compute])
     assert opt.materialize == "ghost" and opt.fuse_passes
     G, D = init_util.init_models(opt)
     tr = Trainer(opt, G, D, log_to=str(tmp_path / "log.csv"))
+    from csl_gan_amd import ops
+    assert ops.get_compute_dtype() == compute
     tr.setup_privacy_engine()
     g = torch.Generator().manual_seed(17)
     img = (torch.randn(B, 3, 64, 64, generator=g) * 0.5).clamp(-1, 1)
@@ -313,3 +319,68 @@ def test_benchmarked_config_matches_mask_shared_oracle_at_bs128(tmp_path):
             errs["penalty_grad " + n] = rel(last["penalty_grads"][i], pg)
     bad = {k: v for k, v in errs.items() if not v <= 1e-3}
     assert not bad, bad
+
+
+def test_config3_immediate_sensitivity_per_param_matches_mask_shared_oracle_at_bs128(tmp_path):
+    """BASELINE configs[3] at its full per-GPU size: CelebA DCResNet WGAN-GP, `-dpm is -ispp True`, bs = 128 (train.py:103-107,
+    457-470) — the BatchNorm generator, the critic's parameter gradients with create_graph and NINE double-backward sweeps, one
+    sensitivity per parameter tensor = max over the 128 samples.  Against the CPU oracle at the same size with the device's
+    activation masks replayed: sensitivities at 1e-3, every parameter gradient per entry at 1e-3 of its scale, losses and the
+    penalty at 1e-3.  (Immediate sensitivity itself is parity-unpinned — the fork is absent — so the oracle is the build's spec
+    here; what this test adds over the B = 4 / 6 cases is the kernel selection of the 128-row launches and a max over 128 rows.)"""
+    from csl_gan_amd import init_util, nn as hnn, options
+    from csl_gan_amd.trainer import Trainer
+    from oracle import nets as onets
+    from oracle.dstep import OracleDStep, StepConfig
+    from oracle.nets import build_models
+    opt = options.parse(["CelebA", "-dpm", "is", "-ispp", "True", "-nms", "32", "-bs", str(B), "-gd", "cuda:0", "-dd", "cuda:0",
+                         "-o", str(tmp_path), "--manual_seed", "1", "--sigma", "0.5"])
+    assert opt.imm_sens_per_param and not opt.per_sample_grad and list(opt.penalty) == ["WGAN-GP"]
+    G, D = init_util.init_models(opt)
+    tr = Trainer(opt, G, D, log_to=str(tmp_path / "log.csv"))
+    pe = tr.setup_privacy_engine()
+    Go, Do = build_models(dataset="CelebA", model="DeepConvResNet", im_size=opt.im_size, weights_seed=42, manual_seed=1,
+                          per_sample_grad=False, g_latent_dim=128)
+    cfg = StepConfig(dp_mode="is", sigma=0.0, penalty=("WGAN-GP",), lr=opt.d_lr, adam_b1=opt.adam_b1, adam_b2=opt.adam_b2,
+                     imm_sens_per_param=True, imm_sens_scaling_vec=None)
+    oracle = OracleDStep(Go, Do, cfg)
+    g = torch.Generator().manual_seed(23)
+    img = torch.rand(B, 3, 64, 64, generator=g) * 2 - 1
+    ms_p = torch.rand(B, 3, 64, 64, generator=g) * 0.6
+    z, alpha = torch.randn(B, 128, generator=g), torch.rand(B, generator=g)
+    tr.explicit = dict(pen_real=ms_p, alpha=alpha, keep=True)
+    pe.host_noise = [torch.zeros(p.numel()) for p in Do.parameters()]
+    rec = hnn.ActivationMaskRecorder(G=tr.G, D=tr.D)
+    hnn.set_mask_recorder(rec)
+    try:
+        tr.train_D(img.cuda(), None, z.cuda(), None, use_dp=True)
+    finally:
+        hnn.set_mask_recorder(None)
+    torch.cuda.synchronize()
+    s_g = np.atleast_1d(np.asarray(pe.batch_sensitivity, dtype=np.float64))
+    torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+    player = onets.MaskPlayer(rec.masks, G=Go, D=Do)
+    onets.set_mask_player(player)
+    try:
+        obs = oracle.step(img, None, z, None, pen_real=ms_p, alpha=alpha, apply_update=False)
+    finally:
+        onets.set_mask_player(None)
+    assert player.exhausted()
+    s_o = np.atleast_1d(np.asarray(obs["batch_sensitivity"], dtype=np.float64))
+    assert s_g.shape == s_o.shape == (9,)
+    np.testing.assert_allclose(s_g, s_o, rtol=1e-3, atol=1e-6 * s_o.max())
+
+    def rel(a, b):
+        a, b = torch.as_tensor(a).detach().cpu().double().reshape(-1), torch.as_tensor(b).detach().cpu().double().reshape(-1)
+        return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+    errs = {"fake_img": rel(tr.last["fake_img"], obs["fake_img"]), "d_real_loss": rel(tr.last["d_real_loss"], obs["d_real_loss"]),
+            "d_fake_loss": rel(tr.last["d_fake_loss"], obs["d_fake_loss"]), "penalty": rel(tr.last["penalty"], obs["penalty"])}
+    gs_is = max(t.abs().max().item() for t in obs["is_param_grads"])
+    for i, (a, b) in enumerate(zip(tr.last["is_param_grads"], obs["is_param_grads"])):
+        if b.abs().max().item() <= 1e-6 * gs_is:
+            assert a.abs().max().item() <= 1e-5 * gs_is
+        else:
+            errs["is_param_grad[%d]" % i] = rel(a, b)
+    bad = {k: v for k, v in errs.items() if not v <= 1e-3}
+    assert not bad, bad
+    print("configs[3] full size: sensitivities", s_g, "worst rel", max(errs.values()))

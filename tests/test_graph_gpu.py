@@ -71,6 +71,11 @@ def _run(tmp_path, tag, argv, B, use_graph, n_steps, img_shape, conditional, smo
     ("celeba_ispp_smooth_b32", ["CelebA", "-dpm", "is", "-ispp", "True", "-nms", "8", "--sigma", "0.5"], 32, (3, 64, 64), False, True),
     ("celeba_ispp_b32", ["CelebA", "-dpm", "is", "-ispp", "True", "-nms", "8", "--sigma", "0.5"], 32, (3, 64, 64), False, False),
     ("mnist_is_cond", ["MNIST", "--model", "Vanilla", "--conditional", "-dpm", "is", "--sigma", "1"], 64, (1, 28, 28), True, True),
+    # BASELINE configs[3] at its FULL per-GPU size (bs = 128, -ispp True, 32 mean samples): nine double-backward sweeps per step
+    ("celeba_ispp_smooth_b128", ["CelebA", "-dpm", "is", "-ispp", "True", "-nms", "32", "--sigma", "0.5"], 128, (3, 64, 64), False, True),
+    # the headline arithmetic (fp32 from three bfloat16 pieces wherever a launch is large enough) at the headline size
+    ("celeba_auto_smooth_b128", ["CelebA", "-dpm", "gc", "-gcm", "adaptive-pl", "-nms", "32", "--sigma", "0.5", "--compute_dtype", "fp32_auto"],
+     128, (3, 64, 64), False, True),
 ])
 def test_graph_replay_equals_eager_steps(tmp_path, name, argv, B, shape, cond, smooth):
     n = 6

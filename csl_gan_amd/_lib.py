@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CSLGAN_LIB_PATH") or os.path.join(_HERE, "libcslgan_hip.so")      # override: kernel experiments
 MAX_SEGS = 16
-ABI_VERSION = 4          # include/cslgan.h CSLGAN_ABI_VERSION
+ABI_VERSION = 5          # include/cslgan.h CSLGAN_ABI_VERSION
 
 EXPORTS = [
     "cslgan_version", "cslgan_last_error", "cslgan_last_kernel", "cslgan_device_count",
@@ -20,6 +20,7 @@ EXPORTS = [
     "cslgan_l2_clip_rows_f32", "cslgan_row_l2norm_f32", "cslgan_row_l2norm_bwd_f32", "cslgan_mean_sample_f32",
     "cslgan_conv2d_fwd_f32", "cslgan_conv2d_fwd_x3_f32", "cslgan_conv2d_dgrad_f32", "cslgan_conv2d_wgrad_grouped_f32",
     "cslgan_conv2d_wgrad_scaled_f32", "cslgan_conv2d_wgrad_blocks_f32", "cslgan_conv2d_wgrad_sqnorm_gram_f32", "cslgan_conv2d_wgrad_skinny_f32", "cslgan_conv2d_s2_fwd_f32",
+    "cslgan_conv2d_dgrad_x3_f32", "cslgan_conv2d_s2_fwd_x3_f32",
     "cslgan_depth_to_space_f32", "cslgan_fold_channels4_f32",
     "cslgan_bias_grad_grouped_f32", "cslgan_act_bwd_f32", "cslgan_groupnorm_act_f32", "cslgan_batchnorm_act_f32", "cslgan_batchnorm_eval_act_f32",
     "cslgan_norm_act_bwd_f32", "cslgan_norm_bwd_ws_floats",
@@ -85,6 +86,7 @@ def lib():
         "cslgan_conv2d_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, vp, i32, vp, vp],
         "cslgan_conv2d_fwd_x3_f32": [C.POINTER(ConvT), vp, vp, vp, i32, vp, vp, i32, vp, vp],
         "cslgan_conv2d_dgrad_f32": [C.POINTER(ConvT), vp, vp, vp, i32, vp, vp, vp],
+        "cslgan_conv2d_dgrad_x3_f32": [C.POINTER(ConvT), vp, vp, vp, vp, i32, vp, vp, vp],
         "cslgan_norm_act_bwd_f32": [vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, i32, vp, vp, vp, vp, vp],
         "cslgan_depth_to_space_f32": [vp, i32, i32, i32, i32, i32, vp, vp],
         "cslgan_fold_channels4_f32": [vp, i64, i32, i32, vp, vp],
@@ -94,6 +96,7 @@ def lib():
         "cslgan_conv2d_wgrad_sqnorm_gram_f32": [C.POINTER(ConvT), vp, vp, f32, vp, vp],
         "cslgan_conv2d_wgrad_skinny_f32": [C.POINTER(ConvT), vp, vp, f32, vp, i32, vp],
         "cslgan_conv2d_s2_fwd_f32": [C.POINTER(ConvT), vp, vp, vp, i32, vp, i32, vp, vp],
+        "cslgan_conv2d_s2_fwd_x3_f32": [C.POINTER(ConvT), vp, vp, vp, vp, i32, vp, i32, vp, vp],
         "cslgan_bias_grad_grouped_f32": [vp, i32, i32, i32, i32, f32, vp, vp, vp],
         "cslgan_act_bwd_f32": [vp, vp, i64, f32, vp, vp],
         "cslgan_groupnorm_act_f32": [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, i32, vp, vp, vp],

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcslgan_hip.so")
-SOURCES = ["clip_kernels.hip", "igemm_kc.hip", "igemm_halo.hip", "igemm_skinny.hip", "igemm_mc.hip", "igemm_wgh.hip", "igemm_bf16.hip", "igemm_bf16s.hip", "conv_c3.hip", "linear_k1.hip", "conv1x1.hip", "gram_norm.hip", "pointwise_kernels.hip", "step_kernels.hip"]
+SOURCES = ["clip_kernels.hip", "igemm_kc.hip", "igemm_halo.hip", "igemm_skinny.hip", "igemm_mc.hip", "igemm_wgh.hip", "igemm_bf16.hip", "igemm_x3.hip", "igemm_bf16s.hip", "conv_c3.hip", "linear_k1.hip", "conv1x1.hip", "gram_norm.hip", "pointwise_kernels.hip", "step_kernels.hip"]
 HEADERS = ["common.h", "igemm.h", os.path.join("..", "..", "include", "cslgan.h")]
 
 

@@ -32,6 +32,7 @@ struct KcClass {
     int w_off;           // float offset of this class's [Nn][Kdim] filter matrix from KcParams::w
     int oy0, ox0;        // output phase: out[img][oy*osy+oy0][ox*osx+ox0][n]
     int tile0;           // first m-tile (in the launch's concatenated m-tile space)
+    int nkw;             // igemm_x3h: taps per row of the (row-major, affine) tap grid
     int ty_min, tx_min, halo_h, halo_w;   // igemm_halo: tap offset range and the (8+range) halo of an 8x8 patch
     int ay_mul, ay_off, ax_mul, ax_off;   // igemm_halo, sub-image view of a: class pixel (y,x) is a[y*ay_mul+ay_off][x*ax_mul+ax_off]
                                           // (0 = unset = identity); the parity sub-images of a stride-2 forward conv

@@ -350,11 +350,12 @@ static int launch_kc_bf16_tile(KcParams& p, bool vecA, bool vecB, hipStream_t st
 }
 
 // Called by launch_kc (igemm_kc.hip) after the operand-size checks, when KcParams::bf16 is set.
-static bool halo_x3_eligible(const KcParams& p);
-static int launch_halo_x3(KcParams& p, hipStream_t st);
+bool x3h_eligible(const KcParams& p);          // igemm_x3.hip: the LDS-halo form (stride-1 tap classes, pre-split filter)
+int launch_x3h(KcParams& p, hipStream_t st);
 
 int launch_kc_bf16(KcParams& p, hipStream_t st, long long out_elems) {
-    if (halo_x3_eligible(p)) return launch_halo_x3(p, st);      // needs the pre-split / pre-rounded filter (p.w3)
+    if (x3h_eligible(p)) return launch_x3h(p, st);      // needs the pre-split / pre-rounded filter (p.w3)
+    if (p.acc_classes) { set_error("igemm_kc_bf16: accumulated classes only run on the LDS-halo form"); return CSLGAN_ERR_INVALID_ARG; }
     for (int c = 0; c < p.n_cls; ++c) {
         KcClass& k = p.cls[c];
         k.patch = (k.T > 1 && k.OHc % 8 == 0 && k.OWc % 8 == 0) ? 1 : 0;
@@ -602,331 +603,6 @@ __global__ __launch_bounds__(256, 2) void igemm_mc_bf16_kernel(const McParams p)
         const float tot = block_sum_256(ss, s_red);
         if (tid == 0) atomicAdd(p.sq + g, tot);
     }
-}
-
-// ---- bf16x3 with an LDS-resident input halo (stride-1 tap classes on 8x8-patchable grids) ------------------------------
-// The gather kernel above re-reads the input window once per filter tap and is bound by L2 bandwidth at 150-190 TF (logical).
-// As in igemm_halo (fp32): a workgroup owns two 8x8 output patches x BN channels; per 16-channel chunk it stages the
-// (8+R-1) x (8+S-1) halo of each patch in LDS ONCE — already split into the three bfloat16 pieces — and every tap reads its A
-// fragments from that image at a per-tap offset; a K step is one tap of one chunk = exactly one 16-k MFMA step.
-// Three pieces triple the LDS bytes per MFMA, and with BOTH operands in LDS the LDS pipe, not the matrix pipe, set the pace
-// (measured: no gain over the gather kernel).  The filter operand therefore never touches LDS: the B fragment of lane (r, h) is
-// 8 consecutive k of filter row r = 32 contiguous bytes of the KRSC filter, loaded straight into registers (two 16-byte loads,
-// L1 / L2 hits: every workgroup reads the same filter), split there, and held in a three-deep ring so the loads fly three
-// steps ahead of their use.  Halo pixel = 16 channels x 2 B = 32 B per piece (A fragment of lane (r, h): channels 8h..8h+7 of
-// pixel r = one ds_read_b128; the 32-byte pixel stride makes that read 2-way conflicted, which is cheaper than a padded image).
-constexpr int HX_MAX = 12 * 12;        // pixels per patch halo (8+4 squared: up to 5x5 taps)
-
-// NP = 3: fp32 from three bfloat16 pieces per operand (six MFMAs per step).  NP = 1: plain bf16 operands (--compute_dtype bf16),
-// one MFMA per step — the filter stream then needs 64 B per CU-cycle from L1/L2, so the ring of filter slices is four deep.
-template <int BN, int NP>
-__global__ __launch_bounds__(256, 2) void igemm_halo_x3_kernel(const KcParams p) {
-    constexpr int RING = NP == 1 ? 4 : 2;
-    constexpr int BM = 128, TM = 2, TN = BN / 64;            // waves 2 (M: one patch each) x 2 (N)
-    __shared__ __attribute__((aligned(16))) uint2 Hs[NP][2 * HX_MAX * 4];     // [piece][patch][pixel][4 x (4 ch bf16)]
-    __shared__ int s_tapoff[IG_MAX_TAPS];
-    __shared__ int s_off[BM];
-    __shared__ int s_roff[BM];
-
-    const int tid = threadIdx.x;
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int wg = xcd_remap(blockIdx.x, nwg);
-    const int tile_mg = wg / p.tiles_n, tile_n = wg - tile_mg * p.tiles_n;
-    int ci = 0;
-#pragma unroll 1
-    while (ci + 1 < p.n_cls && tile_mg >= p.cls[ci + 1].tile0) ++ci;
-    const KcClass& kc = p.cls[ci];
-    const int M = kc.M, OHc = kc.OHc, OWc = kc.OWc, T = kc.T;
-    const int m0 = (tile_mg - kc.tile0) * BM, n0 = tile_n * BN;
-    const int HW_ = kc.halo_w, hpix = kc.halo_h * kc.halo_w;
-    const int img_stride = p.AH * p.AW * p.AC;
-
-    // tap offset in uint2 units; bit 0 = parity of the tap's halo-row offset (selects the swizzled base)
-    if (tid < IG_MAX_TAPS) s_tapoff[tid] = ((((int)kc.ty[tid] - kc.ty_min) * HW_ + ((int)kc.tx[tid] - kc.tx_min)) * 4) | (((int)kc.ty[tid] - kc.ty_min) & 1);
-
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
-    int p_img[2], p_y0[2], p_x0[2];
-    bool p_ok[2];
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-        const int m = m0 + 64 * pp;
-        p_ok[pp] = m < M;
-        const RowCoord rc = kc_decode_row(p_ok[pp] ? m : 0, OHc, OWc, 1);     // first row of the patch = its top-left pixel
-        p_img[pp] = rc.img * img_stride;
-        p_y0[pp] = rc.oy + kc.ty_min;
-        p_x0[pp] = rc.ox + kc.tx_min;
-    }
-    const int lane = tid & 63, wid = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int wm = wid >> 1, wn = wid & 1;                   // wm = patch index
-    // ---- filter operand: straight to registers, from the filter PRE-SPLIT into its three bfloat16 pieces (split_filter_x3_kernel,
-    // cached per parameter version by the caller): lane (r, h), tile j, piece c reads 8 consecutive k of filter row
-    // n0 + wn*TN*32 + j*32 + r = one 16-byte load, no conversion work in the loop
-    // layout [piece][step][n][16 k] with step = chunk * T + tap: the 32 rows x 32 B one wave-load touches are 1 KB contiguous
-    const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w3), 0, 2u * NP * (unsigned)p.Nn * (unsigned)kc.Kdim, 0x00020000);
-    const unsigned piece_bytes = 2u * (unsigned)p.Nn * (unsigned)kc.Kdim;
-    const unsigned step_bytes = 32u * (unsigned)p.Nn;
-    unsigned b_off[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * TN * 32 + j * 32 + r;
-        b_off[j] = n < p.Nn ? 32u * (unsigned)n + 16u * (unsigned)h : OOB16;
-    }
-    u32x4 rb[RING][NP][TN];                                  // ring of filter slices (three pieces: a third step spills, 256 VGPRs)
-    const int n_steps = (p.AC >> 4) * T;
-    auto load_b = [&](int step, int slot) {                 // filter slice of `step` (= chunk * T + tap); zeros past the end
-        const unsigned kb = (unsigned)step * step_bytes;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const unsigned bad = (step >= n_steps || b_off[j] == OOB16) ? OOB16 : 0u;
-#pragma unroll
-            for (int c = 0; c < NP; ++c)
-                rb[slot][c][j] = __builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, (int)((b_off[j] + kb + c * piece_bytes) | bad), 0, 0);
-        }
-    };
-    // ---- halo staging: 2 patches x hpix pixels x 4 groups of 4 channels; <= 2*144*4/256 = 4.5 float4 per thread -----------
-    constexpr int HREG = (2 * HX_MAX * 4 + 255) / 256;
-    float4 rh[HREG];
-    const int h_total = 2 * hpix * 4;
-    auto fetch_halo = [&](int cc) {
-#pragma unroll
-        for (int j = 0; j < HREG; ++j) {
-            const int idx = tid + 256 * j;
-            const int ch = idx & 3, pixg = idx >> 2;
-            const int pp = pixg >= hpix ? 1 : 0;
-            const int pix = pixg - pp * hpix;
-            const int hy = pix / HW_, hx = pix - hy * HW_;
-            const int iy = p_y0[pp] + hy, ix = p_x0[pp] + hx;
-            const bool ok = idx < h_total && p_ok[pp] && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
-            rh[j] = bload4(a_rsrc, (4u * (unsigned)(p_img[pp] + (iy * p.AW + ix) * p.AC + cc * 16 + ch * 4)) | (ok ? 0u : OOB16));
-        }
-    };
-    auto commit_halo = [&]() {
-#pragma unroll
-        for (int j = 0; j < HREG; ++j) {
-            const int idx = tid + 256 * j;
-            if (idx < h_total) {
-                const int ch = idx & 3, pixg = idx >> 2;
-                const int pp = pixg >= hpix ? 1 : 0;
-                const int pix = pixg - pp * hpix;
-                // the two 16-byte halves of a pixel are swapped on odd halo rows: the two patch rows a 16-lane ds_read_b128 group
-                // covers then hit disjoint banks (the plain 32-byte stride is 2-way conflicted; measured 73 % conflict cycles)
-                const int at = (pp * HX_MAX + pix) * 4 + (ch ^ (((pix / HW_) & 1) << 1));
-                if (NP == 1) {
-                    Hs[0][at] = pack4_bf16(rh[j]);
-                } else {
-                    const bf16x3_t t = split4_bf16(rh[j]);
-                    Hs[0][at] = t.hi; Hs[NP > 1 ? 1 : 0][at] = t.mid; Hs[NP > 2 ? 2 : 0][at] = t.lo;
-                }
-            }
-        }
-    };
-
-    int a_base[2][TM];                                       // uint2 offset of this lane's pixel (tap 0,0 corner) per MFMA tile,
-#pragma unroll                                               // for taps landing on an even / odd halo row (half-swap swizzle)
-    for (int i = 0; i < TM; ++i) {
-        const int qq = i * 32 + r;                           // row within the patch
-        const int pix = (wm * HX_MAX + (qq >> 3) * HW_ + (qq & 7)) * 4;
-        a_base[0][i] = pix + ((h ^ ((qq >> 3) & 1)) << 1);
-        a_base[1][i] = pix + ((h ^ (((qq >> 3) + 1) & 1)) << 1);
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-
-    fetch_halo(0);
-#pragma unroll
-    for (int q = 0; q < RING; ++q) load_b(q, q);
-    commit_halo();
-    __syncthreads();
-
-    // A fragments of the NEXT step are read from the halo image while this step's MFMAs run (the image only changes at chunk
-    // boundaries, where the read follows the commit)
-    bf16x8 af_n[NP][TM];
-    auto read_a = [&](int t) {
-        const int tw = s_tapoff[t], toff = tw & ~1, odd = tw & 1;
-#pragma unroll
-        for (int c = 0; c < NP; ++c)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af_n[c][i] = *reinterpret_cast<const bf16x8*>(&Hs[c][(odd ? a_base[1][i] : a_base[0][i]) + toff]);
-    };
-    read_a(0);
-
-    // one K step; SL = ring slot holding this step's filter slice (refilled with the slice of step s+2 once it is consumed)
-    auto k_step = [&](int s, int SL) {
-        const int cc = s / T, t = s - cc * T;
-        // the next chunk's halo is fetched three taps before the chunk ends and committed after the chunk's last tap
-        const int t_fetch = T > 3 ? T - 3 : 0;
-        const bool last_chunk = (cc + 1) * 16 >= p.AC;
-        if (t == t_fetch && !last_chunk) fetch_halo(cc + 1);
-        bf16x8 bf[NP][TN], af[NP][TM];
-#pragma unroll
-        for (int c = 0; c < NP; ++c) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[c][j] = __builtin_bit_cast(bf16x8, rb[SL][c][j]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[c][i] = af_n[c][i];
-        }
-        load_b(s + RING, SL);
-        const bool boundary = t == T - 1;
-        if (!boundary) read_a(t + 1);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {      // smallest terms first
-                f32x16 a = acc[i][j];
-                if (NP == 3) {
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[NP - 1][j], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 1][i], bf[0][j], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP > 1 ? 1 : 0][i], bf[NP > 1 ? 1 : 0][j], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[NP > 1 ? 1 : 0][j], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP > 1 ? 1 : 0][i], bf[0][j], a, 0, 0, 0);
-                }
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], a, 0, 0, 0);
-                acc[i][j] = a;
-            }
-        if (boundary) {
-            if (!last_chunk) {                 // the halo image is the only shared state: one barrier pair per CHUNK, none per tap
-                __syncthreads();               // every wave has finished the chunk's taps
-                commit_halo();
-                __syncthreads();
-            }
-            if (s + 1 < n_steps) read_a(0);
-        }
-    };
-    for (int s = 0; s < n_steps; s += RING) {
-        k_step(s, 0);
-        if (s + 1 < n_steps) k_step(s + 1, 1);
-        if (RING > 2) {
-            if (s + 2 < n_steps) k_step(s + 2, RING > 2 ? 2 : 0);
-            if (s + 3 < n_steps) k_step(s + 3, RING > 2 ? 3 : 0);
-        }
-    }
-    __syncthreads();
-
-    // ---- epilogue (as igemm_halo) -------------------------------------------------------------------------
-    if (tid < BM) {
-        const int m = m0 + tid;
-        int off = -1, roff = 0;
-        if (m < M) {
-            const RowCoord rc = kc_decode_row(m, OHc, OWc, 1);
-            off = kc_out_offset(p, kc, rc);
-            if (p.res) roff = kc_res_offset(p, kc, rc);
-        }
-        s_off[tid] = off;
-        s_roff[tid] = roff;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * TN * 32 + j * 32 + r;
-        if (n >= p.Nn) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int row = wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-                const int off = s_off[row];
-                if (off < 0) continue;
-                float val = acc[i][j][v] + bv;
-                if (p.res) val += p.res[s_roff[row] + n];
-                if (p.act == CSLGAN_ACT_LRELU02) val = val > 0.f ? val : 0.2f * val;
-                else if (p.act == CSLGAN_ACT_RELU) val = val > 0.f ? val : 0.f;
-                else if (p.act == CSLGAN_ACT_TANH) val = tanhf(val);
-                if (p.mask) val *= (p.mask[off + n] > 0.f ? 1.f : 0.2f);
-                p.out[off + n] = val;
-            }
-        }
-    }
-}
-
-// The KRSC filter w[n][t][c] split into its three bfloat16 pieces and re-laid STEP-major for igemm_halo_x3:
-//   w3[piece][step = (c/16) * T + t][n][c % 16]      (needs C % 16 == 0; every step's [Nn][16] slice is contiguous)
-template <int NP>
-__global__ void split_filter_x3_kernel(const float* __restrict__ w, int Nn, int T, int C, unsigned short* __restrict__ w3) {
-    const long long n_el = (long long)Nn * T * C, n4 = n_el >> 2;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        const long long e = i << 2;                       // element (n, t, c..c+3)
-        const int c = (int)(e % C);
-        const long long nt = e / C;
-        const int t = (int)(nt % T), n = (int)(nt / T);
-        const long long dst = ((((long long)(c >> 4) * T + t) * Nn + n) << 4) + (c & 15);
-        const bf16x3_t s3 = split4_bf16(reinterpret_cast<const float4*>(w)[i]);
-        *reinterpret_cast<uint2*>(w3 + dst) = s3.hi;           // = the round-to-nearest-even bfloat16 of w: all the NP = 1 form needs
-        if (NP == 3) {
-            *reinterpret_cast<uint2*>(w3 + n_el + dst) = s3.mid;
-            *reinterpret_cast<uint2*>(w3 + 2 * n_el + dst) = s3.lo;
-        }
-    }
-}
-
-int split_filter_x3(const float* w, int Nn, int T, int C, void* w3, hipStream_t st, int pieces) {
-    if (C % 16) return CSLGAN_OK;                     // the halo form does not take this shape: the workspace stays unused
-    long long nb = ((long long)Nn * T * C / 4 + 255) / 256;
-    nb = nb > 2048 ? 2048 : (nb < 1 ? 1 : nb);
-    if (pieces == 1) hipLaunchKernelGGL(split_filter_x3_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, w, Nn, T, C, reinterpret_cast<unsigned short*>(w3));
-    else hipLaunchKernelGGL(split_filter_x3_kernel<3>, dim3((unsigned)nb), dim3(256), 0, st, w, Nn, T, C, reinterpret_cast<unsigned short*>(w3));
-    return check_launch("split_filter_x3_kernel");
-}
-
-// Shapes the halo form takes: one class, stride 1, an 8x8-patchable grid of at least 16x16, channels a multiple of 16, 2..25 taps
-// within a 12x12 halo, >= 64 output channels, and the pre-split filter (cslgan_conv2d_fwd_x3_f32).
-// rocprofv3 PMC on the generator's 32x32x128 conv: SQ_VALU_MFMA_BUSY_CYCLES = 57 % of the SIMD cycles at a sustained 1.85 GHz
-// (184-214 TF logical = 1.1-1.3 PF of executed bf16 MFMA); 1.6 non-MFMA vector instructions per MFMA; LDS bank conflicts 48 %
-// of LDS-active cycles after the half-swap swizzle (73 % before).
-static bool halo_x3_eligible(const KcParams& p) {
-    static const int env = [] { const char* e = getenv("CSLGAN_X3_HALO"); return e ? atoi(e) : 1; }();
-    if (!env || !p.w3 || p.n_cls != 1 || p.sy != 1 || p.sx != 1 || (p.AC & 15) || p.Nn < 64 || !aligned16(p.a) || !aligned16(p.w3)) return false;
-    for (int c = 0; c < p.n_cls; ++c) {
-        const KcClass& k = p.cls[c];
-        if (k.T < 2 || (k.M & 63) || (k.OHc & 7) || (k.OWc & 7) || (k.Kdim & 3) || (k.w_off & 3) || k.ay_mul > 1 || k.ax_mul > 1) return false;
-        if (k.OHc < 16 || k.OWc < 16) return false;      // 8x8 images: a 12x12 halo is mostly padding, the gather form wins (0.66 vs 0.78 ms)
-        int ymin = 127, ymax = -128, xmin = 127, xmax = -128;
-        for (int t = 0; t < k.T; ++t) {
-            ymin = k.ty[t] < ymin ? k.ty[t] : ymin; ymax = k.ty[t] > ymax ? k.ty[t] : ymax;
-            xmin = k.tx[t] < xmin ? k.tx[t] : xmin; xmax = k.tx[t] > xmax ? k.tx[t] : xmax;
-        }
-        if (ymax - ymin > 4 || xmax - xmin > 4) return false;
-    }
-    return true;
-}
-
-static int launch_halo_x3(KcParams& p, hipStream_t st) {
-    int tm = 0;
-    for (int c = 0; c < p.n_cls; ++c) {
-        KcClass& k = p.cls[c];
-        int ymin = 127, ymax = -128, xmin = 127, xmax = -128;
-        for (int t = 0; t < k.T; ++t) {
-            ymin = k.ty[t] < ymin ? k.ty[t] : ymin; ymax = k.ty[t] > ymax ? k.ty[t] : ymax;
-            xmin = k.tx[t] < xmin ? k.tx[t] : xmin; xmax = k.tx[t] > xmax ? k.tx[t] : xmax;
-        }
-        k.ty_min = ymin; k.tx_min = xmin; k.halo_h = 8 + ymax - ymin; k.halo_w = 8 + xmax - xmin;
-        k.patch = 1;
-        k.tile0 = tm;
-        tm += (k.M + 127) / 128;
-    }
-    p.tiles_m = tm;
-    p.ksplit = 1;
-    p.pair_mode = 0;
-    const bool wide = p.Nn > 64;
-    p.tiles_n = wide ? (p.Nn + 127) / 128 : 1;
-    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);
-    const bool x3 = p.bf16 == 3;
-    note_kernel(x3 ? "igemm_halo_x3_kernel<%d>" : "igemm_halo_bf16_kernel<%d>", wide ? 128 : 64);
-    if (x3) {
-        if (wide) hipLaunchKernelGGL((igemm_halo_x3_kernel<128, 3>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((igemm_halo_x3_kernel<64, 3>), grid, block, 0, st, p);
-    } else {
-        if (wide) hipLaunchKernelGGL((igemm_halo_x3_kernel<128, 1>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((igemm_halo_x3_kernel<64, 1>), grid, block, 0, st, p);
-    }
-    return check_launch("igemm_halo_x3_kernel");
 }
 
 int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, float* sq_accum, hipStream_t st);   // clip_kernels.hip

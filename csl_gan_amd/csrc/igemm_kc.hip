@@ -375,7 +375,9 @@ static long long tiles_for(const KcParams& p, int BM, int BN) {
 }
 
 int launch_kc_bf16(KcParams& p, hipStream_t st, long long out_elems);     // igemm_bf16.hip
-int split_filter_x3(const float* w, int Nn, int T, int C, void* w3, hipStream_t st, int pieces);
+int split_filter_x3(const float* w, int Nn, int T, int C, void* w3, hipStream_t st, int pieces);      // igemm_x3.hip
+int split_classes_x3(const KcParams& p, hipStream_t st);
+bool x3h_eligible(const KcParams& p);
 bool halo_eligible(const KcParams& p);          // igemm_halo.hip
 int launch_halo(KcParams& p, hipStream_t st);
 bool skinny_eligible(const KcParams& p);        // igemm_skinny.hip
@@ -415,7 +417,6 @@ int launch_kc(KcParams& p, hipStream_t st, long long out_elems) {
     if (skinny_env && !p.acc_classes && skinny_eligible(p)) return launch_skinny(p, st);
     if (p.a_bf16) { set_error("igemm_kc: a bfloat16-stored input is only taken by the 1..4-output-channel kernel (64 input channels, stride 1)"); return CSLGAN_ERR_INVALID_ARG; }
     if (p.bf16) {
-        if (p.acc_classes) { set_error("igemm_kc: accumulated classes have no bf16 form"); return CSLGAN_ERR_INVALID_ARG; }
         return launch_kc_bf16(p, st, out_elems);
     }
     static const int halo_env = [] { const char* e = getenv("CSLGAN_KC_HALO"); return e ? atoi(e) : 1; }();
@@ -530,8 +531,28 @@ static int conv2d_fwd_impl(const cslgan_conv_t* c, const float* x, const float* 
 // all accumulating into the same output tile inside one igemm_halo workgroup.  igemm_kc re-gathers the 2-strided input
 // window once per tap (the critic's forward convs ran at 82-105 TF); per class the window is a <= 10x10 halo in LDS.
 // Falls back to cslgan_conv2d_fwd_f32 for shapes the halo kernel does not take.
+static int conv2d_s2_fwd_impl(const cslgan_conv_t* c, const float* x, const float* w, float* wcls_ws, void* w3_ws, int repack,
+                              const float* bias, int act, float* y, void* stream);
+
 int cslgan_conv2d_s2_fwd_f32(const cslgan_conv_t* c, const float* x, const float* w, float* wcls_ws, int repack,
                              const float* bias, int act, float* y, void* stream) {
+    return conv2d_s2_fwd_impl(c, x, w, wcls_ws, nullptr, repack, bias, act, y, stream);
+}
+
+// The same stride-2 forward conv with fp32 emulated from three bfloat16 pieces (cslgan_conv_t.compute = CSLGAN_COMPUTE_BF16X3) or
+// plain bfloat16 operands (CSLGAN_COMPUTE_BF16) on the LDS-halo kernel of csrc/igemm_x3.hip: w3_ws receives the class matrices
+// split into their pieces in step-major order (3 * K*R*S*C bfloat16; rewritten when repack != 0).  Shapes that kernel does not take
+// run cslgan_conv2d_fwd_f32 in the same arithmetic.
+int cslgan_conv2d_s2_fwd_x3_f32(const cslgan_conv_t* c, const float* x, const float* w, float* wcls_ws, void* w3_ws, int repack,
+                                const float* bias, int act, float* y, void* stream) {
+    CSLGAN_REQUIRE(c && w3_ws, "conv2d_s2_fwd_x3: null argument");
+    CSLGAN_REQUIRE(c->compute == CSLGAN_COMPUTE_BF16X3 || c->compute == CSLGAN_COMPUTE_BF16,
+                   "conv2d_s2_fwd_x3: cslgan_conv_t.compute must be CSLGAN_COMPUTE_BF16X3 or CSLGAN_COMPUTE_BF16");
+    return conv2d_s2_fwd_impl(c, x, w, wcls_ws, w3_ws, repack, bias, act, y, stream);
+}
+
+static int conv2d_s2_fwd_impl(const cslgan_conv_t* c, const float* x, const float* w, float* wcls_ws, void* w3_ws, int repack,
+                              const float* bias, int act, float* y, void* stream) {
     CSLGAN_REQUIRE(c && x && w && wcls_ws && y, "conv2d_s2_fwd: null argument");
     int rc = check_conv(c, "conv2d_s2_fwd");
     if (rc) return rc;
@@ -575,7 +596,15 @@ int cslgan_conv2d_s2_fwd_f32(const cslgan_conv_t* c, const float* x, const float
     // launch, no gain or a loss below ~500 tiles (four halo stagings per chunk for 2-9 taps each) -> igemm_kc keeps those.
     static const int s2_min_tiles = [] { const char* e = getenv("CSLGAN_S2_MIN_TILES"); return e ? atoi(e) : 512; }();
     const long long wide_tiles = ((long long)c->N * c->P * c->Q + 127) / 128 * ((c->K + 127) / 128);
-    if (!ok || n == 0 || !halo_env || !s2_env || wide_tiles < s2_min_tiles || c->compute != CSLGAN_COMPUTE_F32 || !halo_eligible(p))
+    if (w3_ws) {        // bf16 matrix cores: three-piece (or plain bf16) operands on the LDS-halo kernel, any tile count
+        p.bf16 = c->compute == CSLGAN_COMPUTE_BF16X3 ? 3 : 1;
+        p.w3 = w3_ws;
+        {       // operand sizes for the eligibility test (launch_kc sets them again)
+            p.a_bytes = 0; p.w_bytes = 0;
+        }
+        if (!ok || n == 0 || !x3h_eligible(p))
+            return cslgan_conv2d_fwd_f32(c, x, w, bias, nullptr, act, y, stream);
+    } else if (!ok || n == 0 || !halo_env || !s2_env || wide_tiles < s2_min_tiles || c->compute != CSLGAN_COMPUTE_F32 || !halo_eligible(p))
         return cslgan_conv2d_fwd_f32(c, x, w, bias, nullptr, act, y, stream);
     if (repack) {
         const long long per = (long long)c->C * 9 * c->K;
@@ -584,16 +613,29 @@ int cslgan_conv2d_s2_fwd_f32(const cslgan_conv_t* c, const float* x, const float
         hipLaunchKernelGGL(repack_filters_kernel, dim3(gxn, (unsigned)n), dim3(256), 0, st, w, wcls_ws, ra);
         rc = check_launch("repack_filters_kernel");
         if (rc) return rc;
+        if (w3_ws) { rc = split_classes_x3(p, st); if (rc) return rc; }
     }
     return launch_kc(p, st, 0);
 }
 
 static int conv2d_dgrad_impl(const cslgan_conv_t* c, const float* gy, const float* w, float* wt_ws, int repack,
-                             const float* mask, float* gx, void* stream, int gy_bf16);
+                             const float* mask, float* gx, void* stream, int gy_bf16, void* w3_ws = nullptr);
 
 int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* c, const float* gy, const float* w, float* wt_ws, int repack,
                             const float* mask, float* gx, void* stream) {
     return conv2d_dgrad_impl(c, gy, w, wt_ws, repack, mask, gx, stream, 0);
+}
+
+// cslgan_conv2d_dgrad_f32 with fp32 emulated from three bfloat16 pieces (CSLGAN_COMPUTE_BF16X3) or plain bfloat16 operands
+// (CSLGAN_COMPUTE_BF16) on the LDS-halo kernel of csrc/igemm_x3.hip: w3_ws receives the repacked class matrices split into their
+// pieces in step-major order (3 * K*R*S*C bfloat16; rewritten when repack != 0).  Shapes that kernel does not take run the gather
+// kernels in the same arithmetic.
+int cslgan_conv2d_dgrad_x3_f32(const cslgan_conv_t* c, const float* gy, const float* w, float* wt_ws, void* w3_ws, int repack,
+                               const float* mask, float* gx, void* stream) {
+    CSLGAN_REQUIRE(c && w3_ws, "conv2d_dgrad_x3: null argument");
+    CSLGAN_REQUIRE(c->compute == CSLGAN_COMPUTE_BF16X3 || c->compute == CSLGAN_COMPUTE_BF16,
+                   "conv2d_dgrad_x3: cslgan_conv_t.compute must be CSLGAN_COMPUTE_BF16X3 or CSLGAN_COMPUTE_BF16");
+    return conv2d_dgrad_impl(c, gy, w, wt_ws, repack, mask, gx, stream, 0, w3_ws);
 }
 
 // cslgan_conv2d_dgrad_f32 for a conv with 1..4 INPUT channels (the critic's RGB first layer: the gradient of the image,
@@ -604,7 +646,7 @@ int cslgan_conv2d_dgrad_skinny_bf16in(const cslgan_conv_t* c, const void* gy_bf1
 }
 
 static int conv2d_dgrad_impl(const cslgan_conv_t* c, const float* gy, const float* w, float* wt_ws, int repack,
-                             const float* mask, float* gx, void* stream, int gy_bf16) {
+                             const float* mask, float* gx, void* stream, int gy_bf16, void* w3_ws) {
     CSLGAN_REQUIRE(c && gy && w && wt_ws && gx, "conv2d_dgrad: null argument");
     int rc = check_conv(c, "conv2d_dgrad");
     if (rc) return rc;
@@ -621,6 +663,7 @@ static int conv2d_dgrad_impl(const cslgan_conv_t* c, const float* gy, const floa
     p.dense_out = (s == 1) ? 1 : 0;
     p.bias = nullptr; p.res = nullptr; p.mask = mask; p.act = CSLGAN_ACT_NONE; p.bf16 = c->compute == CSLGAN_COMPUTE_BF16 ? 1 : (c->compute == CSLGAN_COMPUTE_BF16X3 ? 3 : 0);
     p.a_bf16 = gy_bf16;
+    p.w3 = (w3_ws && c->K % 16 == 0 && aligned16(w3_ws)) ? w3_ws : nullptr;
     int off = 0, ncls = 0;
     for (int py = 0; py < s; ++py)
         for (int px = 0; px < s; ++px) {
@@ -652,6 +695,7 @@ static int conv2d_dgrad_impl(const cslgan_conv_t* c, const float* gy, const floa
         hipLaunchKernelGGL(repack_filters_kernel, dim3(gxn, (unsigned)ncls), dim3(256), 0, st, w, wt_ws, ra);
         rc = check_launch("repack_filters_kernel");
         if (rc) return rc;
+        if (p.w3) { rc = split_classes_x3(p, st); if (rc) return rc; }
     }
     // K can be split only for the dense (stride-1, single-class) form whose output we may zero here
     return launch_kc(p, st, (s == 1 && !mask) ? (long long)c->N * c->H * c->W * c->C : 0);

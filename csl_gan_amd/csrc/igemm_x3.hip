@@ -1,0 +1,504 @@
+// fp32-accurate convolution on the bf16 matrix cores with an LDS-resident input halo ("x3 halo"): forward conv, stride-2
+// forward conv as accumulated parity classes, and the parity classes of the data gradient.  gfx950 only.
+//
+//   Out[m][n] = epilogue( sum_k A(m,k) * Wm[n][k] )      (index maps and classes: igemm.h, same as igemm_halo.hip)
+//
+// Arithmetic (csrc/igemm_bf16.hip states the construction): every fp32 operand is the sum of three bfloat16 pieces
+// hi + mid + lo (3 x 8 mantissa bits); a product is six exact bf16 x bf16 piece products (the three smallest of the nine are
+// below 2^-23 |a||b| and dropped), summed smallest first in the fp32 accumulator of v_mfma_f32_32x32x16_bf16: six MFMAs per
+// 16-k step at 16x the fp32 MFMA rate = 2.67x the exact-fp32 matrix rate at fp32 accuracy (tests: error against fp64 is
+// below the exact-fp32 kernels').  NP = 1 is the plain bf16 form of the same kernel (--compute_dtype bf16 on fp32 tensors).
+//
+// Round 4 rewrite of igemm_halo_x3_kernel (round 2-3, in igemm_bf16.hip).  What rocprofv3 and the ISA showed there: matrix
+// pipe 57 % busy.  Cause found in the ISA: the per-lane halo base `a_base[odd][i]` was indexed by a run-time tap parity, which
+// put the array in SCRATCH — every K step did ds_read (tap table) -> s_waitcnt -> scratch_load -> s_waitcnt vmcnt(0) -> LDS
+// fragment reads, and that vmcnt(0) also waited for the filter loads issued a few instructions earlier (an L2 round trip in
+// front of every 24-MFMA block); the fragment reads were ds_read2_b64 (half rate: the LDS array was typed 8-byte aligned).
+// Here:
+//   * tap offsets are SCALAR arithmetic on an affine tap grid (row-major R' x S' taps with constant steps — every forward
+//     filter and every parity class of a strided data gradient is one); nothing about a tap is looked up in memory;
+//   * the swizzled fragment address is (base + tap) ^ parity: one v_add + v_xor, no table;
+//   * filter slices ride a two-slot register ring that is refilled (with the slice of step s+2) right after the MFMAs of step s
+//     have read it, and the A fragments of the next tap are read into the SAME registers tile by tile as each tile's MFMAs
+//     release them — no write-after-read copies, no second register set (189 VGPRs for the 128x128 three-piece tile);
+//   * the steady-state K loop has no branch inside or between its steps, so the compiler's counted s_waitcnt survive
+//     (any skipped path made SIInsertWaitcnts fall back to vmcnt(0) / lgkmcnt(0) in front of every MFMA block);
+//   * the halo image is double buffered: the next chunk's pixels are fetched at the chunk's first tap, split and written to
+//     the OTHER image at its last tap, one barrier per 16-channel chunk (was: two, with the split in between);
+//   * LDS images are 16-byte typed: fragment reads are ds_read_b128.
+// GEN = true adds what igemm_halo<.,true> has: several classes per launch (the 9/6/6/4-tap parity classes of a 5x5 stride-2
+// data gradient), class pairs, classes accumulated into one output (a stride-2 forward conv as four stride-1 convs over
+// the parity sub-images of x) and four-image patches for 4x4 grids.
+//
+// Replaces (reference file:line): nn.Conv2d forward and its autograd data gradient, DCResNet_models.py:16,60-70,95-104,
+// 131-132; gradient_penalty.py:48-54 (the double backward runs the same two ops).
+#include <stdlib.h>
+#include "common.h"
+#include "igemm.h"
+
+namespace cslgan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr unsigned XOOB = 0xFFFFFFF0u;
+constexpr int XH_MAX = 12 * 12;        // pixels per patch halo (8+4 squared: up to 5x5 taps; four 6x6 halos of a quad patch)
+
+__device__ __forceinline__ unsigned xpack(float lo, float hi) {      // v_cvt_pk_bf16_f32: RNE, lo in bits 0..15
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float xlo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float xhi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+struct x3_t { uint2 hi, mid, lo; };
+__device__ __forceinline__ x3_t xsplit4(const float4& v) {
+    x3_t r;
+    r.hi = make_uint2(xpack(v.x, v.y), xpack(v.z, v.w));
+    const float r0 = v.x - xlo(r.hi.x), r1 = v.y - xhi(r.hi.x), r2 = v.z - xlo(r.hi.y), r3 = v.w - xhi(r.hi.y);   // exact
+    r.mid = make_uint2(xpack(r0, r1), xpack(r2, r3));
+    r.lo = make_uint2(xpack(r0 - xlo(r.mid.x), r1 - xhi(r.mid.x)), xpack(r2 - xlo(r.mid.y), r3 - xhi(r.mid.y)));
+    return r;
+}
+__device__ __forceinline__ float4 xload4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+}  // namespace
+
+// One workgroup = two 64-row patches (128 rows) x BN output channels; waves 2 (M: one patch each) x 2 (N).
+// LDS: halo images [buffer][piece][patch][pixel][2 x 16 B], 2 x NP x 9216 B (55 KB for NP = 3: two workgroups per CU).
+template <int BN, int NP, bool GEN>
+__global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
+    constexpr int BM = 128, TM = 2, TN = BN / 64;
+    constexpr int IMG = 2 * XH_MAX * 2;                        // uint4 units per piece image (2 patches x 144 pixels x 2 halves)
+    __shared__ __attribute__((aligned(16))) uint4 Hs[2][NP][IMG];
+    __shared__ int s_off[BM];
+    __shared__ int s_roff[BM];
+
+    const int tid = threadIdx.x;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int tile_mg = wg / p.tiles_n, tile_n = wg - tile_mg * p.tiles_n;
+    const bool accumulate = GEN && p.acc_classes;
+    const int n_sub = accumulate ? p.n_cls : ((GEN && p.pair_mode) ? 2 : 1);
+    const int lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;                     // wm = patch index
+    const int n0 = tile_n * BN;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
+
+    f32x16 acc[TM][TN];
+#pragma unroll 1
+    for (int sub = 0; sub < n_sub; ++sub) {
+        int ci = 0, tile_in_cls;
+        if (accumulate) {
+            ci = sub;
+            tile_in_cls = tile_mg;
+        } else if (GEN && p.pair_mode) {
+            const int pg = tile_mg / p.tiles_per_cls;
+            ci = p.pair_cls[pg][sub];
+            tile_in_cls = tile_mg - pg * p.tiles_per_cls;
+        } else {
+            if (GEN) {
+#pragma unroll 1
+                while (ci + 1 < p.n_cls && tile_mg >= p.cls[ci + 1].tile0) ++ci;
+            }
+            tile_in_cls = tile_mg - p.cls[ci].tile0;
+        }
+        const KcClass& kc = p.cls[ci];
+        const int M = kc.M, OHc = kc.OHc, OWc = kc.OWc, T = kc.T;
+        const int m0 = tile_in_cls * BM;
+        const int HW_ = kc.halo_w, HH_ = kc.halo_h;
+        const bool quad = GEN && kc.patch == 2;                // 4x4 grids: a 64-row patch = four consecutive images
+        const int hpix_img = HH_ * HW_;
+        const int hpix = quad ? 4 * hpix_img : hpix_img;
+        const int img_stride = p.AH * p.AW * p.AC;
+        const int ay_mul = (GEN && kc.ay_mul) ? kc.ay_mul : 1, ay_off = GEN ? kc.ay_off : 0;
+        const int ax_mul = (GEN && kc.ax_mul) ? kc.ax_mul : 1, ax_off = GEN ? kc.ax_off : 0;
+        // affine tap grid (checked on the host): tap t = (i, j) = (t / nkw, t % nkw), halo offset (dy0 + i*ystep, dx0 + j*xstep)
+        const int nkw = kc.nkw;
+        const int ystep = T > nkw ? (int)kc.ty[nkw] - (int)kc.ty[0] : 0;
+        const int xstep = nkw > 1 ? (int)kc.tx[1] - (int)kc.tx[0] : 0;
+        const int dy0 = (int)kc.ty[0] - kc.ty_min, dx0 = (int)kc.tx[0] - kc.tx_min;
+
+        // ---- halo staging plan: 2 patches x hpix pixels x 4 groups of 4 channels; <= 2*144*4/256 = 4.5 float4 per thread.
+        // Global byte offset (chunk 0) and LDS slot of each element are fixed for the whole class: computed once.
+        constexpr int HREG = (2 * XH_MAX * 4 + 255) / 256;
+        unsigned h_goff[HREG];
+        int h_lds[HREG];                                       // uint2 index into a piece image, -1 = nothing to write
+        {
+            int p_img[2], p_y0[2], p_x0[2];
+            bool p_ok[2];
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int m = m0 + 64 * pp;
+                p_ok[pp] = m < M;
+                const RowCoord rc = kc_decode_row(p_ok[pp] ? m : 0, OHc, OWc, quad ? 0 : 1);   // first row of the patch = its top-left pixel
+                p_img[pp] = rc.img * img_stride;
+                p_y0[pp] = rc.oy + kc.ty_min;
+                p_x0[pp] = rc.ox + kc.tx_min;
+            }
+            const int h_total = 2 * hpix * 4;
+#pragma unroll
+            for (int j = 0; j < HREG; ++j) {
+                const int idx = tid + 256 * j;
+                const int ch = idx & 3, pixg = idx >> 2;
+                const int pp = pixg >= hpix ? 1 : 0;
+                const int pix = pixg - pp * hpix;
+                const int si = quad ? pix / hpix_img : 0;      // sub-image of a quad patch
+                const int rem = pix - si * hpix_img;
+                const int hy = rem / HW_, hx = rem - hy * HW_;
+                const int iy = (p_y0[pp] + hy) * ay_mul + ay_off, ix = (p_x0[pp] + hx) * ax_mul + ax_off;
+                const bool in_img = idx < h_total && p_ok[pp] && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
+                h_goff[j] = (4u * (unsigned)(p_img[pp] + si * img_stride + (iy * p.AW + ix) * p.AC + ch * 4)) | (in_img ? 0u : XOOB);
+                // the two 16-byte halves of a pixel are swapped on odd halo rows: the patch rows a 16-lane ds_read_b128 group covers then
+                // hit disjoint banks (the plain 32-byte pixel stride is 2-way conflicted)
+                h_lds[j] = idx < h_total ? (pp * XH_MAX + pix) * 4 + (ch ^ ((hy & 1) << 1)) : -1;
+            }
+        }
+        float4 rh[HREG];
+        auto fetch_halo = [&](int cc) {
+            const unsigned co = 64u * (unsigned)cc;            // 16 channels x 4 B per chunk
+#pragma unroll
+            for (int j = 0; j < HREG; ++j) rh[j] = xload4(a_rsrc, h_goff[j] + co);      // an invalid element has 0xFFFFFFF0 ORed in: + co stays out of range
+        };
+        auto commit_halo = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < HREG; ++j) {
+                if (h_lds[j] >= 0) {
+                    uint2* img0 = reinterpret_cast<uint2*>(&Hs[buf][0][0]);
+                    if (NP == 1) {
+                        img0[h_lds[j]] = make_uint2(xpack(rh[j].x, rh[j].y), xpack(rh[j].z, rh[j].w));
+                    } else {
+                        const x3_t t3 = xsplit4(rh[j]);
+                        img0[h_lds[j]] = t3.hi;
+                        reinterpret_cast<uint2*>(&Hs[buf][NP > 1 ? 1 : 0][0])[h_lds[j]] = t3.mid;
+                        reinterpret_cast<uint2*>(&Hs[buf][NP > 2 ? 2 : 0][0])[h_lds[j]] = t3.lo;
+                    }
+                }
+            }
+        };
+
+        // ---- filter operand: straight to registers from the filter PRE-SPLIT into bfloat16 pieces in step-major order
+        // [piece][step = chunk*T + tap][n][16 k] (split_filter_x3, cached per weight version by the caller): lane (r, h), tile j,
+        // piece c reads 8 consecutive k of filter row n0 + wn*TN*32 + j*32 + r = one 16-byte load; the 32 rows x 32 B a
+        // wave-load touches are 1 KB contiguous.
+        const unsigned piece_bytes = 2u * (unsigned)p.Nn * (unsigned)kc.Kdim;
+        const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(p.w3) + 2ll * NP * kc.w_off), 0, NP * piece_bytes, 0x00020000);
+        const unsigned step_bytes = 32u * (unsigned)p.Nn;
+        unsigned b_off[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * TN * 32 + j * 32 + r;
+            b_off[j] = n < p.Nn ? 32u * (unsigned)n + 16u * (unsigned)h : XOOB;
+        }
+        const int n_cc = p.AC >> 4;
+        const int n_steps = n_cc * T;
+        u32x4 B0[NP][TN], B1[NP][TN];                          // two-slot ring of filter slices: slot s % 2 is refilled with step s + 2
+        auto load_b = [&](int step, u32x4 (&dst)[NP][TN]) {    // right after the MFMAs of step s have read it (no third slot, no copies)
+            const unsigned kb = (unsigned)step * step_bytes;
+            const unsigned past = step >= n_steps ? XOOB : 0u;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int c = 0; c < NP; ++c)
+                    dst[c][j] = __builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, (int)((b_off[j] + kb + c * piece_bytes) | past), 0, 0);
+        };
+
+        // ---- A fragments: lane (r, h) of tile i holds channels 8h..8h+7 of halo pixel (own pixel + tap) = one ds_read_b128 per piece.
+        int a_idx[TM];                                         // uint4 index of the lane's pixel at tap offset (0,0), swizzle bit included
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int qq = i * 32 + r;                         // row within the patch
+            const int ly = quad ? (qq >> 2) & 3 : qq >> 3;
+            const int lpix = quad ? (qq >> 4) * hpix_img + ly * HW_ + (qq & 3) : ly * HW_ + (qq & 7);
+            a_idx[i] = (wm * XH_MAX + lpix) * 2 + (h ^ (ly & 1));
+        }
+        bf16x8 A0[NP][TM], A1[NP][TM];                         // two sets: the next tap's fragments are read BEFORE this tap's MFMAs are issued
+        auto read_a = [&](int buf, int toff, int odd, bf16x8 (&dst)[NP][TM]) {      // toff = 2 * (dy * halo_w + dx), odd = dy & 1: scalar
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int at = (a_idx[i] + toff) ^ odd;
+#pragma unroll
+                for (int c = 0; c < NP; ++c) dst[c][i] = __builtin_bit_cast(bf16x8, Hs[buf][c][at]);
+            }
+        };
+
+        if (!accumulate || sub == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+        }
+
+        // ---- prologue: halo of chunk 0 into image 0, filter slices of steps 0 and 1, fragments of tap 0 -------------------------
+        fetch_halo(0);
+        load_b(0, B0);
+        load_b(1, B1);
+        commit_halo(0);
+        __syncthreads();
+        const int toff0 = 2 * (dy0 * HW_ + dx0), odd0 = dy0 & 1;
+        read_a(0, toff0, odd0, A0);
+
+        // One K step = one tap of one 16-channel chunk = one 16-k MFMA step on this step's filter slice b_cur.
+        // Control flow is kept to what SIInsertWaitcnts can see through: it merges pending memory operations conservatively at every
+        // join, and a path that skips a step (an `if (s + 1 < n_steps)` guard inside the loop) or a conditional fragment read turned the
+        // counted waits of this loop into vmcnt(0) / lgkmcnt(0) — the L2 round trip of the filter loads issued one step earlier exposed
+        // in front of every MFMA block.  So: the loop runs PAIRS of steps with no guard between them (an odd last step is peeled) and
+        // the next tap's fragments are ALWAYS read inside the MFMA block: the next chunk's image is committed one step before the
+        // chunk ends (after the MFMAs of tap T-2, followed by the chunk's one barrier), so the last tap's step reads tap 0 of the
+        // NEW image like any other step reads its next tap.  The only branches are the two per-chunk events (fetch, commit + barrier).
+        int ti = 0, tj = 0, cc = 0;                            // current tap (row, column of the tap grid) and chunk: scalar
+        auto k_step = [&](int s, u32x4 (&b_cur)[NP][TN], bf16x8 (&A)[NP][TM], bf16x8 (&An)[NP][TM]) {
+            int tjn = tj + 1, tin = ti;
+            if (tjn == nkw) { tjn = 0; tin = ti + 1; }
+            const int tn = tin * nkw + tjn;                    // index of the next tap
+            const bool last_tap = tn == T;                     // this step is the chunk's last tap: the next one is tap 0 of chunk cc + 1
+            const bool commit_now = tn == T - 1 || T == 1;     // ... the tap before it: the next image is written after this step's MFMAs
+            if (last_tap) { tin = 0; tjn = 0; }
+            const bool more_chunks = cc + 1 < n_cc;
+            const int buf = cc & 1;
+            const int rbuf = last_tap ? buf ^ 1 : buf;
+            const int dyn = dy0 + tin * ystep;
+            const int toffn = 2 * (dyn * HW_ + dx0 + tjn * xstep), oddn = dyn & 1;
+            if (ti == 0 && tj == 0 && more_chunks) fetch_halo(cc + 1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {                  // smallest terms first
+                    f32x16 a = acc[i][j];
+                    if (NP == 3) {
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][i], __builtin_bit_cast(bf16x8, b_cur[NP - 1][j]), a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[NP - 1][i], __builtin_bit_cast(bf16x8, b_cur[0][j]), a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[NP > 1 ? 1 : 0][i], __builtin_bit_cast(bf16x8, b_cur[NP > 1 ? 1 : 0][j]), a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][i], __builtin_bit_cast(bf16x8, b_cur[NP > 1 ? 1 : 0][j]), a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[NP > 1 ? 1 : 0][i], __builtin_bit_cast(bf16x8, b_cur[0][j]), a, 0, 0, 0);
+                    }
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][i], __builtin_bit_cast(bf16x8, b_cur[0][j]), a, 0, 0, 0);
+                    acc[i][j] = a;
+                    if (i == 0 && j == 0) {
+                        // The next tap's fragments are read AFTER the first tile's MFMAs are issued and pinned there: at the loop header
+                        // SIInsertWaitcnts waits for every outstanding LDS read (lgkmcnt(0)) in front of the first MFMA — with the reads
+                        // in front of it that wait exposed their latency every other step; here it only covers reads a step old.
+                        __builtin_amdgcn_sched_barrier(0);
+                        read_a(rbuf, toffn, oddn, An);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            load_b(s + 2, b_cur);                              // this slot is free again: one full step of lead for the L2 round trip
+            if (commit_now && more_chunks) {
+                commit_halo(buf ^ 1);                          // the other image: last read one chunk ago, before that chunk's barrier
+                __syncthreads();                               // the new image is complete before the last tap's step reads it
+            }
+            if (last_tap) cc = cc + 1;
+            ti = tin; tj = tjn;
+        };
+        {
+            int s = 0;
+#pragma unroll 1
+            for (; s + 1 < n_steps; s += 2) {
+                k_step(s, B0, A0, A1);
+                k_step(s + 1, B1, A1, A0);
+            }
+            if (s < n_steps) k_step(s, B0, A0, A1);
+        }
+        __syncthreads();          // every wave is done with the halo images (the next class / the epilogue tables reuse LDS state)
+
+        // ---- epilogue (as igemm_halo) -------------------------------------------------------------------------------------
+        if (accumulate && sub + 1 < n_sub) continue;
+        if (tid < BM) {
+            const int m = m0 + tid;
+            int off = -1, roff = 0;
+            if (m < M) {
+                const RowCoord rc = kc_decode_row(m, OHc, OWc, quad ? 0 : 1);
+                off = kc_out_offset(p, kc, rc);
+                if (p.res) roff = kc_res_offset(p, kc, rc);
+            }
+            s_off[tid] = off;
+            s_roff[tid] = roff;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * TN * 32 + j * 32 + r;
+            if (n >= p.Nn) continue;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int row = wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                    const int off = s_off[row];
+                    if (off < 0) continue;
+                    float val = acc[i][j][v] + bv;
+                    if (p.res) val += p.res[s_roff[row] + n];
+                    if (p.act == CSLGAN_ACT_LRELU02) val = val > 0.f ? val : 0.2f * val;
+                    else if (p.act == CSLGAN_ACT_RELU) val = val > 0.f ? val : 0.f;
+                    else if (p.act == CSLGAN_ACT_TANH) val = tanhf(val);
+                    if (p.mask) val *= (p.mask[off + n] > 0.f ? 1.f : 0.2f);
+                    p.out[off + n] = val;
+                }
+            }
+        }
+        __syncthreads();          // the next class of a pair reuses s_off / s_roff
+    }   // sub
+}
+
+// The filter matrix of one class, w[n][t][c] fp32 (KRSC for a forward conv; a repacked class matrix of a data gradient or of a
+// stride-2 forward conv), split into its bfloat16 pieces and re-laid STEP-major for igemm_x3h:
+//   w3[piece][step = (c/16) * T + t][n][c % 16]      (needs C % 16 == 0; every step's [Nn][16] slice is contiguous)
+template <int NP>
+__global__ void split_filter_x3_kernel(const float* __restrict__ w, int Nn, int T, int C, unsigned short* __restrict__ w3) {
+    const long long n_el = (long long)Nn * T * C, n4 = n_el >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const long long e = i << 2;                       // element (n, t, c..c+3)
+        const int c = (int)(e % C);
+        const long long nt = e / C;
+        const int t = (int)(nt % T), n = (int)(nt / T);
+        const long long dst = ((((long long)(c >> 4) * T + t) * Nn + n) << 4) + (c & 15);
+        const x3_t s3 = xsplit4(reinterpret_cast<const float4*>(w)[i]);
+        *reinterpret_cast<uint2*>(w3 + dst) = s3.hi;           // = the round-to-nearest-even bfloat16 of w: all the NP = 1 form needs
+        if (NP == 3) {
+            *reinterpret_cast<uint2*>(w3 + n_el + dst) = s3.mid;
+            *reinterpret_cast<uint2*>(w3 + 2 * n_el + dst) = s3.lo;
+        }
+    }
+}
+
+// w: the class matrix [Nn][T][C]; w3: its piece buffer (pieces * Nn*T*C bfloat16).  C % 16 != 0: nothing is written (the halo form
+// does not take the shape and the workspace stays unused).
+int split_filter_x3(const float* w, int Nn, int T, int C, void* w3, hipStream_t st, int pieces) {
+    if (C % 16) return CSLGAN_OK;
+    long long nb = ((long long)Nn * T * C / 4 + 255) / 256;
+    nb = nb > 2048 ? 2048 : (nb < 1 ? 1 : nb);
+    if (pieces == 1) hipLaunchKernelGGL(split_filter_x3_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, w, Nn, T, C, reinterpret_cast<unsigned short*>(w3));
+    else hipLaunchKernelGGL(split_filter_x3_kernel<3>, dim3((unsigned)nb), dim3(256), 0, st, w, Nn, T, C, reinterpret_cast<unsigned short*>(w3));
+    return check_launch("split_filter_x3_kernel");
+}
+
+// Every class matrix of a launch (KcParams::w + cls[c].w_off, [Nn][T_c][AC]) into KcParams::w3 at NP * w_off bfloat16 elements.
+int split_classes_x3(const KcParams& p, hipStream_t st) {
+    const int pieces = p.bf16 == 3 ? 3 : 1;
+    for (int c = 0; c < p.n_cls; ++c) {
+        const KcClass& k = p.cls[c];
+        unsigned short* dst = reinterpret_cast<unsigned short*>(const_cast<void*>(p.w3)) + (long long)pieces * k.w_off;
+        if (int rc = split_filter_x3(p.w + k.w_off, p.Nn, k.T, p.AC, dst, st, pieces)) return rc;
+    }
+    return CSLGAN_OK;
+}
+
+static void tap_range(const KcClass& k, int& ymin, int& ymax, int& xmin, int& xmax) {
+    ymin = 127; ymax = -128; xmin = 127; xmax = -128;
+    for (int t = 0; t < k.T; ++t) {
+        ymin = k.ty[t] < ymin ? k.ty[t] : ymin; ymax = k.ty[t] > ymax ? k.ty[t] : ymax;
+        xmin = k.tx[t] < xmin ? k.tx[t] : xmin; xmax = k.tx[t] > xmax ? k.tx[t] : xmax;
+    }
+}
+
+// Row-major affine tap grid: returns taps per row (nkw), 0 if the table is not one.
+static int affine_taps(const KcClass& k) {
+    int nkw = 1;
+    while (nkw < k.T && k.ty[nkw] == k.ty[0]) ++nkw;
+    if (k.T % nkw) return 0;
+    const int nkh = k.T / nkw;
+    const int xs = nkw > 1 ? k.tx[1] - k.tx[0] : 0, ys = nkh > 1 ? k.ty[nkw] - k.ty[0] : 0;
+    if ((nkw > 1 && xs != 1 && xs != -1) || (nkh > 1 && ys != 1 && ys != -1)) return 0;
+    for (int t = 0; t < k.T; ++t)
+        if (k.ty[t] != k.ty[0] + (t / nkw) * ys || k.tx[t] != k.tx[0] + (t % nkw) * xs) return 0;
+    return nkw;
+}
+
+// Shapes the x3 halo form takes: stride-1 classes on 8x8-patchable (or 4x4) grids, channels a multiple of 16, 2..25 affine taps
+// within a 12x12 (6x6) halo, >= 64 output channels, and the pre-split filter (p.w3).
+bool x3h_eligible(const KcParams& p) {
+    static const int env = [] { const char* e = getenv("CSLGAN_X3_HALO"); return e ? atoi(e) : 1; }();
+    if (!env || !p.w3 || !p.bf16 || p.sy != 1 || p.sx != 1 || (p.AC & 15) || p.Nn < 64 || p.ksplit > 1 || !aligned16(p.a) || !aligned16(p.w3)) return false;
+    static const int quad_min = [] { const char* e = getenv("CSLGAN_X3_QUAD_MIN"); return e ? atoi(e) : 2048; }();
+    for (int c = 0; c < p.n_cls; ++c) {
+        const KcClass& k = p.cls[c];
+        const bool quad = k.OHc == 4 && k.OWc == 4;
+        if (k.T < 2 || (k.M & 63) || (k.Kdim & 3) || (k.w_off & 7)) return false;
+        if (quad && k.M < quad_min) return false;
+        if (!quad && ((k.OHc & 7) || (k.OWc & 7))) return false;
+        if (!affine_taps(k)) return false;
+        int ymin, ymax, xmin, xmax;
+        tap_range(k, ymin, ymax, xmin, xmax);
+        const int lim = quad ? 2 : 4;       // four 6x6 halos fill the 144-pixel LDS image
+        if (ymax - ymin > lim || xmax - xmin > lim) return false;
+    }
+    return true;
+}
+
+int launch_x3h(KcParams& p, hipStream_t st) {
+    int tm = 0;
+    bool gen = p.acc_classes != 0 || p.n_cls > 1;
+    for (int c = 0; c < p.n_cls; ++c) {
+        KcClass& k = p.cls[c];
+        int ymin, ymax, xmin, xmax;
+        tap_range(k, ymin, ymax, xmin, xmax);
+        const bool quad = k.OHc == 4 && k.OWc == 4;
+        const int side = quad ? 4 : 8;
+        k.ty_min = ymin; k.tx_min = xmin; k.halo_h = side + ymax - ymin; k.halo_w = side + xmax - xmin;
+        k.patch = quad ? 2 : 1;
+        k.nkw = affine_taps(k);
+        k.tile0 = tm;
+        tm += (k.M + 127) / 128;
+        gen = gen || quad || k.ay_mul > 1 || k.ax_mul > 1;
+    }
+    p.tiles_m = tm;
+    p.ksplit = 1;
+    p.pair_mode = 0;
+    bool same_m = true, same_t = true;
+    for (int c = 1; c < p.n_cls; ++c) { same_m = same_m && p.cls[c].M == p.cls[0].M; same_t = same_t && p.cls[c].T == p.cls[0].T; }
+    bool wide = p.Nn > 64;
+    if (p.acc_classes) p.tiles_m = (p.cls[0].M + 127) / 128;       // all classes in every workgroup
+    // unequal classes (9/6/6/4 taps): the heaviest runs with the lightest in ONE workgroup (9+4, 6+6 K steps) while the halved grid
+    // still fills the chip — the rule of igemm_halo.hip
+    static const int pair_min = [] { const char* e = getenv("CSLGAN_X3_PAIR_MIN"); return e ? atoi(e) : 256; }();
+    if (!p.acc_classes && p.n_cls == 4 && same_m && !same_t) {
+        const int tpc = (p.cls[0].M + 127) / 128;
+        const long long paired = 2ll * tpc * (wide ? (p.Nn + 127) / 128 : (p.Nn + 63) / 64);
+        if (paired >= pair_min) {
+            int o[4] = {0, 1, 2, 3};
+            for (int i = 0; i < 4; ++i)
+                for (int j = i + 1; j < 4; ++j)
+                    if (p.cls[o[j]].T > p.cls[o[i]].T) { const int t = o[i]; o[i] = o[j]; o[j] = t; }
+            p.pair_mode = 1;
+            p.pair_cls[0][0] = o[0]; p.pair_cls[0][1] = o[3];
+            p.pair_cls[1][0] = o[1]; p.pair_cls[1][1] = o[2];
+            p.tiles_per_cls = tpc;
+            p.tiles_m = 2 * tpc;
+        }
+    }
+    // 64-wide N tiles when the 128-wide grid would leave CUs idle (128-row launches of the critic's last layers)
+    static const int wide_min = [] { const char* e = getenv("CSLGAN_X3_WIDE_MIN"); return e ? atoi(e) : 192; }();
+    if (wide && (long long)p.tiles_m * ((p.Nn + 127) / 128) < wide_min) wide = false;
+    p.tiles_n = wide ? (p.Nn + 127) / 128 : (p.Nn + 63) / 64;
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);
+    const bool x3 = p.bf16 == 3;
+    note_kernel(x3 ? "igemm_x3h_kernel<%d,3,%s>" : "igemm_x3h_kernel<%d,1,%s>", wide ? 128 : 64, gen ? "true" : "false");
+    if (x3) {
+        if (wide && gen) hipLaunchKernelGGL((igemm_x3h_kernel<128, 3, true>), grid, block, 0, st, p);
+        else if (wide) hipLaunchKernelGGL((igemm_x3h_kernel<128, 3, false>), grid, block, 0, st, p);
+        else if (gen) hipLaunchKernelGGL((igemm_x3h_kernel<64, 3, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((igemm_x3h_kernel<64, 3, false>), grid, block, 0, st, p);
+    } else {
+        if (wide && gen) hipLaunchKernelGGL((igemm_x3h_kernel<128, 1, true>), grid, block, 0, st, p);
+        else if (wide) hipLaunchKernelGGL((igemm_x3h_kernel<128, 1, false>), grid, block, 0, st, p);
+        else if (gen) hipLaunchKernelGGL((igemm_x3h_kernel<64, 1, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((igemm_x3h_kernel<64, 1, false>), grid, block, 0, st, p);
+    }
+    return check_launch("igemm_x3h_kernel");
+}
+
+}  // namespace cslgan

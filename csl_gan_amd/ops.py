@@ -48,9 +48,14 @@ def _kc_compute(rows, n_out, kdim):
     length kdim.  fp32_auto: measured same-box (scripts/compute_modes.py) the three-piece path wins once the launch has
     >= 128 tiles of 128x128 and a long reduction (150-185 vs 110-135 TF on the generator's convs, 100-155 vs 81-112 TF on
     the critic's 384-row passes) and loses on the 128-row launches of the small layers."""
-    if _auto and n_out >= 64 and kdim >= 512 and ((rows + 127) // 128) * ((n_out + 127) // 128) >= 128:
+    if _auto and n_out >= 64 and kdim >= _AUTO_MIN_K and ((rows + 127) // 128) * ((n_out + 127) // 128) >= _AUTO_MIN_TILES:
         return COMPUTE_BF16X3
     return _compute
+
+
+# fp32_auto thresholds (A/B switches; scripts/compute_modes.py): 128x128 tiles of the launch, reduction length
+_AUTO_MIN_TILES = int(os.environ.get("CSLGAN_AUTO_MIN_TILES", "128"))
+_AUTO_MIN_K = int(os.environ.get("CSLGAN_AUTO_MIN_K", "512"))
 
 
 class compute_dtype:
@@ -397,6 +402,18 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, ou
     flop = 2.0 * N * P * Q * K * R * S * c_alg * alg_scale    # the dense conv the reference executes
     nbytes = 4.0 * (N * H * W * c_alg + K * R * S * c_alg + N * P * Q * K)
     xflop = 2.0 * N * P * Q * K * R * S * Cc
+    if (d.compute in (COMPUTE_BF16X3, COMPUTE_BF16) and stride == 2 and R == S and R % 2 == 1 and R > 1 and Cc % 16 == 0 and K >= 64
+            and residual is None and w.numel() % 8 == 0):
+        # parity sub-images through the LDS-halo kernel of the bf16 matrix cores (csrc/igemm_x3.hip): one workspace holds the fp32
+        # class matrices and, behind them, their bfloat16 pieces in step-major order
+        nw = w.numel()
+        ws, repack = repack_cache.get("s2_fwd_x3" if d.compute == COMPUTE_BF16X3 else "s2_fwd_b16", w, nw + (3 * nw + 1) // 2, wkey)
+        _timed("conv2d_fwd", flop, nbytes, lambda: check(
+            _lib.lib().cslgan_conv2d_s2_fwd_x3_f32(C.byref(d), _p(x), _p(w), _p(ws), C.c_void_p(ws.data_ptr() + 4 * nw), repack, _p(bias), act,
+                                                   _p(y), _stream()),
+            "conv2d_s2_fwd_x3"), exec_flop=xflop, tag=lambda: "N%d %dx%d C%d K%d R%d s2 x3" % (N, H, W, Cc, K, R))
+        repack_cache.packed()
+        return y
     if stride == 2 and R == S and R % 2 == 1 and R > 1 and Cc % 32 == 0 and K >= 64 and residual is None:
         # parity sub-images through the LDS-halo kernel (the C entry falls back to the generic kernel for other grids)
         ws, repack = repack_cache.get("s2_fwd", w, w.numel(), wkey)
@@ -542,13 +559,25 @@ def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None, wkey=None, out_dtype=
     if K2 != K or (P2, Q2) != (P, Q):
         raise RuntimeError("conv2d_dgrad: gy shape %s inconsistent with input %dx%d" % (tuple(gy.shape), H, W))
     gx = torch.empty((N, H, W, Cc), device=gy.device, dtype=torch.float32)
-    ws, repack = repack_cache.get("dgrad%d" % stride, w, w.numel(), wkey)
     if mask is not None:
         _chk(mask, "mask")
         if tuple(mask.shape) != tuple(gx.shape):
             raise RuntimeError("conv2d_dgrad: mask shape mismatch")
     flop = 2.0 * N * P * Q * K * R * S * Cc
     nbytes = 4.0 * (N * H * W * Cc + K * R * S * Cc + N * P * Q * K)
+    if (d.compute in (COMPUTE_BF16X3, COMPUTE_BF16) and K % 16 == 0 and Cc >= 64 and R * S > 1 and w.numel() % 8 == 0
+            and (H // stride) % 4 == 0 and (W // stride) % 4 == 0 and H % stride == 0 and W % stride == 0):
+        # LDS-halo kernel of the bf16 matrix cores (csrc/igemm_x3.hip): the repacked class matrices and, behind them, their bfloat16
+        # pieces in step-major order share one cached workspace
+        nw = w.numel()
+        ws, repack = repack_cache.get(("dgrad%d_x3" if d.compute == COMPUTE_BF16X3 else "dgrad%d_b16") % stride, w, nw + (3 * nw + 1) // 2, wkey)
+        _timed("conv2d_dgrad", flop, nbytes, lambda: check(
+            _lib.lib().cslgan_conv2d_dgrad_x3_f32(C.byref(d), _p(gy), _p(w), _p(ws), C.c_void_p(ws.data_ptr() + 4 * nw), repack, _p(mask), _p(gx),
+                                                  _stream()), "conv2d_dgrad_x3"),
+            tag=lambda: "N%d %dx%d C%d K%d R%d s%d x3" % (N, H, W, Cc, K, R, stride))
+        repack_cache.packed()
+        return gx
+    ws, repack = repack_cache.get("dgrad%d" % stride, w, w.numel(), wkey)
     _timed("conv2d_dgrad", flop, nbytes, lambda: check(
         _lib.lib().cslgan_conv2d_dgrad_f32(C.byref(d), _p(gy), _p(w), _p(ws), repack, _p(mask), _p(gx), _stream()), "conv2d_dgrad"),
         tag=lambda: "N%d %dx%d C%d K%d R%d s%d" % (N, H, W, Cc, K, R, stride))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CSLGAN_ABI_VERSION 4
+#define CSLGAN_ABI_VERSION 5
 
 typedef enum {
     CSLGAN_OK = 0,
@@ -171,6 +171,15 @@ int cslgan_conv2d_fwd_x3_f32(const cslgan_conv_t* p, const float* x, const float
 int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* p, const float* gy, const float* w, float* wt_ws, int repack,
                             const float* mask, float* gx, void* stream);
 
+/* cslgan_conv2d_dgrad_f32 with compute == CSLGAN_COMPUTE_BF16X3 (fp32 from three bfloat16 pieces) or CSLGAN_COMPUTE_BF16 on the
+ * LDS-halo kernel of csrc/igemm_x3.hip (ABI v5): w3_ws is a second caller workspace of 3 * K*R*S*C bfloat16 receiving the
+ * repacked parity-class matrices split into their pieces in step-major order (rebuilt with wt_ws when repack != 0).  Takes
+ * stride 1-2, K % 16 == 0, C >= 64, class grids 8x8-patchable or 4x4; other shapes run the gather kernels in the same
+ * arithmetic and ignore w3_ws.  Same call it replaces: the autograd data gradient of nn.Conv2d (DCResNet_models.py:131-132)
+ * and its use inside the penalty's double backward (gradient_penalty.py:48-54). */
+int cslgan_conv2d_dgrad_x3_f32(const cslgan_conv_t* p, const float* gy, const float* w, float* wt_ws, void* w3_ws, int repack,
+                               const float* mask, float* gx, void* stream);
+
 /* Grouped weight gradient:  gw[g][k][r][s][c] = alpha * sum_{n in group g} sum_{p,q} gy[n,p,q,k] x[n,..,c]
  * with groups of `group` consecutive samples (N % group == 0).
  *   group == 1 -> per-sample gradients p.grad_sample (Opacus hook, train.py:387)
@@ -199,6 +208,13 @@ int cslgan_conv2d_wgrad_blocks_f32(const cslgan_conv_t* p, const float* gy, cons
  * back for shapes the halo kernel does not take (C % 32, K >= 64, 8x8-patchable or 4x4 output grid). */
 int cslgan_conv2d_s2_fwd_f32(const cslgan_conv_t* p, const float* x, const float* w, float* wcls_ws, int repack,
                              const float* bias, int act, float* y, void* stream);
+
+/* The same stride-2 forward conv with compute == CSLGAN_COMPUTE_BF16X3 / CSLGAN_COMPUTE_BF16 on the LDS-halo kernel of
+ * csrc/igemm_x3.hip (ABI v5): w3_ws = 3 * K*R*R*C bfloat16 receiving the parity-class matrices split into their pieces
+ * (rebuilt with wcls_ws when repack != 0).  C % 16 == 0, K >= 64, 8x8-patchable or 4x4 output grid; other shapes fall back
+ * to cslgan_conv2d_fwd_f32 in the same arithmetic. */
+int cslgan_conv2d_s2_fwd_x3_f32(const cslgan_conv_t* p, const float* x, const float* w, float* wcls_ws, void* w3_ws, int repack,
+                                const float* bias, int act, float* y, void* stream);
 
 /* Clip-weighted grouped weight gradient: as cslgan_conv2d_wgrad_grouped_f32 with gy of sample n multiplied by
  * row_scale[n] on load.  With row_scale = the per-sample clip factors f_b and group = N this is the clipped sum

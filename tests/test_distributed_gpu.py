@@ -196,5 +196,5 @@ def test_bench_two_ranks_reports_the_eager_step_by_default(tmp_path):
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["launch"] == "eager" and line["graph_error"] is None
-    assert line["config"]["global_batch"] == 256 and abs(line["value"] - 2 * line["per_gpu"]) < 1e-6 * line["value"]
+    assert line["config"]["global_batch"] == 256 and abs(line["value"] - 2 * line["per_gpu"]) <= 0.02
     assert "cpu_baseline" not in line                       # rank 0 at N = 1 only

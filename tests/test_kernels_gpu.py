@@ -1078,3 +1078,54 @@ def test_ragged_column_sums_and_deferred_sums():
     r2 = torch.empty(mats[1].shape[1], device="cuda")
     ops.sum_rows(mats[1].cuda(), r2)             # outside a block: immediate
     _close(r2, mats[1].double().sum(0).float(), rtol=1e-5, what="immediate column sum")
+
+
+# ---- round 4: the LDS-halo kernel of the three-piece path (csrc/igemm_x3.hip) on every launch form it has ---------------------------
+X3H_CASES = [
+    # kind, N, H, W, C, K, R, stride, pad, what the case reaches
+    ("fwd", 4, 16, 16, 64, 128, 5, 1, 2, "one class, 128-wide tiles, T = 25 (odd: the filter ring changes parity every chunk)"),
+    ("fwd", 3, 16, 16, 16, 64, 5, 1, 2, "a single 16-channel chunk, 64-wide tiles, an odd number of 64-row patches"),
+    ("fwd", 2, 8, 8, 48, 160, 3, 1, 1, "three chunks, T = 9, ragged N (160 filters), 8x8 images (halo mostly padding)"),
+    ("fwd", 2, 32, 32, 32, 64, 5, 1, 2, "two chunks, 64 filters"),
+    ("fwd", 2, 16, 24, 32, 96, 3, 1, 1, "non-square grid"),
+    ("fwd", 6, 32, 32, 64, 128, 5, 2, 2, "stride-2 forward = four accumulated parity classes on sub-image views (9/6/6/4 taps)"),
+    ("fwd", 16, 8, 8, 256, 512, 5, 2, 2, "stride-2 forward onto 4x4 grids: four-image patches with sub-image views"),
+    ("fwd", 6, 16, 16, 32, 64, 5, 2, 2, "stride-2 forward, 64 filters, 8x8 output grids"),
+    ("dgrad", 4, 32, 32, 64, 128, 5, 2, 2, "four parity classes in one launch (16x16 class grids)"),
+    ("dgrad", 64, 32, 32, 64, 128, 5, 2, 2, "class pairs: 9 + 4 and 6 + 6 taps in one workgroup"),
+    ("dgrad", 32, 8, 8, 256, 512, 5, 2, 2, "4x4 class grids: four-image patches, 256 input channels of the gradient"),
+    ("dgrad", 3, 16, 16, 64, 64, 5, 1, 2, "stride-1 data gradient: one class with descending taps"),
+    ("dgrad", 5, 16, 16, 128, 48, 3, 1, 1, "K = 48 reduction channels: three chunks"),
+]
+
+
+@pytest.mark.parametrize("case", X3H_CASES, ids=[c[-1].split(":")[0][:40].replace(" ", "_") for c in X3H_CASES])
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_x3_halo_kernel_forms(case, mode):
+    """igemm_x3h_kernel against an fp64 torch reference: fp32-level error (<= 4e-6 of scale, the bound of test_bf16x3_is_fp32_accurate)
+    for the three-piece arithmetic, 1e-4 against fp32 math on bf16-ROUNDED operands for the one-piece form.  Bias, LeakyReLU and the
+    LeakyReLU mask ride along; the launch must really be the halo kernel (cslgan_last_kernel)."""
+    from csl_gan_amd import _lib
+    ops = _ops()
+    kind, N, H, W, C, K, R, s, p, _ = case
+    g = torch.Generator().manual_seed(1000 + sum(case[1:9]))
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
+    P, Q = (H + 2 * p - R) // s + 1, (W + 2 * p - R) // s + 1
+    gy = torch.randn(N, K, P, Q, generator=g)
+    b = torch.randn(K, generator=g)
+    m = torch.randn(N, C, H, W, generator=g)
+    rnd = (lambda t: t.bfloat16().double()) if mode == "bf16" else (lambda t: t.double())
+    if kind == "fwd":
+        ref = F.leaky_relu(F.conv2d(rnd(x), rnd(w), b.double(), stride=s, padding=p), 0.2)
+        with ops.compute_dtype(mode):
+            got = ops.conv2d_fwd(_nhwc(x), _krsc(w), b.cuda(), stride=s, pad=p, act=1, wkey=("t", id(w))).permute(0, 3, 1, 2)
+    else:
+        ref = F.conv_transpose2d(rnd(gy), rnd(w), None, stride=s, padding=p,
+                                 output_padding=(H + 2 * p - R - (P - 1) * s, W + 2 * p - R - (Q - 1) * s)) * torch.where(m > 0, 1.0, 0.2).double()
+        with ops.compute_dtype(mode):
+            got = ops.conv2d_dgrad(_nhwc(gy), _krsc(w), (H, W), stride=s, pad=p, mask=_nhwc(m), wkey=("t", id(w))).permute(0, 3, 1, 2)
+    name = _lib.lib().cslgan_last_kernel().decode()
+    assert name.startswith("igemm_x3h_kernel"), "case %s dispatched to %s" % (case, name)
+    e = _err64(got, ref)
+    assert e <= (4e-6 if mode == "bf16x3" else 1e-4), "%s %s: error %.3e of scale vs fp64 (%s)" % (mode, case[:9], e, name)

@@ -47,6 +47,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr unsigned XOOB = 0xFFFFFFF0u;
+constexpr unsigned XFAR = 0xFFFF0000u;  // an out-of-range byte offset that STAYS out of range when a chunk / step offset (< 64 KB) is added to it
 constexpr int XH_MAX = 12 * 12;        // pixels per patch halo (8+4 squared: up to 5x5 taps; four 6x6 halos of a quad patch)
 
 __device__ __forceinline__ unsigned xpack(float lo, float hi) {      // v_cvt_pk_bf16_f32: RNE, lo in bits 0..15
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
                 const int hy = rem / HW_, hx = rem - hy * HW_;
                 const int iy = (p_y0[pp] + hy) * ay_mul + ay_off, ix = (p_x0[pp] + hx) * ax_mul + ax_off;
                 const bool in_img = idx < h_total && p_ok[pp] && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
-                h_goff[j] = (4u * (unsigned)(p_img[pp] + si * img_stride + (iy * p.AW + ix) * p.AC + ch * 4)) | (in_img ? 0u : XOOB);
+                h_goff[j] = in_img ? 4u * (unsigned)(p_img[pp] + si * img_stride + (iy * p.AW + ix) * p.AC + ch * 4) : XFAR;
                 // the two 16-byte halves of a pixel are swapped on odd halo rows: the patch rows a 16-lane ds_read_b128 group covers then
                 // hit disjoint banks (the plain 32-byte pixel stride is 2-way conflicted)
                 h_lds[j] = idx < h_total ? (pp * XH_MAX + pix) * 4 + (ch ^ ((hy & 1) << 1)) : -1;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
         auto fetch_halo = [&](int cc) {
             const unsigned co = 64u * (unsigned)cc;            // 16 channels x 4 B per chunk
 #pragma unroll
-            for (int j = 0; j < HREG; ++j) rh[j] = xload4(a_rsrc, h_goff[j] + co);      // an invalid element has 0xFFFFFFF0 ORed in: + co stays out of range
+            for (int j = 0; j < HREG; ++j) rh[j] = xload4(a_rsrc, h_goff[j] + co);      // an invalid element sits at XFAR: + co (< 64 KB) stays out of range
         };
         auto commit_halo = [&](int buf) {
 #pragma unroll
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * TN * 32 + j * 32 + r;
-            b_off[j] = n < p.Nn ? 32u * (unsigned)n + 16u * (unsigned)h : XOOB;
+            b_off[j] = n < p.Nn ? 32u * (unsigned)n + 16u * (unsigned)h : XOOB;       // tested again in load_b
         }
         const int n_cc = p.AC >> 4;
         const int n_steps = n_cc * T;
@@ -206,10 +207,12 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
             const unsigned kb = (unsigned)step * step_bytes;
             const unsigned past = step >= n_steps ? XOOB : 0u;
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j) {
+                const unsigned bad = past | (b_off[j] == XOOB ? XOOB : 0u);
 #pragma unroll
                 for (int c = 0; c < NP; ++c)
-                    dst[c][j] = __builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, (int)((b_off[j] + kb + c * piece_bytes) | past), 0, 0);
+                    dst[c][j] = __builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, (int)((b_off[j] + kb + c * piece_bytes) | bad), 0, 0);
+            }
         };
 
         // ---- A fragments: lane (r, h) of tile i holds channels 8h..8h+7 of halo pixel (own pixel + tap) = one ds_read_b128 per piece.
@@ -440,6 +443,7 @@ bool x3h_eligible(const KcParams& p) {
 }
 
 int launch_x3h(KcParams& p, hipStream_t st) {
+    if (p.a_bytes >= XFAR) { set_error("igemm_x3h: input tensor of 4 GB"); return CSLGAN_ERR_INVALID_ARG; }
     int tm = 0;
     bool gen = p.acc_classes != 0 || p.n_cls > 1;
     for (int c = 0; c < p.n_cls; ++c) {

@@ -54,7 +54,7 @@ def _kc_compute(rows, n_out, kdim):
 
 
 # fp32_auto thresholds (A/B switches; scripts/compute_modes.py): 128x128 tiles of the launch, reduction length
-_AUTO_MIN_TILES = int(os.environ.get("CSLGAN_AUTO_MIN_TILES", "128"))
+_AUTO_MIN_TILES = int(os.environ.get("CSLGAN_AUTO_MIN_TILES", "32"))
 _AUTO_MIN_K = int(os.environ.get("CSLGAN_AUTO_MIN_K", "512"))
 
 

@@ -1089,11 +1089,11 @@ X3H_CASES = [
     ("fwd", 2, 32, 32, 32, 64, 5, 1, 2, "two chunks, 64 filters"),
     ("fwd", 2, 16, 24, 32, 96, 3, 1, 1, "non-square grid"),
     ("fwd", 6, 32, 32, 64, 128, 5, 2, 2, "stride-2 forward = four accumulated parity classes on sub-image views (9/6/6/4 taps)"),
-    ("fwd", 16, 8, 8, 256, 512, 5, 2, 2, "stride-2 forward onto 4x4 grids: four-image patches with sub-image views"),
+    ("fwd", 128, 8, 8, 128, 192, 5, 2, 2, "stride-2 forward onto 4x4 grids: four-image patches with sub-image views"),
     ("fwd", 6, 16, 16, 32, 64, 5, 2, 2, "stride-2 forward, 64 filters, 8x8 output grids"),
     ("dgrad", 4, 32, 32, 64, 128, 5, 2, 2, "four parity classes in one launch (16x16 class grids)"),
     ("dgrad", 64, 32, 32, 64, 128, 5, 2, 2, "class pairs: 9 + 4 and 6 + 6 taps in one workgroup"),
-    ("dgrad", 32, 8, 8, 256, 512, 5, 2, 2, "4x4 class grids: four-image patches, 256 input channels of the gradient"),
+    ("dgrad", 128, 8, 8, 128, 192, 5, 2, 2, "4x4 class grids: four-image patches"),
     ("dgrad", 3, 16, 16, 64, 64, 5, 1, 2, "stride-1 data gradient: one class with descending taps"),
     ("dgrad", 5, 16, 16, 128, 48, 3, 1, 1, "K = 48 reduction channels: three chunks"),
 ]

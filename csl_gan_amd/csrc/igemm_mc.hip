@@ -289,6 +289,7 @@ __global__ __launch_bounds__(256) void bias_grad_grouped_vec_kernel(const float*
 int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, float* sq_accum, hipStream_t st);   // clip_kernels.hip
 
 bool wgh_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const void* x);      // igemm_wgh.hip
+bool x3w_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const void* x);      // igemm_wgh.hip: the three-piece (bf16x3) form
 int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st,
                const float* row_scale, int n_seg = 0, const int* seg_first = nullptr, float* const* seg_gw = nullptr,
                float* const* seg_sq = nullptr);      // igemm_wgh.hip
@@ -351,7 +352,8 @@ static int wgrad_grouped_impl(const cslgan_conv_t* c, const float* gy, const flo
     if (c3_env && !row_scale && c3_wgrad_eligible(c, group, out_bf16, gy))     // the critic's RGB first layer (conv_c3.hip)
         return launch_c3_wgrad(c, gy, x, alpha, gw, sq, (hipStream_t)stream);
     static const int wgh_env = [] { const char* e = getenv("CSLGAN_WGH"); return e ? atoi(e) : 1; }();
-    if (wgh_env && c->compute == CSLGAN_COMPUTE_F32 && wgh_eligible(c, out_bf16, gy, x))
+    if (wgh_env && ((c->compute == CSLGAN_COMPUTE_F32 && wgh_eligible(c, out_bf16, gy, x)) ||
+                    (c->compute == CSLGAN_COMPUTE_BF16X3 && x3w_eligible(c, out_bf16, gy, x))))
         return launch_wgh(c, gy, x, group, alpha, gw, sq, (hipStream_t)stream, row_scale);
     McParams p{};
     p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->P; p.Q = c->Q; p.Kc = c->K;
@@ -396,8 +398,8 @@ int cslgan_conv2d_wgrad_blocks_f32(const cslgan_conv_t* c, const float* gy, cons
         CSLGAN_REQUIRE(block_first[i] > block_first[i - 1] && block_first[i] < c->N, "conv2d_wgrad_blocks: block starts must increase inside [0, N)");
     const int P = (c->H + 2 * c->pad - c->R) / c->stride + 1, Q = (c->W + 2 * c->pad - c->S) / c->stride + 1;
     CSLGAN_REQUIRE(P == c->P && Q == c->Q, "conv2d_wgrad_blocks: output %dx%d does not match P,Q=%d,%d", P, Q, c->P, c->Q);
-    CSLGAN_REQUIRE(c->compute == CSLGAN_COMPUTE_F32 && wgh_eligible(c, 0, gy, x),
-                   "conv2d_wgrad_blocks: shape not taken by the LDS-resident kernel (fp32, stride 1-2, 2..5 columns, K %% 64, C %% 64, 8x8-patchable output)");
+    CSLGAN_REQUIRE((c->compute == CSLGAN_COMPUTE_F32 && wgh_eligible(c, 0, gy, x)) || (c->compute == CSLGAN_COMPUTE_BF16X3 && x3w_eligible(c, 0, gy, x)),
+                   "conv2d_wgrad_blocks: shape not taken by the LDS-resident kernels (fp32 or bf16x3, stride 1-2, 2..5 columns, K %% 64, C %% 64, 8x8-patchable output)");
     int first[CSLGAN_MAX_WGRAD_BLOCKS];
     for (int i = 0; i < n_blocks; ++i) first[i] = block_first[i];
     return launch_wgh(c, gy, x, 1, alpha, nullptr, nullptr, (hipStream_t)stream, nullptr, n_blocks, first, gw, sq);

@@ -173,6 +173,234 @@ __global__ __launch_bounds__(256, 2) void igemm_wgh_kernel(const WghParams p) {
     }
 }
 
+bool wgh_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const void* x);
+
+// ---- the same contraction with fp32 emulated from three bfloat16 pieces on the bf16 matrix cores (round 4) ----------------------------
+// cslgan_conv_t.compute == CSLGAN_COMPUTE_BF16X3 (csrc/igemm_bf16.hip states the arithmetic: x = hi + mid + lo in bfloat16, six exact
+// piece products per multiply-add, smallest first, fp32 accumulate — fp32-accurate at 2.67x the fp32 matrix rate).
+//
+// Same ownership as igemm_wgh_kernel — a workgroup = (group, 64 output channels, 64 input channels, filter row r), all S = 5 taps of the
+// row, accumulators 5 x (32 m x 32 c) per wavefront — but the reduction index (pixel) is the SLOW index of both operands while
+// v_mfma_f32_32x32x16_bf16 wants 8 consecutive k per lane, and each operand value must be split into its pieces exactly once:
+//   * a stage = HALF an 8x8 output patch (4 rows x 8 = 32 pixels = two 16-k MFMA steps): its gy rows [32 px][64 m] and the input slab the
+//     filter row needs (4 rows x (7*stride + 5) columns x 64 c) are loaded as fp32 (16-byte loads, range-checked), scaled by the sample's
+//     clip weight where one is given (in fp32, BEFORE the split: the same product the fp32 kernel forms), split into three bfloat16
+//     pieces and written to LDS as [piece][32-channel plane][pixel][32 ch] — 64-byte rows;
+//   * MFMA operands come back through ds_read_b64_tr_b16 (gfx950's transposing LDS read: a 16-lane group addresses 4 pixel rows x 16
+//     channels and every lane receives 4 consecutive pixels of ITS channel; two reads = one operand).  The four rows a group reads are
+//     consecutive output pixels: consecutive slab pixels at stride 1 (64-byte pitch: bank bases 0/16/32/48) and every other slab pixel
+//     at stride 2 (96-byte pitch: 0/48/32/16) — conflict-free in both cases;
+//   * the next stage's global loads are issued before the MFMA phase and held in registers across it (7 float4), so a stage is
+//     barrier - split/store - barrier - MFMAs, and with two workgroups per CU one multiplies while the other splits.
+// Per wavefront and 16-k step: 6 + 30 transposing reads (8 B per lane) for 30 MFMAs.
+typedef float x3w_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 x3w_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 x3w_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short x3w_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) x3w_s16x4* x3w_lds_ptr;
+typedef unsigned int x3w_u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+__device__ __forceinline__ unsigned w_pack(float lo, float hi) {
+    const x3w_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, x3w_bf16x2));
+}
+__device__ __forceinline__ float w_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float w_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ void w_split4(const float4& v, uint2& hi, uint2& mid, uint2& lo) {
+    hi = make_uint2(w_pack(v.x, v.y), w_pack(v.z, v.w));
+    const float r0 = v.x - w_lo(hi.x), r1 = v.y - w_hi(hi.x), r2 = v.z - w_lo(hi.y), r3 = v.w - w_hi(hi.y);   // exact
+    mid = make_uint2(w_pack(r0, r1), w_pack(r2, r3));
+    lo = make_uint2(w_pack(r0 - w_lo(mid.x), r1 - w_hi(mid.x)), w_pack(r2 - w_lo(mid.y), r3 - w_hi(mid.y)));
+}
+__device__ __forceinline__ float4 w_bld(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const x3w_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ x3w_bf16x8 w_tr_pair(const unsigned char* lo_addr, const unsigned char* hi_addr) {
+    const x3w_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((x3w_lds_ptr)lo_addr);
+    const x3w_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((x3w_lds_ptr)hi_addr);
+    const uint4 w = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y, __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
+    return __builtin_bit_cast(x3w_bf16x8, w);
+}
+}  // namespace
+
+template <int STRIDE>
+__global__ __launch_bounds__(256, 2) void igemm_x3w_kernel(const WghParams p) {
+    constexpr int S = 5;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    constexpr int XW = 7 * STRIDE + S;                 // staged columns of the slab
+    constexpr int XPITCH = STRIDE == 1 ? 64 : 96;      // bytes per slab pixel in a 32-channel plane (see the bank note above)
+    constexpr int XPIX = 4 * XW;                       // slab pixels per stage (4 input rows)
+    constexpr int A_PLANE = 32 * 64, X_PLANE = XPIX * XPITCH;
+    constexpr int NX = (XPIX * 16 + 255) / 256;        // float4 of the slab per thread
+    __shared__ __attribute__((aligned(16))) unsigned char As[3][2][A_PLANE];     // [piece][m half][pixel][32 m]
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[3][2][X_PLANE];     // [piece][c half][slab pixel][32 c]
+    __shared__ float s_red[4];
+
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int split = bid % p.ksplit; bid /= p.ksplit;
+    const int r = bid % p.R; bid /= p.R;
+    const int tc = bid % p.tiles_c; bid /= p.tiles_c;
+    const int tm = bid % p.tiles_m;
+    const int g = bid / p.tiles_m;
+    const int m0 = tm * 64, c0 = tc * WG_BC;
+
+    const int lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int gq = (lane >> 2) & 3, gp = lane & 3, ghalf = (lane >> 4) & 1;
+
+    const __amdgpu_buffer_rsrc_t gy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gy), 0, (unsigned)(4ll * p.N * p.P * p.Q * p.K), 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (unsigned)(4ll * p.N * p.H * p.W * p.C), 0x00020000);
+
+    f32x16 acc[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[s][v] = 0.f;
+
+    // ---- staging coordinates (fixed per thread) --------------------------------------------------------------------------------------
+    // gy: 32 px x 16 float4 = 512 -> 2 per thread; x: XPIX px x 16 float4 -> NX per thread
+    int a_pix[2], a_m4[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int idx = tid + 256 * j; a_pix[j] = idx >> 4; a_m4[j] = idx & 15; }
+    float4 rg[2], rx[NX];
+    float rs_next = 1.f;
+    const int n_patch = p.group * p.ppi;
+    const int pq8 = p.Q >> 3;
+    // stage st = 2 * patch + half, this workgroup's patches: split, split + ksplit, ...
+    auto load_stage = [&](int pi, int half) {
+        const int il = pi / p.ppi, pr = pi - il * p.ppi;
+        const int img = g * p.group + il;
+        const int py0 = ((pr / pq8) << 3) + 4 * half, px0 = (pr - (pr / pq8) * pq8) << 3;
+        rs_next = p.row_scale ? p.row_scale[img] : 1.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned gpix = (unsigned)((img * p.P + py0 + (a_pix[j] >> 3)) * p.Q + px0 + (a_pix[j] & 7));
+            rg[j] = w_bld(gy_rsrc, 4u * (gpix * (unsigned)p.K + (unsigned)(m0 + a_m4[j] * 4)));
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int idx = tid + 256 * j;
+            const int c4 = idx & 15, pc = idx >> 4;
+            const int row = pc / XW, col = pc - row * XW;
+            const int iy = (py0 + row) * STRIDE + r - p.pad, ix = px0 * STRIDE - p.pad + col;
+            const bool ok = pc < XPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            rx[j] = w_bld(x_rsrc, (4u * (unsigned)(((img * p.H + iy) * p.W + ix) * p.C + c0 + c4 * 4)) | (ok ? 0u : OOB));
+        }
+    };
+    auto store_stage = [&](float rs) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float4 v = rg[j];
+            v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
+            uint2 hi, mid, lo;
+            w_split4(v, hi, mid, lo);
+            const int at = a_pix[j] * 64 + (a_m4[j] & 7) * 8, pl = a_m4[j] >> 3;
+            *reinterpret_cast<uint2*>(&As[0][pl][at]) = hi;
+            *reinterpret_cast<uint2*>(&As[1][pl][at]) = mid;
+            *reinterpret_cast<uint2*>(&As[2][pl][at]) = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int idx = tid + 256 * j;
+            const int c4 = idx & 15, pc = idx >> 4;
+            if (pc < XPIX) {
+                uint2 hi, mid, lo;
+                w_split4(rx[j], hi, mid, lo);
+                const int at = pc * XPITCH + (c4 & 7) * 8, pl = c4 >> 3;
+                *reinterpret_cast<uint2*>(&Xs[0][pl][at]) = hi;
+                *reinterpret_cast<uint2*>(&Xs[1][pl][at]) = mid;
+                *reinterpret_cast<uint2*>(&Xs[2][pl][at]) = lo;
+            }
+        }
+    };
+    // transposed-read byte offsets of this lane inside a plane, k-step 0, tap 0: [u = which 4-pixel half of the lane's 8 k]
+    int a_tr[2], b_tr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        a_tr[u] = (8 * h + 4 * u + gq) * 64 + 32 * ghalf + 8 * gp;                          // pixel k = 16 ks + 8 h + 4 u + gq
+        b_tr[u] = (h * XW + (4 * u + gq) * STRIDE) * XPITCH + 32 * ghalf + 8 * gp;          // k -> (qy = 2 ks + h, qx = 4 u + gq)
+    }
+    auto mma_stage = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            x3w_bf16x8 a[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a[c] = w_tr_pair(&As[c][wm][a_tr[0] + ks * 16 * 64], &As[c][wm][a_tr[1] + ks * 16 * 64]);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                x3w_bf16x8 b[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    b[c] = w_tr_pair(&Xs[c][wn][b_tr[0] + ks * 2 * XW * XPITCH + s * XPITCH], &Xs[c][wn][b_tr[1] + ks * 2 * XW * XPITCH + s * XPITCH]);
+                f32x16 t = acc[s];                   // smallest terms first
+                t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], t, 0, 0, 0);
+                acc[s] = t;
+            }
+        }
+    };
+
+    const int n_stage = 2 * ((n_patch - split + p.ksplit - 1) / p.ksplit);      // this workgroup's stages (0 when split >= n_patch)
+    if (n_stage > 0) load_stage(split, 0);
+#pragma unroll 1
+    for (int st = 0; st < n_stage; ++st) {
+        const float rs = rs_next;
+        __syncthreads();                        // every wavefront is done with the previous stage's images
+        store_stage(rs);
+        __syncthreads();
+        if (st + 1 < n_stage) load_stage(split + ((st + 1) >> 1) * p.ksplit, (st + 1) & 1);
+        mma_stage();
+    }
+
+    // ---- epilogue (as igemm_wgh_kernel, one 32-row tile per wavefront along m) -------------------------------------------------------------
+    float ss = 0.f;
+    const long long row_len = (long long)p.R * S * p.C;      // floats per output channel m
+    float* __restrict__ outg = p.gw ? p.gw + (long long)g * p.K * row_len : nullptr;
+    float* sqg = p.sq ? p.sq + g : nullptr;
+    if (p.n_seg > 0) {
+        int sg = 0;
+#pragma unroll 1
+        while (sg + 1 < p.n_seg && g >= p.seg_first[sg + 1]) ++sg;
+        const int gl = g - p.seg_first[sg];
+        outg = p.seg_gw[sg] ? p.seg_gw[sg] + (long long)gl * p.K * row_len : nullptr;
+        sqg = p.seg_sq[sg] ? p.seg_sq[sg] + gl : nullptr;
+    }
+    const long long col0 = (long long)r * S * p.C;
+    const int c = c0 + wn * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int m = m0 + wm * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+            const float val = p.alpha * acc[s][v];
+            ss = fmaf(val, val, ss);
+            if (outg) {
+                float* dst = outg + (long long)m * row_len + col0 + (long long)s * p.C + c;
+                if (p.ksplit > 1) atomicAdd(dst, val);
+                else *dst = val;
+            }
+        }
+    if (sqg && p.ksplit <= 1) {
+        const float tot = block_sum_256(ss, s_red);
+        if (tid == 0) atomicAdd(sqg, tot);
+    }
+}
+
+// Shapes the three-piece form takes: what igemm_wgh takes with 5 filter columns, both tensors below 4 GB (32-bit buffer offsets).
+bool x3w_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const void* x) {
+    static const int env = [] { const char* e = getenv("CSLGAN_X3W"); return e ? atoi(e) : 1; }();
+    return env && wgh_eligible(c, out_bf16, gy, x) && c->S == 5 && 4ll * c->N * c->P * c->Q * c->K < 0xFFFFFFF0ll &&
+           4ll * c->N * c->H * c->W * c->C < 0xFFFFFFF0ll;
+}
+
 int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, float* sq_accum, hipStream_t st);   // clip_kernels.hip
 
 // Shapes this kernel takes (the rest stays on igemm_mc).
@@ -183,6 +411,7 @@ bool wgh_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const vo
 
 int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st,
                const float* row_scale, int n_seg, const int* seg_first, float* const* seg_gw, float* const* seg_sq) {
+    const bool x3 = c->compute == CSLGAN_COMPUTE_BF16X3;      // the caller has checked x3w_eligible
     WghParams p{};
     p.gy = gy; p.x = x; p.gw = gw; p.sq = sq; p.row_scale = row_scale;
     p.n_seg = n_seg;
@@ -192,7 +421,7 @@ int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int grou
     p.stride = c->stride; p.pad = c->pad; p.group = group; p.n_groups = c->N / group; p.alpha = alpha;
     // K = 64, 192, ...: 64-channel m tiles (forcing them on K = 128 to even out 640 workgroups over 512 slots was measured:
     // 176 -> 171 us on conv2, 210 -> 235 us on conv3 — not kept)
-    const bool half_m = c->K % WG_BM != 0;
+    const bool half_m = x3 || c->K % WG_BM != 0;          // the three-piece kernel owns 64 output channels per workgroup
     p.tiles_m = half_m ? c->K / 64 : c->K / WG_BM; p.tiles_c = c->C / WG_BC; p.ppi = (c->P >> 3) * (c->Q >> 3);
     p.xw = 7 * c->stride + c->S;
     const long long base = (long long)p.n_groups * p.tiles_m * p.tiles_c * c->R;
@@ -211,6 +440,15 @@ int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int grou
     const long long nb = base * p.ksplit;
     if (nb > 0x7fffffffll) { set_error("wgrad: grid too large"); return CSLGAN_ERR_INVALID_ARG; }
     const dim3 grid((unsigned)nb), block(256);
+    if (x3) {
+        note_kernel("igemm_x3w_kernel<%d>", c->stride);
+        if (c->stride == 1) hipLaunchKernelGGL(igemm_x3w_kernel<1>, grid, block, 0, st, p);
+        else hipLaunchKernelGGL(igemm_x3w_kernel<2>, grid, block, 0, st, p);
+        int rc = check_launch("igemm_x3w_kernel");
+        if (rc) return rc;
+        if (p.ksplit > 1 && sq) rc = sqnorm_rows_accumulate(gw, p.n_groups, (long long)c->K * c->R * c->S * c->C, sq, st);
+        return rc;
+    }
     note_kernel("igemm_wgh_kernel<%d,%d>", c->S < 2 ? 2 : c->S, half_m ? 1 : 2);
     if (half_m) {
         switch (c->S) {

@@ -53,6 +53,8 @@ def _kc_compute(rows, n_out, kdim):
     return _compute
 
 
+_X3_WGRAD = os.environ.get("CSLGAN_X3_WGRAD", "1") == "1"      # A/B: fp32_auto sends eligible weight gradients to the three-piece kernel
+_AUTO_WG_MIN_FLOP = float(os.environ.get("CSLGAN_AUTO_WG_MIN_GFLOP", "0.5")) * 1e9
 _X3_S2 = os.environ.get("CSLGAN_X3_S2", "1") == "1"            # A/B: the LDS-halo form of the bf16 paths for stride-2 forward convs
 _X3_DGRAD = os.environ.get("CSLGAN_X3_DGRAD", "1") == "1"      # ... and for data gradients (0: the gather kernels, as in round 3)
 # fp32_auto thresholds (A/B switches; scripts/compute_modes.py): 128x128 tiles of the launch, reduction length
@@ -304,6 +306,9 @@ def _conv_desc(N, H, W, Cc, K, R, S, stride, pad, kind="wgrad"):
         comp = _kc_compute(N * P * Q, K, R * S * Cc)
     elif kind == "dgrad":
         comp = _kc_compute(N * H * W, Cc, (R * S * K) // (stride * stride))
+    elif (_auto and _X3_WGRAD and S == 5 and stride in (1, 2) and K % 64 == 0 and Cc % 64 == 0 and P % 8 == 0 and Q % 8 == 0
+          and 2.0 * N * P * Q * K * R * S * Cc >= _AUTO_WG_MIN_FLOP):
+        comp = COMPUTE_BF16X3          # weight gradient on the LDS-resident three-piece kernel (csrc/igemm_wgh.hip: igemm_x3w_kernel)
     if comp == COMPUTE_BF16 and H == 1 and W == 1 and R == 1 and S == 1 and 2.0 * N * K * Cc < 1e9:
         # small linear layers (the critic's head, the generator's first layer): a few hundred MFLOP on skinny GEMMs where the bf16
         # gather kernels ran at < 1 TF (0.35 ms for 268 MFLOP); the fp32 kernels take 15-30 us and are exact
@@ -587,12 +592,17 @@ def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None, wkey=None, out_dtype=
     return gx
 
 
+def _wgh_arith(S):
+    """The LDS-resident weight-gradient kernels exist in exact fp32 (2..5 filter columns) and in the three-piece form (5 columns)."""
+    return _compute == COMPUTE_F32 or (_compute == COMPUTE_BF16X3 and S == 5)
+
+
 def dense_wgrad_group(N, K, Cc, R, S, PQ, stride=1, out_hw=None):
     """Samples per slab for a dense (summed) weight gradient.  The slab count sets the workgroup count, and the launch
     time follows how well that count fills 256 CUs x 3 resident workgroups (800 workgroups take two rounds, 3200 take
     4.2: measured 1.45 vs 1.16 ms on the same 55 GFLOP); more slabs cost their write + re-read by the column sum.
     Model: t(g) = FLOP / (100 TF x fill(g)) + 2 x slab bytes / 4 TB/s, minimised over g | N."""
-    if (_compute == COMPUTE_F32 and out_hw is not None and stride in (1, 2) and 2 <= S <= 5 and K % 64 == 0 and Cc % 64 == 0
+    if (_wgh_arith(S) and out_hw is not None and stride in (1, 2) and 2 <= S <= 5 and K % 64 == 0 and Cc % 64 == 0
             and out_hw[0] % 8 == 0 and out_hw[1] % 8 == 0):
         # igemm_wgh (LDS-resident operands): (K/128)(C/64)R tiles per slab.  Big launches (the generator's convs, >= 40 GFLOP):
         # ONE slab — the kernel splits the patch loop over workgroups itself (atomic adds), no slab traffic.  Small ones:
@@ -828,7 +838,7 @@ def wgrad_blocks_eligible(gy_shape, x_shape, R, S, stride):
     """Shapes cslgan_conv2d_wgrad_blocks_f32 takes (the LDS-resident fp32 kernel): mirrors wgh_eligible in csrc/igemm_wgh.hip."""
     _, P, Q, K = gy_shape
     Cc = x_shape[-1]
-    return (_compute == COMPUTE_F32 and stride in (1, 2) and 2 <= S <= 5 and K % 64 == 0 and Cc % 64 == 0 and P % 8 == 0 and Q % 8 == 0)
+    return (_wgh_arith(S) and stride in (1, 2) and 2 <= S <= 5 and K % 64 == 0 and Cc % 64 == 0 and P % 8 == 0 and Q % 8 == 0)
 
 
 def conv2d_wgrad_blocks(gy, x, R, S, stride, pad, alpha, blocks):

@@ -72,4 +72,35 @@ for name, N, H, W, C, K, R, s, p, which in SHAPES:
                 row += "  %s dgrad %.3f ms %5.0f TF [%s]" % (mode, td * 1e3, flop / td / 1e12, kn)
                 tot[mode] += td
     print(row, flush=True)
+WSHAPES = [
+    # name, N, H, W, C, K, stride, group (0: the dense-sum policy of ops.dense_wgrad_group), clip-weighted
+    ("D conv2 per-sample 128", 128, 32, 32, 64, 128, 2, 1, False),
+    ("D conv2 per-sample 384", 384, 32, 32, 64, 128, 2, 1, False),
+    ("D conv3 clip-weighted 256 g4", 256, 16, 16, 128, 256, 2, 4, True),
+    ("D conv2 dense 128", 128, 32, 32, 64, 128, 2, 0, False),
+    ("D conv3 dense 128", 128, 16, 16, 128, 256, 2, 0, False),
+    ("G b3 conv dense 128", 128, 32, 32, 128, 128, 1, 0, False),
+    ("G b4 conv dense 128", 128, 64, 64, 64, 64, 1, 0, False),
+]
+wtot = {m: 0.0 for m in modes}
+for name, N, H, W, C, K, s, group, scaled in WSHAPES:
+    if a.only and a.only not in name:
+        continue
+    R, p = 5, 2
+    x = torch.randn(N, H, W, C, device="cuda")
+    P = (H + 2 * p - R) // s + 1
+    gy = torch.randn(N, P, P, K, device="cuda")
+    f = torch.rand(N, device="cuda") if scaled else None
+    flop = 2.0 * N * P * P * K * R * R * C
+    row = "%-30s" % name
+    for mode in modes:
+        with ops.compute_dtype(mode):
+            grp = group if group else ops.dense_wgrad_group(N, K, C, R, R, P * P, stride=s, out_hw=(P, P))
+            out = torch.empty((N // grp, K, R, R, C), device="cuda")
+            t = timeit(lambda: ops.conv2d_wgrad_grouped(gy, x, R, R, stride=s, pad=p, group=grp, row_scale=f, out=out), a.iters)
+            kn = _lib.lib().cslgan_last_kernel().decode()
+        row += "  %s g%d %.3f ms %5.0f TF [%s]" % (mode, grp, t * 1e3, flop / t / 1e12, kn)
+        wtot[mode] += t
+    print(row, flush=True)
+print("weight gradients, sum: " + "  ".join("%s %.3f ms" % (m, wtot[m] * 1e3) for m in modes))
 print("sum of the table: " + "  ".join("%s %.3f ms" % (m, tot[m] * 1e3) for m in modes))

@@ -1129,3 +1129,76 @@ def test_x3_halo_kernel_forms(case, mode):
     assert name.startswith("igemm_x3h_kernel"), "case %s dispatched to %s" % (case, name)
     e = _err64(got, ref)
     assert e <= (4e-6 if mode == "bf16x3" else 1e-4), "%s %s: error %.3e of scale vs fp64 (%s)" % (mode, case[:9], e, name)
+
+
+X3W_CASES = [
+    # N, H, W, C, K, stride, group (0 = all), scaled, what
+    (6, 32, 32, 64, 128, 2, 1, False, "per-sample gradients of the critic's second conv (four patches per image)"),
+    (8, 16, 16, 128, 256, 2, 4, True, "clip-weighted group sums of the third conv (one patch per image)"),
+    (8, 16, 16, 128, 256, 2, 0, False, "one dense slab: patches split over workgroups, float atomics"),
+    (3, 16, 16, 64, 64, 1, 1, False, "stride 1, 64 x 64 channels"),
+    (2, 32, 32, 128, 64, 1, 0, True, "stride 1 generator-side shape, clip weights, dense"),
+    (4, 8, 8, 192, 128, 1, 2, False, "8x8 images at stride 1: the slab is mostly padding; three input-channel tiles"),
+]
+
+
+@pytest.mark.parametrize("case", X3W_CASES, ids=[c[-1][:38].replace(" ", "_") for c in X3W_CASES])
+def test_x3_weight_gradient_kernel(case):
+    """igemm_x3w_kernel (csrc/igemm_wgh.hip): grouped / per-sample / clip-weighted weight gradients and their squared norms on the
+    three-piece path against fp64 — the fp32-level bound of test_bf16x3_is_fp32_accurate (4e-6 of scale; 2e-5 where float atomics
+    reorder a dense sum), and no worse than 3x the exact-fp32 kernel's own error."""
+    from csl_gan_amd import _lib
+    ops = _ops()
+    N, H, W, C, K, s, group, scaled, _ = case
+    R, p = 5, 2
+    group = N if group == 0 else group
+    g = torch.Generator().manual_seed(77 + sum(case[:7]))
+    x = torch.randn(N, C, H, W, generator=g)
+    P, Q = (H + 2 * p - R) // s + 1, (W + 2 * p - R) // s + 1
+    gy = torch.randn(N, K, P, Q, generator=g)
+    f = (torch.rand(N, generator=g) * 0.9 + 0.1) if scaled else torch.ones(N)
+    alpha = 1.3
+    refs = []
+    for gi in range(N // group):
+        sl = slice(gi * group, (gi + 1) * group)
+        wz = torch.zeros(K, C, R, R, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x[sl].double(), wz, None, stride=s, padding=p)
+        refs.append(alpha * torch.autograd.grad(y, wz, gy[sl].double() * f[sl].double().view(-1, 1, 1, 1))[0])
+    ref = torch.stack(refs)
+    errs = {}
+    for mode in ("fp32", "bf16x3"):
+        with ops.compute_dtype(mode):
+            sq = None if scaled else torch.zeros(N // group, device="cuda")
+            gw = ops.conv2d_wgrad_grouped(_nhwc(gy), _nhwc(x), R, R, stride=s, pad=p, group=group, alpha=alpha, sq=sq,
+                                          row_scale=f.cuda() if scaled else None)
+            name = _lib.lib().cslgan_last_kernel().decode()
+        assert name.startswith("igemm_x3w_kernel" if mode == "bf16x3" else "igemm_wgh_kernel"), (mode, name)
+        errs[mode] = (_err64(gw.permute(0, 1, 4, 2, 3), ref), None if sq is None else _err64(sq, ref.reshape(ref.shape[0], -1).pow(2).sum(1)))
+    e32, e3 = errs["fp32"][0], errs["bf16x3"][0]
+    print("x3w %s: error vs fp64 — exact-fp32 kernel %.2e, three-piece kernel %.2e" % (case[:8], e32, e3))
+    assert e3 <= 4e-6 and e3 <= 3 * e32 + 1e-6, (e3, e32)
+    if errs["bf16x3"][1] is not None:
+        assert errs["bf16x3"][1] <= 2e-5, errs["bf16x3"][1]
+
+
+def test_x3_weight_gradient_row_blocks():
+    """cslgan_conv2d_wgrad_blocks_f32 on the three-piece kernel equals the per-block grouped calls in the same arithmetic."""
+    ops = _ops()
+    N, H, W, C, K, R, s, p = 6, 32, 32, 64, 128, 5, 2, 2
+    g = torch.Generator().manual_seed(5)
+    x = _nhwc(torch.randn(N, C, H, W, generator=g))
+    gy = _nhwc(torch.randn(N, K, 16, 16, generator=g))
+    n, L = N // 3, K * R * R * C
+    with ops.compute_dtype("bf16x3"):
+        assert ops.wgrad_blocks_eligible(gy.shape, x.shape, R, R, s)
+        sq_a, sq_c = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        gw_b, gw_c = torch.empty(n, L, device="cuda"), torch.empty(n, L, device="cuda")
+        ops.conv2d_wgrad_blocks(gy, x, R, R, s, p, 1.5, [(n, None, sq_a), (n, gw_b, None), (n, gw_c, sq_c)])
+        for i, (gw, sq) in enumerate(((None, sq_a), (gw_b, None), (gw_c, sq_c))):
+            sl = slice(i * n, (i + 1) * n)
+            rsq = torch.zeros(n, device="cuda")
+            ref = ops.conv2d_wgrad_grouped(gy[sl].contiguous(), x[sl].contiguous(), R, R, stride=s, pad=p, group=1, alpha=1.5, sq=rsq)
+            if gw is not None:
+                assert torch.equal(gw.view_as(ref), ref)
+            if sq is not None:
+                _close(sq, rsq, rtol=1e-6, what="x3 block %d sq" % i)

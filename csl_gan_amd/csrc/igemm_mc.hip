@@ -290,6 +290,7 @@ int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, flo
 
 bool wgh_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const void* x);      // igemm_wgh.hip
 bool x3w_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const void* x);      // igemm_wgh.hip: the three-piece (bf16x3) form
+bool x3w_quad_eligible(const cslgan_conv_t* c, int group, int out_bf16, const void* gy, const void* x);     // ... on 4x4 output grids
 int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st,
                const float* row_scale, int n_seg = 0, const int* seg_first = nullptr, float* const* seg_gw = nullptr,
                float* const* seg_sq = nullptr);      // igemm_wgh.hip
@@ -353,7 +354,7 @@ static int wgrad_grouped_impl(const cslgan_conv_t* c, const float* gy, const flo
         return launch_c3_wgrad(c, gy, x, alpha, gw, sq, (hipStream_t)stream);
     static const int wgh_env = [] { const char* e = getenv("CSLGAN_WGH"); return e ? atoi(e) : 1; }();
     if (wgh_env && ((c->compute == CSLGAN_COMPUTE_F32 && wgh_eligible(c, out_bf16, gy, x)) ||
-                    (c->compute == CSLGAN_COMPUTE_BF16X3 && x3w_eligible(c, out_bf16, gy, x))))
+                    (c->compute == CSLGAN_COMPUTE_BF16X3 && (x3w_eligible(c, out_bf16, gy, x) || x3w_quad_eligible(c, group, out_bf16, gy, x)))))
         return launch_wgh(c, gy, x, group, alpha, gw, sq, (hipStream_t)stream, row_scale);
     McParams p{};
     p.gy = gy; p.x = x; p.N = c->N; p.H = c->H; p.W = c->W; p.C = c->C; p.P = c->P; p.Q = c->Q; p.Kc = c->K;

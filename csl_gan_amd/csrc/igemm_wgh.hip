@@ -225,13 +225,16 @@ __device__ __forceinline__ x3w_bf16x8 w_tr_pair(const unsigned char* lo_addr, co
 }
 }  // namespace
 
-template <int STRIDE>
+// QUAD (stride 2 only): 4x4 output grids (the critic's last conv) — a stage is the 2 x 16 output pixels of TWO consecutive samples, each
+// with its own 4-row x 11-column slab; needs an even group (dense and clip-weighted sums; per-sample gradients of that layer are
+// never formed: ghost clipping takes its norms from Gram matrices).
+template <int STRIDE, bool QUAD = false>
 __global__ __launch_bounds__(256, 2) void igemm_x3w_kernel(const WghParams p) {
     constexpr int S = 5;
     constexpr unsigned OOB = 0xFFFFFFF0u;
-    constexpr int XW = 7 * STRIDE + S;                 // staged columns of the slab
+    constexpr int XW = QUAD ? 3 * STRIDE + S : 7 * STRIDE + S;      // staged columns of the slab (of one sample for QUAD)
     constexpr int XPITCH = STRIDE == 1 ? 64 : 96;      // bytes per slab pixel in a 32-channel plane (see the bank note above)
-    constexpr int XPIX = 4 * XW;                       // slab pixels per stage (4 input rows)
+    constexpr int XPIX = QUAD ? 2 * 4 * XW : 4 * XW;   // slab pixels per stage (4 input rows; two samples for QUAD)
     constexpr int A_PLANE = 32 * 64, X_PLANE = XPIX * XPITCH;
     constexpr int NX = (XPIX * 16 + 255) / 256;        // float4 of the slab per thread
     __shared__ __attribute__((aligned(16))) unsigned char As[3][2][A_PLANE];     // [piece][m half][pixel][32 m]
@@ -271,7 +274,27 @@ __global__ __launch_bounds__(256, 2) void igemm_x3w_kernel(const WghParams p) {
     const int n_patch = p.group * p.ppi;
     const int pq8 = p.Q >> 3;
     // stage st = 2 * patch + half, this workgroup's patches: split, split + ksplit, ...
+    float rs_next2 = 1.f;                              // QUAD: the second sample's clip weight
     auto load_stage = [&](int pi, int half) {
+        if (QUAD) {                                    // pi = pair of samples (2 pi, 2 pi + 1) of the group; 32 consecutive gy pixels
+            const int img0 = g * p.group + 2 * pi;
+            rs_next = p.row_scale ? p.row_scale[img0] : 1.f;
+            rs_next2 = p.row_scale ? p.row_scale[img0 + 1] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                rg[j] = w_bld(gy_rsrc, 4u * ((unsigned)(img0 * 16 + a_pix[j]) * (unsigned)p.K + (unsigned)(m0 + a_m4[j] * 4)));
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const int idx = tid + 256 * j;
+                const int c4 = idx & 15, pc = idx >> 4;
+                const int smp = pc / (4 * XW), pr2 = pc - smp * 4 * XW;
+                const int row = pr2 / XW, col = pr2 - row * XW;
+                const int iy = row * STRIDE + r - p.pad, ix = col - p.pad;
+                const bool ok = pc < XPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                rx[j] = w_bld(x_rsrc, (4u * (unsigned)((((img0 + smp) * p.H + iy) * p.W + ix) * p.C + c0 + c4 * 4)) | (ok ? 0u : OOB));
+            }
+            return;
+        }
         const int il = pi / p.ppi, pr = pi - il * p.ppi;
         const int img = g * p.group + il;
         const int py0 = ((pr / pq8) << 3) + 4 * half, px0 = (pr - (pr / pq8) * pq8) << 3;
@@ -291,10 +314,11 @@ __global__ __launch_bounds__(256, 2) void igemm_x3w_kernel(const WghParams p) {
             rx[j] = w_bld(x_rsrc, (4u * (unsigned)(((img * p.H + iy) * p.W + ix) * p.C + c0 + c4 * 4)) | (ok ? 0u : OOB));
         }
     };
-    auto store_stage = [&](float rs) {
+    auto store_stage = [&](float rs, float rs2) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float4 v = rg[j];
+            if (QUAD && a_pix[j] >= 16) rs = rs2;      // (j = 1 for every thread: pixels 16..31 are the second sample's)
             v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
             uint2 hi, mid, lo;
             w_split4(v, hi, mid, lo);
@@ -322,8 +346,10 @@ __global__ __launch_bounds__(256, 2) void igemm_x3w_kernel(const WghParams p) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         a_tr[u] = (8 * h + 4 * u + gq) * 64 + 32 * ghalf + 8 * gp;                          // pixel k = 16 ks + 8 h + 4 u + gq
-        b_tr[u] = (h * XW + (4 * u + gq) * STRIDE) * XPITCH + 32 * ghalf + 8 * gp;          // k -> (qy = 2 ks + h, qx = 4 u + gq)
+        if (QUAD) b_tr[u] = ((2 * h + u) * XW + gq * STRIDE) * XPITCH + 32 * ghalf + 8 * gp;   // k -> (sample ks, qy = 2 h + u, qx = gq)
+        else b_tr[u] = (h * XW + (4 * u + gq) * STRIDE) * XPITCH + 32 * ghalf + 8 * gp;     // k -> (qy = 2 ks + h, qx = 4 u + gq)
     }
+    constexpr int KS_STEP = (QUAD ? 4 * XW : 2 * XW) * XPITCH;      // slab bytes between the two k-steps of a stage
     auto mma_stage = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -335,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3w_kernel(const WghParams p) {
                 x3w_bf16x8 b[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    b[c] = w_tr_pair(&Xs[c][wn][b_tr[0] + ks * 2 * XW * XPITCH + s * XPITCH], &Xs[c][wn][b_tr[1] + ks * 2 * XW * XPITCH + s * XPITCH]);
+                    b[c] = w_tr_pair(&Xs[c][wn][b_tr[0] + ks * KS_STEP + s * XPITCH], &Xs[c][wn][b_tr[1] + ks * KS_STEP + s * XPITCH]);
                 f32x16 t = acc[s];                   // smallest terms first
                 t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], t, 0, 0, 0);
                 t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], t, 0, 0, 0);
@@ -348,15 +374,20 @@ __global__ __launch_bounds__(256, 2) void igemm_x3w_kernel(const WghParams p) {
         }
     };
 
-    const int n_stage = 2 * ((n_patch - split + p.ksplit - 1) / p.ksplit);      // this workgroup's stages (0 when split >= n_patch)
+    // this workgroup's stages (0 when split is past the end): patches split, split + ksplit, ... (two halves each), or sample pairs
+    const int n_units = QUAD ? p.group >> 1 : n_patch;
+    const int n_stage = (QUAD ? 1 : 2) * ((n_units - split + p.ksplit - 1) / p.ksplit);
     if (n_stage > 0) load_stage(split, 0);
 #pragma unroll 1
     for (int st = 0; st < n_stage; ++st) {
-        const float rs = rs_next;
+        const float rs = rs_next, rs2 = rs_next2;
         __syncthreads();                        // every wavefront is done with the previous stage's images
-        store_stage(rs);
+        store_stage(rs, rs2);
         __syncthreads();
-        if (st + 1 < n_stage) load_stage(split + ((st + 1) >> 1) * p.ksplit, (st + 1) & 1);
+        if (st + 1 < n_stage) {
+            if (QUAD) load_stage(split + (st + 1) * p.ksplit, 0);
+            else load_stage(split + ((st + 1) >> 1) * p.ksplit, (st + 1) & 1);
+        }
         mma_stage();
     }
 
@@ -401,6 +432,15 @@ bool x3w_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const vo
            4ll * c->N * c->H * c->W * c->C < 0xFFFFFFF0ll;
 }
 
+// The 4x4-output form (the critic's last conv): stride 2, 5 filter columns, pad 2, 8x8 input, channel counts multiples of 64, an even
+// number of samples per group.
+bool x3w_quad_eligible(const cslgan_conv_t* c, int group, int out_bf16, const void* gy, const void* x) {
+    static const int env = [] { const char* e = getenv("CSLGAN_X3W_QUAD"); return e ? atoi(e) : 1; }();
+    return env && !out_bf16 && c->stride == 2 && c->S == 5 && c->R <= 5 && c->P == 4 && c->Q == 4 && c->H == 8 && c->W == 8 && c->pad == 2 &&
+           c->K % 64 == 0 && c->C % WG_BC == 0 && group % 2 == 0 && aligned16(gy) && aligned16(x) &&
+           4ll * c->N * 16 * c->K < 0xFFFFFFF0ll && 4ll * c->N * 64 * c->C < 0xFFFFFFF0ll;
+}
+
 int sqnorm_rows_accumulate(const float* in, long long n_rows, long long len, float* sq_accum, hipStream_t st);   // clip_kernels.hip
 
 // Shapes this kernel takes (the rest stays on igemm_mc).
@@ -411,7 +451,8 @@ bool wgh_eligible(const cslgan_conv_t* c, int out_bf16, const void* gy, const vo
 
 int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int group, float alpha, float* gw, float* sq, hipStream_t st,
                const float* row_scale, int n_seg, const int* seg_first, float* const* seg_gw, float* const* seg_sq) {
-    const bool x3 = c->compute == CSLGAN_COMPUTE_BF16X3;      // the caller has checked x3w_eligible
+    const bool x3 = c->compute == CSLGAN_COMPUTE_BF16X3;      // the caller has checked x3w_eligible / x3w_quad_eligible
+    const bool quad = x3 && c->P == 4 && c->Q == 4;
     WghParams p{};
     p.gy = gy; p.x = x; p.gw = gw; p.sq = sq; p.row_scale = row_scale;
     p.n_seg = n_seg;
@@ -425,7 +466,7 @@ int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int grou
     p.tiles_m = half_m ? c->K / 64 : c->K / WG_BM; p.tiles_c = c->C / WG_BC; p.ppi = (c->P >> 3) * (c->Q >> 3);
     p.xw = 7 * c->stride + c->S;
     const long long base = (long long)p.n_groups * p.tiles_m * p.tiles_c * c->R;
-    const int n_patch = group * p.ppi;
+    const int n_patch = quad ? group / 2 : group * p.ppi;       // units the patch loop walks (sample pairs for the 4x4 form)
     p.ksplit = 1;
     if (gw && n_seg == 0 && base < 768 && n_patch >= 8) {      // few tiles, long patch loops: split the patches, add atomically
         long long want = (1280 + base - 1) / base;
@@ -441,8 +482,9 @@ int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int grou
     if (nb > 0x7fffffffll) { set_error("wgrad: grid too large"); return CSLGAN_ERR_INVALID_ARG; }
     const dim3 grid((unsigned)nb), block(256);
     if (x3) {
-        note_kernel("igemm_x3w_kernel<%d>", c->stride);
-        if (c->stride == 1) hipLaunchKernelGGL(igemm_x3w_kernel<1>, grid, block, 0, st, p);
+        note_kernel(quad ? "igemm_x3w_kernel<%d,quad>" : "igemm_x3w_kernel<%d>", c->stride);
+        if (quad) hipLaunchKernelGGL((igemm_x3w_kernel<2, true>), grid, block, 0, st, p);
+        else if (c->stride == 1) hipLaunchKernelGGL(igemm_x3w_kernel<1>, grid, block, 0, st, p);
         else hipLaunchKernelGGL(igemm_x3w_kernel<2>, grid, block, 0, st, p);
         int rc = check_launch("igemm_x3w_kernel");
         if (rc) return rc;

@@ -279,14 +279,16 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {                  // smallest terms first
                     f32x16 a = acc[i][j];
+                    // the FILTER fragment is the first operand: a lane's 16 results are then 4 x 4 consecutive channels of ITS pixel
+                    // (row index of D = filter (v & 3) + 8 (v >> 2) + 4 h, column = pixel lane & 31) and leave as 16-byte stores
                     if (NP == 3) {
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][i], __builtin_bit_cast(bf16x8, b_cur[NP - 1][j]), a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[NP - 1][i], __builtin_bit_cast(bf16x8, b_cur[0][j]), a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[NP > 1 ? 1 : 0][i], __builtin_bit_cast(bf16x8, b_cur[NP > 1 ? 1 : 0][j]), a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][i], __builtin_bit_cast(bf16x8, b_cur[NP > 1 ? 1 : 0][j]), a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[NP > 1 ? 1 : 0][i], __builtin_bit_cast(bf16x8, b_cur[0][j]), a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b_cur[NP - 1][j]), A[0][i], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b_cur[0][j]), A[NP - 1][i], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b_cur[NP > 1 ? 1 : 0][j]), A[NP > 1 ? 1 : 0][i], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b_cur[NP > 1 ? 1 : 0][j]), A[0][i], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b_cur[0][j]), A[NP > 1 ? 1 : 0][i], a, 0, 0, 0);
                     }
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][i], __builtin_bit_cast(bf16x8, b_cur[0][j]), a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b_cur[0][j]), A[0][i], a, 0, 0, 0);
                     acc[i][j] = a;
                     if (i == 0 && j == 0) {
                         // The next tap's fragments are read AFTER the first tile's MFMAs are issued and pinned there: at the loop header
@@ -331,25 +333,43 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
             s_roff[tid] = roff;
         }
         __syncthreads();
+        // lane (r, h) holds, of tile (i, j), pixel row r and channels j*32 + 8 q + 4 h + (0..3) for q = 0..3: bias / residual / mask are
+        // read and the result is stored as 4-element vectors (p.Nn % 4 == 0 and 16-byte aligned operands: checked by x3h_eligible)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * TN * 32 + j * 32 + r;
-            if (n >= p.Nn) continue;
-            const float bv = p.bias ? p.bias[n] : 0.f;
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm * 64 + i * 32 + r;
+            const int off = s_off[row], roff = s_roff[row];
+            if (off < 0) continue;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+            for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int row = wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-                    const int off = s_off[row];
-                    if (off < 0) continue;
-                    float val = acc[i][j][v] + bv;
-                    if (p.res) val += p.res[s_roff[row] + n];
-                    if (p.act == CSLGAN_ACT_LRELU02) val = val > 0.f ? val : 0.2f * val;
-                    else if (p.act == CSLGAN_ACT_RELU) val = val > 0.f ? val : 0.f;
-                    else if (p.act == CSLGAN_ACT_TANH) val = tanhf(val);
-                    if (p.mask) val *= (p.mask[off + n] > 0.f ? 1.f : 0.2f);
-                    p.out[off + n] = val;
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * TN * 32 + j * 32 + 8 * q + 4 * h;
+                    if (n >= p.Nn) continue;
+                    float4 val = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                    if (p.bias) {
+                        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                        val.x += bv.x; val.y += bv.y; val.z += bv.z; val.w += bv.w;
+                    }
+                    if (p.res) {
+                        const float4 rv = *reinterpret_cast<const float4*>(p.res + roff + n);
+                        val.x += rv.x; val.y += rv.y; val.z += rv.z; val.w += rv.w;
+                    }
+                    if (p.act == CSLGAN_ACT_LRELU02) {
+                        val.x = val.x > 0.f ? val.x : 0.2f * val.x; val.y = val.y > 0.f ? val.y : 0.2f * val.y;
+                        val.z = val.z > 0.f ? val.z : 0.2f * val.z; val.w = val.w > 0.f ? val.w : 0.2f * val.w;
+                    } else if (p.act == CSLGAN_ACT_RELU) {
+                        val.x = val.x > 0.f ? val.x : 0.f; val.y = val.y > 0.f ? val.y : 0.f;
+                        val.z = val.z > 0.f ? val.z : 0.f; val.w = val.w > 0.f ? val.w : 0.f;
+                    } else if (p.act == CSLGAN_ACT_TANH) {
+                        val.x = tanhf(val.x); val.y = tanhf(val.y); val.z = tanhf(val.z); val.w = tanhf(val.w);
+                    }
+                    if (p.mask) {
+                        const float4 mv = *reinterpret_cast<const float4*>(p.mask + off + n);
+                        val.x *= mv.x > 0.f ? 1.f : 0.2f; val.y *= mv.y > 0.f ? 1.f : 0.2f;
+                        val.z *= mv.z > 0.f ? 1.f : 0.2f; val.w *= mv.w > 0.f ? 1.f : 0.2f;
+                    }
+                    *reinterpret_cast<float4*>(p.out + off + n) = val;
                 }
             }
         }
@@ -426,6 +446,8 @@ static int affine_taps(const KcClass& k) {
 bool x3h_eligible(const KcParams& p) {
     static const int env = [] { const char* e = getenv("CSLGAN_X3_HALO"); return e ? atoi(e) : 1; }();
     if (!env || !p.w3 || !p.bf16 || p.sy != 1 || p.sx != 1 || (p.AC & 15) || p.Nn < 64 || p.ksplit > 1 || !aligned16(p.a) || !aligned16(p.w3)) return false;
+    // 4-element epilogue vectors: channel counts and the output row pitch multiples of 4, every epilogue operand 16-byte aligned
+    if ((p.Nn & 3) || (p.ldo & 3) || !aligned16(p.out) || (p.bias && !aligned16(p.bias)) || (p.res && !aligned16(p.res)) || (p.mask && !aligned16(p.mask))) return false;
     static const int quad_min = [] { const char* e = getenv("CSLGAN_X3_QUAD_MIN"); return e ? atoi(e) : 2048; }();
     for (int c = 0; c < p.n_cls; ++c) {
         const KcClass& k = p.cls[c];

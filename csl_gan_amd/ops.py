@@ -298,7 +298,7 @@ def conv_out_size(H, R, stride, pad):
     return (H + 2 * pad - R) // stride + 1
 
 
-def _conv_desc(N, H, W, Cc, K, R, S, stride, pad, kind="wgrad"):
+def _conv_desc(N, H, W, Cc, K, R, S, stride, pad, kind="wgrad", group=None):
     """kind: "fwd" / "dgrad" may take the bf16x3 path under fp32_auto; weight gradients never do."""
     P, Q = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
     comp = _compute
@@ -306,8 +306,9 @@ def _conv_desc(N, H, W, Cc, K, R, S, stride, pad, kind="wgrad"):
         comp = _kc_compute(N * P * Q, K, R * S * Cc)
     elif kind == "dgrad":
         comp = _kc_compute(N * H * W, Cc, (R * S * K) // (stride * stride))
-    elif (_auto and _X3_WGRAD and S == 5 and stride in (1, 2) and K % 64 == 0 and Cc % 64 == 0 and P % 8 == 0 and Q % 8 == 0
-          and 2.0 * N * P * Q * K * R * S * Cc >= _AUTO_WG_MIN_FLOP):
+    elif (kind == "wgrad" and _auto and _X3_WGRAD and S == 5 and stride in (1, 2) and K % 64 == 0 and Cc % 64 == 0 and 2.0 * N * P * Q * K * R * S * Cc >= _AUTO_WG_MIN_FLOP
+          and ((P % 8 == 0 and Q % 8 == 0) or
+               ((P, Q, H, W, stride, pad) == (4, 4, 8, 8, 2, 2) and group is not None and group % 2 == 0))):
         comp = COMPUTE_BF16X3          # weight gradient on the LDS-resident three-piece kernel (csrc/igemm_wgh.hip: igemm_x3w_kernel)
     if comp == COMPUTE_BF16 and H == 1 and W == 1 and R == 1 and S == 1 and 2.0 * N * K * Cc < 1e9:
         # small linear layers (the critic's head, the generator's first layer): a few hundred MFLOP on skinny GEMMs where the bf16
@@ -664,7 +665,7 @@ def conv2d_wgrad_sqnorm_gram(gy, x, R, S, stride=1, pad=0, alpha=1.0, sq=None):
     _chk(gy, "gy"); _chk(x, "x")
     N, H, W, Cc = x.shape
     N2, P, Q, K = gy.shape
-    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad)
+    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, kind="gram")
     if N2 != N or (P2, Q2) != (P, Q):
         raise RuntimeError("conv2d_wgrad_sqnorm_gram: gy %s inconsistent with x %s" % (tuple(gy.shape), tuple(x.shape)))
     if sq is None:
@@ -752,7 +753,7 @@ def conv2d_wgrad_grouped(gy, x, R, S, stride=1, pad=0, group=1, alpha=1.0, want_
             out.view(g4.shape[:-1] + (3,)).copy_(g4[..., :3])
             return out
         return g4[..., :3].contiguous()
-    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad)
+    d, P2, Q2 = _conv_desc(N, H, W, Cc, K, R, S, stride, pad, group=group)
     if N2 != N or (P2, Q2) != (P, Q):
         raise RuntimeError("conv2d_wgrad: gy %s inconsistent with x %s" % (tuple(gy.shape), tuple(x.shape)))
     if N % group:

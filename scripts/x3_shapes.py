@@ -79,6 +79,8 @@ WSHAPES = [
     ("D conv3 clip-weighted 256 g4", 256, 16, 16, 128, 256, 2, 4, True),
     ("D conv2 dense 128", 128, 32, 32, 64, 128, 2, 0, False),
     ("D conv3 dense 128", 128, 16, 16, 128, 256, 2, 0, False),
+    ("D conv4 clip-weighted 256 g16", 256, 8, 8, 256, 512, 2, 16, True),
+    ("D conv4 dense 128 g16", 128, 8, 8, 256, 512, 2, 16, False),
     ("G b3 conv dense 128", 128, 32, 32, 128, 128, 1, 0, False),
     ("G b4 conv dense 128", 128, 64, 64, 64, 64, 1, 0, False),
 ]

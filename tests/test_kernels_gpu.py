@@ -1202,3 +1202,31 @@ def test_x3_weight_gradient_row_blocks():
                 assert torch.equal(gw.view_as(ref), ref)
             if sq is not None:
                 _close(sq, rsq, rtol=1e-6, what="x3 block %d sq" % i)
+
+
+@pytest.mark.parametrize("group,scaled", [(0, False), (16, True), (2, False)])
+def test_x3_weight_gradient_4x4_outputs(group, scaled):
+    """igemm_x3w_kernel<2, quad>: the critic's last conv (8x8 -> 4x4, stride 2): dense / clip-weighted group sums over pairs of samples."""
+    from csl_gan_amd import _lib
+    ops = _ops()
+    N, H, W, C, K, R, s, p = 32, 8, 8, 128, 192, 5, 2, 2
+    group = N if group == 0 else group
+    g = torch.Generator().manual_seed(31 + group)
+    x = torch.randn(N, C, H, W, generator=g)
+    gy = torch.randn(N, K, 4, 4, generator=g)
+    f = (torch.rand(N, generator=g) * 0.9 + 0.1) if scaled else torch.ones(N)
+    refs = []
+    for gi in range(N // group):
+        sl = slice(gi * group, (gi + 1) * group)
+        wz = torch.zeros(K, C, R, R, dtype=torch.float64, requires_grad=True)
+        refs.append(torch.autograd.grad(F.conv2d(x[sl].double(), wz, None, stride=s, padding=p), wz, gy[sl].double() * f[sl].double().view(-1, 1, 1, 1))[0])
+    ref = torch.stack(refs)
+    with ops.compute_dtype("bf16x3"):
+        sq = None if scaled else torch.zeros(N // group, device="cuda")
+        gw = ops.conv2d_wgrad_grouped(_nhwc(gy), _nhwc(x), R, R, stride=s, pad=p, group=group, sq=sq, row_scale=f.cuda() if scaled else None)
+        name = _lib.lib().cslgan_last_kernel().decode()
+    assert name.startswith("igemm_x3w_kernel<2,quad>"), name
+    e = _err64(gw.permute(0, 1, 4, 2, 3), ref)
+    assert e <= 4e-6, e
+    if sq is not None:
+        assert _err64(sq, ref.reshape(ref.shape[0], -1).pow(2).sum(1)) <= 2e-5

@@ -295,6 +295,13 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void igemm_kc_kernel(cons
 // Repack KRSC filters into per-class [Nout][taps][Cred] matrices.
 //   transposed == 1 (data gradient): wt[off + (c*Tc + t)*K + k]      = w[((k*R + kh_t)*S + kw_t)*C + c]
 //   transposed == 0 (stride-2 forward parity classes): wt[off + (k*Tc + t)*C + c] = the (kh,kw) of tap t
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float x) {      // the rounding v_cvt_pk_bf16_f32 performs (finite inputs)
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+    const f2_t v = {x, 0.f};
+    return (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(v, b2_t)) & 0xffffu);
+}
+
 struct RepackArgs {
     int K, R, S, C;
     int n_class;
@@ -304,6 +311,13 @@ struct RepackArgs {
     // transposed: the single (kh,kw) of tap t.  phases: [kh_lo,kh_hi) x [kw_lo,kw_hi) folded onto tap t
     signed char kh_lo[IG_MAX_CLS][IG_MAX_TAPS], kh_hi[IG_MAX_CLS][IG_MAX_TAPS];
     signed char kw_lo[IG_MAX_CLS][IG_MAX_TAPS], kw_hi[IG_MAX_CLS][IG_MAX_TAPS];
+    // pieces > 0 (the LDS-halo kernels of the bf16 matrix cores, csrc/igemm_x3.hip): the same launch also writes every class matrix
+    // split into `pieces` bfloat16 pieces in step-major order, w3[pieces * cls_off + piece * rows*Tc*red + ((red_ch / 16) * Tc + t) * rows * 16
+    // + row * 16 + red_ch % 16]  (rows = C, red = K when transposed; rows = K, red = C otherwise; red % 16 == 0) — round 3 ran one
+    // repack launch + one split launch PER CLASS (five launches per conv and direction, thirty per D-step on weights that change
+    // every step)
+    int pieces;
+    unsigned short* w3;
 };
 
 __global__ void repack_filters_kernel(const float* __restrict__ w, float* __restrict__ wt, RepackArgs a) {
@@ -328,6 +342,19 @@ __global__ void repack_filters_kernel(const float* __restrict__ w, float* __rest
             for (int kw = a.kw_lo[cls][t]; kw < a.kw_hi[cls][t]; ++kw)
                 sum += w[(((long long)k * a.R + kh) * a.S + kw) * a.C + c];
         wt[a.cls_off[cls] + i] = sum;
+        if (a.pieces) {
+            const int rows = a.transposed ? a.C : a.K, row = a.transposed ? c : k, red = a.transposed ? k : c;
+            unsigned short* dst = a.w3 + (long long)a.pieces * a.cls_off[cls] + ((((long long)(red >> 4) * Tc + t) * rows + row) << 4) + (red & 15);
+            const unsigned short hi = f32_to_bf16_rne(sum);
+            dst[0] = hi;
+            if (a.pieces == 3) {
+                const float r1 = sum - __uint_as_float((unsigned)hi << 16);
+                const unsigned short mid = f32_to_bf16_rne(r1);
+                const long long plane = total;
+                dst[plane] = mid;
+                dst[2 * plane] = f32_to_bf16_rne(r1 - __uint_as_float((unsigned)mid << 16));
+            }
+        }
     }
 }
 
@@ -376,7 +403,6 @@ static long long tiles_for(const KcParams& p, int BM, int BN) {
 
 int launch_kc_bf16(KcParams& p, hipStream_t st, long long out_elems);     // igemm_bf16.hip
 int split_filter_x3(const float* w, int Nn, int T, int C, void* w3, hipStream_t st, int pieces);      // igemm_x3.hip
-int split_classes_x3(const KcParams& p, hipStream_t st);
 bool x3h_eligible(const KcParams& p);
 bool halo_eligible(const KcParams& p);          // igemm_halo.hip
 int launch_halo(KcParams& p, hipStream_t st);
@@ -610,10 +636,10 @@ static int conv2d_s2_fwd_impl(const cslgan_conv_t* c, const float* x, const floa
         const long long per = (long long)c->C * 9 * c->K;
         unsigned gxn = (unsigned)((per + 255) / 256);
         gxn = gxn > 1024 ? 1024 : (gxn < 1 ? 1 : gxn);
+        if (w3_ws) { ra.pieces = p.bf16 == 3 ? 3 : 1; ra.w3 = reinterpret_cast<unsigned short*>(w3_ws); }
         hipLaunchKernelGGL(repack_filters_kernel, dim3(gxn, (unsigned)n), dim3(256), 0, st, w, wcls_ws, ra);
         rc = check_launch("repack_filters_kernel");
         if (rc) return rc;
-        if (w3_ws) { rc = split_classes_x3(p, st); if (rc) return rc; }
     }
     return launch_kc(p, st, 0);
 }
@@ -692,10 +718,10 @@ static int conv2d_dgrad_impl(const cslgan_conv_t* c, const float* gy, const floa
     if (repack) {
         unsigned gxn = (unsigned)(((long long)c->K * c->C * c->R * c->S / (s * s) + 255) / 256);
         gxn = gxn > 1024 ? 1024 : (gxn < 1 ? 1 : gxn);
+        if (p.w3) { ra.pieces = p.bf16 == 3 ? 3 : 1; ra.w3 = reinterpret_cast<unsigned short*>(const_cast<void*>(p.w3)); }
         hipLaunchKernelGGL(repack_filters_kernel, dim3(gxn, (unsigned)ncls), dim3(256), 0, st, w, wt_ws, ra);
         rc = check_launch("repack_filters_kernel");
         if (rc) return rc;
-        if (p.w3) { rc = split_classes_x3(p, st); if (rc) return rc; }
     }
     // K can be split only for the dense (stride-1, single-class) form whose output we may zero here
     return launch_kc(p, st, (s == 1 && !mask) ? (long long)c->N * c->H * c->W * c->C : 0);

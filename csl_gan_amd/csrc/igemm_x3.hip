@@ -409,17 +409,6 @@ int split_filter_x3(const float* w, int Nn, int T, int C, void* w3, hipStream_t 
     return check_launch("split_filter_x3_kernel");
 }
 
-// Every class matrix of a launch (KcParams::w + cls[c].w_off, [Nn][T_c][AC]) into KcParams::w3 at NP * w_off bfloat16 elements.
-int split_classes_x3(const KcParams& p, hipStream_t st) {
-    const int pieces = p.bf16 == 3 ? 3 : 1;
-    for (int c = 0; c < p.n_cls; ++c) {
-        const KcClass& k = p.cls[c];
-        unsigned short* dst = reinterpret_cast<unsigned short*>(const_cast<void*>(p.w3)) + (long long)pieces * k.w_off;
-        if (int rc = split_filter_x3(p.w + k.w_off, p.Nn, k.T, p.AC, dst, st, pieces)) return rc;
-    }
-    return CSLGAN_OK;
-}
-
 static void tap_range(const KcClass& k, int& ymin, int& ymax, int& xmin, int& xmax) {
     ymin = 127; ymax = -128; xmin = 127; xmax = -128;
     for (int t = 0; t < k.T; ++t) {

@@ -46,7 +46,19 @@ class MeanSampler:
             os.makedirs(save_path, exist_ok=True)
             np.save(save_path + "mean_samples.npy", self.mean_samples.cpu().numpy())
 
-    def sample(self, size, noise_std=0.01, noise_mean_std=0.01, requested_labels=None):
+    def _nhwc_table(self):
+        """The mean samples in the activation layout of the HIP critic (NHWC, csl_gan_amd DESIGN §3), made once per tensor: sample()
+        then gathers rows that ARE channels-last images and the critic's first conv reads the batch without a layout pass."""
+        ms = self.mean_samples
+        key = (ms.data_ptr(), ms._version, tuple(ms.shape))
+        if getattr(self, "_nhwc_key", None) != key:
+            self._nhwc, self._nhwc_key = ms.permute(0, 1, 3, 4, 2).contiguous(), key
+        return self._nhwc
+
+    def sample(self, size, noise_std=0.01, noise_mean_std=0.01, requested_labels=None, out=None):
+        """out (device path only): a channels-last dense [size, ch, res, res] tensor that receives the batch (a slice of the
+        trainer's fused critic batch); the returned tensor is then `out`.  On the device the batch is ALWAYS channels-last
+        (logical NCHW shape, NHWC memory)."""
         dev, gen = self.mean_samples.device, self.generator
         reps = (size - 1) // self.num_samples + 1
         if dev.type == "cuda":
@@ -60,9 +72,17 @@ class MeanSampler:
             if self.num_samples > 1024:          # beyond the kernel's LDS ranking: permutations from one device sort
                 perms = torch.rand(reps, self.num_samples, device=dev, generator=gen).argsort(dim=1).reshape(-1)[:size]
             labels = None if (requested_labels is None or self.n_classes == 1) else requested_labels.to(dev)
-            r, labels = ops.mean_sample(self.mean_samples, labels, perms, noise_mean_std, noise_std, self._seed, self._draws, n=size,
-                                        want_labels=True)
-            return r, (labels if self.n_classes > 1 else None)
+            tab = self._nhwc_table() if self.mean_samples.dim() == 5 else self.mean_samples
+            dst = None
+            if out is not None:
+                dst = out.permute(0, 2, 3, 1) if out.dim() == 4 else out
+                if not dst.is_contiguous():
+                    raise RuntimeError("MeanSampler.sample: out must be a channels-last dense tensor")
+            r, labels = ops.mean_sample(tab, labels, perms, noise_mean_std, noise_std, self._seed, self._draws, n=size,
+                                        want_labels=True, out=dst)
+            if self.mean_samples.dim() == 5:
+                r = r.permute(0, 3, 1, 2)           # logical NCHW over NHWC memory (zero-copy)
+            return (out if out is not None else r), (labels if self.n_classes > 1 else None)
         perms = torch.cat([torch.randperm(self.num_samples, device=dev, generator=gen) for _ in range(reps)])[:size]
         if requested_labels is None:
             requested_labels = torch.randint(0, self.n_classes, (size,), device=dev, generator=gen)

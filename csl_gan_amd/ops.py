@@ -1131,7 +1131,7 @@ def l2_clip_rows(t, Cval):
     return out.reshape(t.shape)
 
 
-def mean_sample(mean_samples, labels, perms, noise_mean_std, noise_std, seed, offset, n=None, want_labels=False):
+def mean_sample(mean_samples, labels, perms, noise_mean_std, noise_std, seed, offset, n=None, want_labels=False, out=None):
     """MeanSampler.sample's gather + per-image jitter + per-pixel noise (mean_sampler.py:75-84) in one pass.
     mean_samples [n_classes, num_samples, ...] fp32, labels / perms [n] int64 or None: missing permutations (and, with several
     classes, missing labels) are drawn inside the kernel; n is then required.  want_labels: also return the labels used."""
@@ -1147,7 +1147,12 @@ def mean_sample(mean_samples, labels, perms, noise_mean_std, noise_std, seed, of
     for t, nm in ((labels, "labels"), (perms, "perms")):
         if t is not None and (t.dtype != torch.int64 or not t.is_cuda or t.numel() != n):
             raise RuntimeError("mean_sample: %s must be an int64 device tensor of %d entries" % (nm, n))
-    out = torch.empty((n,) + tuple(mean_samples.shape[2:]), device=mean_samples.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((n,) + tuple(mean_samples.shape[2:]), device=mean_samples.device, dtype=torch.float32)
+    else:           # caller-owned destination (a slice of the trainer's fused critic batch): n dense rows of ln floats
+        _chk(out, "out")
+        if out.numel() != n * ln:
+            raise RuntimeError("mean_sample: out has %d elements, expected %d" % (out.numel(), n * ln))
     lab_out = torch.empty(n, device=mean_samples.device, dtype=torch.int64) if (want_labels and labels is None and n_cls > 1) else None
     check(_lib.lib().cslgan_mean_sample_f32(_p(mean_samples), n_cls, num, ln, None if labels is None else _p(labels.contiguous()),
                                             None if perms is None else _p(perms.contiguous()), n,

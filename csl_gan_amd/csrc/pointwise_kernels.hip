@@ -679,6 +679,36 @@ int cslgan_batchnorm_eval_act_f32(const float* x, const float* gamma, const floa
                              norm_vec_ok(x, y, x_shuffled, C, 1), st);
 }
 
+// ---- input pipeline (round 4): uint8 NHWC image rows -> normalised fp32 NHWC, with the per-image horizontal flip -------------------
+// out[n][h][w][c] = src[n][h][flip[n] ? W-1-w : w][c] * scale + bias     (datasets.py:41-47: ToTensor, RandomHorizontalFlip, Normalize)
+__global__ void u8_to_f32_nhwc_kernel(const unsigned char* __restrict__ src, const unsigned char* __restrict__ flip, int N, int H, int W, int C,
+                                      float scale, float bias, float* __restrict__ out) {
+    const long long total = (long long)N * H * W * C;
+    const long long per_img = (long long)H * W * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / per_img;
+        long long si = i;
+        if (flip && flip[n]) {
+            const long long r = i - n * per_img;
+            const long long row = r / ((long long)W * C);
+            const int wc = (int)(r - row * W * C);
+            const int w = wc / C, c = wc - w * C;
+            si = n * per_img + row * W * C + (long long)(W - 1 - w) * C + c;
+        }
+        out[i] = (float)src[si] * scale + bias;
+    }
+}
+
+int cslgan_u8_to_f32_nhwc(const void* src_u8, const void* flip_u8, int N, int H, int W, int C, float scale, float bias, float* out, void* stream) {
+    CSLGAN_REQUIRE(src_u8 && out, "u8_to_f32_nhwc: null argument");
+    CSLGAN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "u8_to_f32_nhwc: non-positive dimension");
+    const long long total = (long long)N * H * W * C;
+    unsigned nb = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(u8_to_f32_nhwc_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned char*>(src_u8),
+                       reinterpret_cast<const unsigned char*>(flip_u8), N, H, W, C, scale, bias, out);
+    return check_launch("u8_to_f32_nhwc_kernel");
+}
+
 int cslgan_depth_to_space_f32(const float* x, int N, int H, int W, int C, int inverse, float* y, void* stream) {
     CSLGAN_REQUIRE(x && y, "depth_to_space: null argument");
     CSLGAN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "depth_to_space: needs C %% 4 == 0 (C=%d)", C);

@@ -46,9 +46,50 @@ def _private_loader(ds, opt, rank, world, **kw):
     return DataLoader(ds, batch_size=opt.batch_size, sampler=sampler, drop_last=True, **kw)
 
 
+def init_cached_data(opt, rank=0, world=1):
+    """The real files through the preprocessed-tensor cache and the device prefetcher (csl_gan_amd/pipeline.py; `--data_cache PATH`):
+    the cache is built once from the same dataset classes (flip off — the flip is drawn per batch on the host and applied by the
+    conversion kernel), then every epoch streams uint8 NHWC rows to the device.  Same return tuple as init_real_data; the loaders
+    yield DEVICE tensors (channels-last images)."""
+    from . import datasets as ds, pipeline as pl
+    dev = opt.d_device if torch.cuda.is_available() and str(opt.d_device).startswith("cuda") else "cpu"
+
+    def cached(tag, make):
+        path = "%s.%s" % (opt.data_cache, tag)
+        if not os.path.exists(pl.cache_paths(path)[2]):
+            if rank == 0:
+                pl.build_cache(make(), path)
+            if world > 1:
+                torch.distributed.barrier()
+        return pl.CachedImages(path)
+
+    if opt.dataset == "MNIST":
+        tr = ds.MNISTDataset(opt.data_path, train=True, per_class=opt.train_set_size // 10)
+        data = pl.CachedImages.from_arrays((tr.x.squeeze(1).numpy() * 255.0).round().astype("uint8")[..., None], tr.y.numpy(), signed=False)
+        pub = None
+        if opt.public_set_size > 0:
+            te = ds.MNISTDataset(opt.data_path, train=False)
+            pub = pl.CachedImages.from_arrays((te.x.squeeze(1).numpy() * 255.0).round().astype("uint8")[..., None], te.y.numpy(), signed=False)
+        flip = False
+    else:
+        data = cached("train%d_%d" % (opt.train_set_size, opt.im_size), lambda: ds.CelebADataset(
+            opt.data_path, im_size=opt.im_size, length=opt.train_set_size, attr_file=opt.label_path, attr=opt.label_attr, flip=False))
+        pub = cached("public%d_%d" % (opt.public_set_size, opt.im_size), lambda: ds.CelebADataset(
+            opt.data_path, im_size=opt.im_size, length=opt.public_set_size, offset=opt.train_set_size, attr_file=opt.label_path,
+            attr=opt.label_attr, flip=False)) if opt.public_set_size > 0 else None
+        flip = True
+    seed = int(getattr(opt, "dist_data_seed", 0)) if world > 1 else int(opt.manual_seed)
+    dl = pl.DevicePrefetcher(data, pl.EpochSampler(len(data), opt.batch_size, rank, world, seed=seed), device=dev, flip=flip, seed=int(opt.manual_seed))
+    pdl = pl.DevicePrefetcher(pub, pl.EpochSampler(len(pub), opt.batch_size, seed=seed + 1), device=dev, flip=flip, seed=int(opt.manual_seed) + 1) \
+        if pub is not None else None
+    return data, dl, pub, pdl
+
+
 def init_real_data(opt, rank=0, world=1):
     """init_util.init_data (init_util.py:13-42) on the real files: returns (dataset, loader, public set, loader)."""
     from . import datasets as ds
+    if getattr(opt, "data_cache", None):
+        return init_cached_data(opt, rank, world)
     pub = None
     if opt.dataset == "MNIST":
         data = ds.MNISTDataset(opt.data_path, train=True, per_class=opt.train_set_size // 10)

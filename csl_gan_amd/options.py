@@ -5,6 +5,9 @@ tables (options.py:11-91), the derived flags (options.py:230-235), the incompati
 Additions of this build (all optional, none changes a reference default):
   --im_size 128        the 128x128 extension of BASELINE.json config 5
   --synthetic          use the synthetic in-memory dataset (the container has no MNIST/CelebA files)
+  --data_cache PATH    real data through the preprocessed-tensor cache and the device prefetcher (csl_gan_amd/pipeline.py): the files
+                       under --data_path are decoded / resized / cropped ONCE into PATH.*.u8 (uint8 NHWC memmap) and every batch is
+                       uploaded as bytes on a side stream and normalised + flipped by one kernel
   --max_iters N        stop after N training iterations (smoke runs)
   --dist               one process per GPU under torch.distributed (RCCL); see csl_gan_amd/distributed.py
   --fuse_passes B      run the adaptive / generated / real discriminator passes as one forward+backward over the
@@ -163,6 +166,7 @@ _ARGS = [
     (("-p", "--profile_training"), dict(default=False, action="store_true")),
     # ---- additions of this build ----
     (("--synthetic",), dict(default=False, action="store_true")),
+    (("--data_cache",), dict(type=str, default=None)),
     (("--max_iters",), dict(type=int, default=0)),
     (("--dist",), dict(default=False, action="store_true")),
     (("--materialize",), dict(type=str, choices=["all", "private", "ghost"], default="ghost")),

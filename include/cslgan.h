@@ -413,6 +413,14 @@ int cslgan_lipschitz_term_f32(const float* t, int64_t n_rows, int64_t len, int o
 int cslgan_lipschitz_term_bwd_f32(const float* t, const float* norm, const float* g_total, const float* g_per, int64_t n_rows,
                                   int64_t len, int one_sided, float coef, float* gt, void* stream);
 
+
+/* ---- input pipeline (ABI v5) ----------------------------------------------------------------------------------------------------
+ * out[n][h][w][c] = src[n][h][flip[n] ? W-1-w : w][c] * scale + bias: a batch of uint8 NHWC images (the preprocessed-tensor cache of
+ * csl_gan_amd/pipeline.py, uploaded as 1 byte per element) becomes the normalised fp32 channels-last batch the critic reads.
+ * Replaces the per-image ToTensor / RandomHorizontalFlip / Normalize of datasets.py:41-47 (flip: nullable [N] bytes drawn by the host
+ * with p = 0.5; scale = 1/127.5, bias = -1 for Normalize(0.5, 0.5)). */
+int cslgan_u8_to_f32_nhwc(const void* src_u8, const void* flip_u8, int N, int H, int W, int C, float scale, float bias, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,7 +77,8 @@ def test_device_prefetcher_and_conversion_kernel(tmp_path):
     u8 = torch.from_numpy(cache.x[:B].copy())
     flip = torch.from_numpy((rng.random(B) < 0.5).astype(np.uint8))
     out = torch.empty((B, H, W, C), device="cuda")
-    ops.check(_lib.lib().cslgan_u8_to_f32_nhwc(ops._p(u8.cuda()), ops._p(flip.cuda()), B, H, W, C, cache.scale, cache.bias, ops._p(out),
+    d_u8, d_flip = u8.cuda(), flip.cuda()
+    ops.check(_lib.lib().cslgan_u8_to_f32_nhwc(ops._p(d_u8), ops._p(d_flip), B, H, W, C, cache.scale, cache.bias, ops._p(out),
                                                torch.cuda.current_stream().cuda_stream), "u8_to_f32_nhwc")
     ref = cache.to_float(u8.numpy(), flip.numpy())
     assert torch.equal(out.permute(0, 3, 1, 2).cpu(), ref)

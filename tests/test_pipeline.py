@@ -81,7 +81,7 @@ def test_device_prefetcher_and_conversion_kernel(tmp_path):
     ops.check(_lib.lib().cslgan_u8_to_f32_nhwc(ops._p(d_u8), ops._p(d_flip), B, H, W, C, cache.scale, cache.bias, ops._p(out),
                                                torch.cuda.current_stream().cuda_stream), "u8_to_f32_nhwc")
     ref = cache.to_float(u8.numpy(), flip.numpy())
-    assert torch.equal(out.permute(0, 3, 1, 2).cpu(), ref)
+    assert (out.permute(0, 3, 1, 2).cpu() - ref).abs().max().item() <= 2e-7        # (the kernel contracts x * scale + bias into one fma)
     # the prefetcher: three epochs' worth of batches arrive on the device in sampler order, channels-last, while slots are recycled
     samp = pl.EpochSampler(n, B, seed=9)
     pf = pl.DevicePrefetcher(cache, samp, device="cuda:0", flip=False, depth=2)
@@ -92,7 +92,7 @@ def test_device_prefetcher_and_conversion_kernel(tmp_path):
         for img, lab in pf:
             assert img.is_cuda and img.shape == (B, C, H, W) and img.permute(0, 2, 3, 1).is_contiguous()
             got = img.cpu()                                   # (synchronises: the slot may be recycled after this)
-            assert torch.equal(got, cache.to_float(cache.x[idx[k:k + B]])), (epoch, k)
+            assert (got - cache.to_float(cache.x[idx[k:k + B]])).abs().max().item() <= 2e-7, (epoch, k)
             assert torch.equal(lab.cpu(), torch.from_numpy(cache.labels[idx[k:k + B]]))
             k += B
         assert k == (n // B) * B

@@ -20,7 +20,7 @@ EXPORTS = [
     "cslgan_l2_clip_rows_f32", "cslgan_row_l2norm_f32", "cslgan_row_l2norm_bwd_f32", "cslgan_mean_sample_f32",
     "cslgan_conv2d_fwd_f32", "cslgan_conv2d_fwd_x3_f32", "cslgan_conv2d_dgrad_f32", "cslgan_conv2d_wgrad_grouped_f32",
     "cslgan_conv2d_wgrad_scaled_f32", "cslgan_conv2d_wgrad_blocks_f32", "cslgan_conv2d_wgrad_sqnorm_gram_f32", "cslgan_conv2d_wgrad_skinny_f32", "cslgan_conv2d_s2_fwd_f32",
-    "cslgan_conv2d_dgrad_x3_f32", "cslgan_conv2d_s2_fwd_x3_f32", "cslgan_u8_to_f32_nhwc",
+    "cslgan_conv2d_dgrad_x3_f32", "cslgan_conv2d_s2_fwd_x3_f32", "cslgan_u8_to_f32_nhwc", "cslgan_split_filter_x3_f32",
     "cslgan_depth_to_space_f32", "cslgan_fold_channels4_f32",
     "cslgan_bias_grad_grouped_f32", "cslgan_act_bwd_f32", "cslgan_groupnorm_act_f32", "cslgan_batchnorm_act_f32", "cslgan_batchnorm_eval_act_f32",
     "cslgan_norm_act_bwd_f32", "cslgan_norm_bwd_ws_floats",
@@ -118,6 +118,7 @@ def lib():
         "cslgan_conv2d_wgrad_grouped_bf16s": [C.POINTER(ConvT), vp, vp, i32, f32, vp, i32, vp, vp],
         "cslgan_cast_f32_bf16": [vp, vp, i64, vp],
         "cslgan_u8_to_f32_nhwc": [vp, vp, i32, i32, i32, i32, C.c_float, C.c_float, vp, vp],
+        "cslgan_split_filter_x3_f32": [vp, i32, i32, i32, vp, i32, vp],
         "cslgan_cast_bf16_f32": [vp, vp, i64, vp],
         "cslgan_act_bwd_bf16": [vp, vp, i64, f32, vp, vp],
         "cslgan_bias_grad_grouped_bf16": [vp, i32, i32, i32, i32, f32, vp, vp, vp],

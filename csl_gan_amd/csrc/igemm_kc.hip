@@ -508,6 +508,12 @@ int cslgan_conv2d_fwd_f32(const cslgan_conv_t* c, const float* x, const float* w
     return conv2d_fwd_impl(c, x, w, nullptr, bias, residual, act, y, stream);
 }
 
+int cslgan_split_filter_x3_f32(const float* w, int rows, int taps, int red, void* w3_ws, int pieces, void* stream) {
+    CSLGAN_REQUIRE(w && w3_ws && rows > 0 && taps > 0 && red > 0 && (pieces == 1 || pieces == 3), "split_filter_x3: bad argument");
+    CSLGAN_REQUIRE(aligned16(w) && aligned16(w3_ws) && ((long long)rows * taps * red) % 4 == 0, "split_filter_x3: filter must be 16-byte aligned with a multiple of 4 elements");
+    return split_filter_x3(w, rows, taps, red, w3_ws, (hipStream_t)stream, pieces);
+}
+
 int cslgan_conv2d_fwd_x3_f32(const cslgan_conv_t* c, const float* x, const float* w, void* w3_ws, int repack, const float* bias,
                              const float* residual, int act, float* y, void* stream) {
     CSLGAN_REQUIRE(c && w && w3_ws, "conv2d_fwd_x3: null argument");

@@ -41,11 +41,10 @@ __global__ void act_bwd_kernel(const float* __restrict__ g, const float* __restr
 // global atomic per channel per block.
 constexpr int NS_ROWS_MIN = 64;   // rows per block, lower bound (the launch picks a multiple: ~1024 blocks in all)
 
-// FUSED: `stats` is a persistent, zero-initialised scratch [2*n_stats] followed by one uint32 ticket PER ROW GROUP (gridDim.y of
-// them); the last workgroup of a row group to finish turns that group's scratch entries into the final (sum, centred sum of
-// squares) pairs in `final_stats` and leaves scratch and ticket zeroed for the next launch — no memset before and no finalize
-// launch after (two 4-us dispatches per normalisation layer).  The ticket is per row group on purpose: ONE ticket for the whole
-// grid serialises ~1000 same-address atomics in L2 (measured: 30 -> 146 us on the 64x64 layer).
+// PART: `final_stats` is the partials array [row group][workgroup of the row group][group][2] (see launch_norm): every workgroup
+// leaves its own (S1, S2) pairs there and the apply kernel adds them — no zeroed accumulator, no atomics, no finalize launch.
+// (Round 3's attempt to finish the statistics in the LAST workgroup of a row group behind a ticket needed a device-scope fence in
+// every workgroup and made this kernel 5x slower; it is gone.)
 // Element access for the normalisation kernels: fp32 tensors, or bfloat16-stored activations (csrc/igemm_bf16s.hip's storage mode;
 // statistics and arithmetic are fp32 either way, a bf16 output is rounded to nearest even).
 typedef unsigned short bf16_t;
@@ -68,7 +67,7 @@ __device__ __forceinline__ void st4(bf16_t* p, long long i, float a, float b, fl
     *reinterpret_cast<uint2*>(p + i) = make_uint2(rne_bf16(a) | (rne_bf16(b) << 16), rne_bf16(c) | (rne_bf16(d) << 16));
 }
 
-template <bool VEC, bool FUSED, typename TX>
+template <bool VEC, bool PART, typename TX>
 __global__ __launch_bounds__(256) void norm_stats_kernel(const TX* __restrict__ x, long long rows_per_stat, int C, int cpg,
                                                          int n_groups, int rows_per_block, float* __restrict__ stats,
                                                          float* __restrict__ final_stats, long long n_stats) {
@@ -122,38 +121,16 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const TX* __restrict__ 
         }
     }
     __syncthreads();
-    // the channels of a group share the shift: fold them in LDS, one global atomic per (group, moment)
+    // the channels of a group share the shift: fold them in LDS; then ONE value per (group, moment) leaves the workgroup —
+    // PART: written to this workgroup's slot of the partials array (no atomics, no zeroed accumulator: the apply kernel adds the
+    // <= 64 slots of a row group in its prologue); otherwise one global atomic into the zeroed statistics
     for (int i = tid; i < 2 * n_groups; i += 256) {
         const int g = i >> 1, which = i & 1;
         float t = 0.f;
         for (int j = 0; j < cpg; ++j) t += s_acc[2 * (g * cpg + j) + which];
-        atomicAdd(&stats[2 * (sr * n_groups + g) + which], t);
+        if (PART) final_stats[((sr * gridDim.x + blockIdx.x) * n_groups + g) * 2 + which] = t;
+        else atomicAdd(&stats[2 * (sr * n_groups + g) + which], t);
     }
-    if (!FUSED) return;
-    __shared__ bool last;
-    __threadfence();
-    __syncthreads();
-    unsigned* ticket = reinterpret_cast<unsigned*>(stats + 2 * n_stats) + sr;
-    if (tid == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    const float cnt = (float)rows_per_stat * (float)cpg;
-    for (long long s = sr * n_groups + tid; s < (sr + 1) * n_groups; s += 256) {
-        const long long srow = sr;
-        const int g = (int)(s - srow * n_groups);
-        const float k = ldf(x, srow * rows_per_stat * C + g * cpg);
-        const float S1 = __hip_atomic_load(stats + 2 * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float S2 = __hip_atomic_load(stats + 2 * s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        stats[2 * s] = 0.f;
-        stats[2 * s + 1] = 0.f;
-        const float m1 = S1 / cnt;
-        float css = S2 - S1 * m1;
-        if (css < 0.f) css = 0.f;
-        final_stats[2 * s] = (k + m1) * cnt;
-        final_stats[2 * s + 1] = css;
-    }
-    if (tid == 0) *ticket = 0u;
 }
 
 // (S1, S2) about the shift k  ->  (sum x, sum (x-mean)^2)
@@ -253,22 +230,59 @@ __global__ void norm_apply_kernel(const TX* __restrict__ x, const float* __restr
 template <bool D2S, typename TX, typename TY>
 __global__ __launch_bounds__(256) void norm_apply_rows_kernel(const TX* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ stats, long long rows_per_stat, int C, int cpg, int n_groups,
-                                                              float eps, int relu, TY* __restrict__ y, int H, int W, TY* __restrict__ xs) {
+                                                              float eps, int relu, TY* __restrict__ y, int H, int W, TY* __restrict__ xs,
+                                                              const float* __restrict__ part, int n_part, float* __restrict__ stats_out) {
     const int c4n = C >> 2;                           // a power of two (256 % c4n == 0)
     const int lg = __ffs(c4n) - 1;
     const int c = (threadIdx.x & (c4n - 1)) << 2;
     const long long sr = blockIdx.y;
-    const float inv_cnt = 1.f / ((float)rows_per_stat * (float)cpg);
+    const float cnt = (float)rows_per_stat * (float)cpg;
+    const float inv_cnt = 1.f / cnt;
+    const long long base = sr * rows_per_stat * C;
     float mean[4], rstd[4], ga[4], be[4];
+    if (part) {
+        // Two-launch form (round 4): the statistics kernel left one (S1, S2) pair about the shift k per workgroup and group; add the
+        // row group's n_part slots here (2 * n_groups threads, n_part loads each), finish them in LDS, and let the row group's first
+        // workgroup publish the final (sum x, centred sum of squares) pairs for whoever reads the statistics later (the backward).
+        extern __shared__ float s_st[];               // [2 * n_groups]: (sum x, centred sum of squares)
+        for (int i = threadIdx.x; i < n_groups; i += 256) {
+            float S1 = 0.f, S2 = 0.f;
+            for (int b = 0; b < n_part; ++b) {
+                const float* q = part + ((sr * n_part + b) * n_groups + i) * 2;
+                S1 += q[0];
+                S2 += q[1];
+            }
+            const float k = ldf(x, base + (long long)i * cpg);
+            const float m1 = S1 / cnt;
+            float css = S2 - S1 * m1;
+            css = css < 0.f ? 0.f : css;
+            s_st[2 * i] = (k + m1) * cnt;
+            s_st[2 * i + 1] = css;
+            if (stats_out && blockIdx.x == 0) {
+                stats_out[2 * (sr * n_groups + i)] = (k + m1) * cnt;
+                stats_out[2 * (sr * n_groups + i) + 1] = css;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int g = (c + e) / cpg;
+            mean[e] = s_st[2 * g] * inv_cnt;
+            rstd[e] = rsqrtf(s_st[2 * g + 1] * inv_cnt + eps);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long long s = sr * n_groups + (c + e) / cpg;
+            mean[e] = stats[2 * s] * inv_cnt;
+            rstd[e] = rsqrtf(stats[2 * s + 1] * inv_cnt + eps);
+        }
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const long long s = sr * n_groups + (c + e) / cpg;
-        mean[e] = stats[2 * s] * inv_cnt;
-        rstd[e] = rsqrtf(stats[2 * s + 1] * inv_cnt + eps);
         ga[e] = gamma[c + e];
         be[e] = beta[c + e];
     }
-    const long long base = sr * rows_per_stat * C;
     const unsigned n4 = (unsigned)((rows_per_stat * C) >> 2);          // launcher: rows_per_stat * C < 2^32
     const bool per_image = rows_per_stat == (long long)H * W;
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
@@ -478,8 +492,8 @@ __global__ void bn_running_kernel(const float* __restrict__ stats, int C, float 
 
 template <typename TX, typename TY>
 static int launch_norm_apply(const TX* x, const float* gamma, const float* beta, long long R, long long rows_per_stat, int C,
-                             int cpg, int n_groups, float eps, int relu, const float* stats, TY* y, int d2s_H, int d2s_W,
-                             TY* xs, bool vec, hipStream_t st) {
+                             int cpg, int n_groups, float eps, int relu, float* stats, TY* y, int d2s_H, int d2s_W,
+                             TY* xs, bool vec, hipStream_t st, const float* part = nullptr, int n_part = 0) {
     const long long total = R * C;
     static const int rows_env = [] { const char* e = getenv("CSLGAN_NORM_ROWS"); return e ? atoi(e) : 1; }();
     const long long n_rg = R / rows_per_stat;
@@ -488,8 +502,9 @@ static int launch_norm_apply(const TX* x, const float* gamma, const float* beta,
         const long long cap = (4096 + n_rg - 1) / n_rg;                 // about 4096 workgroups in all
         bx = bx > cap ? cap : (bx < 1 ? 1 : bx);
         const dim3 g2((unsigned)bx, (unsigned)n_rg), b2(256);
-        if (d2s_W > 0) hipLaunchKernelGGL((norm_apply_rows_kernel<true, TX, TY>), g2, b2, 0, st, x, gamma, beta, stats, rows_per_stat, C, cpg, n_groups, eps, relu, y, d2s_H, d2s_W, xs);
-        else hipLaunchKernelGGL((norm_apply_rows_kernel<false, TX, TY>), g2, b2, 0, st, x, gamma, beta, stats, rows_per_stat, C, cpg, n_groups, eps, relu, y, 0, 0, (TY*)nullptr);
+        const size_t lds = part ? sizeof(float) * 2 * n_groups : 0;
+        if (d2s_W > 0) hipLaunchKernelGGL((norm_apply_rows_kernel<true, TX, TY>), g2, b2, lds, st, x, gamma, beta, stats, rows_per_stat, C, cpg, n_groups, eps, relu, y, d2s_H, d2s_W, xs, part, n_part, stats);
+        else hipLaunchKernelGGL((norm_apply_rows_kernel<false, TX, TY>), g2, b2, lds, st, x, gamma, beta, stats, rows_per_stat, C, cpg, n_groups, eps, relu, y, 0, 0, (TY*)nullptr, part, n_part, stats);
         return check_launch("norm_apply_rows_kernel");
     }
     long long nb = (total / 4 + 255) / 256;
@@ -521,17 +536,20 @@ static int launch_norm(const TX* x, const float* gamma, const float* beta, long 
     long long rpb = (rows_per_stat * n_row_groups / 1024 + NS_ROWS_MIN - 1) / NS_ROWS_MIN * NS_ROWS_MIN;
     rpb = rpb < NS_ROWS_MIN ? NS_ROWS_MIN : (rpb > 4096 ? 4096 : rpb);
     const dim3 grid((unsigned)((rows_per_stat + rpb - 1) / rpb), (unsigned)n_row_groups), block(256);
-    if (!(scratch && grid.x <= 64)) {
-        if (int rc = zero_floats(stats, (size_t)2 * n_stats, st)) return rc;
-    }
     const size_t lds = sizeof(float) * C;
-    if (scratch && grid.x <= 64) {         // few workgroups per row group share a ticket (BatchNorm's single row group: classic path)
-        if (vec) hipLaunchKernelGGL((norm_stats_kernel<true, true, TX>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, scratch, stats, n_stats);
-        else hipLaunchKernelGGL((norm_stats_kernel<false, true, TX>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, scratch, stats, n_stats);
+    // Two-launch form: per-workgroup partial statistics into `scratch` (2 * n_stats * grid.x floats, grid.x <= CSLGAN_NORM_PARTIAL_BLOCKS),
+    // summed by the apply kernel's prologue — no zeroed accumulator, no global atomics, no finalize launch (round 3: four launches per
+    // normalisation, 36 per D-step; its ticket-fused attempt needed a device-scope fence per workgroup and lost).
+    static const int part_env = [] { const char* e = getenv("CSLGAN_NORM_PARTIALS"); return e ? atoi(e) : 1; }();
+    static const int rows_env2 = [] { const char* e = getenv("CSLGAN_NORM_ROWS"); return e ? atoi(e) : 1; }();
+    if (part_env && scratch && vec && rows_env2 && grid.x <= CSLGAN_NORM_PARTIAL_BLOCKS && rows_per_stat * C < (1ll << 32) && n_row_groups <= 65535 &&
+        2 * (size_t)n_groups * sizeof(float) <= 32768) {
+        hipLaunchKernelGGL((norm_stats_kernel<true, true, TX>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, stats, scratch, n_stats);
         const int rc1 = check_launch("norm_stats_kernel");
         if (rc1) return rc1;
-        return launch_norm_apply(x, gamma, beta, R, rows_per_stat, C, cpg, n_groups, eps, relu, stats, y, d2s_H, d2s_W, xs, vec, st);
+        return launch_norm_apply(x, gamma, beta, R, rows_per_stat, C, cpg, n_groups, eps, relu, stats, y, d2s_H, d2s_W, xs, vec, st, scratch, (int)grid.x);
     }
+    if (int rc = zero_floats(stats, (size_t)2 * n_stats, st)) return rc;
     if (vec) hipLaunchKernelGGL((norm_stats_kernel<true, false, TX>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, stats, (float*)nullptr, n_stats);
     else hipLaunchKernelGGL((norm_stats_kernel<false, false, TX>), grid, block, 2 * lds, st, x, rows_per_stat, C, cpg, n_groups, (int)rpb, stats, (float*)nullptr, n_stats);
     int rc = check_launch("norm_stats_kernel");

@@ -55,6 +55,16 @@ def _record_mask(module, y, act=None, nhwc=True):
     return y
 
 
+class VersionRef:
+    """The version counter of a parameter, readable again later: the cache key of a workspace DERIVED from a parameter (the pieces of a
+    folded filter) — ops.repack_cache.refresh_pinned() re-reads it to decide whether a pinned workspace must be rebuilt."""
+
+    def __init__(self, p):
+        self.p = p
+
+    version = property(lambda self: self.p._version)
+
+
 class PerSampleSink:
     """Interface the DP engine implements to receive per-sample gradients from a layer's backward."""
 
@@ -128,7 +138,7 @@ class HipConv2d(nn.Conv2d, _PerSampleMixin):
         # wf is derived from the parameter (its own version counter is always 0, and a later fold may reuse its address): caches
         # downstream of it are keyed on the PARAMETER's version under a token of their own
         return HF.Conv.apply(x_ps, wf, self.bias, 1, self.padding[0], self.act, None, None if wk is None else (wk, "fold4"), 4.0,
-                             self.weight._version)
+                             VersionRef(self.weight))
 
     def _wkey(self, w):
         # only a zero-copy view of the parameter shares its version counter; a re-laid-out copy must not be cached

@@ -171,32 +171,53 @@ class _RepackCache:
     generator's UpsampleConv layers) keyed by the filter tensor's storage and autograd version counter: any in-place
     torch op bumps the counter, and HipAdam — which writes the weights through raw pointers — bumps it explicitly
     (torch.autograd.graph.increment_version).  A D-step reuses each critic layer's repack four times and the
-    generator's folded filters until the next generator step."""
+    generator's folded filters until the next generator step.
+
+    Pinned entries (round 4): a recorded HIP graph bakes the ADDRESS of every workspace it reads.  The generator is frozen during
+    D-steps, so its folded / pre-split filters need not be re-made by every replay: GraphedDStep pins the generator's entries (made
+    by the eager warm-up steps), records the step with cache hits on them, and calls refresh_pinned() before each replay — an entry
+    whose source parameter has a new version (a train_G step ran) is rebuilt IN PLACE by the closure it was made with.  A pinned
+    entry is never evicted or replaced; a version mismatch seen by get() reuses its buffer (repack = 1)."""
 
     def __init__(self, max_entries=256):
         self.d, self.max = {}, max_entries      # callers pass wkey (a never-reused per-module token, csl_gan_amd.nn) only for module-owned filters
+        self.pinned = {}                         # key -> number of recorded graphs that read the entry's buffer
 
     def get(self, kind, w, numel, wkey=None, version=None):
-        """version: the autograd version to key on when `w` is itself derived from a parameter (its own counter is always 0).
+        """version: the autograd version to key on when `w` is itself derived from a parameter (its own counter is always 0): an int,
+        or an object with a `.version` property (csl_gan_amd.nn.VersionRef) that refresh_pinned() can read again later.
         A hit from another stream than the one that packed the buffer waits for that pack (the D-step runs its gradient-penalty
         branch on a second stream, and both branches read the critic's re-packed filters)."""
         if wkey is None:          # not known to be a live parameter (a temporary may reuse an address): never cache
             return torch.empty(numel, device=w.device, dtype=torch.float32), 1
         key = (kind, wkey, w.data_ptr(), tuple(w.shape))
-        ver = w._version if version is None else version
+        src = version if hasattr(version, "version") else (w if version is None else None)
+        ver = w._version if version is None else (version.version if hasattr(version, "version") else version)
         hit = self.d.get(key)
         cur = torch.cuda.current_stream()
-        if hit is not None and hit[0] == ver and hit[1].numel() == numel and hit[1].device == w.device:
-            if hit[2] != cur.cuda_stream and hit[3] is not None:
-                cur.wait_event(hit[3])
-            self._fresh = None
-            return hit[1], 0
+        if hit is not None and hit[1].numel() == numel and hit[1].device == w.device:
+            if hit[0] == ver:
+                if hit[2] != cur.cuda_stream and hit[3] is not None:
+                    cur.wait_event(hit[3])
+                self._fresh = None
+                return hit[1], 0
+            if key in self.pinned:        # a recorded graph reads this buffer: rebuild it where it is
+                hit[0], hit[2], hit[3] = ver, cur.cuda_stream, None
+                self._fresh = key
+                return hit[1], 1
         if len(self.d) >= self.max:
-            self.d.clear()
+            self.clear()
         ws = torch.empty(numel, device=w.device, dtype=torch.float32)
-        self.d[key] = [ver, ws, cur.cuda_stream, None]
+        self.d[key] = [ver, ws, cur.cuda_stream, None, None, src]
         self._fresh = key
         return ws, 1
+
+    def set_rebuild(self, fn):
+        """Attach to the entry get() has just made (a miss) the closure that re-makes its contents in place: fn() launches the
+        packing kernels on the current stream.  Only entries with a rebuild closure and a version source can be pinned."""
+        key = getattr(self, "_fresh", None)
+        if key is not None and key in self.d:
+            self.d[key][4] = fn
 
     def packed(self):
         """Called right after the launch that filled the most recent fresh buffer: marks the point other streams must wait for."""
@@ -209,8 +230,44 @@ class _RepackCache:
 
     multi_stream = False        # set while a second stream is in use (Trainer): events are only recorded then
 
+    def pin(self, tokens):
+        """Pin every entry that belongs to a module token in `tokens` (key[1] is the token or a tuple starting with it) and can be
+        rebuilt in place.  Returns the pinned keys (hand them back to unpin())."""
+        keys = []
+        for key, e in self.d.items():
+            tok = key[1][0] if isinstance(key[1], tuple) else key[1]
+            if tok in tokens and e[4] is not None and e[5] is not None:
+                self.pinned[key] = self.pinned.get(key, 0) + 1
+                e[3] = None           # (the caller has synchronised the device: no cross-stream wait is owed any more)
+                keys.append(key)
+        return keys
+
+    def unpin(self, keys):
+        for key in keys:
+            n = self.pinned.get(key, 0) - 1
+            if n > 0:
+                self.pinned[key] = n
+            else:
+                self.pinned.pop(key, None)
+
+    def refresh_pinned(self):
+        """Rebuild (in place, in insertion order: a folded filter before its pieces) every pinned entry whose source has a new
+        version.  Returns how many were rebuilt."""
+        n = 0
+        for key in self.d:
+            if key not in self.pinned:
+                continue
+            e = self.d[key]
+            ver = e[5].version if hasattr(e[5], "version") else e[5]._version
+            if ver != e[0]:
+                e[4]()
+                e[0], e[2], e[3] = ver, torch.cuda.current_stream().cuda_stream, None
+                n += 1
+        return n
+
     def clear(self):
-        self.d.clear()
+        """Drop every entry that is not pinned."""
+        self.d = {k: v for k, v in self.d.items() if k in self.pinned}
 
 
 repack_cache = _RepackCache()
@@ -436,6 +493,9 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, ou
         _timed("conv2d_fwd", flop, nbytes, lambda: check(
             _lib.lib().cslgan_conv2d_fwd_x3_f32(C.byref(d), _p(x), _p(w), _p(ws), repack, _p(bias), _p(residual), act, _p(y), _stream()),
             "conv2d_fwd_x3"), exec_flop=xflop, tag=lambda: "N%d %dx%d C%d K%d R%d s%d" % (N, H, W, Cc, K, R, stride))
+        if repack:
+            pieces = 3 if d.compute == COMPUTE_BF16X3 else 1
+            repack_cache.set_rebuild(lambda: check(_lib.lib().cslgan_split_filter_x3_f32(_p(w), K, R * S, Cc, _p(ws), pieces, _stream()), "split_filter_x3"))
         repack_cache.packed()
         return y
     _timed("conv2d_fwd", flop, nbytes, lambda: check(
@@ -474,7 +534,9 @@ def fold_channels4(w, wkey=None):
         raise RuntimeError("fold_channels4: C=%d is not a multiple of 4" % Cc)
     wf, fresh = repack_cache.get("fold4", w, w.numel() // 4, wkey)
     if fresh:
-        check(_lib.lib().cslgan_fold_channels4_f32(_p(w), K * R * S, Cc, 0, _p(wf), _stream()), "fold_channels4")
+        fold = lambda: check(_lib.lib().cslgan_fold_channels4_f32(_p(w), K * R * S, Cc, 0, _p(wf), _stream()), "fold_channels4")
+        fold()
+        repack_cache.set_rebuild(fold)
         repack_cache.packed()
     return wf.view(K, R, S, Cc // 4)
 
@@ -1210,23 +1272,21 @@ def _d2s_out(x, d2s, want_raw, dtype=torch.float32):
 _norm_scratch = {}
 
 
-_NORM_FUSED = os.environ.get("CSLGAN_NORM_FUSED", "0") == "1"
+_NORM_PARTIALS = os.environ.get("CSLGAN_NORM_PARTIALS", "1") == "1"
+NORM_PARTIAL_BLOCKS = 64            # include/cslgan.h CSLGAN_NORM_PARTIAL_BLOCKS
 
 
-def _scratch(dev, n_floats):
-    """None unless CSLGAN_NORM_FUSED=1 (A/B switch).  Measured on MI355X: finishing the statistics in the stats kernel's last
-    workgroup needs a device-scope release fence in EVERY workgroup, and with one L2 per XCD that fence writes the XCD's L2 back —
-    the 64x64 layer's stats kernel went 30 -> 146 us (0.47 ms per step lost against two 4-us launches saved per layer).  The
-    default is therefore the three-launch form: memset, stats (atomics), finalize.
-
-    Persistent zeroed accumulator of the normalisation statistics (+ the ticket word): the kernels leave it zeroed, so it is
-    filled once per device (and again only when a larger one is needed).  Launches are ordered on torch's current stream."""
-    if not _NORM_FUSED:
+def _scratch(dev, n_stats_floats):
+    """Workspace for the per-workgroup partial statistics of the two-launch normalisation (cslgan_groupnorm_act_f32's `scratch`):
+    n_stats_floats (= 2 * statistics) x NORM_PARTIAL_BLOCKS floats, persistent per (device, stream) — launches on one stream are
+    ordered, and nothing in it outlives the apply launch that follows.  None with CSLGAN_NORM_PARTIALS=0 (A/B: the four-launch form)."""
+    if not _NORM_PARTIALS:
         return None
+    need = int(n_stats_floats) * NORM_PARTIAL_BLOCKS
     key = (dev, torch.cuda.current_stream().cuda_stream)
     t = _norm_scratch.get(key)
-    if t is None or t.numel() < n_floats + 1:
-        t = _norm_scratch[key] = torch.zeros(max(n_floats + 1, 16385), device=dev, dtype=torch.float32)
+    if t is None or t.numel() < need:
+        t = _norm_scratch[key] = torch.empty(max(need, 1 << 16), device=dev, dtype=torch.float32)
     return t
 
 
@@ -1247,7 +1307,7 @@ def groupnorm_act(x, gamma, beta, groups, eps=1e-5, relu=True, return_stats=Fals
     N, H, W, Cc = x.shape
     y, xs, dW = _d2s_out(x, d2s, want_raw)
     ws = torch.empty(2 * N * groups, device=x.device, dtype=torch.float32)
-    sc = _scratch(x.device, 2 * N * groups + N)
+    sc = _scratch(x.device, 2 * N * groups)
     check(_lib.lib().cslgan_groupnorm_act_f32(_p(x), _p(gamma), _p(beta), N, H * W, Cc, groups, float(eps), 1 if relu else 0,
                                               _p(ws), _p(y), dW, _p(xs), _p(sc), _stream()), "groupnorm_act")
     out = (y, xs) if want_raw else y
@@ -1269,7 +1329,7 @@ def batchnorm_act(x, gamma, beta, running_mean=None, running_var=None, momentum=
     ws = torch.empty(2 * Cc, device=x.device, dtype=torch.float32)
     check(_lib.lib().cslgan_batchnorm_act_f32(_p(x), _p(gamma), _p(beta), rows, Cc, float(eps), 1 if relu else 0, float(momentum),
                                               _p(running_mean), _p(running_var), _p(ws), _p(y), rpi, dW, _p(xs),
-                                              _p(_scratch(x.device, 2 * Cc + 1)), _stream()), "batchnorm_act")
+                                              _p(_scratch(x.device, 2 * Cc)), _stream()), "batchnorm_act")
     out = (y, xs) if want_raw else y
     return (out, ws) if return_stats else out
 

@@ -16,6 +16,8 @@ MI355X-first host changes (results identical):
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 from torch import autograd
@@ -865,6 +867,7 @@ class GraphedDStep:
             raise NotImplementedError("GraphedDStep covers the DP D-steps whose host never reads the device inside the step: dp_mode=gc "
                                       "and dp_mode=is (not the moving-average scaling mode, which reads gradient norms on the host)")
         self.graph, self.bufs, self.capture_error = None, None, None
+        self._pinned = []                  # generator filter workspaces pinned in ops.repack_cache for the recorded graph
         self._prev = (trainer.d_optimizer.capturable, trainer.explicit)
         trainer.d_optimizer.capturable = True
 
@@ -872,6 +875,10 @@ class GraphedDStep:
         """Give the trainer back to plain eager stepping (bench.py times other variants on the same trainer afterwards)."""
         self.tr.d_optimizer.capturable, self.tr.explicit = self._prev
         self.graph = None
+        if self._pinned:
+            from . import ops
+            ops.repack_cache.unpin(self._pinned)
+            self._pinned = []
 
     def _alloc(self, img, labels):
         o, dev, B = self.tr.opt, self.tr.opt.d_device, img.shape[0]
@@ -943,9 +950,14 @@ class GraphedDStep:
             # replay: a constant Adam step and a constant noise offset)
             tr.d_optimizer.prepare_capture()
             pe.ensure_noise_counter()
-            # every repacked / folded filter of the step must be RECORDED: a cache hit at capture time would bake in "no repack"
-            # plus a pointer to an eager buffer — stale weights (and freed memory) on every replay once train_G or a replayed Adam
-            # has moved the parameters
+            # every repacked / folded filter of the CRITIC must be RECORDED: a cache hit at capture time would bake in "no repack"
+            # plus a pointer to an eager buffer — stale weights (and freed memory) on every replay once a replayed Adam has moved the
+            # parameters.  The GENERATOR is frozen during D-steps: its folded / pre-split filters (made by the eager
+            # warm-up steps) are PINNED instead — the recording hits them, no replay re-makes them, and refresh_pinned() rebuilds
+            # them in place before a replay when a train_G step has changed the weights (round 4; 8 launches per step gone).
+            torch.cuda.synchronize()
+            if os.environ.get("CSLGAN_PIN_G_FILTERS", "1") == "1":
+                self._pinned = ops.repack_cache.pin({m._wtoken for m in tr.G.modules() if hasattr(m, "_wtoken")})
             ops.repack_cache.clear()
             torch.cuda.synchronize()
             steps0, calls0 = pe.steps, pe._noise_calls
@@ -988,10 +1000,13 @@ class GraphedDStep:
                 self.use_graph, self.capture_error = False, repr(e)[:300]
                 return self._eager()
             self.graph = graph
-            ops.repack_cache.clear()             # entries made during capture point into the graph's private pool
+            ops.repack_cache.clear()             # entries made during capture point into the graph's private pool (pinned ones stay)
             self.graph.replay()                  # the step itself
             tr.d_optimizer.bump_versions()
             return
+        if self._pinned:
+            from . import ops
+            ops.repack_cache.refresh_pinned()    # a train_G step since the last replay: the generator's filter workspaces, in place
         self.graph.replay()
         pe = tr.privacy_engine                   # what the recorded python would have done on the host
         pe.steps += 1

@@ -163,6 +163,10 @@ int cslgan_conv2d_fwd_f32(const cslgan_conv_t* p, const float* x, const float* w
  * the LDS-halo kernel whose filter operand goes straight from that workspace to registers; other shapes ignore it. */
 int cslgan_conv2d_fwd_x3_f32(const cslgan_conv_t* p, const float* x, const float* w, void* w3_ws, int repack,
                              const float* bias, const float* residual, int act, float* y, void* stream);
+/* The workspace of cslgan_conv2d_fwd_x3_f32 on its own (ABI v5): w[rows][taps][red] fp32 -> w3_ws[pieces][(red/16)*taps + tap][rows][16]
+ * bfloat16 (pieces = 3: hi / mid / lo; 1: the rounded filter).  Lets a caller that replays a recorded graph refresh the pieces of a
+ * FROZEN filter in place only when the filter has changed, instead of inside every replay; red % 16 != 0 writes nothing. */
+int cslgan_split_filter_x3_f32(const float* w, int rows, int taps, int red, void* w3_ws, int pieces, void* stream);
 
 /* gx = conv_transpose(gy, w) [* lrelu'(mask)]: the data gradient (autograd of the conv above;
  * "conv_transpose2d" in the north star).  wt_ws: caller workspace of K*R*S*C floats receiving
@@ -338,9 +342,11 @@ int cslgan_fold_channels4_f32(const float* in, int64_t rows, int C, int unfold, 
  * y[n][2h+i][2w+j][c'] = act(norm(x))[n][h][w][4c'+2i+j] (C % 4 == 0); x_shuffled (nullable) receives the raw x in the
  * same layout — the inputs of ResBlockUp's convUp and shortcut (DCResNet_models.py:29-34) from one read of x.
  * d2s_W == 0: y has x's layout and x_shuffled must be NULL.
- * scratch (nullable): persistent device buffer of 2*N*groups floats + N uint32 tickets, zero-initialised by the caller ONCE; the
- * statistics are then accumulated there and finalised by the last workgroup of each image, which leaves it zeroed (no memset, no
- * finalize launch).  One scratch must not be shared by launches on different streams. */
+ * scratch (nullable; ABI v5 meaning): caller workspace of 2*N*groups*CSLGAN_NORM_PARTIAL_BLOCKS floats (no initialisation needed)
+ * for per-workgroup partial statistics: the normalisation then runs as TWO launches (statistics, apply — the apply kernel adds the
+ * partials in its prologue and publishes the final pairs to stats_ws) instead of four (zero, statistics with atomics, finalize,
+ * apply).  One scratch must not be shared by launches on different streams. */
+#define CSLGAN_NORM_PARTIAL_BLOCKS 64
 int cslgan_groupnorm_act_f32(const float* x, const float* gamma, const float* beta, int N, int HW, int C,
                              int groups, float eps, int relu, float* stats_ws, float* y, int d2s_W, float* x_shuffled,
                              float* scratch, void* stream);

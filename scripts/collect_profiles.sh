@@ -1,10 +1,10 @@
 #!/bin/bash
 # Run on the GPU box from the repo root (gpurun): kernel statistics, HBM-traffic counters and the bench lines of one code state.
 # Outputs land in gpurun_out/$PROF_TAG/; copy the summaries into profiles/ afterwards (scripts/collect_profiles.sh is the recipe the
-# committed profiles/r03_* files were made with).
+# committed profiles/r03_* and r04_* files were made with; the default bench command now runs the fp32_auto headline).
 set -e
 ROOT=$(pwd)
-TAG=${PROF_TAG:-prof_r03}
+TAG=${PROF_TAG:-prof_r04}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 # 1. the bench line itself (eager region + HIP-graph region + variants + CPU baseline) and the isolated per-shape launch table
@@ -23,6 +23,8 @@ cd $ROOT
 python3 scripts/pmc_traffic.py $(ls $OUT/fetch/*counter_collection.csv | head -1) $(ls $OUT/write/*counter_collection.csv | head -1) ${PMC_STEPS:-11} $OUT/pmc_traffic.json
 cp $(ls $OUT/stats/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 rm -rf $OUT/fetch $OUT/write $OUT/stats
+# 3b. the exact-fp32 arithmetic of rounds 1-3 on the same box (its own launch table)
+python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --loop-steps 0 --no-variants --compute fp32 --dump-shapes $OUT/launch_shapes_fp32_exact.txt > $OUT/bench_fp32_exact.json 2> /dev/null || true
 # 4. the other BASELINE configurations on the same harness
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --loop-steps 0 --no-variants --opt "-dpm is -ispp True" > $OUT/bench_is.json 2> /dev/null || true
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --loop-steps 0 --no-variants --opt "--compute_dtype bf16 --im_size 128" > $OUT/bench_bf16_128.json 2> /dev/null || true

@@ -23,13 +23,13 @@ for k in set(f) | set(w):
     d[k] = {"launches_per_step": n / steps, "fetch_MB_per_launch": fb / max(n, 1) / 1e6, "write_MB_per_launch": wb / max(n, 1) / 1e6,
             "MB_per_step": (fb + wb) / steps / 1e6}
 d = dict(sorted(d.items(), key=lambda kv: -kv[1]["MB_per_step"])[:24])
-kc = {k: v for k, v in d.items() if k.startswith(("igemm_kc", "igemm_halo", "igemm_skinny"))}     # the conv2d_fwd / dgrad family
+kc = {k: v for k, v in d.items() if k.startswith(("igemm_kc", "igemm_halo", "igemm_skinny", "igemm_x3h"))}     # the conv2d_fwd / dgrad family
 launches, mb = sum(v["launches_per_step"] for v in kc.values()), sum(v["MB_per_step"] for v in kc.values())
 res = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) around `python3 bench.py --steps 3 --warmup 1 "
                "--no-cpu-baseline` on 1x MI355X; KB counters x1024; FETCH_SIZE doubled (gfx950 reports half of a wide coalesced stream, "
                "MI355X_MICROARCH.md HBM section); Infinity-Cache hits are counted, so this is an upper bound on HBM bytes",
        "step_total_MB_top24_kernels": sum(v["MB_per_step"] for v in d.values()),
-       "conv_family": {"kernels": "igemm_kc + igemm_halo + igemm_skinny, all instantiations (conv2d_fwd / conv2d_dgrad entries)",
+       "conv_family": {"kernels": "igemm_kc + igemm_halo + igemm_x3h + igemm_skinny, all instantiations (conv2d_fwd / conv2d_dgrad entries)",
                        "launches_per_step": launches, "MB_per_step": mb, "MB_per_launch": mb / launches},
        "per_kernel": d}
 json.dump(res, open(out, "w"), indent=1)

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3w_kernel(const WghParams p) {
     constexpr int XW = QUAD ? 3 * STRIDE + S : 7 * STRIDE + S;      // staged columns of the slab (of one sample for QUAD)
     constexpr int XPITCH = STRIDE == 1 ? 64 : 96;      // bytes per slab pixel in a 32-channel plane (see the bank note above)
     constexpr int XPIX = QUAD ? 2 * 4 * XW : 4 * XW;   // slab pixels per stage (4 input rows; two samples for QUAD)
-    constexpr int A_PLANE = 32 * 64, X_PLANE = XPIX * XPITCH;
+    constexpr int A_PLANE = 32 * 64 + 128, X_PLANE = XPIX * XPITCH;     // (+128 B: the two m planes a 16-lane store group covers land on disjoint banks)
     constexpr int NX = (XPIX * 16 + 255) / 256;        // float4 of the slab per thread
     __shared__ __attribute__((aligned(16))) unsigned char As[3][2][A_PLANE];     // [piece][m half][pixel][32 m]
     __shared__ __attribute__((aligned(16))) unsigned char Xs[3][2][X_PLANE];     // [piece][c half][slab pixel][32 c]

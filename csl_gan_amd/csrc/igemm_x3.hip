@@ -48,7 +48,13 @@ namespace {
 
 constexpr unsigned XOOB = 0xFFFFFFF0u;
 constexpr unsigned XFAR = 0xFFFF0000u;  // an out-of-range byte offset that STAYS out of range when a chunk / step offset (< 64 KB) is added to it
-constexpr int XH_MAX = 12 * 12;        // pixels per patch halo (8+4 squared: up to 5x5 taps; four 6x6 halos of a quad patch)
+constexpr int XH_MAX = 160;            // pixels of a patch's LDS image: 12 rows x 12 (8+4 squared: up to 5x5 taps), or four 6x6 halos at a
+                                       // pitch of 40 (quad patches)
+// LDS pitches are FIXED, whatever the halo's real width: the 16-lane groups of ds_read_b128 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31})
+// touch four patch rows at once, and with 32-byte pixels only row pitches of 8 / 12 / 16 pixels (quad patches: rows of 6, images 40
+// apart) keep their 16-byte reads on distinct banks.  A 3x3-tap class (halo 10 wide) indexed with ITS width ran 2-way conflicted on
+// half the reads (rocprofv3: SQ_LDS_BANK_CONFLICT = 45 % of SQ_LDS_IDX_ACTIVE on the critic's launches, 0 on the generator's 12-wide halos).
+constexpr int XROW = 12, XQROW = 6, XQIMG = 40;
 
 __device__ __forceinline__ unsigned xpack(float lo, float hi) {      // v_cvt_pk_bf16_f32: RNE, lo in bits 0..15
     const f32x2 v = {lo, hi};
@@ -160,7 +166,8 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
                 h_goff[j] = in_img ? 4u * (unsigned)(p_img[pp] + si * img_stride + (iy * p.AW + ix) * p.AC + ch * 4) : XFAR;
                 // the two 16-byte halves of a pixel are swapped on odd halo rows: the patch rows a 16-lane ds_read_b128 group covers then
                 // hit disjoint banks (the plain 32-byte pixel stride is 2-way conflicted)
-                h_lds[j] = idx < h_total ? (pp * XH_MAX + pix) * 4 + (ch ^ ((hy & 1) << 1)) : -1;
+                const int lpx = quad ? si * XQIMG + hy * XQROW + hx : hy * XROW + hx;
+                h_lds[j] = idx < h_total ? (pp * XH_MAX + lpx) * 4 + (ch ^ ((hy & 1) << 1)) : -1;
             }
         }
         float4 rh[HREG];
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
         for (int i = 0; i < TM; ++i) {
             const int qq = i * 32 + r;                         // row within the patch
             const int ly = quad ? (qq >> 2) & 3 : qq >> 3;
-            const int lpix = quad ? (qq >> 4) * hpix_img + ly * HW_ + (qq & 3) : ly * HW_ + (qq & 7);
+            const int lpix = quad ? (qq >> 4) * XQIMG + ly * XQROW + (qq & 3) : ly * XROW + (qq & 7);
             a_idx[i] = (wm * XH_MAX + lpix) * 2 + (h ^ (ly & 1));
         }
         bf16x8 A0[NP][TM], A1[NP][TM];                         // two sets: the next tap's fragments are read BEFORE this tap's MFMAs are issued
@@ -249,7 +256,8 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
         load_b(1, B1);
         commit_halo(0);
         __syncthreads();
-        const int toff0 = 2 * (dy0 * HW_ + dx0), odd0 = dy0 & 1;
+        const int HWL = quad ? XQROW : XROW;                  // LDS row pitch in pixels
+        const int toff0 = 2 * (dy0 * HWL + dx0), odd0 = dy0 & 1;
         read_a(0, toff0, odd0, A0);
 
         // One K step = one tap of one 16-channel chunk = one 16-k MFMA step on this step's filter slice b_cur.
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
             const int buf = cc & 1;
             const int rbuf = last_tap ? buf ^ 1 : buf;
             const int dyn = dy0 + tin * ystep;
-            const int toffn = 2 * (dyn * HW_ + dx0 + tjn * xstep), oddn = dyn & 1;
+            const int toffn = 2 * (dyn * HWL + dx0 + tjn * xstep), oddn = dyn & 1;
             if (ti == 0 && tj == 0 && more_chunks) fetch_halo(cc + 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {

@@ -342,7 +342,10 @@ __global__ void repack_filters_kernel(const float* __restrict__ w, float* __rest
             for (int kw = a.kw_lo[cls][t]; kw < a.kw_hi[cls][t]; ++kw)
                 sum += w[(((long long)k * a.R + kh) * a.S + kw) * a.C + c];
         wt[a.cls_off[cls] + i] = sum;
-        if (a.pieces) {
+        if (a.pieces == 4) {        // exact fp32 on the LDS-halo kernel (igemm_x3h<., 0, .>): the class matrix again, step-major, fp32
+            const int rows = a.transposed ? a.C : a.K, row = a.transposed ? c : k, red = a.transposed ? k : c;
+            reinterpret_cast<float*>(a.w3)[(long long)a.cls_off[cls] + ((((long long)(red >> 4) * Tc + t) * rows + row) << 4) + (red & 15)] = sum;
+        } else if (a.pieces) {
             const int rows = a.transposed ? a.C : a.K, row = a.transposed ? c : k, red = a.transposed ? k : c;
             unsigned short* dst = a.w3 + (long long)a.pieces * a.cls_off[cls] + ((((long long)(red >> 4) * Tc + t) * rows + row) << 4) + (red & 15);
             const unsigned short hi = f32_to_bf16_rne(sum);
@@ -404,6 +407,7 @@ static long long tiles_for(const KcParams& p, int BM, int BN) {
 int launch_kc_bf16(KcParams& p, hipStream_t st, long long out_elems);     // igemm_bf16.hip
 int split_filter_x3(const float* w, int Nn, int T, int C, void* w3, hipStream_t st, int pieces);      // igemm_x3.hip
 bool x3h_eligible(const KcParams& p);
+int launch_x3h(KcParams& p, hipStream_t st);
 bool halo_eligible(const KcParams& p);          // igemm_halo.hip
 int launch_halo(KcParams& p, hipStream_t st);
 bool skinny_eligible(const KcParams& p);        // igemm_skinny.hip
@@ -445,6 +449,7 @@ int launch_kc(KcParams& p, hipStream_t st, long long out_elems) {
     if (p.bf16) {
         return launch_kc_bf16(p, st, out_elems);
     }
+    if (p.w3 && x3h_eligible(p)) return launch_x3h(p, st);          // exact fp32 on the round-4 halo kernel (step-major fp32 filter copy in p.w3)
     static const int halo_env = [] { const char* e = getenv("CSLGAN_KC_HALO"); return e ? atoi(e) : 1; }();
     if (halo_env && halo_eligible(p)) return launch_halo(p, st);
     static const int patch_env = [] { const char* e = getenv("CSLGAN_KC_PATCH"); return e ? atoi(e) : 1; }();
@@ -509,7 +514,7 @@ int cslgan_conv2d_fwd_f32(const cslgan_conv_t* c, const float* x, const float* w
 }
 
 int cslgan_split_filter_x3_f32(const float* w, int rows, int taps, int red, void* w3_ws, int pieces, void* stream) {
-    CSLGAN_REQUIRE(w && w3_ws && rows > 0 && taps > 0 && red > 0 && (pieces == 1 || pieces == 3), "split_filter_x3: bad argument");
+    CSLGAN_REQUIRE(w && w3_ws && rows > 0 && taps > 0 && red > 0 && (pieces == 0 || pieces == 1 || pieces == 3), "split_filter_x3: bad argument");
     CSLGAN_REQUIRE(aligned16(w) && aligned16(w3_ws) && ((long long)rows * taps * red) % 4 == 0, "split_filter_x3: filter must be 16-byte aligned with a multiple of 4 elements");
     return split_filter_x3(w, rows, taps, red, w3_ws, (hipStream_t)stream, pieces);
 }
@@ -517,11 +522,10 @@ int cslgan_split_filter_x3_f32(const float* w, int rows, int taps, int red, void
 int cslgan_conv2d_fwd_x3_f32(const cslgan_conv_t* c, const float* x, const float* w, void* w3_ws, int repack, const float* bias,
                              const float* residual, int act, float* y, void* stream) {
     CSLGAN_REQUIRE(c && w && w3_ws, "conv2d_fwd_x3: null argument");
-    CSLGAN_REQUIRE(c->compute == CSLGAN_COMPUTE_BF16X3 || c->compute == CSLGAN_COMPUTE_BF16,
-                   "conv2d_fwd_x3: cslgan_conv_t.compute must be CSLGAN_COMPUTE_BF16X3 or CSLGAN_COMPUTE_BF16");
     CSLGAN_REQUIRE(aligned16(w) && aligned16(w3_ws) && ((long long)c->K * c->R * c->S * c->C) % 4 == 0, "conv2d_fwd_x3: filter must be 16-byte aligned with a multiple of 4 elements");
-    if (repack) {
-        int rc = split_filter_x3(w, c->K, c->R * c->S, c->C, w3_ws, (hipStream_t)stream, c->compute == CSLGAN_COMPUTE_BF16X3 ? 3 : 1);
+    if (repack) {       // CSLGAN_COMPUTE_F32: a step-major fp32 copy (the exact-fp32 form of the LDS-halo kernel, K*R*S*C floats)
+        int rc = split_filter_x3(w, c->K, c->R * c->S, c->C, w3_ws, (hipStream_t)stream,
+                                 c->compute == CSLGAN_COMPUTE_BF16X3 ? 3 : (c->compute == CSLGAN_COMPUTE_BF16 ? 1 : 0));
         if (rc) return rc;
     }
     return conv2d_fwd_impl(c, x, w, w3_ws, bias, residual, act, y, stream);
@@ -578,8 +582,6 @@ int cslgan_conv2d_s2_fwd_f32(const cslgan_conv_t* c, const float* x, const float
 int cslgan_conv2d_s2_fwd_x3_f32(const cslgan_conv_t* c, const float* x, const float* w, float* wcls_ws, void* w3_ws, int repack,
                                 const float* bias, int act, float* y, void* stream) {
     CSLGAN_REQUIRE(c && w3_ws, "conv2d_s2_fwd_x3: null argument");
-    CSLGAN_REQUIRE(c->compute == CSLGAN_COMPUTE_BF16X3 || c->compute == CSLGAN_COMPUTE_BF16,
-                   "conv2d_s2_fwd_x3: cslgan_conv_t.compute must be CSLGAN_COMPUTE_BF16X3 or CSLGAN_COMPUTE_BF16");
     return conv2d_s2_fwd_impl(c, x, w, wcls_ws, w3_ws, repack, bias, act, y, stream);
 }
 
@@ -628,8 +630,8 @@ static int conv2d_s2_fwd_impl(const cslgan_conv_t* c, const float* x, const floa
     // launch, no gain or a loss below ~500 tiles (four halo stagings per chunk for 2-9 taps each) -> igemm_kc keeps those.
     static const int s2_min_tiles = [] { const char* e = getenv("CSLGAN_S2_MIN_TILES"); return e ? atoi(e) : 512; }();
     const long long wide_tiles = ((long long)c->N * c->P * c->Q + 127) / 128 * ((c->K + 127) / 128);
-    if (w3_ws) {        // bf16 matrix cores: three-piece (or plain bf16) operands on the LDS-halo kernel, any tile count
-        p.bf16 = c->compute == CSLGAN_COMPUTE_BF16X3 ? 3 : 1;
+    if (w3_ws) {        // the round-4 LDS-halo kernel: three-piece, plain bf16 or exact fp32 operands, any tile count
+        p.bf16 = c->compute == CSLGAN_COMPUTE_BF16X3 ? 3 : (c->compute == CSLGAN_COMPUTE_BF16 ? 1 : 0);
         p.w3 = w3_ws;
         {       // operand sizes for the eligibility test (launch_kc sets them again)
             p.a_bytes = 0; p.w_bytes = 0;
@@ -642,7 +644,7 @@ static int conv2d_s2_fwd_impl(const cslgan_conv_t* c, const float* x, const floa
         const long long per = (long long)c->C * 9 * c->K;
         unsigned gxn = (unsigned)((per + 255) / 256);
         gxn = gxn > 1024 ? 1024 : (gxn < 1 ? 1 : gxn);
-        if (w3_ws) { ra.pieces = p.bf16 == 3 ? 3 : 1; ra.w3 = reinterpret_cast<unsigned short*>(w3_ws); }
+        if (w3_ws) { ra.pieces = p.bf16 == 3 ? 3 : (p.bf16 ? 1 : 4); ra.w3 = reinterpret_cast<unsigned short*>(w3_ws); }
         hipLaunchKernelGGL(repack_filters_kernel, dim3(gxn, (unsigned)n), dim3(256), 0, st, w, wcls_ws, ra);
         rc = check_launch("repack_filters_kernel");
         if (rc) return rc;
@@ -665,8 +667,6 @@ int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* c, const float* gy, const float
 int cslgan_conv2d_dgrad_x3_f32(const cslgan_conv_t* c, const float* gy, const float* w, float* wt_ws, void* w3_ws, int repack,
                                const float* mask, float* gx, void* stream) {
     CSLGAN_REQUIRE(c && w3_ws, "conv2d_dgrad_x3: null argument");
-    CSLGAN_REQUIRE(c->compute == CSLGAN_COMPUTE_BF16X3 || c->compute == CSLGAN_COMPUTE_BF16,
-                   "conv2d_dgrad_x3: cslgan_conv_t.compute must be CSLGAN_COMPUTE_BF16X3 or CSLGAN_COMPUTE_BF16");
     return conv2d_dgrad_impl(c, gy, w, wt_ws, repack, mask, gx, stream, 0, w3_ws);
 }
 
@@ -724,7 +724,7 @@ static int conv2d_dgrad_impl(const cslgan_conv_t* c, const float* gy, const floa
     if (repack) {
         unsigned gxn = (unsigned)(((long long)c->K * c->C * c->R * c->S / (s * s) + 255) / 256);
         gxn = gxn > 1024 ? 1024 : (gxn < 1 ? 1 : gxn);
-        if (p.w3) { ra.pieces = p.bf16 == 3 ? 3 : 1; ra.w3 = reinterpret_cast<unsigned short*>(const_cast<void*>(p.w3)); }
+        if (p.w3) { ra.pieces = p.bf16 == 3 ? 3 : (p.bf16 ? 1 : 4); ra.w3 = reinterpret_cast<unsigned short*>(const_cast<void*>(p.w3)); }
         hipLaunchKernelGGL(repack_filters_kernel, dim3(gxn, (unsigned)ncls), dim3(256), 0, st, w, wt_ws, ra);
         rc = check_launch("repack_filters_kernel");
         if (rc) return rc;

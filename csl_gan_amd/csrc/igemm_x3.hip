@@ -83,8 +83,14 @@ __device__ __forceinline__ float4 xload4(__amdgpu_buffer_rsrc_t r, unsigned byte
 template <int BN, int NP, bool GEN>
 __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
     constexpr int BM = 128, TM = 2, TN = BN / 64;
-    constexpr int IMG = 2 * XH_MAX * 2;                        // uint4 units per piece image (2 patches x 144 pixels x 2 halves)
-    __shared__ __attribute__((aligned(16))) uint4 Hs[2][NP][IMG];
+    // NP = 0: EXACT fp32 (round 4, second half): the same loop on v_mfma_f32_32x32x2_f32 — fp32 halo pixels (16 channels = 64 B) in ONE
+    // image per buffer, the filter in step-major fp32 order [step][n][16], eight fp32 MFMAs per tile and 16-channel step.
+    constexpr bool F32 = NP == 0;
+    constexpr int NI = F32 ? 1 : NP;                           // LDS images per buffer
+    constexpr int NO = F32 ? 2 : NP;                           // 16-byte operand registers per tile and step (fp32: the two 8-channel halves)
+    constexpr int PXU = F32 ? 4 : 2;                           // uint4 units per halo pixel
+    constexpr int IMG = 2 * XH_MAX * PXU;                      // uint4 units per image (2 patches)
+    __shared__ __attribute__((aligned(16))) uint4 Hs[2][NI][IMG];
     __shared__ int s_off[BM];
     __shared__ int s_roff[BM];
 
@@ -167,7 +173,10 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
                 // the two 16-byte halves of a pixel are swapped on odd halo rows: the patch rows a 16-lane ds_read_b128 group covers then
                 // hit disjoint banks (the plain 32-byte pixel stride is 2-way conflicted)
                 const int lpx = quad ? si * XQIMG + hy * XQROW + hx : hy * XROW + hx;
-                h_lds[j] = idx < h_total ? (pp * XH_MAX + lpx) * 4 + (ch ^ ((hy & 1) << 1)) : -1;
+                // bf16 pieces: uint2 slot, the two 16-byte halves of a pixel swapped on odd halo rows; fp32: uint4 slot, the four 16-byte
+                // chunks of a pixel rotated by (hx + hy) & 3 — both keep the 16-lane groups of ds_read_b128 on distinct banks (bank model in
+                // the file header / DESIGN §4.14)
+                h_lds[j] = idx >= h_total ? -1 : (F32 ? (pp * XH_MAX + lpx) * 4 + (ch ^ ((hx + hy) & 3)) : (pp * XH_MAX + lpx) * 4 + (ch ^ ((hy & 1) << 1)));
             }
         }
         float4 rh[HREG];
@@ -181,13 +190,15 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
             for (int j = 0; j < HREG; ++j) {
                 if (h_lds[j] >= 0) {
                     uint2* img0 = reinterpret_cast<uint2*>(&Hs[buf][0][0]);
-                    if (NP == 1) {
+                    if (F32) {
+                        Hs[buf][0][h_lds[j]] = make_uint4(__float_as_uint(rh[j].x), __float_as_uint(rh[j].y), __float_as_uint(rh[j].z), __float_as_uint(rh[j].w));
+                    } else if (NP == 1) {
                         img0[h_lds[j]] = make_uint2(xpack(rh[j].x, rh[j].y), xpack(rh[j].z, rh[j].w));
                     } else {
                         const x3_t t3 = xsplit4(rh[j]);
                         img0[h_lds[j]] = t3.hi;
-                        reinterpret_cast<uint2*>(&Hs[buf][NP > 1 ? 1 : 0][0])[h_lds[j]] = t3.mid;
-                        reinterpret_cast<uint2*>(&Hs[buf][NP > 2 ? 2 : 0][0])[h_lds[j]] = t3.lo;
+                        reinterpret_cast<uint2*>(&Hs[buf][NI > 1 ? 1 : 0][0])[h_lds[j]] = t3.mid;
+                        reinterpret_cast<uint2*>(&Hs[buf][NI > 2 ? 2 : 0][0])[h_lds[j]] = t3.lo;
                     }
                 }
             }
@@ -197,47 +208,67 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
         // [piece][step = chunk*T + tap][n][16 k] (split_filter_x3, cached per weight version by the caller): lane (r, h), tile j,
         // piece c reads 8 consecutive k of filter row n0 + wn*TN*32 + j*32 + r = one 16-byte load; the 32 rows x 32 B a
         // wave-load touches are 1 KB contiguous.
-        const unsigned piece_bytes = 2u * (unsigned)p.Nn * (unsigned)kc.Kdim;
+        // fp32 (NP = 0): ONE step-major fp32 copy [step][n][16 floats]; operand e of lane (r, h) = channels 8e + 4h .. + 3 of filter row n.
+        const unsigned piece_bytes = F32 ? 32u : 2u * (unsigned)p.Nn * (unsigned)kc.Kdim;     // distance between a tile's operand registers
         const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(reinterpret_cast<const char*>(p.w3) + 2ll * NP * kc.w_off), 0, NP * piece_bytes, 0x00020000);
-        const unsigned step_bytes = 32u * (unsigned)p.Nn;
+            const_cast<char*>(reinterpret_cast<const char*>(p.w3) + (F32 ? 4ll : 2ll * NP) * kc.w_off), 0,
+            F32 ? 4u * (unsigned)p.Nn * (unsigned)kc.Kdim : NP * piece_bytes, 0x00020000);
+        const unsigned n_bytes = F32 ? 64u : 32u;                 // bytes of one filter row in a step's slice
+        const unsigned step_bytes = n_bytes * (unsigned)p.Nn;
         unsigned b_off[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * TN * 32 + j * 32 + r;
-            b_off[j] = n < p.Nn ? 32u * (unsigned)n + 16u * (unsigned)h : XOOB;       // tested again in load_b
+            b_off[j] = n < p.Nn ? n_bytes * (unsigned)n + 16u * (unsigned)h : XOOB;       // tested again in load_b
         }
         const int n_cc = p.AC >> 4;
         const int n_steps = n_cc * T;
-        u32x4 B0[NP][TN], B1[NP][TN];                          // two-slot ring of filter slices: slot s % 2 is refilled with step s + 2
-        auto load_b = [&](int step, u32x4 (&dst)[NP][TN]) {    // right after the MFMAs of step s have read it (no third slot, no copies)
+        u32x4 B0[NO][TN], B1[NO][TN];                          // two-slot ring of filter slices: slot s % 2 is refilled with step s + 2
+        auto load_b = [&](int step, u32x4 (&dst)[NO][TN]) {    // right after the MFMAs of step s have read it (no third slot, no copies)
             const unsigned kb = (unsigned)step * step_bytes;
             const unsigned past = step >= n_steps ? XOOB : 0u;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const unsigned bad = past | (b_off[j] == XOOB ? XOOB : 0u);
 #pragma unroll
-                for (int c = 0; c < NP; ++c)
+                for (int c = 0; c < NO; ++c)
                     dst[c][j] = __builtin_amdgcn_raw_buffer_load_b128(w3_rsrc, (int)((b_off[j] + kb + c * piece_bytes) | bad), 0, 0);
             }
         };
 
         // ---- A fragments: lane (r, h) of tile i holds channels 8h..8h+7 of halo pixel (own pixel + tap) = one ds_read_b128 per piece.
-        int a_idx[TM];                                         // uint4 index of the lane's pixel at tap offset (0,0), swizzle bit included
+        int a_idx[TM];                                         // uint4 index of the lane's pixel at tap offset (0,0) (bf16: swizzle bit included)
+        int a_rot[TM];                                         // fp32: (lx + ly) & 3 of the lane's pixel
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int qq = i * 32 + r;                         // row within the patch
             const int ly = quad ? (qq >> 2) & 3 : qq >> 3;
-            const int lpix = quad ? (qq >> 4) * XQIMG + ly * XQROW + (qq & 3) : ly * XROW + (qq & 7);
-            a_idx[i] = (wm * XH_MAX + lpix) * 2 + (h ^ (ly & 1));
+            const int lx = quad ? qq & 3 : qq & 7;
+            const int lpix = quad ? (qq >> 4) * XQIMG + ly * XQROW + lx : ly * XROW + lx;
+            a_idx[i] = F32 ? (wm * XH_MAX + lpix) * 4 : (wm * XH_MAX + lpix) * 2 + (h ^ (ly & 1));
+            a_rot[i] = (lx + ly) & 3;
         }
-        bf16x8 A0[NP][TM], A1[NP][TM];                         // two sets: the next tap's fragments are read BEFORE this tap's MFMAs are issued
-        auto read_a = [&](int buf, int toff, int odd, bf16x8 (&dst)[NP][TM]) {      // toff = 2 * (dy * halo_w + dx), odd = dy & 1: scalar
+        const int HWL = quad ? XQROW : XROW;                  // LDS row pitch in pixels
+        u32x4 A0[NO][TM], A1[NO][TM];                          // two sets: the next tap's fragments are read while this tap's MFMAs run
+        auto read_a = [&](int buf, int dy, int dx, u32x4 (&dst)[NO][TM]) {      // halo offset of the tap: scalar
+            const int poff = dy * HWL + dx;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int at = (a_idx[i] + toff) ^ odd;
+                if (F32) {
+                    const int rot = (a_rot[i] + dy + dx) & 3, base = a_idx[i] + 4 * poff;
 #pragma unroll
-                for (int c = 0; c < NP; ++c) dst[c][i] = __builtin_bit_cast(bf16x8, Hs[buf][c][at]);
+                    for (int c = 0; c < NO; ++c) {
+                        const uint4 v = Hs[buf][0][base + ((2 * c + h) ^ rot)];
+                        dst[c][i] = u32x4{v.x, v.y, v.z, v.w};
+                    }
+                } else {
+                    const int at = (a_idx[i] + 2 * poff) ^ (dy & 1);
+#pragma unroll
+                    for (int c = 0; c < NO; ++c) {
+                        const uint4 v = Hs[buf][c < NI ? c : 0][at];
+                        dst[c][i] = u32x4{v.x, v.y, v.z, v.w};
+                    }
+                }
             }
         };
 
@@ -256,9 +287,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
         load_b(1, B1);
         commit_halo(0);
         __syncthreads();
-        const int HWL = quad ? XQROW : XROW;                  // LDS row pitch in pixels
-        const int toff0 = 2 * (dy0 * HWL + dx0), odd0 = dy0 & 1;
-        read_a(0, toff0, odd0, A0);
+        read_a(0, dy0, dx0, A0);
 
         // One K step = one tap of one 16-channel chunk = one 16-k MFMA step on this step's filter slice b_cur.
         // Control flow is kept to what SIInsertWaitcnts can see through: it merges pending memory operations conservatively at every
@@ -269,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
         // chunk ends (after the MFMAs of tap T-2, followed by the chunk's one barrier), so the last tap's step reads tap 0 of the
         // NEW image like any other step reads its next tap.  The only branches are the two per-chunk events (fetch, commit + barrier).
         int ti = 0, tj = 0, cc = 0;                            // current tap (row, column of the tap grid) and chunk: scalar
-        auto k_step = [&](int s, u32x4 (&b_cur)[NP][TN], bf16x8 (&A)[NP][TM], bf16x8 (&An)[NP][TM]) {
+        auto k_step = [&](int s, u32x4 (&b_cur)[NO][TN], u32x4 (&A)[NO][TM], u32x4 (&An)[NO][TM]) {
             int tjn = tj + 1, tin = ti;
             if (tjn == nkw) { tjn = 0; tin = ti + 1; }
             const int tn = tin * nkw + tjn;                    // index of the next tap
@@ -279,8 +308,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
             const bool more_chunks = cc + 1 < n_cc;
             const int buf = cc & 1;
             const int rbuf = last_tap ? buf ^ 1 : buf;
-            const int dyn = dy0 + tin * ystep;
-            const int toffn = 2 * (dyn * HWL + dx0 + tjn * xstep), oddn = dyn & 1;
+            const int dyn = dy0 + tin * ystep, dxn = dx0 + tjn * xstep;
             if (ti == 0 && tj == 0 && more_chunks) fetch_halo(cc + 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -289,21 +317,32 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
                     f32x16 a = acc[i][j];
                     // the FILTER fragment is the first operand: a lane's 16 results are then 4 x 4 consecutive channels of ITS pixel
                     // (row index of D = filter (v & 3) + 8 (v >> 2) + 4 h, column = pixel lane & 31) and leave as 16-byte stores
-                    if (NP == 3) {
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b_cur[NP - 1][j]), A[0][i], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b_cur[0][j]), A[NP - 1][i], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b_cur[NP > 1 ? 1 : 0][j]), A[NP > 1 ? 1 : 0][i], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b_cur[NP > 1 ? 1 : 0][j]), A[0][i], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b_cur[0][j]), A[NP > 1 ? 1 : 0][i], a, 0, 0, 0);
+                    if constexpr (F32) {
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {          // k = 8c + 4h + e at MFMA e: the same permutation of k for both operands
+                            a = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(b_cur[c][j].x), __uint_as_float(A[c][i].x), a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(b_cur[c][j].y), __uint_as_float(A[c][i].y), a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(b_cur[c][j].z), __uint_as_float(A[c][i].z), a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(b_cur[c][j].w), __uint_as_float(A[c][i].w), a, 0, 0, 0);
+                        }
+                    } else {
+                        auto bf = [](const u32x4& v) { return __builtin_bit_cast(bf16x8, v); };
+                        if (NP == 3) {
+                            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(b_cur[NO - 1][j]), bf(A[0][i]), a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(b_cur[0][j]), bf(A[NO - 1][i]), a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(b_cur[NO > 1 ? 1 : 0][j]), bf(A[NO > 1 ? 1 : 0][i]), a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(b_cur[NO > 1 ? 1 : 0][j]), bf(A[0][i]), a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(b_cur[0][j]), bf(A[NO > 1 ? 1 : 0][i]), a, 0, 0, 0);
+                        }
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(b_cur[0][j]), bf(A[0][i]), a, 0, 0, 0);
                     }
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b_cur[0][j]), A[0][i], a, 0, 0, 0);
                     acc[i][j] = a;
                     if (i == 0 && j == 0) {
                         // The next tap's fragments are read AFTER the first tile's MFMAs are issued and pinned there: at the loop header
                         // SIInsertWaitcnts waits for every outstanding LDS read (lgkmcnt(0)) in front of the first MFMA — with the reads
                         // in front of it that wait exposed their latency every other step; here it only covers reads a step old.
                         __builtin_amdgcn_sched_barrier(0);
-                        read_a(rbuf, toffn, oddn, An);
+                        read_a(rbuf, dyn, dxn, An);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -397,6 +436,10 @@ __global__ void split_filter_x3_kernel(const float* __restrict__ w, int Nn, int 
         const long long nt = e / C;
         const int t = (int)(nt % T), n = (int)(nt / T);
         const long long dst = ((((long long)(c >> 4) * T + t) * Nn + n) << 4) + (c & 15);
+        if (NP == 0) {          // exact fp32: the same step-major order, fp32 elements
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(w3) + dst) = reinterpret_cast<const float4*>(w)[i];
+            continue;
+        }
         const x3_t s3 = xsplit4(reinterpret_cast<const float4*>(w)[i]);
         *reinterpret_cast<uint2*>(w3 + dst) = s3.hi;           // = the round-to-nearest-even bfloat16 of w: all the NP = 1 form needs
         if (NP == 3) {
@@ -412,7 +455,8 @@ int split_filter_x3(const float* w, int Nn, int T, int C, void* w3, hipStream_t 
     if (C % 16) return CSLGAN_OK;
     long long nb = ((long long)Nn * T * C / 4 + 255) / 256;
     nb = nb > 2048 ? 2048 : (nb < 1 ? 1 : nb);
-    if (pieces == 1) hipLaunchKernelGGL(split_filter_x3_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, w, Nn, T, C, reinterpret_cast<unsigned short*>(w3));
+    if (pieces == 0) hipLaunchKernelGGL(split_filter_x3_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, w, Nn, T, C, reinterpret_cast<unsigned short*>(w3));
+    else if (pieces == 1) hipLaunchKernelGGL(split_filter_x3_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, w, Nn, T, C, reinterpret_cast<unsigned short*>(w3));
     else hipLaunchKernelGGL(split_filter_x3_kernel<3>, dim3((unsigned)nb), dim3(256), 0, st, w, Nn, T, C, reinterpret_cast<unsigned short*>(w3));
     return check_launch("split_filter_x3_kernel");
 }
@@ -442,7 +486,9 @@ static int affine_taps(const KcClass& k) {
 // within a 12x12 (6x6) halo, >= 64 output channels, and the pre-split filter (p.w3).
 bool x3h_eligible(const KcParams& p) {
     static const int env = [] { const char* e = getenv("CSLGAN_X3_HALO"); return e ? atoi(e) : 1; }();
-    if (!env || !p.w3 || !p.bf16 || p.sy != 1 || p.sx != 1 || (p.AC & 15) || p.Nn < 64 || p.ksplit > 1 || !aligned16(p.a) || !aligned16(p.w3)) return false;
+    static const int env32 = [] { const char* e = getenv("CSLGAN_F32_HALO"); return e ? atoi(e) : 1; }();
+    if (!p.bf16 && !env32) return false;          // exact fp32 on this kernel (NP = 0) is an A/B switch of its own
+    if (!env || !p.w3 || p.sy != 1 || p.sx != 1 || (p.AC & 15) || p.Nn < 64 || p.ksplit > 1 || !aligned16(p.a) || !aligned16(p.w3)) return false;
     // 4-element epilogue vectors: channel counts and the output row pitch multiples of 4, every epilogue operand 16-byte aligned
     if ((p.Nn & 3) || (p.ldo & 3) || !aligned16(p.out) || (p.bias && !aligned16(p.bias)) || (p.res && !aligned16(p.res)) || (p.mask && !aligned16(p.mask))) return false;
     static const int quad_min = [] { const char* e = getenv("CSLGAN_X3_QUAD_MIN"); return e ? atoi(e) : 2048; }();
@@ -450,7 +496,7 @@ bool x3h_eligible(const KcParams& p) {
         const KcClass& k = p.cls[c];
         const bool quad = k.OHc == 4 && k.OWc == 4;
         if (k.T < 2 || (k.M & 63) || (k.Kdim & 3) || (k.w_off & 7)) return false;
-        if (quad && k.M < quad_min) return false;
+        if (quad && (k.M < quad_min || !p.bf16)) return false;   // exact fp32 keeps its round-3 kernels on 4x4 grids (measured: 52-73 vs 74-84 TF)
         if (!quad && ((k.OHc & 7) || (k.OWc & 7))) return false;
         if (!affine_taps(k)) return false;
         int ymin, ymax, xmin, xmax;
@@ -509,8 +555,13 @@ int launch_x3h(KcParams& p, hipStream_t st) {
     p.tiles_n = wide ? (p.Nn + 127) / 128 : (p.Nn + 63) / 64;
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);
     const bool x3 = p.bf16 == 3;
-    note_kernel(x3 ? "igemm_x3h_kernel<%d,3,%s>" : "igemm_x3h_kernel<%d,1,%s>", wide ? 128 : 64, gen ? "true" : "false");
-    if (x3) {
+    note_kernel(x3 ? "igemm_x3h_kernel<%d,3,%s>" : (p.bf16 ? "igemm_x3h_kernel<%d,1,%s>" : "igemm_x3h_kernel<%d,0,%s>"), wide ? 128 : 64, gen ? "true" : "false");
+    if (!p.bf16) {
+        if (wide && gen) hipLaunchKernelGGL((igemm_x3h_kernel<128, 0, true>), grid, block, 0, st, p);
+        else if (wide) hipLaunchKernelGGL((igemm_x3h_kernel<128, 0, false>), grid, block, 0, st, p);
+        else if (gen) hipLaunchKernelGGL((igemm_x3h_kernel<64, 0, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((igemm_x3h_kernel<64, 0, false>), grid, block, 0, st, p);
+    } else if (x3) {
         if (wide && gen) hipLaunchKernelGGL((igemm_x3h_kernel<128, 3, true>), grid, block, 0, st, p);
         else if (wide) hipLaunchKernelGGL((igemm_x3h_kernel<128, 3, false>), grid, block, 0, st, p);
         else if (gen) hipLaunchKernelGGL((igemm_x3h_kernel<64, 3, true>), grid, block, 0, st, p);

@@ -53,6 +53,17 @@ def _kc_compute(rows, n_out, kdim):
     return _compute
 
 
+_F32_HALO = os.environ.get("CSLGAN_F32_HALO", "1") == "1"        # A/B: exact-fp32 launches the round-4 LDS-halo kernel takes run on it (igemm_x3h<., 0, .>)
+
+
+def set_f32_halo(on):
+    """Switch the exact-fp32 form of the round-4 halo kernel on or off at run time (returns the previous setting): the same products
+    summed in a different order, so the golden tests use it to prove which activation units sit within rounding of zero."""
+    global _F32_HALO
+    prev, _F32_HALO = _F32_HALO, bool(on)
+    return prev
+
+
 _X3_WGRAD = os.environ.get("CSLGAN_X3_WGRAD", "1") == "1"      # A/B: fp32_auto sends eligible weight gradients to the three-piece kernel
 _AUTO_WG_MIN_FLOP = float(os.environ.get("CSLGAN_AUTO_WG_MIN_GFLOP", "0.5")) * 1e9
 _X3_S2 = os.environ.get("CSLGAN_X3_S2", "1") == "1"            # A/B: the LDS-halo form of the bf16 paths for stride-2 forward convs
@@ -467,16 +478,18 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, ou
     flop = 2.0 * N * P * Q * K * R * S * c_alg * alg_scale    # the dense conv the reference executes
     nbytes = 4.0 * (N * H * W * c_alg + K * R * S * c_alg + N * P * Q * K)
     xflop = 2.0 * N * P * Q * K * R * S * Cc
-    if (d.compute in (COMPUTE_BF16X3, COMPUTE_BF16) and stride == 2 and R == S and R % 2 == 1 and R > 1 and Cc % 16 == 0 and K >= 64
+    halo_arith = d.compute in (COMPUTE_BF16X3, COMPUTE_BF16) or (d.compute == COMPUTE_F32 and _F32_HALO)
+    kind_sfx = {COMPUTE_BF16X3: "x3", COMPUTE_BF16: "b16", COMPUTE_F32: "f32h"}[d.compute]
+    if (halo_arith and stride == 2 and R == S and R % 2 == 1 and R > 1 and Cc % 16 == 0 and K >= 64
             and residual is None and w.numel() % 8 == 0 and _X3_S2):
         # parity sub-images through the LDS-halo kernel of the bf16 matrix cores (csrc/igemm_x3.hip): one workspace holds the fp32
         # class matrices and, behind them, their bfloat16 pieces in step-major order
         nw = w.numel()
-        ws, repack = repack_cache.get("s2_fwd_x3" if d.compute == COMPUTE_BF16X3 else "s2_fwd_b16", w, nw + (3 * nw + 1) // 2, wkey)
+        ws, repack = repack_cache.get("s2_fwd_" + kind_sfx, w, nw + (3 * nw + 1) // 2, wkey)
         _timed("conv2d_fwd", flop, nbytes, lambda: check(
             _lib.lib().cslgan_conv2d_s2_fwd_x3_f32(C.byref(d), _p(x), _p(w), _p(ws), C.c_void_p(ws.data_ptr() + 4 * nw), repack, _p(bias), act,
                                                    _p(y), _stream()),
-            "conv2d_s2_fwd_x3"), exec_flop=xflop, tag=lambda: "N%d %dx%d C%d K%d R%d s2 x3" % (N, H, W, Cc, K, R))
+            "conv2d_s2_fwd_x3"), exec_flop=xflop, tag=lambda: "N%d %dx%d C%d K%d R%d s2 %s" % (N, H, W, Cc, K, R, kind_sfx))
         repack_cache.packed()
         return y
     if stride == 2 and R == S and R % 2 == 1 and R > 1 and Cc % 32 == 0 and K >= 64 and residual is None:
@@ -487,14 +500,15 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, ou
             "conv2d_s2_fwd"), exec_flop=xflop, tag=lambda: "N%d %dx%d C%d K%d R%d s2 halo" % (N, H, W, Cc, K, R))
         repack_cache.packed()
         return y
-    if d.compute in (COMPUTE_BF16X3, COMPUTE_BF16) and stride == 1 and R * S > 1 and Cc % 16 == 0 and K >= 64 and P % 8 == 0 and Q % 8 == 0:
-        # the LDS-halo form of the bf16 paths reads the filter pre-split into bfloat16 pieces / pre-rounded (cached per parameter version)
-        ws, repack = repack_cache.get("x3w" if d.compute == COMPUTE_BF16X3 else "bf16w", w, (3 * w.numel() + 1) // 2, wkey, version=wversion)
+    if halo_arith and stride == 1 and R * S > 1 and Cc % 16 == 0 and K >= 64 and P % 8 == 0 and Q % 8 == 0 and K % 4 == 0:
+        # the round-4 LDS-halo kernel reads the filter in step-major order: pre-split into bfloat16 pieces / pre-rounded / as an fp32 copy
+        # (cached per parameter version)
+        ws, repack = repack_cache.get({COMPUTE_BF16X3: "x3w", COMPUTE_BF16: "bf16w", COMPUTE_F32: "f32w"}[d.compute], w, (3 * w.numel() + 1) // 2, wkey, version=wversion)
         _timed("conv2d_fwd", flop, nbytes, lambda: check(
             _lib.lib().cslgan_conv2d_fwd_x3_f32(C.byref(d), _p(x), _p(w), _p(ws), repack, _p(bias), _p(residual), act, _p(y), _stream()),
             "conv2d_fwd_x3"), exec_flop=xflop, tag=lambda: "N%d %dx%d C%d K%d R%d s%d" % (N, H, W, Cc, K, R, stride))
         if repack:
-            pieces = 3 if d.compute == COMPUTE_BF16X3 else 1
+            pieces = {COMPUTE_BF16X3: 3, COMPUTE_BF16: 1, COMPUTE_F32: 0}[d.compute]
             repack_cache.set_rebuild(lambda: check(_lib.lib().cslgan_split_filter_x3_f32(_p(w), K, R * S, Cc, _p(ws), pieces, _stream()), "split_filter_x3"))
         repack_cache.packed()
         return y
@@ -635,16 +649,18 @@ def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None, wkey=None, out_dtype=
             raise RuntimeError("conv2d_dgrad: mask shape mismatch")
     flop = 2.0 * N * P * Q * K * R * S * Cc
     nbytes = 4.0 * (N * H * W * Cc + K * R * S * Cc + N * P * Q * K)
-    if (d.compute in (COMPUTE_BF16X3, COMPUTE_BF16) and K % 16 == 0 and Cc >= 64 and R * S > 1 and w.numel() % 8 == 0
+    if ((d.compute in (COMPUTE_BF16X3, COMPUTE_BF16) or (d.compute == COMPUTE_F32 and _F32_HALO)) and K % 16 == 0 and Cc >= 64 and Cc % 4 == 0
+            and R * S > 1 and w.numel() % 8 == 0
             and (H // stride) % 4 == 0 and (W // stride) % 4 == 0 and H % stride == 0 and W % stride == 0 and _X3_DGRAD):
         # LDS-halo kernel of the bf16 matrix cores (csrc/igemm_x3.hip): the repacked class matrices and, behind them, their bfloat16
         # pieces in step-major order share one cached workspace
         nw = w.numel()
-        ws, repack = repack_cache.get(("dgrad%d_x3" if d.compute == COMPUTE_BF16X3 else "dgrad%d_b16") % stride, w, nw + (3 * nw + 1) // 2, wkey)
+        sfx = {COMPUTE_BF16X3: "x3", COMPUTE_BF16: "b16", COMPUTE_F32: "f32h"}[d.compute]
+        ws, repack = repack_cache.get("dgrad%d_%s" % (stride, sfx), w, nw + (3 * nw + 1) // 2, wkey)
         _timed("conv2d_dgrad", flop, nbytes, lambda: check(
             _lib.lib().cslgan_conv2d_dgrad_x3_f32(C.byref(d), _p(gy), _p(w), _p(ws), C.c_void_p(ws.data_ptr() + 4 * nw), repack, _p(mask), _p(gx),
                                                   _stream()), "conv2d_dgrad_x3"),
-            tag=lambda: "N%d %dx%d C%d K%d R%d s%d x3" % (N, H, W, Cc, K, R, stride))
+            tag=lambda: "N%d %dx%d C%d K%d R%d s%d %s" % (N, H, W, Cc, K, R, stride, sfx))
         repack_cache.packed()
         return gx
     ws, repack = repack_cache.get("dgrad%d" % stride, w, w.numel(), wkey)

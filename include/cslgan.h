@@ -160,11 +160,14 @@ int cslgan_conv2d_fwd_f32(const cslgan_conv_t* p, const float* x, const float* w
  * (or compute == CSLGAN_COMPUTE_BF16 and the filter pre-rounded: one piece, the same layout):
  * w3_ws is a caller workspace of 3 * K*R*S*C bfloat16 (= 1.5 * K*R*S*C floats), rebuilt from w when repack != 0 and reused
  * otherwise (the caller knows when w changed).  Stride-1 convs on 8x8-patchable grids with C % 16 == 0 and K >= 64 then run on
- * the LDS-halo kernel whose filter operand goes straight from that workspace to registers; other shapes ignore it. */
+ * the LDS-halo kernel whose filter operand goes straight from that workspace to registers; other shapes ignore it.
+ * compute == CSLGAN_COMPUTE_F32 is accepted too (round 4): the workspace then holds an fp32 copy of the filter in the same
+ * step-major order (K*R*S*C floats of the same allocation) and the kernel runs v_mfma_f32_32x32x2_f32 on the same staging —
+ * exact fp32 products, the result of cslgan_conv2d_fwd_f32 up to summation order. */
 int cslgan_conv2d_fwd_x3_f32(const cslgan_conv_t* p, const float* x, const float* w, void* w3_ws, int repack,
                              const float* bias, const float* residual, int act, float* y, void* stream);
 /* The workspace of cslgan_conv2d_fwd_x3_f32 on its own (ABI v5): w[rows][taps][red] fp32 -> w3_ws[pieces][(red/16)*taps + tap][rows][16]
- * bfloat16 (pieces = 3: hi / mid / lo; 1: the rounded filter).  Lets a caller that replays a recorded graph refresh the pieces of a
+ * bfloat16 (pieces = 3: hi / mid / lo; 1: the rounded filter; 0: an fp32 copy, [step][rows][16] floats).  Lets a caller that replays a recorded graph refresh the pieces of a
  * FROZEN filter in place only when the filter has changed, instead of inside every replay; red % 16 != 0 writes nothing. */
 int cslgan_split_filter_x3_f32(const float* w, int rows, int taps, int red, void* w3_ws, int pieces, void* stream);
 
@@ -179,7 +182,8 @@ int cslgan_conv2d_dgrad_f32(const cslgan_conv_t* p, const float* gy, const float
  * LDS-halo kernel of csrc/igemm_x3.hip (ABI v5): w3_ws is a second caller workspace of 3 * K*R*S*C bfloat16 receiving the
  * repacked parity-class matrices split into their pieces in step-major order (rebuilt with wt_ws when repack != 0).  Takes
  * stride 1-2, K % 16 == 0, C >= 64, class grids 8x8-patchable or 4x4; other shapes run the gather kernels in the same
- * arithmetic and ignore w3_ws.  Same call it replaces: the autograd data gradient of nn.Conv2d (DCResNet_models.py:131-132)
+ * arithmetic and ignore w3_ws.  compute == CSLGAN_COMPUTE_F32: w3_ws receives fp32 step-major class matrices and the launch is the
+ * exact-fp32 form of the same kernel (8x8-patchable class grids only).  Same call it replaces: the autograd data gradient of nn.Conv2d (DCResNet_models.py:131-132)
  * and its use inside the penalty's double backward (gradient_penalty.py:48-54). */
 int cslgan_conv2d_dgrad_x3_f32(const cslgan_conv_t* p, const float* gy, const float* w, float* wt_ws, void* w3_ws, int repack,
                                const float* mask, float* gx, void* stream);
@@ -216,7 +220,7 @@ int cslgan_conv2d_s2_fwd_f32(const cslgan_conv_t* p, const float* x, const float
 /* The same stride-2 forward conv with compute == CSLGAN_COMPUTE_BF16X3 / CSLGAN_COMPUTE_BF16 on the LDS-halo kernel of
  * csrc/igemm_x3.hip (ABI v5): w3_ws = 3 * K*R*R*C bfloat16 receiving the parity-class matrices split into their pieces
  * (rebuilt with wcls_ws when repack != 0).  C % 16 == 0, K >= 64, 8x8-patchable or 4x4 output grid; other shapes fall back
- * to cslgan_conv2d_fwd_f32 in the same arithmetic. */
+ * to cslgan_conv2d_fwd_f32 in the same arithmetic.  compute == CSLGAN_COMPUTE_F32: as for cslgan_conv2d_dgrad_x3_f32. */
 int cslgan_conv2d_s2_fwd_x3_f32(const cslgan_conv_t* p, const float* x, const float* w, float* wcls_ws, void* w3_ws, int repack,
                                 const float* bias, int act, float* y, void* stream);
 

@@ -51,7 +51,7 @@ def _close(got, exp, what, tol=TOL, scale=None, flips=False):
 
 
 def _check_grads(z, key, tensors, what, tol=TOL, flip_probe=None):
-    """flip_probe (the fp32-accurate bf16-matrix-core modes only): a callable returning how many LeakyReLU / ReLU units take a
+    """flip_probe (every arithmetic; for exact fp32 it compares the round-3 and round-4 summation orders): a callable returning how many LeakyReLU / ReLU units take a
     DIFFERENT slope in this run than in an exact-fp32 run of the same step on the device.  Both arithmetics are fp32-accurate but round
     differently (~2e-6 of a layer's scale), so a unit whose pre-activation is that close to zero can land on the other side — and a
     flipped unit deep in the critic shifts EVERY upstream gradient entry of its sample a little (B = 4..16 here: 1e-3..3e-3 of a summed
@@ -84,22 +84,27 @@ def _check_grads(z, key, tensors, what, tol=TOL, flip_probe=None):
 
 
 def _flip_probe(tmp_path, name, z, inp, mode_flags, materialize, compute, has_pen):
-    """Number of activation units whose sign differs between the `compute` run and an exact-fp32 run of the same step (device masks
-    recorded by csl_gan_amd.nn.ActivationMaskRecorder); evaluated at most once."""
+    """Number of activation units whose sign differs between the `compute` run and an exact-fp32 run of the same step on the round-3
+    kernels (device masks recorded by csl_gan_amd.nn.ActivationMaskRecorder); evaluated at most once.  For compute == "fp32" the two
+    runs are the same exact-fp32 products summed in two orders: the round-3 kernels and the round-4 halo kernel."""
     cache = []
 
     def probe():
         if not cache:
-            from csl_gan_amd import nn as hnn
+            from csl_gan_amd import nn as hnn, ops
             masks = []
             for k, mode in enumerate(("fp32", compute)):
                 opt, tr = _trainer(tmp_path / ("probe%d" % k), name, z, mode_flags, materialize, mode)
                 rec = hnn.ActivationMaskRecorder(G=tr.G, D=tr.D)
                 hnn.set_mask_recorder(rec)
+                prev = ops.set_f32_halo(False) if k == 0 else None
                 try:
                     _run(tr, inp, has_pen)
                 finally:
                     hnn.set_mask_recorder(None)
+                    if k == 0:
+                        ops.set_f32_halo(prev)
+                        ops.repack_cache.clear()
                 masks.append(rec.masks)
             assert masks[0].keys() == masks[1].keys()
             cache.append(sum(int((a != b).sum()) for k in masks[0] for a, b in zip(masks[0][k], masks[1][k])))
@@ -161,7 +166,7 @@ def test_train_D_adaptive_pl_matches_reference_vectors(tmp_path, golden_dir, nam
     B = int(z["meta"][0])
     opt, tr = _trainer(tmp_path, name, z, ["-gcm", "adaptive-pl"], materialize, compute)
     assert opt.compute_dtype == compute
-    probe = None if compute == "fp32" else _flip_probe(tmp_path, name, z, inp, ["-gcm", "adaptive-pl"], materialize, compute, has_pen)
+    probe = _flip_probe(tmp_path, name, z, inp, ["-gcm", "adaptive-pl"], materialize, compute, has_pen)
     last = _run(tr, inp, has_pen)
     fake = last["fake_img"].detach().cpu().contiguous()
     _close(fake.reshape(-1)[::max(1, fake.numel() // 4096)][:4096], z["fake_sample"], "G(z)")
@@ -191,7 +196,7 @@ def test_train_D_flat_clip_matches_reference_vectors(tmp_path, golden_dir, name,
     has_pen = "penalty" in z.files
     B = int(z["meta"][0])
     opt, tr = _trainer(tmp_path / "flat", name, z, ["-c", repr(float(z["c_flat"]))], "all", compute)
-    mk = lambda flags, mat: None if compute == "fp32" else _flip_probe(tmp_path / ("p" + mat + str(len(flags))), name, z, inp, flags, mat, compute, has_pen)
+    mk = lambda flags, mat: _flip_probe(tmp_path / ("p" + mat + str(len(flags))), name, z, inp, flags, mat, compute, has_pen)
     last = _run(tr, inp, has_pen)
     n = last["norms"].reshape(1, -1)
     _close(n[:, :B], z["flat_norms"][0:1], "flat per-sample norms, generated pass")

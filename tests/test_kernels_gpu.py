@@ -1100,14 +1100,17 @@ X3H_CASES = [
 
 
 @pytest.mark.parametrize("case", X3H_CASES, ids=[c[-1].split(":")[0][:40].replace(" ", "_") for c in X3H_CASES])
-@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16", "fp32"])
 def test_x3_halo_kernel_forms(case, mode):
     """igemm_x3h_kernel against an fp64 torch reference: fp32-level error (<= 4e-6 of scale, the bound of test_bf16x3_is_fp32_accurate)
-    for the three-piece arithmetic, 1e-4 against fp32 math on bf16-ROUNDED operands for the one-piece form.  Bias, LeakyReLU and the
+    for the three-piece arithmetic, 1e-4 against fp32 math on bf16-ROUNDED operands for the one-piece form, 2e-6 for the exact-fp32
+    form (v_mfma_f32_32x32x2_f32 on the same staging; igemm_x3h_kernel<., 0, .>).  Bias, LeakyReLU and the
     LeakyReLU mask ride along; the launch must really be the halo kernel (cslgan_last_kernel)."""
     from csl_gan_amd import _lib
     ops = _ops()
     kind, N, H, W, C, K, R, s, p, _ = case
+    if mode == "fp32" and s == 2 and H == 8:
+        pytest.skip("exact fp32 keeps the round-3 kernels on 4x4 class grids (x3h_eligible)")
     g = torch.Generator().manual_seed(1000 + sum(case[1:9]))
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
@@ -1128,7 +1131,8 @@ def test_x3_halo_kernel_forms(case, mode):
     name = _lib.lib().cslgan_last_kernel().decode()
     assert name.startswith("igemm_x3h_kernel"), "case %s dispatched to %s" % (case, name)
     e = _err64(got, ref)
-    assert e <= (4e-6 if mode == "bf16x3" else 1e-4), "%s %s: error %.3e of scale vs fp64 (%s)" % (mode, case[:9], e, name)
+    assert (",0," in name) == (mode == "fp32") and (",3," in name) == (mode == "bf16x3"), name
+    assert e <= {"bf16x3": 4e-6, "bf16": 1e-4, "fp32": 2e-6}[mode], "%s %s: error %.3e of scale vs fp64 (%s)" % (mode, case[:9], e, name)
 
 
 X3W_CASES = [

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CSLGAN_LIB_PATH") or os.path.join(_HERE, "libcslgan_hip.so")      # override: kernel experiments
 MAX_SEGS = 16
-ABI_VERSION = 5          # include/cslgan.h CSLGAN_ABI_VERSION
+ABI_VERSION = 6          # include/cslgan.h CSLGAN_ABI_VERSION
 
 EXPORTS = [
     "cslgan_version", "cslgan_last_error", "cslgan_last_kernel", "cslgan_device_count",
@@ -44,7 +44,7 @@ class SegsT(C.Structure):
 
 class ConvT(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "compute", "P", "Q")]
+                ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "compute", "P", "Q")] + [("split_ws", C.c_void_p), ("split_ws_floats", C.c_int64)]
 
 
 _lib = None

@@ -66,6 +66,10 @@ struct KcParams {
     int a_bf16;             // igemm_skinny only: the input tensor a is stored as bfloat16 (bf16 storage mode, csrc/igemm_bf16s.hip)
     int acc_classes;        // igemm_halo: 1 = every workgroup runs ALL classes on its m-tile into ONE accumulator (the classes are
                             // partial sums of the same output: a stride-2 conv as four stride-1 convs over parity sub-images)
+    float* part;            // igemm_x3h: scratch for channel-split partial sums (cslgan_conv_t.split_ws) or null
+    long long part_floats;  // its capacity
+    long long out_floats;   // floats of the output tensor (0: unknown, never split)
+    int csplit;             // igemm_x3h: > 1 = the 16-channel chunks are divided over csplit workgroups per tile, partials in `part`
     KcClass cls[IG_MAX_CLS];
 };
 

@@ -554,6 +554,7 @@ static int conv2d_fwd_impl(const cslgan_conv_t* c, const float* x, const float* 
     p.w = w; p.w3 = w3; p.Nn = c->K; p.out = y; p.OHf = c->P; p.OWf = c->Q; p.osy = p.osx = 1; p.ldo = c->K; p.dense_out = 1;
     p.bias = bias; p.res = residual; p.mask = nullptr; p.act = act; p.bf16 = c->compute == CSLGAN_COMPUTE_BF16 ? 1 : (c->compute == CSLGAN_COMPUTE_BF16X3 ? 3 : 0);
     p.a_bf16 = x_bf16;
+    p.part = reinterpret_cast<float*>(c->split_ws); p.part_floats = c->split_ws_floats; p.out_floats = (long long)c->N * c->P * c->Q * c->K;
     p.n_cls = 1;
     KcClass& k = p.cls[0];
     k.M = c->N * c->P * c->Q; k.OHc = c->P; k.OWc = c->Q; k.T = c->R * c->S; k.Kdim = k.T * c->C; k.w_off = 0; k.oy0 = k.ox0 = 0;
@@ -601,6 +602,7 @@ static int conv2d_s2_fwd_impl(const cslgan_conv_t* c, const float* x, const floa
     p.a = x; p.AH = c->H; p.AW = c->W; p.AC = c->C; p.VH = c->H; p.VW = c->W; p.sy = p.sx = 1;
     p.w = wcls_ws; p.Nn = c->K; p.out = y; p.OHf = c->P; p.OWf = c->Q; p.osy = p.osx = 1; p.ldo = c->K; p.dense_out = 0;
     p.bias = bias; p.res = nullptr; p.mask = nullptr; p.act = act; p.acc_classes = 1;
+    p.part = reinterpret_cast<float*>(c->split_ws); p.part_floats = c->split_ws_floats; p.out_floats = (long long)c->N * c->P * c->Q * c->K;
     int n = 0, off = 0;
     bool ok = R * R <= IG_MAX_TAPS;
     for (int a = 0; ok && a < 2; ++a)
@@ -696,6 +698,7 @@ static int conv2d_dgrad_impl(const cslgan_conv_t* c, const float* gy, const floa
     p.bias = nullptr; p.res = nullptr; p.mask = mask; p.act = CSLGAN_ACT_NONE; p.bf16 = c->compute == CSLGAN_COMPUTE_BF16 ? 1 : (c->compute == CSLGAN_COMPUTE_BF16X3 ? 3 : 0);
     p.a_bf16 = gy_bf16;
     p.w3 = (w3_ws && c->K % 16 == 0 && aligned16(w3_ws)) ? w3_ws : nullptr;
+    p.part = reinterpret_cast<float*>(c->split_ws); p.part_floats = c->split_ws_floats; p.out_floats = (long long)c->N * c->H * c->W * c->C;
     int off = 0, ncls = 0;
     for (int py = 0; py < s; ++py)
         for (int px = 0; px < s; ++px) {

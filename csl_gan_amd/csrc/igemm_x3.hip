@@ -96,7 +96,12 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
 
     const int tid = threadIdx.x;
     const int nwg = p.tiles_m * p.tiles_n;
-    const int wg = xcd_remap(blockIdx.x, nwg);
+    // channel split (launch_x3h: launches of < 512 workgroups): csplit workgroups per tile, each on its own range of 16-channel
+    // chunks, partial sums to p.part[split]; the splits of one tile are neighbours (same XCD: they share the tile's halo in L2)
+    const int cs = p.csplit > 1 ? p.csplit : 1;
+    const int wgs = xcd_remap(blockIdx.x, nwg * cs);
+    const int split = cs > 1 ? wgs % cs : 0;
+    const int wg = cs > 1 ? wgs / cs : wgs;
     const int tile_mg = wg / p.tiles_n, tile_n = wg - tile_mg * p.tiles_n;
     const bool accumulate = GEN && p.acc_classes;
     const int n_sub = accumulate ? p.n_cls : ((GEN && p.pair_mode) ? 2 : 1);
@@ -179,9 +184,12 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
                 h_lds[j] = idx >= h_total ? -1 : (F32 ? (pp * XH_MAX + lpx) * 4 + (ch ^ ((hx + hy) & 3)) : (pp * XH_MAX + lpx) * 4 + (ch ^ ((hy & 1) << 1)));
             }
         }
+        const int n_cc_all = p.AC >> 4;
+        const int cc_lo = cs > 1 ? split * n_cc_all / cs : 0;
+        const int n_cc = cs > 1 ? (split + 1) * n_cc_all / cs - cc_lo : n_cc_all;      // this workgroup's chunks: cc_lo .. cc_lo + n_cc - 1
         float4 rh[HREG];
         auto fetch_halo = [&](int cc) {
-            const unsigned co = 64u * (unsigned)cc;            // 16 channels x 4 B per chunk
+            const unsigned co = 64u * (unsigned)(cc + cc_lo);  // 16 channels x 4 B per chunk
 #pragma unroll
             for (int j = 0; j < HREG; ++j) rh[j] = xload4(a_rsrc, h_goff[j] + co);      // an invalid element sits at XFAR: + co (< 64 KB) stays out of range
         };
@@ -221,11 +229,11 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
             const int n = n0 + wn * TN * 32 + j * 32 + r;
             b_off[j] = n < p.Nn ? n_bytes * (unsigned)n + 16u * (unsigned)h : XOOB;       // tested again in load_b
         }
-        const int n_cc = p.AC >> 4;
         const int n_steps = n_cc * T;
+        const unsigned step0_bytes = (unsigned)(cc_lo * T) * step_bytes;
         u32x4 B0[NO][TN], B1[NO][TN];                          // two-slot ring of filter slices: slot s % 2 is refilled with step s + 2
         auto load_b = [&](int step, u32x4 (&dst)[NO][TN]) {    // right after the MFMAs of step s have read it (no third slot, no copies)
-            const unsigned kb = (unsigned)step * step_bytes;
+            const unsigned kb = (unsigned)step * step_bytes + step0_bytes;
             const unsigned past = step >= n_steps ? XOOB : 0u;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -394,6 +402,10 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
                     const int n = n0 + wn * TN * 32 + j * 32 + 8 * q + 4 * h;
                     if (n >= p.Nn) continue;
                     float4 val = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                    if (cs > 1) {           // partial sums: bias / activation / mask are x3h_split_reduce_kernel's
+                        *reinterpret_cast<float4*>(p.part + (long long)split * p.out_floats + off + n) = val;
+                        continue;
+                    }
                     if (p.bias) {
                         const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
                         val.x += bv.x; val.y += bv.y; val.z += bv.z; val.w += bv.w;
@@ -422,6 +434,37 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
         }
         __syncthreads();          // the next class of a pair reuses s_off / s_roff
     }   // sub
+}
+
+// Second launch of a channel-split igemm_x3h: out = epilogue(part[0] + part[1] + ... + part[cs-1]) in that fixed order (a float
+// atomic would make the sum order — and the last bit of every output — depend on workgroup scheduling).  Output rows are Nn floats
+// (ldo == Nn, checked by the host); bias / activation / LeakyReLU-mask as the kernel's own epilogue.
+__global__ __launch_bounds__(256) void x3h_split_reduce_kernel(const float* __restrict__ part, int cs, long long stride, float* __restrict__ out,
+                                                               long long n4, int Nn, const float* __restrict__ bias,
+                                                               const float* __restrict__ mask, int act) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 v = reinterpret_cast<const float4*>(part)[i];
+        for (int s = 1; s < cs; ++s) {
+            const float4 u = reinterpret_cast<const float4*>(part + s * stride)[i];
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        if (bias) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + (int)((i << 2) % Nn));
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        }
+        if (act == CSLGAN_ACT_LRELU02) {
+            v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y; v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w;
+        } else if (act == CSLGAN_ACT_RELU) {
+            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        } else if (act == CSLGAN_ACT_TANH) {
+            v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
+        }
+        if (mask) {
+            const float4 mv = reinterpret_cast<const float4*>(mask)[i];
+            v.x *= mv.x > 0.f ? 1.f : 0.2f; v.y *= mv.y > 0.f ? 1.f : 0.2f; v.z *= mv.z > 0.f ? 1.f : 0.2f; v.w *= mv.w > 0.f ? 1.f : 0.2f;
+        }
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
 }
 
 // The filter matrix of one class, w[n][t][c] fp32 (KRSC for a forward conv; a repacked class matrix of a data gradient or of a
@@ -553,9 +596,28 @@ int launch_x3h(KcParams& p, hipStream_t st) {
     static const int wide_min = [] { const char* e = getenv("CSLGAN_X3_WIDE_MIN"); return e ? atoi(e) : 192; }();
     if (wide && (long long)p.tiles_m * ((p.Nn + 127) / 128) < wide_min) wide = false;
     p.tiles_n = wide ? (p.Nn + 127) / 128 : (p.Nn + 63) / 64;
-    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);
+    // Channel split: a launch of fewer than 512 workgroups (two per CU) leaves CUs idle or with one wave per SIMD — the critic's
+    // third and fourth convs run 64..384 tiles.  With scratch from the caller the 16-channel chunks are divided over `csplit`
+    // workgroups per tile; cost model = rounds of 256 CUs x work per workgroup, ceil(tiles * s / 256) / s, smallest s on ties,
+    // at least two chunks per workgroup (prologue + epilogue stay a small share).
+    p.csplit = 1;
+    static const int split_env = [] { const char* e = getenv("CSLGAN_X3_SPLIT"); return e ? atoi(e) : 8; }();       // max split, 0/1 = off
+    const long long tiles = (long long)p.tiles_m * p.tiles_n;
+    if (split_env > 1 && p.part && !p.res && p.ldo == p.Nn && p.out_floats > 0 && (p.out_floats & 3) == 0 && aligned16(p.part) && tiles < 512) {
+        const int n_cc = p.AC >> 4;
+        double best = (double)((tiles + 255) / 256);
+        for (int s = 2; s <= split_env && n_cc / s >= 2 && (long long)s * p.out_floats <= p.part_floats; ++s) {
+            const double cost = (double)((tiles * s + 255) / 256) / s + 0.02 * s;      // + the partial stores / the reduce pass
+            if (cost < best - 1e-9) { best = cost; p.csplit = s; }
+        }
+    }
+    const dim3 grid((unsigned)(tiles * p.csplit)), block(256);
     const bool x3 = p.bf16 == 3;
-    note_kernel(x3 ? "igemm_x3h_kernel<%d,3,%s>" : (p.bf16 ? "igemm_x3h_kernel<%d,1,%s>" : "igemm_x3h_kernel<%d,0,%s>"), wide ? 128 : 64, gen ? "true" : "false");
+    if (p.csplit > 1)       // "/sN": N workgroups per tile + the reduce launch (the device kernel name is the part before the slash)
+        note_kernel(x3 ? "igemm_x3h_kernel<%d,3,%s>/s%d" : (p.bf16 ? "igemm_x3h_kernel<%d,1,%s>/s%d" : "igemm_x3h_kernel<%d,0,%s>/s%d"), wide ? 128 : 64,
+                    gen ? "true" : "false", p.csplit);
+    else
+        note_kernel(x3 ? "igemm_x3h_kernel<%d,3,%s>" : (p.bf16 ? "igemm_x3h_kernel<%d,1,%s>" : "igemm_x3h_kernel<%d,0,%s>"), wide ? 128 : 64, gen ? "true" : "false");
     if (!p.bf16) {
         if (wide && gen) hipLaunchKernelGGL((igemm_x3h_kernel<128, 0, true>), grid, block, 0, st, p);
         else if (wide) hipLaunchKernelGGL((igemm_x3h_kernel<128, 0, false>), grid, block, 0, st, p);
@@ -572,7 +634,15 @@ int launch_x3h(KcParams& p, hipStream_t st) {
         else if (gen) hipLaunchKernelGGL((igemm_x3h_kernel<64, 1, true>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((igemm_x3h_kernel<64, 1, false>), grid, block, 0, st, p);
     }
-    return check_launch("igemm_x3h_kernel");
+    if (int rc = check_launch("igemm_x3h_kernel")) return rc;
+    if (p.csplit > 1) {
+        const long long n4 = p.out_floats >> 2;
+        long long nb = (n4 + 255) / 256;
+        nb = nb > 4096 ? 4096 : nb;
+        hipLaunchKernelGGL(x3h_split_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, p.part, p.csplit, p.out_floats, p.out, n4, p.Nn, p.bias, p.mask, p.act);
+        return check_launch("x3h_split_reduce_kernel");
+    }
+    return CSLGAN_OK;
 }
 
 }  // namespace cslgan

@@ -56,6 +56,25 @@ def _kc_compute(rows, n_out, kdim):
 _F32_HALO = os.environ.get("CSLGAN_F32_HALO", "1") == "1"        # A/B: exact-fp32 launches the round-4 LDS-halo kernel takes run on it (igemm_x3h<., 0, .>)
 
 
+# Largest channel split of a low-fill halo launch (<= 1: never split).  OFF by default: measured alone the critic's last convs gain
+# (conv4 forward, 384 rows: 167 -> 200 TF; 128 rows: 86 -> 140 TF), but inside the two-stream recorded step the other branch
+# already fills the idle CUs and the step does not move (6.797 ms split, 6.731 ms unsplit, 6.723 ms split + 128-wide tiles: noise)
+# while every split launch adds a reduce launch.  CSLGAN_X3_SPLIT=8 switches it on (single-stream / eager runs).
+_X3_SPLIT = int(os.environ.get("CSLGAN_X3_SPLIT", "0"))
+
+
+def _split_scratch(d, rows, cols, red_channels, out):
+    """Scratch for the channel split of the LDS-halo kernel (cslgan_conv_t.split_ws): a launch of fewer than 512 128x128 tiles may
+    divide its reduction channels over up to _X3_SPLIT workgroups per tile, at least two 16-channel chunks each.  The tensor comes
+    from the caching allocator like the output (stream-ordered, graph-pool safe); the C side decides the actual split."""
+    s = min(_X3_SPLIT, (red_channels // 16) // 2)
+    if s < 2 or -(-rows // 128) * -(-cols // 128) >= 512:
+        return None
+    ws = torch.empty(s * out.numel(), device=out.device, dtype=torch.float32)
+    d.split_ws, d.split_ws_floats = ws.data_ptr(), ws.numel()
+    return ws
+
+
 def set_f32_halo(on):
     """Switch the exact-fp32 form of the round-4 halo kernel on or off at run time (returns the previous setting): the same products
     summed in a different order, so the golden tests use it to prove which activation units sit within rounding of zero."""
@@ -486,10 +505,12 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, ou
         # class matrices and, behind them, their bfloat16 pieces in step-major order
         nw = w.numel()
         ws, repack = repack_cache.get("s2_fwd_" + kind_sfx, w, nw + (3 * nw + 1) // 2, wkey)
+        part = _split_scratch(d, N * P * Q, K, Cc, y)
         _timed("conv2d_fwd", flop, nbytes, lambda: check(
             _lib.lib().cslgan_conv2d_s2_fwd_x3_f32(C.byref(d), _p(x), _p(w), _p(ws), C.c_void_p(ws.data_ptr() + 4 * nw), repack, _p(bias), act,
                                                    _p(y), _stream()),
             "conv2d_s2_fwd_x3"), exec_flop=xflop, tag=lambda: "N%d %dx%d C%d K%d R%d s2 %s" % (N, H, W, Cc, K, R, kind_sfx))
+        del part
         repack_cache.packed()
         return y
     if stride == 2 and R == S and R % 2 == 1 and R > 1 and Cc % 32 == 0 and K >= 64 and residual is None:
@@ -657,10 +678,12 @@ def conv2d_dgrad(gy, w, in_hw, stride=1, pad=0, mask=None, wkey=None, out_dtype=
         nw = w.numel()
         sfx = {COMPUTE_BF16X3: "x3", COMPUTE_BF16: "b16", COMPUTE_F32: "f32h"}[d.compute]
         ws, repack = repack_cache.get("dgrad%d_%s" % (stride, sfx), w, nw + (3 * nw + 1) // 2, wkey)
+        part = _split_scratch(d, N * H * W, Cc, K, gx)
         _timed("conv2d_dgrad", flop, nbytes, lambda: check(
             _lib.lib().cslgan_conv2d_dgrad_x3_f32(C.byref(d), _p(gy), _p(w), _p(ws), C.c_void_p(ws.data_ptr() + 4 * nw), repack, _p(mask), _p(gx),
                                                   _stream()), "conv2d_dgrad_x3"),
             tag=lambda: "N%d %dx%d C%d K%d R%d s%d %s" % (N, H, W, Cc, K, R, stride, sfx))
+        del part
         repack_cache.packed()
         return gx
     ws, repack = repack_cache.get("dgrad%d" % stride, w, w.numel(), wkey)

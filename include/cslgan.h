@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CSLGAN_ABI_VERSION 5
+#define CSLGAN_ABI_VERSION 6
 
 typedef enum {
     CSLGAN_OK = 0,
@@ -145,6 +145,12 @@ typedef struct {
     int32_t stride, pad;
     int32_t compute;             /* CSLGAN_COMPUTE_F32 (exact fp32 MFMA) or CSLGAN_COMPUTE_BF16 (see below) */
     int32_t P, Q;                /* output y[N][P][Q][K]                                     */
+    /* ABI v6: optional device scratch for launches that would leave most of the chip idle (the critic's last convs: 64-384
+     * workgroups on 256 CUs).  When given, the LDS-halo kernel of csrc/igemm_x3.hip may divide the REDUCTION channels over up to
+     * split_ws_floats / (output floats) workgroups per output tile, each writing its partial sums here, and a second launch adds
+     * the partials in a fixed order and applies bias / activation / mask (deterministic: no atomics).  NULL / 0: never split. */
+    void* split_ws;
+    int64_t split_ws_floats;
 } cslgan_conv_t;
 
 /* y = act(conv(x, w) + bias [+ residual]).  Replaces torch.nn.Conv2d / nn.Linear forward at

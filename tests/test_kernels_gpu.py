@@ -1100,15 +1100,21 @@ X3H_CASES = [
 
 
 @pytest.mark.parametrize("case", X3H_CASES, ids=[c[-1].split(":")[0][:40].replace(" ", "_") for c in X3H_CASES])
+@pytest.mark.parametrize("split", [True, False], ids=["split", "nosplit"])
 @pytest.mark.parametrize("mode", ["bf16x3", "bf16", "fp32"])
-def test_x3_halo_kernel_forms(case, mode):
+def test_x3_halo_kernel_forms(case, mode, split, monkeypatch):
     """igemm_x3h_kernel against an fp64 torch reference: fp32-level error (<= 4e-6 of scale, the bound of test_bf16x3_is_fp32_accurate)
     for the three-piece arithmetic, 1e-4 against fp32 math on bf16-ROUNDED operands for the one-piece form, 2e-6 for the exact-fp32
     form (v_mfma_f32_32x32x2_f32 on the same staging; igemm_x3h_kernel<., 0, .>).  Bias, LeakyReLU and the
-    LeakyReLU mask ride along; the launch must really be the halo kernel (cslgan_last_kernel)."""
+    LeakyReLU mask ride along; the launch must really be the halo kernel (cslgan_last_kernel).  split: launches of fewer than 512
+    tiles divide their reduction channels over workgroups ("/sN" in the kernel note: partial sums + the ordered reduce launch) — the
+    strided forward and data-gradient cases here all do when the reduction has >= 64 channels; nosplit keeps the one-launch form covered."""
     from csl_gan_amd import _lib
     ops = _ops()
+    monkeypatch.setattr(ops, "_X3_SPLIT", 8 if split else 0)
     kind, N, H, W, C, K, R, s, p, _ = case
+    if not split and (kind, s) == ("fwd", 1):
+        pytest.skip("stride-1 forward launches never split: covered by the split=True run")
     if mode == "fp32" and s == 2 and H == 8:
         pytest.skip("exact fp32 keeps the round-3 kernels on 4x4 class grids (x3h_eligible)")
     g = torch.Generator().manual_seed(1000 + sum(case[1:9]))
@@ -1132,6 +1138,9 @@ def test_x3_halo_kernel_forms(case, mode):
     assert name.startswith("igemm_x3h_kernel"), "case %s dispatched to %s" % (case, name)
     e = _err64(got, ref)
     assert (",0," in name) == (mode == "fp32") and (",3," in name) == (mode == "bf16x3"), name
+    red, rows, cols = (C, N * P * Q, K) if kind == "fwd" else (K, N * H * W, C)
+    want_split = split and (kind, s) != ("fwd", 1) and red >= 64 and -(-rows // 128) * -(-cols // 128) < 512
+    assert ("/s" in name) == want_split, (name, want_split)
     assert e <= {"bf16x3": 4e-6, "bf16": 1e-4, "fp32": 2e-6}[mode], "%s %s: error %.3e of scale vs fp64 (%s)" % (mode, case[:9], e, name)
 
 

@@ -81,6 +81,12 @@ class _BatchNormAct(nn.BatchNorm2d):
         return F.relu(super().forward(x))
 
 
+def _gn_fusable(x):
+    """GroupNorm statistics may come from the producing conv's epilogue: a frozen fp32 device forward with no recorder attached."""
+    from . import nn as hnn
+    return (not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32 and not ops.storage_bf16() and hnn._mask_recorder is None
+
+
 def _norm_act(bn, ch):
     return _BatchNormAct(ch) if bn else HipGroupNormAct(32, ch, relu=True)
 
@@ -97,12 +103,28 @@ class ResBlockUp(nn.Module):
         self.conv = HipConv2d(out_ch, out_ch, filter_size, padding="same")
 
     def forward_nhwc(self, x):
+        return self.forward_nhwc_parts(x)[0]
+
+    def forward_nhwc_parts(self, x, x_part=None, next_norm=None):
+        """(block output, GroupNorm partial statistics of it for `next_norm` or None).  In a frozen forward (the generator inside a
+        D-step) every GroupNorm of the stack reads its statistics from the epilogue of the conv that produced its input
+        (ops.gn_partials, cslgan_conv_t.gn_part): x_part are the ones the previous block left for this block's bn1."""
         if x.shape[-1] % 4:
             raise NotImplementedError("ResBlockUp on HIP needs in_ch %% 4 == 0 (got %d)" % x.shape[-1])
-        a_ps, x_ps = self.bn1.forward_shuffled(x)       # one read of x: depth_to_space(relu(norm(x))) and depth_to_space(x)
+        fuse = _gn_fusable(x)
+        a_ps, x_ps = self.bn1.forward_shuffled(x, part=x_part) if x_part is not None else self.bn1.forward_shuffled(x)
         s = self.shortcut.forward_shuffled(x_ps)        # 1x1 conv over the C/4 shuffled channels, full resolution
-        o = self.convUp.forward_shuffled(a_ps)
-        return self.conv.forward_nhwc(self.bn2.forward_nhwc(o), residual=s)
+        if fuse and isinstance(self.bn2, HipGroupNormAct):
+            with ops.gn_partials(self.bn2.num_groups) as cell:
+                o = self.convUp.forward_shuffled(a_ps)
+            h = self.bn2.forward_nhwc(o, part=cell.part)
+        else:
+            h = self.bn2.forward_nhwc(self.convUp.forward_shuffled(a_ps))
+        if fuse and isinstance(next_norm, HipGroupNormAct):
+            with ops.gn_partials(next_norm.num_groups) as cell:
+                out = self.conv.forward_nhwc(h, residual=s)
+            return out, cell.part
+        return self.conv.forward_nhwc(h, residual=s), None
 
     def forward(self, x):
         if x.is_cuda:
@@ -128,9 +150,12 @@ class DCResNetGenerator(Generator):
                 x = blk(x)
             return self.convOut(self.bn(x))
         x = HF.nhwc(x)
-        for blk in self.blocks:
-            x = blk.forward_nhwc(x)
-        return HF.nchw_view(self.convOut.forward_nhwc(self.bn.forward_nhwc(x)))
+        part = None
+        for i, blk in enumerate(self.blocks):           # each block leaves the statistics the NEXT normalisation needs (frozen forward)
+            nxt = self.blocks[i + 1].bn1 if i + 1 < len(self.blocks) else self.bn
+            x, part = blk.forward_nhwc_parts(x, part, nxt)
+        h = self.bn.forward_nhwc(x, part=part) if part is not None else self.bn.forward_nhwc(x)
+        return HF.nchw_view(self.convOut.forward_nhwc(h))
 
     def loss(self, d_output, device):
         return -torch.mean(d_output)

@@ -450,6 +450,7 @@ int launch_kc(KcParams& p, hipStream_t st, long long out_elems) {
         return launch_kc_bf16(p, st, out_elems);
     }
     if (p.w3 && x3h_eligible(p)) return launch_x3h(p, st);          // exact fp32 on the round-4 halo kernel (step-major fp32 filter copy in p.w3)
+    if (p.gn_part) { set_error("conv2d_fwd: gn_part given but the shape does not run on the LDS-halo kernel"); return CSLGAN_ERR_INVALID_ARG; }
     static const int halo_env = [] { const char* e = getenv("CSLGAN_KC_HALO"); return e ? atoi(e) : 1; }();
     if (halo_env && halo_eligible(p)) return launch_halo(p, st);
     static const int patch_env = [] { const char* e = getenv("CSLGAN_KC_PATCH"); return e ? atoi(e) : 1; }();
@@ -538,6 +539,12 @@ static int conv2d_fwd_impl(const cslgan_conv_t* c, const float* x, const float* 
     if (rc) return rc;
     CSLGAN_REQUIRE(act >= 0 && act <= 3, "conv2d_fwd: unknown activation %d", act);
     static const int c3_env = [] { const char* e = getenv("CSLGAN_C3"); return e ? atoi(e) : 1; }();
+    if (c->gn_part) {       // GroupNorm partials come from the halo kernel's epilogue only (cslgan_conv_t.gn_part)
+        const int cpg = c->gn_groups > 0 && c->K % c->gn_groups == 0 ? c->K / c->gn_groups : 0;
+        CSLGAN_REQUIRE(w3 && !x_bf16 && c->stride == 1 && act == CSLGAN_ACT_NONE && c->P % 8 == 0 && c->Q % 8 == 0 && cpg >= 1 && cpg <= 32 &&
+                       (cpg & (cpg - 1)) == 0 && c->R * c->S > 1 && (long long)c->P * c->Q / 64 <= CSLGAN_NORM_PARTIAL_BLOCKS,
+                       "conv2d_fwd: gn_part needs cslgan_conv2d_fwd_x3_f32, stride 1, an 8x8-patchable output of <= 4096 pixels, no activation and K / gn_groups a power of two <= 32");
+    }
     if (x_bf16) {
         CSLGAN_REQUIRE(c->K <= 4 && c->C == 64 && c->stride == 1 && !residual, "conv2d_fwd_skinny_bf16in: needs 1..4 output channels, 64 input channels, stride 1");
     } else
@@ -555,6 +562,7 @@ static int conv2d_fwd_impl(const cslgan_conv_t* c, const float* x, const float* 
     p.bias = bias; p.res = residual; p.mask = nullptr; p.act = act; p.bf16 = c->compute == CSLGAN_COMPUTE_BF16 ? 1 : (c->compute == CSLGAN_COMPUTE_BF16X3 ? 3 : 0);
     p.a_bf16 = x_bf16;
     p.part = reinterpret_cast<float*>(c->split_ws); p.part_floats = c->split_ws_floats; p.out_floats = (long long)c->N * c->P * c->Q * c->K;
+    if (c->gn_part) { p.gn_part = c->gn_part; p.gn_cpg = c->K / c->gn_groups; p.gn_slots = c->P * c->Q / 64; p.part = nullptr; }
     p.n_cls = 1;
     KcClass& k = p.cls[0];
     k.M = c->N * c->P * c->Q; k.OHc = c->P; k.OWc = c->Q; k.T = c->R * c->S; k.Kdim = k.T * c->C; k.w_off = 0; k.oy0 = k.ox0 = 0;

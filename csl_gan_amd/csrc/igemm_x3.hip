@@ -388,6 +388,10 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
             s_roff[tid] = roff;
         }
         __syncthreads();
+        // GroupNorm partials (cslgan_conv_t.gn_part; single-class launches): per channel the sum and the sum of squares of the STORED
+        // values about the patch's first pixel (a sample of the same distribution: no cancellation), reduced over the patch's 64 rows
+        const bool gn = !GEN && p.gn_part != nullptr;
+        float4 gk[TN][4], g1[TN][4], g2[TN][4];
         // lane (r, h) holds, of tile (i, j), pixel row r and channels j*32 + 8 q + 4 h + (0..3) for q = 0..3: bias / residual / mask are
         // read and the result is stored as 4-element vectors (p.Nn % 4 == 0 and 16-byte aligned operands: checked by x3h_eligible)
 #pragma unroll
@@ -414,6 +418,18 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
                         const float4 rv = *reinterpret_cast<const float4*>(p.res + roff + n);
                         val.x += rv.x; val.y += rv.y; val.z += rv.z; val.w += rv.w;
                     }
+                    if (gn) {
+                        if (i == 0) {
+                            const int src = lane & 32;              // the lane of pixel row 0 in this half
+                            gk[j][q] = make_float4(__shfl(val.x, src), __shfl(val.y, src), __shfl(val.z, src), __shfl(val.w, src));
+                            g1[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            g2[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                        const float4 d = make_float4(val.x - gk[j][q].x, val.y - gk[j][q].y, val.z - gk[j][q].z, val.w - gk[j][q].w);
+                        g1[j][q].x += d.x; g1[j][q].y += d.y; g1[j][q].z += d.z; g1[j][q].w += d.w;
+                        g2[j][q].x = fmaf(d.x, d.x, g2[j][q].x); g2[j][q].y = fmaf(d.y, d.y, g2[j][q].y);
+                        g2[j][q].z = fmaf(d.z, d.z, g2[j][q].z); g2[j][q].w = fmaf(d.w, d.w, g2[j][q].w);
+                    }
                     if (p.act == CSLGAN_ACT_LRELU02) {
                         val.x = val.x > 0.f ? val.x : 0.2f * val.x; val.y = val.y > 0.f ? val.y : 0.2f * val.y;
                         val.z = val.z > 0.f ? val.z : 0.2f * val.z; val.w = val.w > 0.f ? val.w : 0.2f * val.w;
@@ -429,6 +445,79 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
                         val.z *= mv.z > 0.f ? 1.f : 0.2f; val.w *= mv.w > 0.f ? 1.f : 0.2f;
                     }
                     *reinterpret_cast<float4*>(p.out + off + n) = val;
+                }
+            }
+        }
+        if (gn) {
+            // per channel (mean, centred sum of squares) of the wave's patch -> LDS (the halo images are dead) -> one thread per
+            // (patch, group) combines its channels exactly (Chan) and writes the pair the apply kernel's prologue expects
+            float* s_ch = reinterpret_cast<float*>(&Hs[0][0][0]);          // [2 patches][BN channels][2]
+            float* s_k = s_ch + 2 * BN * 2;                                // [2 patches][BN channels]: the shifts
+            const bool valid = s_off[wm * 64] >= 0;
+            // Sum over the 32 pixel-row lanes of a half as a halving butterfly: at every step a lane hands HALF of its values to its
+            // partner and adds the partner's other half to the ones it keeps — NV/2 + NV/4 + ... = NV - NV/32 exchanges instead of
+            // 5 NV (a plain all-lanes reduction of the NV = 64 values cost ~5 k cycles per wave: as much as the statistics launch it
+            // replaced).  Lane r ends with values 2r, 2r+1 (NV = 64) or value r (NV = 32): value index = 2 * channel + moment with
+            // channel = (j, q, e) flattened, so a lane finishes BOTH moments of one channel (or one moment of channel r / 2).
+            constexpr int NV = TN * 32;
+            float v[NV];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float a1[4] = {g1[j][q].x, g1[j][q].y, g1[j][q].z, g1[j][q].w}, a2[4] = {g2[j][q].x, g2[j][q].y, g2[j][q].z, g2[j][q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[((j * 4 + q) * 4 + e) * 2] = a1[e]; v[((j * 4 + q) * 4 + e) * 2 + 1] = a2[e]; }
+                }
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                const int n = NV >> (s + 1), mask = 16 >> s;
+                const bool up = (r & mask) != 0;
+#pragma unroll
+                for (int i = 0; i < n; ++i) {
+                    const float keep = up ? v[n + i] : v[i], send = up ? v[i] : v[n + i];
+                    v[i] = keep + __shfl_xor(send, mask);
+                }
+            }
+            if (valid) {
+                // the shifts: every lane of a half holds all of them; pixel-row lane 0 stores its half's 16 TN channels
+                if (r == 0) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<float4*>(s_k + wm * BN + wn * TN * 32 + j * 32 + 8 * q + 4 * h) = gk[j][q];
+                }
+                if (NV == 64) {         // lane r: channel r = (j, q, e), both moments
+                    const int cl = wn * TN * 32 + (r >> 4) * 32 + 8 * ((r >> 2) & 3) + 4 * h + (r & 3);
+                    s_ch[(wm * BN + cl) * 2] = v[0];
+                    s_ch[(wm * BN + cl) * 2 + 1] = v[1];
+                } else {                // lane r: moment r & 1 of channel r >> 1 = (q, e)
+                    const int cc = r >> 1, cl = wn * TN * 32 + 8 * (cc >> 2) + 4 * h + (cc & 3);
+                    s_ch[(wm * BN + cl) * 2 + (r & 1)] = v[0];
+                }
+            }
+            __syncthreads();
+            const int cpg = p.gn_cpg, gpt = BN / cpg;                      // groups per filter tile (cpg divides 32)
+            if (tid < 2 * gpt) {
+                const int pp = tid / gpt, gl = tid - pp * gpt;
+                const int m = m0 + 64 * pp, c0 = n0 + gl * cpg;
+                if (m < M && c0 < p.Nn) {
+                    const float* q = s_ch + (pp * BN + gl * cpg) * 2;       // (S1, S2) about the shift k of each channel, 64 rows
+                    const float* kq = s_k + pp * BN + gl * cpg;
+                    float sum = 0.f;
+                    for (int c = 0; c < cpg; ++c) sum += kq[c] + q[2 * c] * (1.f / 64.f);
+                    const float mg = sum / (float)cpg;
+                    float m2 = 0.f;
+                    for (int c = 0; c < cpg; ++c) {
+                        const float m1 = q[2 * c] * (1.f / 64.f), dm = kq[c] + m1 - mg;
+                        float c2 = q[2 * c + 1] - q[2 * c] * m1;
+                        m2 += (c2 < 0.f ? 0.f : c2) + 64.f * dm * dm;
+                    }
+                    const int per = OHc * OWc, img = m / per, slot = (m - img * per) >> 6;
+                    float* o = p.gn_part + (((long long)img * p.gn_slots + slot) * (p.Nn / cpg) + c0 / cpg) * 2;
+                    o[0] = mg * 64.f * (float)cpg;
+                    o[1] = m2;
                 }
             }
         }
@@ -567,6 +656,7 @@ int launch_x3h(KcParams& p, hipStream_t st) {
         tm += (k.M + 127) / 128;
         gen = gen || quad || k.ay_mul > 1 || k.ax_mul > 1;
     }
+    if (p.gn_part && gen) { set_error("igemm_x3h: GroupNorm partials need a single-class stride-1 launch"); return CSLGAN_ERR_INVALID_ARG; }
     p.tiles_m = tm;
     p.ksplit = 1;
     p.pair_mode = 0;

@@ -231,7 +231,7 @@ template <bool D2S, typename TX, typename TY>
 __global__ __launch_bounds__(256) void norm_apply_rows_kernel(const TX* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ stats, long long rows_per_stat, int C, int cpg, int n_groups,
                                                               float eps, int relu, TY* __restrict__ y, int H, int W, TY* __restrict__ xs,
-                                                              const float* __restrict__ part, int n_part, float* __restrict__ stats_out) {
+                                                              const float* __restrict__ part, int n_part, float* __restrict__ stats_out, int chan) {
     const int c4n = C >> 2;                           // a power of two (256 % c4n == 0)
     const int lg = __ffs(c4n) - 1;
     const int c = (threadIdx.x & (c4n - 1)) << 2;
@@ -245,7 +245,26 @@ __global__ __launch_bounds__(256) void norm_apply_rows_kernel(const TX* __restri
         // row group's n_part slots here (2 * n_groups threads, n_part loads each), finish them in LDS, and let the row group's first
         // workgroup publish the final (sum x, centred sum of squares) pairs for whoever reads the statistics later (the backward).
         extern __shared__ float s_st[];               // [2 * n_groups]: (sum x, centred sum of squares)
-        for (int i = threadIdx.x; i < n_groups; i += 256) {
+        for (int i = threadIdx.x; chan && i < n_groups; i += 256) {
+            // chan: the partials come from a conv epilogue (cslgan_conv_t.gn_part): per slot the sum of its cnt / n_part values and
+            // their sum of squares about the slot's own mean — combined exactly: M2 = sum_b M2_b + n_b (mean_b - mean)^2
+            float sum = 0.f;
+            for (int b = 0; b < n_part; ++b) sum += part[((sr * n_part + b) * n_groups + i) * 2];
+            const float nb = cnt / (float)n_part, mean_all = sum / cnt;
+            float css = 0.f;
+            for (int b = 0; b < n_part; ++b) {
+                const float* q = part + ((sr * n_part + b) * n_groups + i) * 2;
+                const float dm = q[0] / nb - mean_all;
+                css += q[1] + nb * dm * dm;
+            }
+            s_st[2 * i] = sum;
+            s_st[2 * i + 1] = css;
+            if (stats_out && blockIdx.x == 0) {
+                stats_out[2 * (sr * n_groups + i)] = sum;
+                stats_out[2 * (sr * n_groups + i) + 1] = css;
+            }
+        }
+        for (int i = threadIdx.x; !chan && i < n_groups; i += 256) {
             float S1 = 0.f, S2 = 0.f;
             for (int b = 0; b < n_part; ++b) {
                 const float* q = part + ((sr * n_part + b) * n_groups + i) * 2;
@@ -493,7 +512,7 @@ __global__ void bn_running_kernel(const float* __restrict__ stats, int C, float 
 template <typename TX, typename TY>
 static int launch_norm_apply(const TX* x, const float* gamma, const float* beta, long long R, long long rows_per_stat, int C,
                              int cpg, int n_groups, float eps, int relu, float* stats, TY* y, int d2s_H, int d2s_W,
-                             TY* xs, bool vec, hipStream_t st, const float* part = nullptr, int n_part = 0) {
+                             TY* xs, bool vec, hipStream_t st, const float* part = nullptr, int n_part = 0, int chan = 0) {
     const long long total = R * C;
     static const int rows_env = [] { const char* e = getenv("CSLGAN_NORM_ROWS"); return e ? atoi(e) : 1; }();
     const long long n_rg = R / rows_per_stat;
@@ -503,8 +522,8 @@ static int launch_norm_apply(const TX* x, const float* gamma, const float* beta,
         bx = bx > cap ? cap : (bx < 1 ? 1 : bx);
         const dim3 g2((unsigned)bx, (unsigned)n_rg), b2(256);
         const size_t lds = part ? sizeof(float) * 2 * n_groups : 0;
-        if (d2s_W > 0) hipLaunchKernelGGL((norm_apply_rows_kernel<true, TX, TY>), g2, b2, lds, st, x, gamma, beta, stats, rows_per_stat, C, cpg, n_groups, eps, relu, y, d2s_H, d2s_W, xs, part, n_part, stats);
-        else hipLaunchKernelGGL((norm_apply_rows_kernel<false, TX, TY>), g2, b2, lds, st, x, gamma, beta, stats, rows_per_stat, C, cpg, n_groups, eps, relu, y, 0, 0, (TY*)nullptr, part, n_part, stats);
+        if (d2s_W > 0) hipLaunchKernelGGL((norm_apply_rows_kernel<true, TX, TY>), g2, b2, lds, st, x, gamma, beta, stats, rows_per_stat, C, cpg, n_groups, eps, relu, y, d2s_H, d2s_W, xs, part, n_part, stats, chan);
+        else hipLaunchKernelGGL((norm_apply_rows_kernel<false, TX, TY>), g2, b2, lds, st, x, gamma, beta, stats, rows_per_stat, C, cpg, n_groups, eps, relu, y, 0, 0, (TY*)nullptr, part, n_part, stats, chan);
         return check_launch("norm_apply_rows_kernel");
     }
     long long nb = (total / 4 + 255) / 256;
@@ -638,6 +657,23 @@ int cslgan_groupnorm_act_f32(const float* x, const float* gamma, const float* be
     if (rc) return rc;
     return launch_norm(x, gamma, beta, (long long)N * HW, HW, C, C / groups, groups, eps, relu, stats_ws, y, H, d2s_W, x_shuffled,
                        (hipStream_t)stream, scratch);
+}
+
+// The apply half on statistics left by a conv epilogue (include/cslgan.h: cslgan_conv_t.gn_part).
+int cslgan_groupnorm_apply_parts_f32(const float* x, const float* gamma, const float* beta, int N, int HW, int C, int groups, float eps, int relu,
+                                     const float* part, int n_part, float* stats_ws, float* y, int d2s_W, float* x_shuffled, void* stream) {
+    CSLGAN_REQUIRE(x && gamma && beta && stats_ws && y && part, "groupnorm_apply_parts: null argument");
+    CSLGAN_REQUIRE(N > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, "groupnorm_apply_parts: C=%d not divisible by groups=%d", C, groups);
+    CSLGAN_REQUIRE(N <= 65535 && C <= 8192 && n_part >= 1 && n_part <= CSLGAN_NORM_PARTIAL_BLOCKS && HW == 64 * n_part,
+                   "groupnorm_apply_parts: needs HW == 64 * n_part <= %d * 64", CSLGAN_NORM_PARTIAL_BLOCKS);
+    int H = 0;
+    int rc = check_d2s(HW, C, d2s_W, x_shuffled, &H);
+    if (rc) return rc;
+    static const int rows_env = [] { const char* e = getenv("CSLGAN_NORM_ROWS"); return e ? atoi(e) : 1; }();
+    CSLGAN_REQUIRE(norm_vec_ok(x, y, x_shuffled, C, C / groups) && rows_env && (long long)HW * C < (1ll << 32) && 2 * (size_t)groups * sizeof(float) <= 32768,
+                   "groupnorm_apply_parts: shape not taken by the row-walking apply kernel");
+    return launch_norm_apply(x, gamma, beta, (long long)N * HW, HW, C, C / groups, groups, eps, relu, stats_ws, y, H, d2s_W, x_shuffled, true,
+                             (hipStream_t)stream, part, n_part, 1);
 }
 
 // GroupNorm (+ReLU) at the head of the bf16-stored chain (csrc/igemm_bf16s.hip): x fp32 or bfloat16, y (and x_shuffled) bfloat16;

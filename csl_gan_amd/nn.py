@@ -204,9 +204,12 @@ class HipGroupNormAct(nn.GroupNorm):
         super().__init__(groups, channels)
         self.relu = relu
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, part=None):
+        """part: (partials, slots per image) left by the conv that produced x (ops.gn_partials) — inference only."""
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
             y = HF.NormAct.apply(x, self.weight, self.bias, self.num_groups, self.eps, self.relu, None, None, 0.0)
+        elif part is not None and not ops.storage_bf16() and x.dtype == torch.float32:
+            y = ops.groupnorm_act(x, self.weight.detach(), self.bias.detach(), self.num_groups, eps=self.eps, relu=self.relu, part=part)
         else:
             # --storage_dtype bf16: the frozen generator of a D-step keeps its activations in HBM as bfloat16 from here on (the convs
             # answer bf16 inputs in kind); a differentiated forward (train_G) stays fp32
@@ -214,13 +217,16 @@ class HipGroupNormAct(nn.GroupNorm):
                                   out_dtype=torch.bfloat16 if ops.storage_bf16() else None)
         return _record_mask(self, y) if self.relu else y
 
-    def forward_shuffled(self, x):
+    def forward_shuffled(self, x, part=None):
         """(depth_to_space(act(norm(x))), depth_to_space(x)) — the inputs of ResBlockUp's convUp and shortcut."""
         if (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)) or _mask_recorder is not None:
             raw = x
             if ops.storage_bf16() and x.dtype == torch.float32 and not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
                 raw = ops.cast_bf16(x)        # what the fused kernel writes for the shortcut in the bf16 storage mode
             return HF.DepthToSpace.apply(self.forward_nhwc(x)), HF.DepthToSpace.apply(raw)
+        if part is not None and not ops.storage_bf16() and x.dtype == torch.float32:
+            return ops.groupnorm_act(x, self.weight.detach(), self.bias.detach(), self.num_groups, eps=self.eps, relu=self.relu,
+                                     d2s=True, want_raw=True, part=part)
         return ops.groupnorm_act(x, self.weight.detach(), self.bias.detach(), self.num_groups, eps=self.eps, relu=self.relu,
                                  d2s=True, want_raw=True, out_dtype=torch.bfloat16 if ops.storage_bf16() else None)
 

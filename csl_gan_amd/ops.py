@@ -75,6 +75,26 @@ def _split_scratch(d, rows, cols, red_channels, out):
     return ws
 
 
+_GN_FUSE = os.environ.get("CSLGAN_GN_FUSE", "1") == "1"            # A/B: GroupNorm statistics from the producing conv's epilogue
+
+
+class gn_partials:
+    """Ask the NEXT conv2d_fwd on this thread to leave GroupNorm(groups) partial statistics of its output behind
+    (cslgan_conv_t.gn_part): `with ops.gn_partials(32) as cell: y = conv(...)`, then `groupnorm_act(y, ..., part=cell.part)`.
+    cell.part stays None when the conv's shape or route cannot produce them — the normalisation then runs its own statistics pass."""
+    _req = None
+
+    def __init__(self, groups):
+        self.groups, self.part = int(groups), None
+
+    def __enter__(self):
+        self._prev, gn_partials._req = gn_partials._req, (self if _GN_FUSE else None)
+        return self
+
+    def __exit__(self, *a):
+        gn_partials._req = self._prev
+
+
 def set_f32_halo(on):
     """Switch the exact-fp32 form of the round-4 halo kernel on or off at run time (returns the previous setting): the same products
     summed in a different order, so the golden tests use it to prove which activation units sit within rounding of zero."""
@@ -525,6 +545,14 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, ou
         # the round-4 LDS-halo kernel reads the filter in step-major order: pre-split into bfloat16 pieces / pre-rounded / as an fp32 copy
         # (cached per parameter version)
         ws, repack = repack_cache.get({COMPUTE_BF16X3: "x3w", COMPUTE_BF16: "bf16w", COMPUTE_F32: "f32w"}[d.compute], w, (3 * w.numel() + 1) // 2, wkey, version=wversion)
+        req, gpart = gn_partials._req, None
+        if req is not None:
+            gn_partials._req = None         # one conv per request
+            cpg = K // req.groups if K % req.groups == 0 else 0
+            if act == ACT_NONE and cpg in (1, 2, 4, 8, 16, 32) and P * Q // 64 <= 64 and K % 64 == 0:
+                gpart = torch.empty(N * (P * Q // 64) * req.groups * 2, device=x.device, dtype=torch.float32)
+                d.gn_part, d.gn_groups = gpart.data_ptr(), req.groups
+                req.part = (gpart, P * Q // 64)
         _timed("conv2d_fwd", flop, nbytes, lambda: check(
             _lib.lib().cslgan_conv2d_fwd_x3_f32(C.byref(d), _p(x), _p(w), _p(ws), repack, _p(bias), _p(residual), act, _p(y), _stream()),
             "conv2d_fwd_x3"), exec_flop=xflop, tag=lambda: "N%d %dx%d C%d K%d R%d s%d" % (N, H, W, Cc, K, R, stride))
@@ -1329,7 +1357,7 @@ def _scratch(dev, n_stats_floats):
     return t
 
 
-def groupnorm_act(x, gamma, beta, groups, eps=1e-5, relu=True, return_stats=False, d2s=False, want_raw=False, out_dtype=None):
+def groupnorm_act(x, gamma, beta, groups, eps=1e-5, relu=True, return_stats=False, d2s=False, want_raw=False, out_dtype=None, part=None):
     """GroupNorm(+ReLU).  d2s=True: the output is written depth-to-space shuffled ([N,2H,2W,C/4], see depth_to_space);
     want_raw=True additionally returns the raw x in that layout (one read of x feeds ResBlockUp's convUp and shortcut).
     out_dtype torch.bfloat16 (or a bfloat16 x): bf16-stored outputs (set_storage_dtype), fp32 statistics and arithmetic."""
@@ -1346,6 +1374,12 @@ def groupnorm_act(x, gamma, beta, groups, eps=1e-5, relu=True, return_stats=Fals
     N, H, W, Cc = x.shape
     y, xs, dW = _d2s_out(x, d2s, want_raw)
     ws = torch.empty(2 * N * groups, device=x.device, dtype=torch.float32)
+    if part is not None:        # statistics left by the producing conv's epilogue (gn_partials): the apply launch alone
+        pt, n_part = part
+        check(_lib.lib().cslgan_groupnorm_apply_parts_f32(_p(x), _p(gamma), _p(beta), N, H * W, Cc, groups, float(eps), 1 if relu else 0,
+                                                          _p(pt), n_part, _p(ws), _p(y), dW, _p(xs), _stream()), "groupnorm_apply_parts")
+        out = (y, xs) if want_raw else y
+        return (out, ws) if return_stats else out
     sc = _scratch(x.device, 2 * N * groups)
     check(_lib.lib().cslgan_groupnorm_act_f32(_p(x), _p(gamma), _p(beta), N, H * W, Cc, groups, float(eps), 1 if relu else 0,
                                               _p(ws), _p(y), dW, _p(xs), _p(sc), _stream()), "groupnorm_act")

@@ -151,6 +151,17 @@ typedef struct {
      * the partials in a fixed order and applies bias / activation / mask (deterministic: no atomics).  NULL / 0: never split. */
     void* split_ws;
     int64_t split_ws_floats;
+    /* ABI v6: GroupNorm statistics from the conv's epilogue (cslgan_conv2d_fwd_x3_f32 only).  When gn_part is given, every
+     * workgroup of the halo kernel also leaves, for each of its 64-row patches and each of the gn_groups channel groups it covers,
+     * the pair (sum, centred sum of squares about the patch's own mean) of the values it stores:
+     *   gn_part[((n * (P*Q/64) + patch) * gn_groups + g) * 2 + {0, 1}]
+     * cslgan_groupnorm_apply_parts_f32 combines the P*Q/64 pairs of an image exactly (Chan et al.) — the statistics pass over the
+     * activation (one launch and one read of the tensor per normalisation) is gone.  Needs stride 1, P % 8 == Q % 8 == 0, act ==
+     * NONE, K % gn_groups == 0 with K / gn_groups in {1, 2, 4, 8, 16, 32} and a shape the halo kernel takes; anything else is an
+     * error (the caller then normalises with cslgan_groupnorm_act_f32). */
+    float* gn_part;
+    int32_t gn_groups;
+    int32_t _reserved;
 } cslgan_conv_t;
 
 /* y = act(conv(x, w) + bias [+ residual]).  Replaces torch.nn.Conv2d / nn.Linear forward at
@@ -357,6 +368,12 @@ int cslgan_fold_channels4_f32(const float* in, int64_t rows, int C, int unfold, 
  * partials in its prologue and publishes the final pairs to stats_ws) instead of four (zero, statistics with atomics, finalize,
  * apply).  One scratch must not be shared by launches on different streams. */
 #define CSLGAN_NORM_PARTIAL_BLOCKS 64
+/* The apply half of cslgan_groupnorm_act_f32 on statistics a conv epilogue left behind (cslgan_conv_t.gn_part): part holds
+ * n_part = HW/64 (sum, centred sum of squares) pairs per image and group; everything else as cslgan_groupnorm_act_f32
+ * (stats_ws receives the final pairs).  n_part <= CSLGAN_NORM_PARTIAL_BLOCKS. */
+int cslgan_groupnorm_apply_parts_f32(const float* x, const float* gamma, const float* beta, int N, int HW, int C, int groups,
+                                     float eps, int relu, const float* part, int n_part, float* stats_ws, float* y, int d2s_W,
+                                     float* x_shuffled, void* stream);
 int cslgan_groupnorm_act_f32(const float* x, const float* gamma, const float* beta, int N, int HW, int C,
                              int groups, float eps, int relu, float* stats_ws, float* y, int d2s_W, float* x_shuffled,
                              float* scratch, void* stream);

@@ -1243,3 +1243,62 @@ def test_x3_weight_gradient_4x4_outputs(group, scaled):
     assert e <= 4e-6, e
     if sq is not None:
         assert _err64(sq, ref.reshape(ref.shape[0], -1).pow(2).sum(1)) <= 2e-5
+
+
+GN_FUSE_CASES = [
+    # N, H, W, C, K, residual, what
+    (3, 8, 8, 32, 512, False, "one patch per image, 16 channels per group, four 128-filter tiles"),
+    (2, 16, 16, 64, 256, True, "four patches per image, residual added before the statistics"),
+    (2, 32, 32, 32, 128, False, "16 patches per image, groups of 4 = one float4 of a lane"),
+    (2, 64, 64, 16, 64, True, "64 patches per image (the limit), 64-filter tiles, groups of 2"),
+    (5, 8, 8, 16, 64, False, "odd image count: the last workgroup holds one valid patch"),
+]
+
+
+@pytest.mark.parametrize("case", GN_FUSE_CASES, ids=[c[-1][:36].replace(" ", "_") for c in GN_FUSE_CASES])
+@pytest.mark.parametrize("mode", ["bf16x3", "fp32"])
+def test_groupnorm_statistics_from_the_conv_epilogue(case, mode):
+    """cslgan_conv_t.gn_part + cslgan_groupnorm_apply_parts_f32: the halo kernel's epilogue leaves per-patch (sum, centred sum of
+    squares) pairs of the values it stores, the apply kernel combines them exactly.  Against GroupNorm on the SAME conv output with
+    its own statistics pass (<= 2e-6 of the output's scale: both are fp32 reductions in different orders) and against fp64
+    F.group_norm of the fp64 conv (the conv's own error bound); the plain and the depth-to-space output layouts."""
+    ops = _ops()
+    N, H, W, C, K, with_res, _ = case
+    g = torch.Generator().manual_seed(31 + sum(case[:5]))
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, 5, 5, generator=g) / (C * 25) ** 0.5
+    b = torch.randn(K, generator=g) * 3.0                    # means well away from zero: E[x^2] - mean^2 would cancel
+    res = torch.randn(N, K, H, W, generator=g) if with_res else None
+    gam, bet = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+    with ops.compute_dtype(mode):
+        with ops.gn_partials(32) as cell:
+            y = ops.conv2d_fwd(_nhwc(x), _krsc(w), b.cuda(), stride=1, pad=2, act=0, residual=None if res is None else _nhwc(res), wkey=("gn", id(w)))
+        assert cell.part is not None and cell.part[1] == H * W // 64
+        y_plain = ops.conv2d_fwd(_nhwc(x), _krsc(w), b.cuda(), stride=1, pad=2, act=0, residual=None if res is None else _nhwc(res), wkey=("gn", id(w)))
+    assert torch.equal(y, y_plain), "the statistics epilogue must not change the stored values"
+    own = ops.groupnorm_act(y, gam.cuda(), bet.cuda(), 32, relu=True)
+    fused = ops.groupnorm_act(y, gam.cuda(), bet.cuda(), 32, relu=True, part=cell.part)
+    scale = own.abs().max().item()
+    assert (fused - own).abs().max().item() <= 2e-6 * scale
+    o2, r2 = ops.groupnorm_act(y, gam.cuda(), bet.cuda(), 32, relu=True, d2s=True, want_raw=True)
+    f2, fr2 = ops.groupnorm_act(y, gam.cuda(), bet.cuda(), 32, relu=True, d2s=True, want_raw=True, part=cell.part)
+    assert (f2 - o2).abs().max().item() <= 2e-6 * scale and torch.equal(fr2, r2)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=2) + (0 if res is None else res.double())
+    ref = F.relu(F.group_norm(ref, 32, gam.double(), bet.double()))
+    assert _err64(fused.permute(0, 3, 1, 2), ref) <= (2e-5 if mode == "bf16x3" else 1e-5)
+
+
+def test_generator_forward_with_epilogue_statistics_matches_the_two_launch_form(monkeypatch):
+    """The frozen DCResNet generator forward (what a D-step runs): every GroupNorm reads the statistics its producing conv left
+    (eight statistics launches less per step) — same images as with CSLGAN_GN_FUSE off, to 5e-6 of their range."""
+    from csl_gan_amd import init_util, options
+    ops = _ops()
+    opt = options.parse(["CelebA", "-dpm", "gc", "-nms", "4", "-bs", "4", "-gd", "cuda:0", "-dd", "cuda:0", "-o", "/tmp/cslgan_gnf", "--manual_seed", "3", "--synthetic"])
+    G, _ = init_util.init_models(opt)
+    z = torch.randn(4, opt.g_latent_dim, device="cuda:0")
+    outs = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(ops, "_GN_FUSE", fuse)
+        with torch.no_grad(), ops.compute_dtype("fp32_auto"):
+            outs[fuse] = G(z).clone()
+    assert (outs[True] - outs[False]).abs().max().item() <= 5e-6 * 2.0

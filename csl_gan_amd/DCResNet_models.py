@@ -87,6 +87,16 @@ def _gn_fusable(x):
     return (not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32 and not ops.storage_bf16() and hnn._mask_recorder is None
 
 
+def _norm_as_affine(norm, x, part, conv):
+    """GroupNorm(+ReLU) `norm` of x folded into the staging of `conv` (the only consumer): (scale, shift, relu) tables from the
+    statistics x's producer left (ops.groupnorm_affine), or None when the statistics or the conv's route are not there."""
+    if part is None or not ops.in_affine_ok(x, conv.weight.permute(0, 2, 3, 1), conv.stride[0], conv.padding[0]):
+        return None
+    N, H, W, C = x.shape
+    sc, sh = ops.groupnorm_affine(part, norm.weight.detach(), norm.bias.detach(), norm.num_groups, norm.eps, N, H * W, C)
+    return sc, sh, bool(norm.relu)
+
+
 def _norm_act(bn, ch):
     return _BatchNormAct(ch) if bn else HipGroupNormAct(32, ch, relu=True)
 
@@ -114,17 +124,19 @@ class ResBlockUp(nn.Module):
         fuse = _gn_fusable(x)
         a_ps, x_ps = self.bn1.forward_shuffled(x, part=x_part) if x_part is not None else self.bn1.forward_shuffled(x)
         s = self.shortcut.forward_shuffled(x_ps)        # 1x1 conv over the C/4 shuffled channels, full resolution
+        affine = None
         if fuse and isinstance(self.bn2, HipGroupNormAct):
             with ops.gn_partials(self.bn2.num_groups) as cell:
                 o = self.convUp.forward_shuffled(a_ps)
-            h = self.bn2.forward_nhwc(o, part=cell.part)
+            affine = _norm_as_affine(self.bn2, o, cell.part, self.conv)
+            h = o if affine is not None else self.bn2.forward_nhwc(o, part=cell.part)
         else:
             h = self.bn2.forward_nhwc(self.convUp.forward_shuffled(a_ps))
         if fuse and isinstance(next_norm, HipGroupNormAct):
             with ops.gn_partials(next_norm.num_groups) as cell:
-                out = self.conv.forward_nhwc(h, residual=s)
+                out = self.conv.forward_nhwc(h, residual=s, in_affine=affine)
             return out, cell.part
-        return self.conv.forward_nhwc(h, residual=s), None
+        return self.conv.forward_nhwc(h, residual=s, in_affine=affine), None
 
     def forward(self, x):
         if x.is_cuda:
@@ -154,6 +166,9 @@ class DCResNetGenerator(Generator):
         for i, blk in enumerate(self.blocks):           # each block leaves the statistics the NEXT normalisation needs (frozen forward)
             nxt = self.blocks[i + 1].bn1 if i + 1 < len(self.blocks) else self.bn
             x, part = blk.forward_nhwc_parts(x, part, nxt)
+        affine = _norm_as_affine(self.bn, x, part, self.convOut) if part is not None else None
+        if affine is not None:                          # the last normalisation rides in the output conv's staging
+            return HF.nchw_view(self.convOut.forward_nhwc(x, in_affine=affine))
         h = self.bn.forward_nhwc(x, part=part) if part is not None else self.bn.forward_nhwc(x)
         return HF.nchw_view(self.convOut.forward_nhwc(h))
 

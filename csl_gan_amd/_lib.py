@@ -22,7 +22,7 @@ EXPORTS = [
     "cslgan_conv2d_wgrad_scaled_f32", "cslgan_conv2d_wgrad_blocks_f32", "cslgan_conv2d_wgrad_sqnorm_gram_f32", "cslgan_conv2d_wgrad_skinny_f32", "cslgan_conv2d_s2_fwd_f32",
     "cslgan_conv2d_dgrad_x3_f32", "cslgan_conv2d_s2_fwd_x3_f32", "cslgan_u8_to_f32_nhwc", "cslgan_split_filter_x3_f32",
     "cslgan_depth_to_space_f32", "cslgan_fold_channels4_f32",
-    "cslgan_bias_grad_grouped_f32", "cslgan_act_bwd_f32", "cslgan_groupnorm_act_f32", "cslgan_groupnorm_apply_parts_f32", "cslgan_batchnorm_act_f32", "cslgan_batchnorm_eval_act_f32",
+    "cslgan_bias_grad_grouped_f32", "cslgan_act_bwd_f32", "cslgan_groupnorm_act_f32", "cslgan_groupnorm_apply_parts_f32", "cslgan_groupnorm_affine_parts_f32", "cslgan_batchnorm_act_f32", "cslgan_batchnorm_eval_act_f32",
     "cslgan_norm_act_bwd_f32", "cslgan_norm_bwd_ws_floats",
     "cslgan_adam_step_f32", "cslgan_adam_step_dev_f32", "cslgan_adam_multi_f32",
     "cslgan_segment_means_f32", "cslgan_segment_means_bwd_f32", "cslgan_dstep_stats_f32", "cslgan_grad_log_stats_f32",
@@ -44,7 +44,7 @@ class SegsT(C.Structure):
 
 class ConvT(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "compute", "P", "Q")] + [("split_ws", C.c_void_p), ("split_ws_floats", C.c_int64), ("gn_part", C.c_void_p), ("gn_groups", C.c_int32), ("_reserved", C.c_int32)]
+                ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "compute", "P", "Q")] + [("split_ws", C.c_void_p), ("split_ws_floats", C.c_int64), ("gn_part", C.c_void_p), ("gn_groups", C.c_int32), ("in_relu", C.c_int32), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p)]
 
 
 _lib = None
@@ -100,6 +100,7 @@ def lib():
         "cslgan_bias_grad_grouped_f32": [vp, i32, i32, i32, i32, f32, vp, vp, vp],
         "cslgan_act_bwd_f32": [vp, vp, i64, f32, vp, vp],
         "cslgan_groupnorm_act_f32": [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, i32, vp, vp, vp],
+        "cslgan_groupnorm_affine_parts_f32": [vp, i32, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp],
         "cslgan_groupnorm_apply_parts_f32": [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, i32, vp, vp, i32, vp, vp],
         "cslgan_batchnorm_act_f32": [vp, vp, vp, i64, i32, f32, i32, f32, vp, vp, vp, vp, i64, i32, vp, vp, vp],
         "cslgan_batchnorm_eval_act_f32": [vp, vp, vp, vp, vp, i64, i32, f32, i32, vp, vp, i64, i32, vp, vp],

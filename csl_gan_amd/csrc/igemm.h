@@ -69,6 +69,9 @@ struct KcParams {
     float* part;            // igemm_x3h: scratch for channel-split partial sums (cslgan_conv_t.split_ws) or null
     long long part_floats;  // its capacity
     long long out_floats;   // floats of the output tensor (0: unknown, never split)
+    const float* in_scale;  // igemm_x3h (single class) / igemm_skinny: per-(image, channel) affine map applied while staging a
+    const float* in_shift;  // (cslgan_conv_t.in_scale / in_shift), or null
+    int in_relu;
     float* gn_part;         // igemm_x3h (single class): per-patch GroupNorm partial statistics of the stored values (cslgan_conv_t.gn_part)
     int gn_cpg;             // channels per group
     int gn_slots;           // patches per image (OH * OW / 64)

@@ -355,7 +355,7 @@ int launch_x3h(KcParams& p, hipStream_t st);
 
 int launch_kc_bf16(KcParams& p, hipStream_t st, long long out_elems) {
     if (x3h_eligible(p)) return launch_x3h(p, st);      // needs the pre-split / pre-rounded filter (p.w3)
-    if (p.gn_part) { set_error("conv2d_fwd: gn_part given but the shape does not run on the LDS-halo kernel"); return CSLGAN_ERR_INVALID_ARG; }
+    if (p.gn_part || p.in_scale) { set_error("conv2d_fwd: gn_part / in_scale given but the shape does not run on the LDS-halo kernel"); return CSLGAN_ERR_INVALID_ARG; }
     if (p.acc_classes) { set_error("igemm_kc_bf16: accumulated classes only run on the LDS-halo form"); return CSLGAN_ERR_INVALID_ARG; }
     for (int c = 0; c < p.n_cls; ++c) {
         KcClass& k = p.cls[c];

@@ -444,13 +444,16 @@ int launch_kc(KcParams& p, hipStream_t st, long long out_elems) {
     }
     // 1..4 output channels: vector-ALU kernel, fp32 in every compute mode (a 32-wide MFMA tile would be 29/32 padding)
     static const int skinny_env = [] { const char* e = getenv("CSLGAN_KC_SKINNY"); return e ? atoi(e) : 1; }();
-    if (skinny_env && !p.acc_classes && skinny_eligible(p)) return launch_skinny(p, st);
+    if (skinny_env && !p.acc_classes && skinny_eligible(p)) {
+        if (p.gn_part) { set_error("conv2d_fwd: gn_part is not produced by the 1..4-output-channel kernel"); return CSLGAN_ERR_INVALID_ARG; }
+        return launch_skinny(p, st);
+    }
     if (p.a_bf16) { set_error("igemm_kc: a bfloat16-stored input is only taken by the 1..4-output-channel kernel (64 input channels, stride 1)"); return CSLGAN_ERR_INVALID_ARG; }
     if (p.bf16) {
         return launch_kc_bf16(p, st, out_elems);
     }
     if (p.w3 && x3h_eligible(p)) return launch_x3h(p, st);          // exact fp32 on the round-4 halo kernel (step-major fp32 filter copy in p.w3)
-    if (p.gn_part) { set_error("conv2d_fwd: gn_part given but the shape does not run on the LDS-halo kernel"); return CSLGAN_ERR_INVALID_ARG; }
+    if (p.gn_part || p.in_scale) { set_error("conv2d_fwd: gn_part / in_scale given but the shape does not run on the LDS-halo kernel"); return CSLGAN_ERR_INVALID_ARG; }
     static const int halo_env = [] { const char* e = getenv("CSLGAN_KC_HALO"); return e ? atoi(e) : 1; }();
     if (halo_env && halo_eligible(p)) return launch_halo(p, st);
     static const int patch_env = [] { const char* e = getenv("CSLGAN_KC_PATCH"); return e ? atoi(e) : 1; }();
@@ -539,6 +542,10 @@ static int conv2d_fwd_impl(const cslgan_conv_t* c, const float* x, const float* 
     if (rc) return rc;
     CSLGAN_REQUIRE(act >= 0 && act <= 3, "conv2d_fwd: unknown activation %d", act);
     static const int c3_env = [] { const char* e = getenv("CSLGAN_C3"); return e ? atoi(e) : 1; }();
+    if (c->in_scale) {      // the input affine map is applied by the halo kernel's and the 1..4-output kernel's staging only
+        CSLGAN_REQUIRE(c->in_shift && !x_bf16 && c->stride == 1 && c->R * c->S > 1 && aligned16(c->in_scale) && aligned16(c->in_shift),
+                       "conv2d_fwd: in_scale needs in_shift, stride 1, a filter larger than 1x1 and 16-byte aligned tables");
+    }
     if (c->gn_part) {       // GroupNorm partials come from the halo kernel's epilogue only (cslgan_conv_t.gn_part)
         const int cpg = c->gn_groups > 0 && c->K % c->gn_groups == 0 ? c->K / c->gn_groups : 0;
         CSLGAN_REQUIRE(w3 && !x_bf16 && c->stride == 1 && act == CSLGAN_ACT_NONE && c->P % 8 == 0 && c->Q % 8 == 0 && cpg >= 1 && cpg <= 32 &&
@@ -563,6 +570,7 @@ static int conv2d_fwd_impl(const cslgan_conv_t* c, const float* x, const float* 
     p.a_bf16 = x_bf16;
     p.part = reinterpret_cast<float*>(c->split_ws); p.part_floats = c->split_ws_floats; p.out_floats = (long long)c->N * c->P * c->Q * c->K;
     if (c->gn_part) { p.gn_part = c->gn_part; p.gn_cpg = c->K / c->gn_groups; p.gn_slots = c->P * c->Q / 64; p.part = nullptr; }
+    if (c->in_scale) { p.in_scale = c->in_scale; p.in_shift = c->in_shift; p.in_relu = c->in_relu; p.part = nullptr; }
     p.n_cls = 1;
     KcClass& k = p.cls[0];
     k.M = c->N * c->P * c->Q; k.OHc = c->P; k.OWc = c->Q; k.T = c->R * c->S; k.Kdim = k.T * c->C; k.w_off = 0; k.oy0 = k.ox0 = 0;

@@ -75,6 +75,15 @@ __global__ __launch_bounds__(256) void igemm_skinny_kernel(const KcParams p) {
     } else {
         constexpr int HREG = (SK_HALO * 16 + 255) / 256;
         float4 rh[HREG];
+        unsigned okm = 0;
+        // cslgan_conv_t.in_scale: GroupNorm (+ ReLU) of the producing layer as a per-(image, channel) affine map applied on the way
+        // into LDS (one patch = one image, and a thread keeps the same four channels for all its slots); padding stays zero
+        const bool aff = p.in_scale != nullptr;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (aff) {
+            sc = *reinterpret_cast<const float4*>(p.in_scale + rc0.img * SK_C + cl * 4);
+            sh = *reinterpret_cast<const float4*>(p.in_shift + rc0.img * SK_C + cl * 4);
+        }
 #pragma unroll
         for (int j = 0; j < HREG; ++j) {
             const int idx = tid + 256 * j;
@@ -82,11 +91,20 @@ __global__ __launch_bounds__(256) void igemm_skinny_kernel(const KcParams p) {
             const int hy = pix / HW_, hx = pix - hy * HW_;
             const int iy = y0 + hy, ix = x0 + hx;
             const bool ok = pix < hpix && (unsigned)iy < (unsigned)p.VH && (unsigned)ix < (unsigned)p.VW;
+            okm |= (ok ? 1u : 0u) << j;
             rh[j] = sbuf_load4(a_rsrc, ok ? 4u * (unsigned)(img_base + (iy * p.AW + ix) * SK_C + c4 * 4) : SOOB);
         }
 #pragma unroll
         for (int j = 0; j < HREG; ++j) {
             const int idx = tid + 256 * j;
+            if (aff) {
+                const float lo = p.in_relu ? 0.f : -__builtin_inff();
+                const bool in = (okm >> j) & 1u;
+                rh[j].x = in ? fmaxf(fmaf(sc.x, rh[j].x, sh.x), lo) : 0.f;
+                rh[j].y = in ? fmaxf(fmaf(sc.y, rh[j].y, sh.y), lo) : 0.f;
+                rh[j].z = in ? fmaxf(fmaf(sc.z, rh[j].z, sh.z), lo) : 0.f;
+                rh[j].w = in ? fmaxf(fmaf(sc.w, rh[j].w, sh.w), lo) : 0.f;
+            }
             if ((idx >> 4) < hpix) Hs[idx] = rh[j];
         }
     }

@@ -80,7 +80,11 @@ __device__ __forceinline__ float4 xload4(__amdgpu_buffer_rsrc_t r, unsigned byte
 
 // One workgroup = two 64-row patches (128 rows) x BN output channels; waves 2 (M: one patch each) x 2 (N).
 // LDS: halo images [buffer][piece][patch][pixel][2 x 16 B], 2 x NP x 9216 B (55 KB for NP = 3: two workgroups per CU).
-template <int BN, int NP, bool GEN>
+// AFF (single-class launches): the staged operand is max(in_scale[img][c] * a + in_shift[img][c], in_relu ? 0 : -inf) — GroupNorm
+// (+ ReLU) of the producing layer applied between the global load and the split into pieces (cslgan_conv_t.in_scale); padding
+// pixels stay zero.  A template parameter, not a flag: a conditional table load inside the chunk's fetch region would make
+// SIInsertWaitcnts merge the counted waits of the loop conservatively (the lesson of the loop below).
+template <int BN, int NP, bool GEN, bool AFF = false>
 __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
     constexpr int BM = 128, TM = 2, TN = BN / 64;
     // NP = 0: EXACT fp32 (round 4, second half): the same loop on v_mfma_f32_32x32x2_f32 — fp32 halo pixels (16 channels = 64 B) in ONE
@@ -150,6 +154,8 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
         constexpr int HREG = (2 * XH_MAX * 4 + 255) / 256;
         unsigned h_goff[HREG];
         int h_lds[HREG];                                       // uint2 index into a piece image, -1 = nothing to write
+        unsigned pp_mask = 0;                                  // AFF: bit j = the patch of staging slot j
+        int aff_off[2] = {0, 0};                               // AFF: float index of this thread's 4 channels in the patch's image row of the tables
         {
             int p_img[2], p_y0[2], p_x0[2];
             bool p_ok[2];
@@ -159,6 +165,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
                 p_ok[pp] = m < M;
                 const RowCoord rc = kc_decode_row(p_ok[pp] ? m : 0, OHc, OWc, quad ? 0 : 1);   // first row of the patch = its top-left pixel
                 p_img[pp] = rc.img * img_stride;
+                if (AFF) aff_off[pp] = rc.img * p.AC + (tid & 3) * 4;
                 p_y0[pp] = rc.oy + kc.ty_min;
                 p_x0[pp] = rc.ox + kc.tx_min;
             }
@@ -168,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
                 const int idx = tid + 256 * j;
                 const int ch = idx & 3, pixg = idx >> 2;
                 const int pp = pixg >= hpix ? 1 : 0;
+                pp_mask |= (unsigned)pp << j;
                 const int pix = pixg - pp * hpix;
                 const int si = quad ? pix / hpix_img : 0;      // sub-image of a quad patch
                 const int rem = pix - si * hpix_img;
@@ -187,15 +195,37 @@ __global__ __launch_bounds__(256, 2) void igemm_x3h_kernel(const KcParams p) {
         const int n_cc_all = p.AC >> 4;
         const int cc_lo = cs > 1 ? split * n_cc_all / cs : 0;
         const int n_cc = cs > 1 ? (split + 1) * n_cc_all / cs - cc_lo : n_cc_all;      // this workgroup's chunks: cc_lo .. cc_lo + n_cc - 1
+        const float lo = (AFF && !p.in_relu) ? -__builtin_inff() : 0.f;
         float4 rh[HREG];
+        // AFF: scale / shift of the thread's 4 channels, per patch, for the chunk in flight.  Four named registers and selects: as
+        // arrays picked by the slot's patch bit they were "promoted" to LDS (dynamic index), with an lgkmcnt(0) in every commit
+        float4 sc0, sc1, sh0, sh1;
+        // buffer descriptors made once: with plain pointers the compiler re-read p.in_scale / p.in_shift from the kernel arguments
+        // inside the loop (s_load: lgkmcnt) and every such read drained the LDS fragment reads in flight (+10 % kernel time)
+        const __amdgpu_buffer_rsrc_t sc_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(AFF ? p.in_scale : p.a), 0, 0xFFFFFFF0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t sh_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(AFF ? p.in_shift : p.a), 0, 0xFFFFFFF0u, 0x00020000);
         auto fetch_halo = [&](int cc) {
             const unsigned co = 64u * (unsigned)(cc + cc_lo);  // 16 channels x 4 B per chunk
 #pragma unroll
             for (int j = 0; j < HREG; ++j) rh[j] = xload4(a_rsrc, h_goff[j] + co);      // an invalid element sits at XFAR: + co (< 64 KB) stays out of range
+            if (AFF) {
+                sc0 = xload4(sc_rsrc, 4u * (unsigned)aff_off[0] + co); sh0 = xload4(sh_rsrc, 4u * (unsigned)aff_off[0] + co);
+                sc1 = xload4(sc_rsrc, 4u * (unsigned)aff_off[1] + co); sh1 = xload4(sh_rsrc, 4u * (unsigned)aff_off[1] + co);
+            }
         };
         auto commit_halo = [&](int buf) {
 #pragma unroll
             for (int j = 0; j < HREG; ++j) {
+                if (AFF) {
+                    const bool second = (pp_mask >> j) & 1u;
+                    // padding stays zero (it pads the NORMALISED activation): scale and shift are multiplied by 0 there — the loaded
+                    // value of such a slot is the buffer's out-of-range 0, so max(0 * 0 + 0, lo) = 0; arithmetic, not a branch
+                    const float m = h_goff[j] != XFAR ? 1.f : 0.f;
+                    rh[j].x = fmaxf(fmaf((second ? sc1.x : sc0.x) * m, rh[j].x, (second ? sh1.x : sh0.x) * m), lo);
+                    rh[j].y = fmaxf(fmaf((second ? sc1.y : sc0.y) * m, rh[j].y, (second ? sh1.y : sh0.y) * m), lo);
+                    rh[j].z = fmaxf(fmaf((second ? sc1.z : sc0.z) * m, rh[j].z, (second ? sh1.z : sh0.z) * m), lo);
+                    rh[j].w = fmaxf(fmaf((second ? sc1.w : sc0.w) * m, rh[j].w, (second ? sh1.w : sh0.w) * m), lo);
+                }
                 if (h_lds[j] >= 0) {
                     uint2* img0 = reinterpret_cast<uint2*>(&Hs[buf][0][0]);
                     if (F32) {
@@ -657,6 +687,10 @@ int launch_x3h(KcParams& p, hipStream_t st) {
         gen = gen || quad || k.ay_mul > 1 || k.ax_mul > 1;
     }
     if (p.gn_part && gen) { set_error("igemm_x3h: GroupNorm partials need a single-class stride-1 launch"); return CSLGAN_ERR_INVALID_ARG; }
+    if (p.in_scale && (gen || p.bf16 == 1 || !p.in_shift || !aligned16(p.in_scale) || !aligned16(p.in_shift))) {
+        set_error("igemm_x3h: the input affine map needs a single-class stride-1 launch in fp32 or three-piece arithmetic and 16-byte aligned tables");
+        return CSLGAN_ERR_INVALID_ARG;
+    }
     p.tiles_m = tm;
     p.ksplit = 1;
     p.pair_mode = 0;
@@ -706,9 +740,16 @@ int launch_x3h(KcParams& p, hipStream_t st) {
     if (p.csplit > 1)       // "/sN": N workgroups per tile + the reduce launch (the device kernel name is the part before the slash)
         note_kernel(x3 ? "igemm_x3h_kernel<%d,3,%s>/s%d" : (p.bf16 ? "igemm_x3h_kernel<%d,1,%s>/s%d" : "igemm_x3h_kernel<%d,0,%s>/s%d"), wide ? 128 : 64,
                     gen ? "true" : "false", p.csplit);
+    else if (p.in_scale)
+        note_kernel(x3 ? "igemm_x3h_kernel<%d,3,false,true>" : "igemm_x3h_kernel<%d,0,false,true>", wide ? 128 : 64);
     else
         note_kernel(x3 ? "igemm_x3h_kernel<%d,3,%s>" : (p.bf16 ? "igemm_x3h_kernel<%d,1,%s>" : "igemm_x3h_kernel<%d,0,%s>"), wide ? 128 : 64, gen ? "true" : "false");
-    if (!p.bf16) {
+    if (p.in_scale) {
+        if (x3 && wide) hipLaunchKernelGGL((igemm_x3h_kernel<128, 3, false, true>), grid, block, 0, st, p);
+        else if (x3) hipLaunchKernelGGL((igemm_x3h_kernel<64, 3, false, true>), grid, block, 0, st, p);
+        else if (wide) hipLaunchKernelGGL((igemm_x3h_kernel<128, 0, false, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((igemm_x3h_kernel<64, 0, false, true>), grid, block, 0, st, p);
+    } else if (!p.bf16) {
         if (wide && gen) hipLaunchKernelGGL((igemm_x3h_kernel<128, 0, true>), grid, block, 0, st, p);
         else if (wide) hipLaunchKernelGGL((igemm_x3h_kernel<128, 0, false>), grid, block, 0, st, p);
         else if (gen) hipLaunchKernelGGL((igemm_x3h_kernel<64, 0, true>), grid, block, 0, st, p);

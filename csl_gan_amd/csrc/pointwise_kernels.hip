@@ -659,6 +659,64 @@ int cslgan_groupnorm_act_f32(const float* x, const float* gamma, const float* be
                        (hipStream_t)stream, scratch);
 }
 
+// (scale, shift) of every (image, channel) from the conv-epilogue partials: one workgroup per image.  The n_part (<= 64) pairs of
+// a group are read by 256 / n_groups threads in parallel (a lone thread per channel walking all 64 slots took 23-33 us on the
+// generator's last block: latency, not bytes), combined as in the apply kernel's prologue (Chan), in a fixed order.
+__global__ __launch_bounds__(256) void gn_affine_parts_kernel(const float* __restrict__ part, int n_part, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int C, int cpg, float cnt, float eps,
+                                                              float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ float s_red[256];
+    __shared__ float s_mean[256], s_rstd[256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int n_groups = C / cpg;                       // <= 256 (host)
+    const int ways = 256 / n_groups;                    // threads per group
+    const int g = tid % n_groups, k = tid / n_groups;
+    const float* base = part + (long long)n * n_part * n_groups * 2;
+    const float nb = cnt / (float)n_part;
+    float sum = 0.f;
+    if (k < ways) for (int b = k; b < n_part; b += ways) sum += base[(b * n_groups + g) * 2];
+    s_red[tid] = sum;
+    __syncthreads();
+    if (tid < n_groups) {
+        float t = 0.f;
+        for (int j = 0; j < ways; ++j) t += s_red[j * n_groups + tid];
+        s_mean[tid] = t / cnt;
+    }
+    __syncthreads();
+    float css = 0.f;
+    if (k < ways) {
+        const float mean = s_mean[g];
+        for (int b = k; b < n_part; b += ways) {
+            const float* q = base + (b * n_groups + g) * 2;
+            const float dm = q[0] / nb - mean;
+            css += q[1] + nb * dm * dm;
+        }
+    }
+    s_red[tid] = css;
+    __syncthreads();
+    if (tid < n_groups) {
+        float t = 0.f;
+        for (int j = 0; j < ways; ++j) t += s_red[j * n_groups + tid];
+        s_rstd[tid] = rsqrtf(t / cnt + eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const float a = gamma[c] * s_rstd[c / cpg];
+        scale[(long long)n * C + c] = a;
+        shift[(long long)n * C + c] = beta[c] - s_mean[c / cpg] * a;
+    }
+}
+
+int cslgan_groupnorm_affine_parts_f32(const float* part, int n_part, const float* gamma, const float* beta, int N, int HW, int C, int groups,
+                                      float eps, float* scale, float* shift, void* stream) {
+    CSLGAN_REQUIRE(part && gamma && beta && scale && shift, "groupnorm_affine_parts: null argument");
+    CSLGAN_REQUIRE(N > 0 && HW > 0 && C > 0 && groups > 0 && groups <= 256 && C % groups == 0 && n_part >= 1 && HW == 64 * n_part,
+                   "groupnorm_affine_parts: needs C %% groups == 0, groups <= 256 and HW == 64 * n_part");
+    hipLaunchKernelGGL(gn_affine_parts_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, part, n_part,
+                       gamma, beta, C, C / groups, (float)HW * (float)(C / groups), eps, scale, shift);
+    return check_launch("gn_affine_parts_kernel");
+}
+
 // The apply half on statistics left by a conv epilogue (include/cslgan.h: cslgan_conv_t.gn_part).
 int cslgan_groupnorm_apply_parts_f32(const float* x, const float* gamma, const float* beta, int N, int HW, int C, int groups, float eps, int relu,
                                      const float* part, int n_part, float* stats_ws, float* y, int d2s_W, float* x_shuffled, void* stream) {

@@ -487,9 +487,39 @@ def _conv2d_fwd_stored(x, w, bias, stride, pad, residual, act, out, wkey, alg_sc
     return y
 
 
+def in_affine_ok(x, w, stride, pad):
+    """Can conv2d_fwd(x, w, in_affine=...) fold a per-(image, channel) affine map into its staging?  The stride-1 launches of the
+    LDS-halo kernel (fp32 / three-piece arithmetic) and the 1..4-output-channel kernel (64 input channels)."""
+    if not (_GN_FUSE and x.is_cuda and x.dtype == torch.float32 and stride == 1 and x.dim() == 4):
+        return False
+    N, H, W, Cc = x.shape
+    K, R, S, _ = w.shape
+    P, Q = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
+    if R * S == 1 or P % 8 or Q % 8:
+        return False
+    if K <= 4:
+        return Cc == 64 and R * S <= 9
+    comp = _kc_compute(N * P * Q, K, R * S * Cc)
+    return (comp == COMPUTE_BF16X3 or (comp == COMPUTE_F32 and _F32_HALO)) and Cc % 16 == 0 and K >= 64 and K % 4 == 0
+
+
+def groupnorm_affine(part, gamma, beta, groups, eps, N, HW, Cc):
+    """(scale, shift)[N, C] of GroupNorm(groups) from a conv epilogue's partial statistics (gn_partials): the normalisation as the
+    affine map conv2d_fwd(in_affine=...) applies while it stages its input."""
+    pt, n_part = part
+    sc = torch.empty((N, Cc), device=pt.device, dtype=torch.float32)
+    sh = torch.empty((N, Cc), device=pt.device, dtype=torch.float32)
+    check(_lib.lib().cslgan_groupnorm_affine_parts_f32(_p(pt), n_part, _p(gamma), _p(beta), N, HW, Cc, groups, float(eps), _p(sc), _p(sh),
+                                                       _stream()), "groupnorm_affine_parts")
+    return sc, sh
+
+
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, out=None, wkey=None, alg_scale=1.0, wversion=None,
-               out_dtype=None):
+               out_dtype=None, in_affine=None):
     """y[N,P,Q,K] = act(conv(x[N,H,W,C], w[K,R,S,C]) + bias [+ residual[N,P,Q,K]]).
+
+    in_affine = (scale[N,C], shift[N,C], relu): x is replaced by max(scale * x + shift, 0 if relu else -inf) while it is staged
+    (cslgan_conv_t.in_scale; only where in_affine_ok says so — an error otherwise).
 
     alg_scale: FLOP the reference spends on this layer / FLOP of this call (4 for an UpsampleConv's conv, which the
     reference runs over four identical channel groups) — bench accounting only.
@@ -514,6 +544,12 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, residual=None, act=ACT_NONE, ou
         _chk(residual, "residual")
         if tuple(residual.shape) != (N, P, Q, K):
             raise RuntimeError("conv2d_fwd: residual shape %s, expected %s" % (tuple(residual.shape), (N, P, Q, K)))
+    if in_affine is not None:
+        a_sc, a_sh, a_relu = in_affine
+        _chk(a_sc, "in_affine scale"); _chk(a_sh, "in_affine shift")
+        if tuple(a_sc.shape) != (N, Cc) or tuple(a_sh.shape) != (N, Cc):
+            raise RuntimeError("conv2d_fwd: in_affine tables must be [N, C] = [%d, %d]" % (N, Cc))
+        d.in_scale, d.in_shift, d.in_relu = a_sc.data_ptr(), a_sh.data_ptr(), 1 if a_relu else 0
     flop = 2.0 * N * P * Q * K * R * S * c_alg * alg_scale    # the dense conv the reference executes
     nbytes = 4.0 * (N * H * W * c_alg + K * R * S * c_alg + N * P * Q * K)
     xflop = 2.0 * N * P * Q * K * R * S * Cc

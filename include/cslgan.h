@@ -161,7 +161,15 @@ typedef struct {
      * error (the caller then normalises with cslgan_groupnorm_act_f32). */
     float* gn_part;
     int32_t gn_groups;
-    int32_t _reserved;
+    int32_t in_relu;
+    /* ABI v6: a per-(sample, channel) affine map (+ ReLU when in_relu != 0) applied to x while it is staged —
+     *   x'[n][h][w][c] = max(in_scale[n*C + c] * x[n][h][w][c] + in_shift[n*C + c], in_relu ? 0 : -inf), zero padding AFTER the map —
+     * i.e. GroupNorm + ReLU folded into the consuming conv (cslgan_groupnorm_affine_parts_f32 makes the two tables from the
+     * producing conv's statistics): the normalised activation is never written to HBM.  Taken by cslgan_conv2d_fwd_x3_f32 on the
+     * shapes the LDS-halo kernel runs and by the 1..4-output-channel kernel behind cslgan_conv2d_fwd_f32 (64 input channels);
+     * anything else is an error.  NULL: x is used as it is. */
+    const float* in_scale;
+    const float* in_shift;
 } cslgan_conv_t;
 
 /* y = act(conv(x, w) + bias [+ residual]).  Replaces torch.nn.Conv2d / nn.Linear forward at
@@ -371,6 +379,10 @@ int cslgan_fold_channels4_f32(const float* in, int64_t rows, int C, int unfold, 
 /* The apply half of cslgan_groupnorm_act_f32 on statistics a conv epilogue left behind (cslgan_conv_t.gn_part): part holds
  * n_part = HW/64 (sum, centred sum of squares) pairs per image and group; everything else as cslgan_groupnorm_act_f32
  * (stats_ws receives the final pairs).  n_part <= CSLGAN_NORM_PARTIAL_BLOCKS. */
+/* The same statistics as a per-(sample, channel) affine map for cslgan_conv_t.in_scale / in_shift:
+ * scale[n*C + c] = gamma[c] * rstd(n, group of c), shift[n*C + c] = beta[c] - mean(n, group of c) * scale[n*C + c]. */
+int cslgan_groupnorm_affine_parts_f32(const float* part, int n_part, const float* gamma, const float* beta, int N, int HW, int C, int groups,
+                                      float eps, float* scale, float* shift, void* stream);
 int cslgan_groupnorm_apply_parts_f32(const float* x, const float* gamma, const float* beta, int N, int HW, int C, int groups,
                                      float eps, int relu, const float* part, int n_part, float* stats_ws, float* y, int d2s_W,
                                      float* x_shuffled, void* stream);

@@ -1302,3 +1302,46 @@ def test_generator_forward_with_epilogue_statistics_matches_the_two_launch_form(
         with torch.no_grad(), ops.compute_dtype("fp32_auto"):
             outs[fuse] = G(z).clone()
     assert (outs[True] - outs[False]).abs().max().item() <= 5e-6 * 2.0
+
+
+AFFINE_CASES = [
+    # N, H, W, C, K, R, residual, what
+    (3, 8, 8, 512, 128, 5, False, "32 chunks, one patch per image"),
+    (2, 32, 32, 128, 128, 5, True, "the block's second conv: residual epilogue, 16 patches per image"),
+    (3, 16, 16, 64, 64, 5, False, "64-filter tiles, an odd image count (a workgroup with one valid patch)"),
+    (2, 64, 64, 64, 3, 3, False, "the generator's output conv: the 1..4-output-channel kernel"),
+    (5, 16, 16, 64, 2, 3, False, "two output channels, 3x3, odd image count"),
+]
+
+
+@pytest.mark.parametrize("case", AFFINE_CASES, ids=[c[-1][:36].replace(" ", "_") for c in AFFINE_CASES])
+@pytest.mark.parametrize("mode", ["fp32_auto", "fp32"])
+def test_groupnorm_folded_into_the_consuming_conv(case, mode):
+    """cslgan_conv_t.in_scale / in_shift: conv(relu(GroupNorm(x))) with the normalisation applied while the conv stages x, against
+    the two-kernel form on the same x (GroupNorm written to HBM, then the conv): <= 4e-6 of the output scale (three-piece / fp32
+    products of inputs that differ by one fp32 rounding), zero padding applied AFTER the map (border pixels are the ones that show
+    a wrong order), and against fp64."""
+    ops = _ops()
+    N, H, W, C, K, R, with_res, _ = case
+    g = torch.Generator().manual_seed(57 + sum(case[:6]))
+    x = torch.randn(N, C, H, W, generator=g) * 2.0 + 1.5
+    w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
+    b = torch.randn(K, generator=g)
+    res = torch.randn(N, K, H, W, generator=g) if with_res else None
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) + 0.3      # beta != 0: padding must not become relu(beta)
+    xd, wd = _nhwc(x), _krsc(w)
+    # statistics of x as a producing conv would leave them: per 64-row patch (sum, centred sum of squares)
+    xp = x.double().view(N, 32, C // 32, H // 8, 8, W // 8, 8).permute(0, 3, 5, 1, 2, 4, 6).reshape(N, (H // 8) * (W // 8), 32, -1)
+    part = torch.stack([xp.sum(-1), ((xp - xp.mean(-1, keepdim=True)) ** 2).sum(-1)], dim=-1).float().contiguous().cuda()
+    with ops.compute_dtype(mode):
+        assert ops.in_affine_ok(xd, wd, 1, R // 2)
+        sc, sh = ops.groupnorm_affine((part, H * W // 64), gam.cuda(), bet.cuda(), 32, 1e-5, N, H * W, C)
+        rd = None if res is None else _nhwc(res)
+        got = ops.conv2d_fwd(xd, wd, b.cuda(), stride=1, pad=R // 2, act=0, residual=rd, wkey=("af", id(w)), in_affine=(sc, sh, True))
+        h = ops.groupnorm_act(xd, gam.cuda(), bet.cuda(), 32, relu=True)
+        two = ops.conv2d_fwd(h, wd, b.cuda(), stride=1, pad=R // 2, act=0, residual=rd, wkey=("af", id(w)))
+    scale = two.abs().max().item()
+    assert (got - two).abs().max().item() <= 4e-6 * scale
+    ref = F.conv2d(F.relu(F.group_norm(x.double(), 32, gam.double(), bet.double())), w.double(), b.double(), padding=R // 2)
+    ref = ref + (0 if res is None else res.double())
+    assert _err64(got.permute(0, 3, 1, 2), ref) <= 1e-5

@@ -154,7 +154,9 @@ class DCResNetGenerator(Generator):
         self.bn = _norm_act(self.bn, channels[-1])
         self.convOut = HipConv2d(channels[-1], self.out_ch, 3, padding="same", act=ops.ACT_TANH)
 
-    def forward(self, z, y=None):
+    def forward(self, z, y=None, out=None):
+        """out (frozen device forward only): an NHWC-contiguous [B, H, W, out_ch] fp32 tensor the output conv writes the images
+        into — the trainer hands in the generated rows' slice of the fused critic batch, so no copy follows."""
         f = self.first_filter_size
         x = self.linIn(self._condition(z, y)).reshape(z.size(0), -1, f, f)
         if not x.is_cuda:
@@ -168,7 +170,7 @@ class DCResNetGenerator(Generator):
             x, part = blk.forward_nhwc_parts(x, part, nxt)
         affine = _norm_as_affine(self.bn, x, part, self.convOut) if part is not None else None
         if affine is not None:                          # the last normalisation rides in the output conv's staging
-            return HF.nchw_view(self.convOut.forward_nhwc(x, in_affine=affine))
+            return HF.nchw_view(self.convOut.forward_nhwc(x, in_affine=affine, out=out))
         h = self.bn.forward_nhwc(x, part=part) if part is not None else self.bn.forward_nhwc(x)
         return HF.nchw_view(self.convOut.forward_nhwc(h))
 

@@ -9,6 +9,7 @@ import torch
 from torch import autograd
 
 from . import functional as HF
+from . import ops
 
 
 def calc_penalty(model, penalty_types, real_data, real_labels, fake_data, fake_labels, device="cpu", per_sample=False,
@@ -69,7 +70,8 @@ def calc_lipschitz_penalty_WRT(model, inputs, input_labels=None, device="cpu", p
     B = x.size(0)
 
     def term(scalar_outputs):
-        g, = autograd.grad(outputs=scalar_outputs, inputs=x, grad_outputs=torch.ones_like(scalar_outputs),
+        ones = ops.ones_like_const(scalar_outputs) if scalar_outputs.is_cuda else torch.ones_like(scalar_outputs)
+        g, = autograd.grad(outputs=scalar_outputs, inputs=x, grad_outputs=ones,
                            create_graph=True, retain_graph=True, only_inputs=True)
         flat = g.reshape(B, -1)
         if flat.is_cuda and flat.dtype == torch.float32:

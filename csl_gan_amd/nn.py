@@ -99,7 +99,7 @@ class HipConv2d(nn.Conv2d, _PerSampleMixin):
         self.act = act
         self._wtoken = next(_tokens)
 
-    def forward_nhwc(self, x, residual=None, in_mask=False, out_masked=False, out_dtype=None, in_affine=None):
+    def forward_nhwc(self, x, residual=None, in_mask=False, out_masked=False, out_dtype=None, in_affine=None, out=None):
         """x: NHWC-contiguous device tensor -> NHWC output (+ residual before the activation).
         out_dtype: torch.bfloat16 stores the output as bfloat16 (ops.set_storage_dtype; the model that owns the chain decides);
         None follows x's element type.
@@ -115,7 +115,7 @@ class HipConv2d(nn.Conv2d, _PerSampleMixin):
             if torch.is_grad_enabled() or self._bpc is not None:
                 raise RuntimeError("in_affine is an inference-only fusion")
             return ops.conv2d_fwd(x, w.detach(), None if self.bias is None else self.bias.detach(), stride=self.stride[0], pad=self.padding[0],
-                                  residual=residual, act=self.act, wkey=self._wkey(w), in_affine=in_affine)
+                                  residual=residual, act=self.act, wkey=self._wkey(w), in_affine=in_affine, out=out)
         bpc = self._bpc
         if bpc is not None:
             x = bpc.clip_input(x)              # backprop_clip.py:103 (PGCWrapper.forward)

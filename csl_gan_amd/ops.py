@@ -95,6 +95,19 @@ class gn_partials:
         gn_partials._req = self._prev
 
 
+_ones_cache = {}
+
+
+def ones_like_const(t):
+    """A persistent tensor of ones with t's shape / dtype / device: the constant cotangent of a backward() or autograd.grad call
+    (torch.ones_like there is one fill launch per call, re-run by every replay of a recorded step).  Never written to."""
+    key = (tuple(t.shape), t.dtype, str(t.device))
+    c = _ones_cache.get(key)
+    if c is None:
+        c = _ones_cache[key] = torch.ones(t.shape, dtype=t.dtype, device=t.device)
+    return c
+
+
 def set_f32_halo(on):
     """Switch the exact-fp32 form of the round-4 halo kernel on or off at run time (returns the previous setting): the same products
     summed in a different order, so the golden tests use it to prove which activation units sit within rounding of zero."""

@@ -370,7 +370,8 @@ class Trainer:
         single_term = len(o.penalty) == 1 and not (o.aux_penalty and getattr(D, "linOutAux", None) is not None)
         if single_term and penalty.is_cuda:
             with ops.deferred_sums():
-                return autograd.grad(penalty, params, create_graph=False, retain_graph=False, allow_unused=True)
+                return autograd.grad(penalty, params, grad_outputs=ops.ones_like_const(penalty), create_graph=False, retain_graph=False,
+                                     allow_unused=True)
         return autograd.grad(penalty, params, create_graph=False, retain_graph=False, allow_unused=True)
 
     def _fused_passes(self, img, labels, z, y, on_fake=None):
@@ -394,7 +395,14 @@ class Trainer:
             blocks.append(xa); roles.append(("norms", xa.size(0))); lab.append(None if ya is None else ya.to(o.d_device))
         yg = None if y is None else y.to(o.g_device)
         with torch.no_grad():
-            fake_img = self.G(z, yg).to(o.d_device)
+            # the generated rows' slice of the fused critic batch, when that buffer exists: the generator's output conv writes the
+            # images there (channels-last) and _assemble_fused finds them in place
+            g_out, buf = None, getattr(self, "_fused_buf", None)
+            r0 = blocks[0].size(0) if blocks else 0
+            if (buf is not None and img.dim() == 4 and buf.is_cuda and str(o.g_device) == str(o.d_device) and buf.shape[0] == r0 + 2 * B
+                    and tuple(buf.shape[1:]) == tuple(img.shape[1:]) and self._g_takes_out()):
+                g_out = buf[r0:r0 + B].permute(0, 2, 3, 1)
+            fake_img = (self.G(z, yg, out=g_out) if g_out is not None else self.G(z, yg)).to(o.d_device)
         if on_fake is not None:
             on_fake(fake_img.detach())
         blocks += [fake_img, img]
@@ -430,7 +438,11 @@ class Trainer:
                 total = total + D.real_loss(outs[0], o.d_device)
                 if o.use_aux_loss:
                     total = total + D.aux_loss(auxs[0], lab[0], o.d_device, fake=False)
-        total.backward()
+        if total.is_cuda:
+            from . import ops
+            total.backward(gradient=ops.ones_like_const(total))     # the constant cotangent: no fill launch per step
+        else:
+            total.backward()
         pe.disable_hooks()
         if adaptive:
             with torch.no_grad():
@@ -443,6 +455,12 @@ class Trainer:
                 pe.set_max_grad_norm_device(r * o.adaptive_scalar if o.use_grad_clip_per_layer else (r.norm(2) * o.adaptive_scalar).reshape(1))
         pe.row_roles = None
         return d_fake, d_fake_aux, d_fake_loss, d_fake_aux_loss, fake_img.detach(), d_real, d_real_aux, d_real_loss, d_real_aux_loss
+
+    def _g_takes_out(self):
+        if getattr(self, "_g_out_kw", None) is None:
+            import inspect
+            self._g_out_kw = "out" in inspect.signature(self.G.forward).parameters
+        return self._g_out_kw
 
     def _assemble_fused(self, blocks):
         """The row blocks of the fused critic pass as ONE channels-last batch.  Round 3 ran torch.cat (an NCHW copy of all rows) and

@@ -25,7 +25,7 @@ EXPORTS = [
     "cslgan_bias_grad_grouped_f32", "cslgan_act_bwd_f32", "cslgan_groupnorm_act_f32", "cslgan_groupnorm_apply_parts_f32", "cslgan_groupnorm_affine_parts_f32", "cslgan_batchnorm_act_f32", "cslgan_batchnorm_eval_act_f32",
     "cslgan_norm_act_bwd_f32", "cslgan_norm_bwd_ws_floats",
     "cslgan_adam_step_f32", "cslgan_adam_step_dev_f32", "cslgan_adam_multi_f32",
-    "cslgan_segment_means_f32", "cslgan_segment_means_bwd_f32", "cslgan_dstep_stats_f32", "cslgan_grad_log_stats_f32",
+    "cslgan_adaptive_clip_f32", "cslgan_segment_means_f32", "cslgan_segment_means_bwd_f32", "cslgan_dstep_stats_f32", "cslgan_grad_log_stats_f32",
     "cslgan_lerp_rows_f32", "cslgan_lipschitz_term_f32", "cslgan_lipschitz_term_bwd_f32",
     "cslgan_conv2d_fwd_bf16s", "cslgan_conv2d_dgrad_bf16s", "cslgan_conv2d_wgrad_grouped_bf16s", "cslgan_cast_f32_bf16", "cslgan_cast_bf16_f32",
     "cslgan_act_bwd_bf16", "cslgan_bias_grad_grouped_bf16", "cslgan_linear_k1_dgrad_bf16s", "cslgan_linear_k1_wgrad_bf16s",
@@ -39,6 +39,18 @@ class SegsT(C.Structure):
         ("n_seg", C.c_int32), ("_pad", C.c_int32),
         ("inp", C.c_void_p * MAX_SEGS), ("out", C.c_void_p * MAX_SEGS), ("noise", C.c_void_p * MAX_SEGS),
         ("len", C.c_int64 * MAX_SEGS), ("row_stride", C.c_int64 * MAX_SEGS), ("rows", C.c_int64 * MAX_SEGS), ("call_counter", C.c_void_p),
+    ]
+
+
+MAX_CLIP_LAYERS, MAX_CLIP_JOBS = 32, 16   # include/cslgan.h CSLGAN_MAX_CLIP_LAYERS / CSLGAN_MAX_CLIP_JOBS
+
+
+class AdaptiveClipT(C.Structure):
+    _fields_ = [
+        ("n_layers", C.c_int32), ("n_mat", C.c_int32), ("n_jobs", C.c_int32), ("_pad", C.c_int32),
+        ("sq_adapt", C.c_void_p * MAX_CLIP_LAYERS), ("sq_rows", C.c_void_p * MAX_CLIP_LAYERS), ("mat_layer", C.c_int32 * MAX_CLIP_LAYERS),
+        ("job_dst", C.c_void_p * MAX_CLIP_JOBS), ("job_first", C.c_int64 * MAX_CLIP_JOBS), ("job_layer", C.c_int32 * MAX_CLIP_JOBS),
+        ("job_count", C.c_int32 * MAX_CLIP_JOBS), ("job_scale", C.c_float * MAX_CLIP_JOBS),
     ]
 
 
@@ -108,6 +120,7 @@ def lib():
         "cslgan_adam_step_dev_f32": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp],
         "cslgan_adam_multi_f32": [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), f32, f32, f32, f32, f32,
                                   i32, vp, vp],
+        "cslgan_adaptive_clip_f32": [C.POINTER(AdaptiveClipT), i64, i64, i32, f32, i32, f32, i64, vp, vp, vp, vp, vp, vp],
         "cslgan_segment_means_f32": [vp, i32, C.POINTER(C.c_int32), C.POINTER(f32), vp, vp, vp],
         "cslgan_segment_means_bwd_f32": [vp, vp, i32, C.POINTER(C.c_int32), C.POINTER(f32), vp, vp],
         "cslgan_dstep_stats_f32": [vp, i32, vp, i32, vp, vp, vp, vp, vp],

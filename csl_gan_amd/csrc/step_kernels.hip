@@ -305,6 +305,64 @@ static int fill_seg_mean(SegMeanArgs& a, int n_seg, const int32_t* sizes, const 
     return off;
 }
 
+// One workgroup: the adaptive statistic of every layer (tree reduction in a fixed order), the clip norm(s), then the stacked
+// squared norms, the clip factors, their gathered rows and the row-weight jobs (include/cslgan.h: cslgan_adaptive_clip_f32).
+__global__ __launch_bounds__(256) void adaptive_clip_kernel(const cslgan_adaptive_clip_t a, long long n_adapt, long long n_rows, int stat_max,
+                                                            float scalar, int per_layer, float eps, long long first_private_row,
+                                                            float* __restrict__ r_out, float* __restrict__ c_out,
+                                                            float* __restrict__ sq_out, float* __restrict__ f_out, float* __restrict__ f_mat) {
+    __shared__ float s_red[256];
+    __shared__ float s_r[CSLGAN_MAX_CLIP_LAYERS], s_c[CSLGAN_MAX_CLIP_LAYERS];
+    const int tid = threadIdx.x, L = a.n_layers;
+    for (int l = 0; l < L; ++l) {
+        float v = 0.f;
+        for (long long i = tid; i < n_adapt; i += 256) {
+            const float nrm = sqrtf(a.sq_adapt[l][i]);
+            v = stat_max ? fmaxf(v, nrm) : v + nrm;
+        }
+        s_red[tid] = v;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (tid < w) s_red[tid] = stat_max ? fmaxf(s_red[tid], s_red[tid + w]) : s_red[tid] + s_red[tid + w];
+            __syncthreads();
+        }
+        if (tid == 0) s_r[l] = stat_max ? s_red[0] : s_red[0] / (float)n_adapt;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int l = 0; l < L; ++l) { r_out[l] = s_r[l]; s_c[l] = s_r[l] * scalar; tot += s_r[l] * s_r[l]; }
+        if (per_layer) for (int l = 0; l < L; ++l) c_out[l] = s_c[l];
+        else { s_c[0] = sqrtf(tot) * scalar; c_out[0] = s_c[0]; }
+    }
+    __syncthreads();
+    for (long long r = tid; r < n_rows; r += 256) {           // the arithmetic of clip_factors_kernel
+        if (per_layer) {
+            for (int l = 0; l < L; ++l) {
+                const float q = a.sq_rows[l][r];
+                sq_out[(long long)l * n_rows + r] = q;
+                float f = s_c[l] / (sqrtf(q) + eps);
+                f = f > 1.f ? 1.f : f;
+                f_out[(long long)l * n_rows + r] = r < first_private_row ? 1.f : f;
+            }
+        } else {
+            float tot = 0.f;
+            for (int l = 0; l < L; ++l) { const float q = a.sq_rows[l][r]; sq_out[(long long)l * n_rows + r] = q; tot += q; }
+            float f = s_c[0] / (sqrtf(tot) + eps);
+            f = f > 1.f ? 1.f : f;
+            f_out[r] = r < first_private_row ? 1.f : f;
+        }
+    }
+    __syncthreads();                                          // f_out written by this workgroup is visible to it from here on
+    if (f_mat && per_layer)
+        for (int m = 0; m < a.n_mat; ++m)
+            for (long long r = tid; r < n_rows; r += 256) f_mat[(long long)m * n_rows + r] = f_out[(long long)a.mat_layer[m] * n_rows + r];
+    for (int j = 0; j < a.n_jobs; ++j) {
+        const float* src = f_out + (per_layer ? (long long)a.job_layer[j] * n_rows : 0) + a.job_first[j];
+        for (int i = tid; i < a.job_count[j]; i += 256) a.job_dst[j][i] = a.job_scale[j] * src[i];
+    }
+}
+
 }  // namespace cslgan
 
 using namespace cslgan;
@@ -386,6 +444,24 @@ int cslgan_lipschitz_term_bwd_f32(const float* t, const float* norm, const float
     hipLaunchKernelGGL(lipschitz_term_bwd_kernel, dim3(gx, (unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, t, norm, g_total,
                        g_per, (long long)len, one_sided, coef, gt);
     return check_launch("lipschitz_term_bwd_kernel");
+}
+
+int cslgan_adaptive_clip_f32(const cslgan_adaptive_clip_t* a, int64_t n_adapt, int64_t n_rows, int stat_max, float scalar, int per_layer,
+                             float eps, int64_t first_private_row, float* r_out, float* c_out, float* sq_out, float* f_out, float* f_mat,
+                             void* stream) {
+    CSLGAN_REQUIRE(a && r_out && c_out && sq_out && f_out, "adaptive_clip: null argument");
+    CSLGAN_REQUIRE(a->n_layers >= 1 && a->n_layers <= CSLGAN_MAX_CLIP_LAYERS && a->n_mat >= 0 && a->n_mat <= CSLGAN_MAX_CLIP_LAYERS &&
+                   a->n_jobs >= 0 && a->n_jobs <= CSLGAN_MAX_CLIP_JOBS && n_adapt >= 1 && n_rows >= 1,
+                   "adaptive_clip: sizes out of range (%d layers, %d gathered, %d jobs)", a->n_layers, a->n_mat, a->n_jobs);
+    for (int l = 0; l < a->n_layers; ++l) CSLGAN_REQUIRE(a->sq_adapt[l] && a->sq_rows[l], "adaptive_clip: layer %d has no norms", l);
+    for (int m = 0; m < a->n_mat; ++m) CSLGAN_REQUIRE(a->mat_layer[m] >= 0 && a->mat_layer[m] < a->n_layers, "adaptive_clip: bad gathered layer");
+    for (int j = 0; j < a->n_jobs; ++j)
+        CSLGAN_REQUIRE(a->job_dst[j] && a->job_count[j] >= 0 && a->job_first[j] >= 0 && a->job_first[j] + a->job_count[j] <= n_rows &&
+                       a->job_layer[j] >= 0 && a->job_layer[j] < a->n_layers, "adaptive_clip: bad row-weight job %d", j);
+    CSLGAN_REQUIRE(a->n_mat == 0 || (f_mat && per_layer), "adaptive_clip: gathered factor rows need f_mat and per-layer clipping");
+    hipLaunchKernelGGL(adaptive_clip_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *a, (long long)n_adapt, (long long)n_rows, stat_max,
+                       scalar, per_layer, eps, (long long)first_private_row, r_out, c_out, sq_out, f_out, f_mat);
+    return check_launch("adaptive_clip_kernel");
 }
 
 int cslgan_adam_multi_f32(int n_seg, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,

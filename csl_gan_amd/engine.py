@@ -490,6 +490,44 @@ class PrivacyEngine(PerSampleSink):
             return self._add_dense(p, tot)
         self._dense[id(p)] = rows
 
+    def adaptive_clip_fused(self, stat, scalar, per_layer):
+        """update_adaptive_clipping_params + calc_clipping_factors of a fused pass as ONE launch (ops.adaptive_clip): the adaptive
+        statistic r of every layer from the "norms" rows, the clip norm(s) r * scalar, the clip factors of the clipped rows, the
+        factor rows of the materialised layers and the row weights of the joint clip-weighted launches — what clip() would otherwise
+        assemble from a dozen small launches.  Returns r, or None when this step's state does not fit (then the caller runs the
+        separate ops).  clip() picks the results up (self._pre) if nothing invalidated them in between."""
+        ps = self.params
+        if not ps or not ps[0].is_cuda or any(("norms", id(p)) not in self._bufs or id(p) not in self._bufs for p in ps):
+            return None
+        n_pass, B = self._bufs[id(ps[0])][1].shape
+        if (self.accum_passes and n_pass > 1) or len(ps) > 32:
+            return None
+        self.join_side_stream()
+        adapt = [self._bufs[("norms", id(p))][1].reshape(-1) for p in ps]
+        rows = [self._bufs[id(p)][1].reshape(-1) for p in ps]
+        mat_idx = [i for i, p in enumerate(ps) if id(p) not in self._ghost]
+        jobs, done = [], set()
+        for i, p in enumerate(ps):
+            stash = self._ghost.get(id(p))
+            for k, (gz, x, R, S, stride, pad, sc, joint) in sorted((stash or {}).items()):
+                if joint is not None:
+                    n_d, scale_d = joint[2], joint[3]
+                    key = ("rs", id(p), n_d, float(scale_d), B, str(gz.device))
+                    rs = self._idx_cache.get(key)
+                    if rs is None:
+                        rs = self._idx_cache[key] = torch.full((n_d + B,), float(scale_d), device=gz.device, dtype=torch.float32)
+                    jobs.append((rs[n_d:], i, k * B, float(sc)))
+                    done.add((id(p), k))
+        if len(jobs) > 16:
+            return None
+        n_private = self._n_private(n_pass)
+        r, c, sq, f, f_mat = ops.adaptive_clip(adapt, rows, stat == "max", scalar, per_layer, CLIP_EPS, (n_pass - n_private) * B,
+                                               mat_layers=mat_idx if (per_layer and len(mat_idx) < len(ps)) else (), jobs=jobs)
+        self.set_max_grad_norm_device(c)
+        self._per_layer = bool(per_layer)
+        self._pre = dict(sq=sq, f=f, f_mat=f_mat, mat_idx=mat_idx, jobs=done, per_layer=bool(per_layer))
+        return r
+
     def norms_rows_sqnorms(self) -> torch.Tensor:
         """[n_params, n] squared norms of the "norms" row block of a fused pass."""
         self.join_side_stream()
@@ -603,8 +641,14 @@ class PrivacyEngine(PerSampleSink):
             sq = self.sample_sqnorms(recompute=recompute_norms)
         n_private = self._n_private(n_pass)
         per_layer = self._per_layer
-        f = ops.clip_factors(sq, self._C_device(sq.device), flat=not per_layer, eps=CLIP_EPS,
-                             first_private_row=(n_pass - n_private) * B)
+        pre, self._pre = getattr(self, "_pre", None), None
+        if pre is not None and (recompute_norms or pre["mat_idx"] != mat_idx or pre["per_layer"] != per_layer or pre["sq"].shape[1] != n_pass * B):
+            pre = None
+        if pre is not None:        # adaptive_clip_fused computed them in the launch that made the clip norms
+            sq, f = pre["sq"], pre["f"]
+        else:
+            f = ops.clip_factors(sq, self._C_device(sq.device), flat=not per_layer, eps=CLIP_EPS,
+                                 first_private_row=(n_pass - n_private) * B)
         self.last_factors, self.last_sq = f, sq
         outs = []
         for p in ps:
@@ -613,7 +657,11 @@ class PrivacyEngine(PerSampleSink):
         if len(mat_idx) == len(ps):
             ops.clip_accum_noise(mats, outs, factors=f)
         else:
-            f_mat = f[self._index_tensor(mat_idx, f.device)].contiguous() if per_layer else f
+            if pre is not None and per_layer and pre["f_mat"] is not None:
+                f_mat = pre["f_mat"]
+            else:
+                f_mat = f[self._index_tensor(mat_idx, f.device)].contiguous() if per_layer else f
+            self._jobs_done = pre["jobs"] if pre is not None else ()
             ops.clip_accum_noise(mats, [outs[i] for i in mat_idx], factors=f_mat)
             # ghost layers: sum_b f_b g_b as one clip-weighted dense wgrad per pass.  The layers' launches are independent and each
             # under-fills the chip (128 - 640 workgroups): every second one goes to a second stream (CSLGAN_CLIP_STREAM=0: off)
@@ -654,7 +702,8 @@ class PrivacyEngine(PerSampleSink):
                 rs = self._idx_cache.get(key)
                 if rs is None:
                     rs = self._idx_cache[key] = torch.full((n_d + B,), float(scale_d), device=f.device, dtype=torch.float32)
-                torch.mul(fi[k], float(scale), out=rs[n_d:])
+                if (id(p), k) not in getattr(self, "_jobs_done", ()):      # (adaptive_clip_fused wrote the suffix already)
+                    torch.mul(fi[k], float(scale), out=rs[n_d:])
                 part = _dense_wgrad(gzj, xj, R, S, stride, pad, 1.0, row_scale=rs, out=dst)
             total = part if total is None else total.add_(part)
         if not single:
@@ -791,6 +840,7 @@ class PrivacyEngine(PerSampleSink):
         self._sq_off = 0
         self._dense.clear()
         self._ghost.clear()
+        self._pre, self._jobs_done = None, ()
         self.row_roles = None
         for p in self.params:
             if hasattr(p, "grad_sample"):

@@ -1222,6 +1222,36 @@ def clip_factors(sq, max_norm, flat, eps=1e-6, first_private_row=0, want_norms=F
     return (f, nrm) if want_norms else f
 
 
+def adaptive_clip(sq_adapt, sq_rows, stat_max, scalar, per_layer, eps, first_private_row, mat_layers=(), jobs=()):
+    """cslgan_adaptive_clip_f32: sq_adapt / sq_rows are lists (one entry per layer) of 1-D fp32 device tensors of equal length each;
+    jobs = [(dst tensor [count], layer, first row, scale)].  Returns (r [L], C [L] | [1], sq [L, n_rows], f, f_mat | None)."""
+    L = len(sq_rows)
+    if L > _lib.MAX_CLIP_LAYERS or len(jobs) > _lib.MAX_CLIP_JOBS or len(mat_layers) > _lib.MAX_CLIP_LAYERS:
+        raise RuntimeError("adaptive_clip: too many layers / jobs for one launch")
+    n_adapt, n_rows = sq_adapt[0].numel(), sq_rows[0].numel()
+    a = _lib.AdaptiveClipT()
+    a.n_layers, a.n_mat, a.n_jobs = L, len(mat_layers), len(jobs)
+    for l in range(L):
+        _chk(sq_adapt[l], "sq_adapt"); _chk(sq_rows[l], "sq_rows")
+        if sq_adapt[l].numel() != n_adapt or sq_rows[l].numel() != n_rows:
+            raise RuntimeError("adaptive_clip: ragged norm vectors")
+        a.sq_adapt[l], a.sq_rows[l] = sq_adapt[l].data_ptr(), sq_rows[l].data_ptr()
+    for m, l in enumerate(mat_layers):
+        a.mat_layer[m] = int(l)
+    for j, (dst, layer, first, scale) in enumerate(jobs):
+        _chk(dst, "job dst")
+        a.job_dst[j], a.job_layer[j], a.job_first[j], a.job_count[j], a.job_scale[j] = dst.data_ptr(), int(layer), int(first), dst.numel(), float(scale)
+    dev = sq_rows[0].device
+    r = torch.empty(L, device=dev, dtype=torch.float32)
+    c = torch.empty(L if per_layer else 1, device=dev, dtype=torch.float32)
+    sq = torch.empty((L, n_rows), device=dev, dtype=torch.float32)
+    f = torch.empty((L, n_rows) if per_layer else (n_rows,), device=dev, dtype=torch.float32)
+    f_mat = torch.empty((len(mat_layers), n_rows), device=dev, dtype=torch.float32) if (mat_layers and per_layer) else None
+    check(_lib.lib().cslgan_adaptive_clip_f32(C.byref(a), n_adapt, n_rows, 1 if stat_max else 0, float(scalar), 1 if per_layer else 0, float(eps),
+                                              int(first_private_row), _p(r), _p(c), _p(sq), _p(f), _p(f_mat), _stream()), "adaptive_clip")
+    return r, c, sq, f, f_mat
+
+
 class deferred_sums:
     """Inside this context the column sums requested through sum_rows() are only queued; they run as ONE multi-segment launch
     (segments of different heights: cslgan_segs_t.rows) at exit.  For callers that take several dense weight gradients and read

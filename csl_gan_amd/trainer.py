@@ -446,13 +446,18 @@ class Trainer:
         pe.disable_hooks()
         if adaptive:
             with torch.no_grad():
-                norms = pe.norms_rows_sqnorms().sqrt()
-                r = norms.mean(dim=1) if o.adaptive_stat == "mean" else norms.max(dim=1).values
-                if self.world_size > 1:
-                    from .distributed import average_across_ranks
-                    r = average_across_ranks(r.contiguous(), use_max=o.adaptive_stat == "max")
+                r = None
+                if self.world_size == 1 and os.environ.get("CSLGAN_FUSED_ADAPTIVE_CLIP", "1") == "1":
+                    # one launch: the statistic, the clip norms, and the clip factors clip() is about to ask for
+                    r = pe.adaptive_clip_fused(o.adaptive_stat, o.adaptive_scalar, bool(o.use_grad_clip_per_layer))
+                if r is None:
+                    norms = pe.norms_rows_sqnorms().sqrt()
+                    r = norms.mean(dim=1) if o.adaptive_stat == "mean" else norms.max(dim=1).values
+                    if self.world_size > 1:
+                        from .distributed import average_across_ranks
+                        r = average_across_ranks(r.contiguous(), use_max=o.adaptive_stat == "max")
+                    pe.set_max_grad_norm_device(r * o.adaptive_scalar if o.use_grad_clip_per_layer else (r.norm(2) * o.adaptive_scalar).reshape(1))
                 self.last["adaptive_stats"] = r
-                pe.set_max_grad_norm_device(r * o.adaptive_scalar if o.use_grad_clip_per_layer else (r.norm(2) * o.adaptive_scalar).reshape(1))
         pe.row_roles = None
         return d_fake, d_fake_aux, d_fake_loss, d_fake_aux_loss, fake_img.detach(), d_real, d_real_aux, d_real_loss, d_real_aux_loss
 

@@ -446,6 +446,31 @@ int cslgan_dstep_stats_f32(const float* d_real, int n_real, const float* d_fake,
 int cslgan_grad_log_stats_f32(const float* sq, int n_layers, int64_t ld, int64_t col0, int B, const float* max_norm, int per_layer,
                               float eps, float* acc_mean, float* acc_std, float* acc_max, float* acc_c, float* acc_clipped,
                               void* stream);
+/* Adaptive clipping of one fused critic pass in ONE launch (train.py:233-243 update_adaptive_clipping_params + :324
+ * calc_clipping_factors; the device form ran stack, sqrt, mean, mul, stack, clip-factor, gather and three row-scale launches):
+ *   r[l]   = mean_i (stat_max: max_i) sqrt(sq_adapt[l][i])                     over the n_adapt adaptive rows of layer l
+ *   C      = scalar * r[l] per layer (per_layer) | scalar * ||r||_2 (one flat clip norm)
+ *   sq_out = the layers' sq_rows stacked [n_layers][n_rows];  f = min(1, C / (norm + eps)), 1 for rows < first_private_row:
+ *            per_layer [n_layers][n_rows] from each layer's own norm, else [n_rows] from the flat norm sqrt(sum_l sq)
+ *   f_mat  (nullable, per_layer) [n_mat][n_rows] = f[mat_layer[m]];  jobs: job_dst[j][i] = job_scale[j] * f[job_layer[j]][job_first[j] + i]
+ *            (flat: f[job_first[j] + i]) for i < job_count[j] — the row weights of the clip-weighted weight-gradient launches.
+ * Pointers inside the struct are DEVICE pointers; the struct itself is read on the host. */
+#define CSLGAN_MAX_CLIP_LAYERS 32
+#define CSLGAN_MAX_CLIP_JOBS 16
+typedef struct {
+    int32_t n_layers, n_mat, n_jobs, _pad;
+    const float* sq_adapt[CSLGAN_MAX_CLIP_LAYERS];
+    const float* sq_rows[CSLGAN_MAX_CLIP_LAYERS];
+    int32_t mat_layer[CSLGAN_MAX_CLIP_LAYERS];
+    float* job_dst[CSLGAN_MAX_CLIP_JOBS];
+    int64_t job_first[CSLGAN_MAX_CLIP_JOBS];
+    int32_t job_layer[CSLGAN_MAX_CLIP_JOBS];
+    int32_t job_count[CSLGAN_MAX_CLIP_JOBS];
+    float job_scale[CSLGAN_MAX_CLIP_JOBS];
+} cslgan_adaptive_clip_t;
+int cslgan_adaptive_clip_f32(const cslgan_adaptive_clip_t* a, int64_t n_adapt, int64_t n_rows, int stat_max, float scalar, int per_layer,
+                             float eps, int64_t first_private_row, float* r_out, float* c_out, float* sq_out, float* f_out, float* f_mat,
+                             void* stream);
 /* gradient_penalty.py:36: out[b,:] = alpha[b] * real[b,:] + (1 - alpha[b]) * fake[b,:]. */
 int cslgan_lerp_rows_f32(const float* real, const float* fake, const float* alpha, int64_t n_rows, int64_t len, float* out,
                          void* stream);

@@ -1345,3 +1345,37 @@ def test_groupnorm_folded_into_the_consuming_conv(case, mode):
     ref = F.conv2d(F.relu(F.group_norm(x.double(), 32, gam.double(), bet.double())), w.double(), b.double(), padding=R // 2)
     ref = ref + (0 if res is None else res.double())
     assert _err64(got.permute(0, 3, 1, 2), ref) <= 1e-5
+
+
+@pytest.mark.parametrize("per_layer", [True, False])
+@pytest.mark.parametrize("stat", ["mean", "max"])
+def test_adaptive_clip_in_one_launch(per_layer, stat):
+    """cslgan_adaptive_clip_f32 against the chain of small ops it replaces (train.py:233-243 + :324): the adaptive statistic,
+    the clip norm(s), the stacked squared norms, the clip factors (1 on the rows before first_private_row), the gathered factor rows
+    of the materialised layers and the row-weight jobs."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    L, n_adapt, n_rows, first = 9, 128, 384, 256
+    adapt = [(torch.rand(n_adapt, generator=g) * (3.0 + l)).cuda() for l in range(L)]
+    rows = [(torch.rand(n_rows, generator=g) * (6.0 + l)).cuda() for l in range(L)]
+    mat = [0, 1, 2, 5] if per_layer else []
+    dsts = [torch.full((128,), -7.0, device="cuda") for _ in range(3)]
+    jobs = [(dsts[0], 3, 256, 1.0 / 128), (dsts[1], 4, 256, 0.5), (dsts[2], 8, 128, 2.0)]
+    r, c, sq, f, f_mat = ops.adaptive_clip(adapt, rows, stat == "max", 1.7, per_layer, 1e-6, first, mat_layers=mat, jobs=jobs)
+    norms = torch.stack(adapt).sqrt()
+    r_ref = norms.mean(dim=1) if stat == "mean" else norms.max(dim=1).values
+    c_ref = r_ref * 1.7 if per_layer else (r_ref.norm(2) * 1.7).reshape(1)
+    sq_ref = torch.stack(rows)
+    f_ref = ops.clip_factors(sq_ref, c_ref.contiguous(), flat=not per_layer, eps=1e-6, first_private_row=first)
+    torch.testing.assert_close(r, r_ref, rtol=2e-6, atol=0)
+    torch.testing.assert_close(c, c_ref, rtol=2e-6, atol=0)
+    assert torch.equal(sq, sq_ref)
+    torch.testing.assert_close(f, f_ref, rtol=3e-6, atol=0)
+    assert bool((f[..., :first] == 1).all())
+    if per_layer:
+        assert torch.equal(f_mat, f[torch.tensor(mat, device="cuda")])
+    else:
+        assert f_mat is None
+    for dst, layer, first_row, scale in jobs:
+        src = f[layer] if per_layer else f
+        torch.testing.assert_close(dst, src[first_row:first_row + dst.numel()] * scale, rtol=1e-6, atol=0)

@@ -637,8 +637,9 @@ class PrivacyEngine(PerSampleSink):
             ops.clip_accum_noise([m.view(n_pass, -1) for m in mats], [s.view(-1) for s in summed_ps])
             mats, n_pass = summed_ps, 1
             sq = ops.sample_sqnorm(mats)
+            self._pre = None
         else:
-            sq = self.sample_sqnorms(recompute=recompute_norms)
+            sq = None
         n_private = self._n_private(n_pass)
         per_layer = self._per_layer
         pre, self._pre = getattr(self, "_pre", None), None
@@ -647,6 +648,8 @@ class PrivacyEngine(PerSampleSink):
         if pre is not None:        # adaptive_clip_fused computed them in the launch that made the clip norms
             sq, f = pre["sq"], pre["f"]
         else:
+            if sq is None:
+                sq = self.sample_sqnorms(recompute=recompute_norms)
             f = ops.clip_factors(sq, self._C_device(sq.device), flat=not per_layer, eps=CLIP_EPS,
                                  first_private_row=(n_pass - n_private) * B)
         self.last_factors, self.last_sq = f, sq

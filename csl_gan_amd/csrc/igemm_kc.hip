@@ -651,22 +651,27 @@ static int conv2d_s2_fwd_impl(const cslgan_conv_t* c, const float* x, const floa
     if (w3_ws) {        // the round-4 LDS-halo kernel: three-piece, plain bf16 or exact fp32 operands, any tile count
         p.bf16 = c->compute == CSLGAN_COMPUTE_BF16X3 ? 3 : (c->compute == CSLGAN_COMPUTE_BF16 ? 1 : 0);
         p.w3 = w3_ws;
-        {       // operand sizes for the eligibility test (launch_kc sets them again)
-            p.a_bytes = 0; p.w_bytes = 0;
-        }
-        if (!ok || n == 0 || !x3h_eligible(p))
-            return cslgan_conv2d_fwd_f32(c, x, w, bias, nullptr, act, y, stream);
-    } else if (!ok || n == 0 || !halo_env || !s2_env || wide_tiles < s2_min_tiles || c->compute != CSLGAN_COMPUTE_F32 || !halo_eligible(p))
-        return cslgan_conv2d_fwd_f32(c, x, w, bias, nullptr, act, y, stream);
-    if (repack) {
+        p.a_bytes = 0; p.w_bytes = 0;      // (launch_kc sets the operand sizes)
+    }
+    // The repack comes BEFORE any fallback: the caller caches "this workspace is current for this weight version" after a call with
+    // repack != 0, and whether THIS call takes the halo kernel depends on its batch size (tile-count threshold, the 4x4-grid row
+    // minimum).  A small-batch call that fell back without packing used to leave the workspace unwritten behind a fresh cache entry,
+    // and a larger-batch call of the same step (the fused 384-row pass after the 128-row penalty branch, at batch sizes where only
+    // one of them clears the threshold) then read it with repack = 0.
+    if (repack && ok && n > 0) {
         const long long per = (long long)c->C * 9 * c->K;
         unsigned gxn = (unsigned)((per + 255) / 256);
         gxn = gxn > 1024 ? 1024 : (gxn < 1 ? 1 : gxn);
-        if (w3_ws) { ra.pieces = p.bf16 == 3 ? 3 : (p.bf16 ? 1 : 4); ra.w3 = reinterpret_cast<unsigned short*>(w3_ws); }
+        if (w3_ws && c->C % 16 == 0 && aligned16(w3_ws)) { ra.pieces = p.bf16 == 3 ? 3 : (p.bf16 ? 1 : 4); ra.w3 = reinterpret_cast<unsigned short*>(w3_ws); }
         hipLaunchKernelGGL(repack_filters_kernel, dim3(gxn, (unsigned)n), dim3(256), 0, st, w, wcls_ws, ra);
         rc = check_launch("repack_filters_kernel");
         if (rc) return rc;
     }
+    if (w3_ws) {
+        if (!ok || n == 0 || !x3h_eligible(p))
+            return cslgan_conv2d_fwd_f32(c, x, w, bias, nullptr, act, y, stream);
+    } else if (!ok || n == 0 || !halo_env || !s2_env || wide_tiles < s2_min_tiles || c->compute != CSLGAN_COMPUTE_F32 || !halo_eligible(p))
+        return cslgan_conv2d_fwd_f32(c, x, w, bias, nullptr, act, y, stream);
     return launch_kc(p, st, 0);
 }
 

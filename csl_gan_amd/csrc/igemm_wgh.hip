@@ -235,7 +235,11 @@ __global__ __launch_bounds__(256, 2) void igemm_x3w_kernel(const WghParams p) {
     constexpr int XW = QUAD ? 3 * STRIDE + S : 7 * STRIDE + S;      // staged columns of the slab (of one sample for QUAD)
     constexpr int XPITCH = STRIDE == 1 ? 64 : 96;      // bytes per slab pixel in a 32-channel plane (see the bank note above)
     constexpr int XPIX = QUAD ? 2 * 4 * XW : 4 * XW;   // slab pixels per stage (4 input rows; two samples for QUAD)
-    constexpr int A_PLANE = 32 * 64 + 128, X_PLANE = XPIX * XPITCH;     // (+128 B: the two m planes a 16-lane store group covers land on disjoint banks)
+    // +64 B per plane: a 16-lane ds_write_b64 group stores one pixel's 64 B into EACH 32-channel plane, and stores bank on (a/4) mod 32
+    // (not mod 64 like the reads): plane strides of 0 mod 128 B put both halves on the same 16 banks — every stage store 2-way
+    // conflicted, 26 % of the kernel's LDS-array cycles (profiles/r04_pmc_x3_kernels.txt, first collection).  64 mod 128 B: disjoint.
+    constexpr int A_PLANE = 32 * 64 + 64, X_PLANE = XPIX * XPITCH + 64;
+    static_assert((A_PLANE / 4) % 32 == 16 && (X_PLANE / 4) % 32 == 16, "plane stride must be 64 mod 128 bytes");
     constexpr int NX = (XPIX * 16 + 255) / 256;        // float4 of the slab per thread
     __shared__ __attribute__((aligned(16))) unsigned char As[3][2][A_PLANE];     // [piece][m half][pixel][32 m]
     __shared__ __attribute__((aligned(16))) unsigned char Xs[3][2][X_PLANE];     // [piece][c half][slab pixel][32 c]
@@ -350,27 +354,42 @@ __global__ __launch_bounds__(256, 2) void igemm_x3w_kernel(const WghParams p) {
         else b_tr[u] = (h * XW + (4 * u + gq) * STRIDE) * XPITCH + 32 * ghalf + 8 * gp;     // k -> (qy = 2 ks + h, qx = 4 u + gq)
     }
     constexpr int KS_STEP = (QUAD ? 4 * XW : 2 * XW) * XPITCH;      // slab bytes between the two k-steps of a stage
+    // Ten (k-step, tap) units per stage, six MFMAs each.  The compiler's own schedule read a tap's fragments right in front of its
+    // MFMAs and waited for them (lgkmcnt(2..3) a dozen times per stage: ~1.5 k cycles of exposed LDS latency beside 1.9 k of MFMAs,
+    // 41-44 % matrix-pipe busy).  Software-pipelined by hand as in igemm_x3h: the NEXT unit's fragments are read right after this
+    // unit's first MFMA is issued and pinned there (sched_barrier), so five MFMAs (160 cycles) cover their latency; the second
+    // k-step's gy fragments ride along with the first unit.
+    auto read_a = [&](int ks, x3w_bf16x8 (&a)[3]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[c] = w_tr_pair(&As[c][wm][a_tr[0] + ks * 16 * 64], &As[c][wm][a_tr[1] + ks * 16 * 64]);
+    };
+    auto read_b = [&](int ks, int s, x3w_bf16x8 (&b)[3]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            b[c] = w_tr_pair(&Xs[c][wn][b_tr[0] + ks * KS_STEP + s * XPITCH], &Xs[c][wn][b_tr[1] + ks * KS_STEP + s * XPITCH]);
+    };
     auto mma_stage = [&]() {
+        x3w_bf16x8 a0[3], a1[3], b0[3], b1[3];
+        read_a(0, a0);
+        read_b(0, 0, b0);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            x3w_bf16x8 a[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) a[c] = w_tr_pair(&As[c][wm][a_tr[0] + ks * 16 * 64], &As[c][wm][a_tr[1] + ks * 16 * 64]);
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                x3w_bf16x8 b[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    b[c] = w_tr_pair(&Xs[c][wn][b_tr[0] + ks * KS_STEP + s * XPITCH], &Xs[c][wn][b_tr[1] + ks * KS_STEP + s * XPITCH]);
-                f32x16 t = acc[s];                   // smallest terms first
-                t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], t, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], t, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], t, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], t, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], t, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], t, 0, 0, 0);
-                acc[s] = t;
-            }
+        for (int i = 0; i < 2 * S; ++i) {
+            const int ks = i / S, s = i - ks * S;
+            x3w_bf16x8 (&a)[3] = ks ? a1 : a0;
+            x3w_bf16x8 (&b)[3] = (i & 1) ? b1 : b0;
+            x3w_bf16x8 (&bn)[3] = (i & 1) ? b0 : b1;
+            f32x16 t = acc[s];                       // smallest terms first
+            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], t, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 < 2 * S) read_b((i + 1) / S, (i + 1) % S, bn);
+            if (i == 0) read_a(1, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], t, 0, 0, 0);
+            acc[s] = t;
         }
     };
 

@@ -1379,3 +1379,27 @@ def test_adaptive_clip_in_one_launch(per_layer, stat):
     for dst, layer, first_row, scale in jobs:
         src = f[layer] if per_layer else f
         torch.testing.assert_close(dst, src[first_row:first_row + dst.numel()] * scale, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "fp32"])
+def test_stride2_forward_workspace_is_packed_when_the_first_call_falls_back(mode):
+    """Whether a stride-2 forward takes the halo kernel depends on its batch size (4x4 output grids need >= 2048 rows), and the
+    caller's cache marks the filter workspace current after ANY call with repack = 1.  A small batch first (fallback kernel), then
+    a large one on the same weight version: the second call reads the workspace with repack = 0, so the first must have packed it
+    (the penalty branch's rows before the fused pass at batch sizes between 64 and 127)."""
+    from csl_gan_amd import _lib
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    C, K = 32, 64
+    w = torch.randn(K, C, 5, 5, generator=g) / (C * 25) ** 0.5
+    wd, key = _krsc(w), ("s2pack", mode)
+    xs, xb = torch.randn(8, C, 8, 8, generator=g), torch.randn(128, C, 8, 8, generator=g)
+    with ops.compute_dtype(mode):
+        ops.conv2d_fwd(_nhwc(xs), wd, None, stride=2, pad=2, act=0, wkey=key)
+        first = _lib.lib().cslgan_last_kernel().decode()
+        got = ops.conv2d_fwd(_nhwc(xb), wd, None, stride=2, pad=2, act=0, wkey=key).permute(0, 3, 1, 2)
+        second = _lib.lib().cslgan_last_kernel().decode()
+    if mode == "bf16x3":
+        assert not first.startswith("igemm_x3h_kernel") and second.startswith("igemm_x3h_kernel"), (first, second)
+    ref = F.conv2d(xb.double(), w.double(), None, stride=2, padding=2)
+    assert _err64(got, ref) <= 4e-6, (first, second)

@@ -30,6 +30,7 @@ struct WghParams {
     int tiles_m, tiles_c, ppi;   // K/128, C/64, patches per image
     int ksplit;                  // workgroups per (group, tile, filter row): they take every ksplit-th patch and add atomically
     int xw;                      // staged columns: 7*stride + S
+    int xcd;                     // 1: XCD-aware workgroup order (xcd_remap)
     const float* row_scale;      // nullable [N]: gy of sample n is multiplied by row_scale[n] while it is staged (clip-weighted sums)
     // row blocks with their own outputs (cslgan_conv2d_wgrad_blocks_f32): groups [seg_first[s], seg_first[s+1]) write
     // seg_gw[s] + (g - seg_first[s]) * K*R*S*C (nothing when null) and add their squared norm into seg_sq[s][g - seg_first[s]]
@@ -49,7 +50,10 @@ __global__ __launch_bounds__(256, 2) void igemm_wgh_kernel(const WghParams p) {
     __shared__ float s_red[4];
 
     const int tid = threadIdx.x;
-    int bid = blockIdx.x;
+    // XCD-aware order (env CSLGAN_WGH_XCD=0: plain): the workgroups of one group — filter rows x channel tiles — re-read the same gy rows
+    // and input slabs; hardware deals consecutive workgroup ids round-robin over the eight XCDs, i.e. eight L2s each fetching that
+    // group's tensors from the fabric.  With the remap an XCD owns a contiguous run of logical ids.
+    int bid = p.xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int split = bid % p.ksplit; bid /= p.ksplit;
     const int r = bid % p.R; bid /= p.R;
     const int tc = bid % p.tiles_c; bid /= p.tiles_c;
@@ -246,7 +250,10 @@ __global__ __launch_bounds__(256, 2) void igemm_x3w_kernel(const WghParams p) {
     __shared__ float s_red[4];
 
     const int tid = threadIdx.x;
-    int bid = blockIdx.x;
+    // XCD-aware order (env CSLGAN_WGH_XCD=0: plain): the workgroups of one group — filter rows x channel tiles — re-read the same gy rows
+    // and input slabs; hardware deals consecutive workgroup ids round-robin over the eight XCDs, i.e. eight L2s each fetching that
+    // group's tensors from the fabric.  With the remap an XCD owns a contiguous run of logical ids.
+    int bid = p.xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int split = bid % p.ksplit; bid /= p.ksplit;
     const int r = bid % p.R; bid /= p.R;
     const int tc = bid % p.tiles_c; bid /= p.tiles_c;
@@ -499,6 +506,8 @@ int launch_wgh(const cslgan_conv_t* c, const float* gy, const float* x, int grou
     }
     const long long nb = base * p.ksplit;
     if (nb > 0x7fffffffll) { set_error("wgrad: grid too large"); return CSLGAN_ERR_INVALID_ARG; }
+    static const int xcd_env = [] { const char* e = getenv("CSLGAN_WGH_XCD"); return e ? atoi(e) : 1; }();
+    p.xcd = xcd_env;
     const dim3 grid((unsigned)nb), block(256);
     if (x3) {
         note_kernel(quad ? "igemm_x3w_kernel<%d,quad>" : "igemm_x3w_kernel<%d>", c->stride);

@@ -738,12 +738,12 @@ int launch_x3h(KcParams& p, hipStream_t st) {
     const dim3 grid((unsigned)(tiles * p.csplit)), block(256);
     const bool x3 = p.bf16 == 3;
     if (p.csplit > 1)       // "/sN": N workgroups per tile + the reduce launch (the device kernel name is the part before the slash)
-        note_kernel(x3 ? "igemm_x3h_kernel<%d,3,%s>/s%d" : (p.bf16 ? "igemm_x3h_kernel<%d,1,%s>/s%d" : "igemm_x3h_kernel<%d,0,%s>/s%d"), wide ? 128 : 64,
+        note_kernel(x3 ? "igemm_x3h_kernel<%d,3,%s,false>/s%d" : (p.bf16 ? "igemm_x3h_kernel<%d,1,%s,false>/s%d" : "igemm_x3h_kernel<%d,0,%s,false>/s%d"), wide ? 128 : 64,
                     gen ? "true" : "false", p.csplit);
     else if (p.in_scale)
         note_kernel(x3 ? "igemm_x3h_kernel<%d,3,false,true>" : "igemm_x3h_kernel<%d,0,false,true>", wide ? 128 : 64);
     else
-        note_kernel(x3 ? "igemm_x3h_kernel<%d,3,%s>" : (p.bf16 ? "igemm_x3h_kernel<%d,1,%s>" : "igemm_x3h_kernel<%d,0,%s>"), wide ? 128 : 64, gen ? "true" : "false");
+        note_kernel(x3 ? "igemm_x3h_kernel<%d,3,%s,false>" : (p.bf16 ? "igemm_x3h_kernel<%d,1,%s,false>" : "igemm_x3h_kernel<%d,0,%s,false>"), wide ? 128 : 64, gen ? "true" : "false");
     if (p.in_scale) {
         if (x3 && wide) hipLaunchKernelGGL((igemm_x3h_kernel<128, 3, false, true>), grid, block, 0, st, p);
         else if (x3) hipLaunchKernelGGL((igemm_x3h_kernel<64, 3, false, true>), grid, block, 0, st, p);

@@ -293,7 +293,7 @@ def main():
                     "share_of_step": round(dom["ms"] / (dt_eager * 1e3), 3),
                     "measured_in": "HIP events around this kernel's launches over the %d eagerly launched timed steps (%.3f ms/step)%s" % (
                         a.steps, dt_eager / a.steps * 1e3,
-                        "; the headline region replays the same launches from a HIP graph, where events cannot be placed" if launch_mode == "hip_graph" else ""),
+                        "; the headline region replays the same launches from a HIP graph, where events cannot be placed" if launch_mode.startswith("hip_graph") else ""),
                     "launch_shapes": {v["name"][len(dom["name"]) + 1:]: {"n_per_step": v["n"] / a.steps, "avg_ms": round(v["ms"] / v["n"], 4),
                                                                          "tflops": round(v["exec_flop"] / (v["ms"] * 1e-3) / 1e12, 1)}
                                       for v in worst[:8]}}
@@ -374,8 +374,9 @@ def main():
     gs = getattr(tr, "graphed", None)
     bail = None
     if gs is not None and world > 1:
-        # Only with CSLGAN_GRAPH_DIST=1 (multi-rank capture is opt-in: csl_gan_amd.distributed.collectives_capturable).  If recording or
-        # replaying the step with its RCCL collectives does not come back, rank 0 still prints the eager measurement, labelled — and the
+        # Default (round 4): segmented replay, no collective inside a graph; CSLGAN_GRAPH_DIST=1 records the RCCL collectives with the step
+        # instead (opt-in: csl_gan_amd.distributed.collectives_capturable); CSLGAN_GRAPH_SEGMENTS=0 keeps N > 1 eager.  If recording or
+        # replaying does not come back, rank 0 still prints the eager measurement, labelled — and the
         # process ends with a NON-ZERO status (3): a hang is a failure of the run, not a result.
         import threading
         limit = float(os.environ.get("CSLGAN_GRAPH_REGION_LIMIT_S", "240"))
@@ -395,7 +396,9 @@ def main():
             for _ in range(gs.warmup + 2):
                 gs(img, None)
             if gs.graph is not None:
-                dt, launch_mode = time_region(lambda: gs(img, None), a.steps), "hip_graph"
+                # N > 1 by default: "hip_graph_segments" — the step replays as graphs that end at each collective, the collectives
+                # themselves issued eagerly between them (GraphedDStep._capture_segments); nothing of RCCL is inside a graph
+                dt, launch_mode = time_region(lambda: gs(img, None), a.steps), ("hip_graph_segments" if getattr(gs, "segmented", False) else "hip_graph")
             else:
                 graph_err = gs.capture_error or "not captured"
         except Exception as e:      # a failed capture must not cost the line: the eager region stands

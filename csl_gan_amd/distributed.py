@@ -40,6 +40,25 @@ def init(backend=None):
     return world, rank, local
 
 
+# Segmented graph replay (round 4): while GraphedDStep records or replays a multi-rank step whose collectives must NOT go into a HIP
+# graph, it installs a callable here.  Every collective of the step is handed to it as a closure: at recording time it ends the graph
+# being captured, issues the collective eagerly (every rank does, so the ranks stay in step) and begins the next graph; a replay runs
+# graph, collective, graph, ...  None: the collective is simply issued.
+_boundary = None
+
+
+def _collective(fn):
+    if _boundary is not None:
+        return _boundary(fn)
+    return fn()
+
+
+def segments_enabled():
+    """Multi-rank steps whose collectives cannot be recorded replay as SEGMENTS around eagerly issued collectives (CSLGAN_GRAPH_SEGMENTS=0:
+    such steps are launched eagerly, the round-3 behaviour)."""
+    return os.environ.get("CSLGAN_GRAPH_SEGMENTS", "1") == "1"
+
+
 class FlatGradReducer:
     """all-reduce(SUM) of one flat gradient bucket.  The engine hands over the flat fp32 buffer its
     per-parameter .grad tensors alias, already scaled by 1/(B_local*R)."""
@@ -53,7 +72,7 @@ class FlatGradReducer:
 
     def __call__(self, flat: torch.Tensor):
         if self.world > 1 or self.always:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            _collective(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group))
             self.bytes_reduced += flat.numel() * flat.element_size()      # (host counter: counts recorded calls, not replays)
         return flat
 
@@ -61,7 +80,7 @@ class FlatGradReducer:
 def average_across_ranks(t: torch.Tensor, use_max=False, group=None):
     """In-place mean (or max) of a small tensor over ranks: adaptive clipping statistics."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX if use_max else dist.ReduceOp.SUM, group=group)
+        _collective(lambda: dist.all_reduce(t, op=dist.ReduceOp.MAX if use_max else dist.ReduceOp.SUM, group=group))
         if not use_max:
             t /= dist.get_world_size(group)
     return t

@@ -110,8 +110,10 @@ class Trainer:
         # immediate-sensitivity maxima — are stream-ordered RCCL launches and are RECORDED with the step (every rank records and replays
         # the same sequence) — OPT-IN with CSLGAN_GRAPH_DIST=1 (round 4: verified on a one-rank RCCL group only, so N > 1 defaults to the
         # eager step); gloo (CPU rehearsals) stages through the host and keeps the eager step.
-        from .distributed import collectives_capturable
-        if (getattr(o, "hip_graph", False) and (self.world_size == 1 or collectives_capturable()) and not o.backprop_clip
+        # Round 4, second half: a multi-rank step whose collectives are not recorded replays as SEGMENTS — the capture ends at each
+        # collective, which is issued eagerly between the replays of the graphs on either side (GraphedDStep._capture_segments).
+        from .distributed import collectives_capturable, segments_enabled
+        if (getattr(o, "hip_graph", False) and (self.world_size == 1 or collectives_capturable() or segments_enabled()) and not o.backprop_clip
                 and (o.dp_mode == "gc" or (o.dp_mode == "is" and o.imm_sens_scaling_mode != "moving-avg-pl"))):
             self.graphed = GraphedDStep(self)
         return pe
@@ -338,6 +340,15 @@ class Trainer:
                 and len(o.penalty) > 0 and o.penalty_use_public_data and hnn._mask_recorder is None and self.D is not None
                 and next(self.D.parameters()).is_cuda)
 
+    def _join_penalty_stream_at_boundary(self):
+        """A segmented recording (distributed._boundary) ends the graph being captured at the next collective: work forked onto the
+        penalty stream must be joined into the capturing stream first.  train_D's own join is then skipped (waiting, inside the NEXT
+        capture, on an event of a finished one is not allowed)."""
+        from . import distributed as Dist
+        if Dist._boundary is not None and self._pending_penalty is not None and not self._gp_joined:
+            torch.cuda.current_stream().wait_stream(self._gp_stream)
+            self._gp_joined = True
+
     def _launch_penalty(self, img, labels, fake_img, y):
         from . import ops
         o, D, pe = self.opt, self.D, self.privacy_engine
@@ -455,6 +466,7 @@ class Trainer:
                     r = norms.mean(dim=1) if o.adaptive_stat == "mean" else norms.max(dim=1).values
                     if self.world_size > 1:
                         from .distributed import average_across_ranks
+                        self._join_penalty_stream_at_boundary()
                         r = average_across_ranks(r.contiguous(), use_max=o.adaptive_stat == "max")
                     pe.set_max_grad_norm_device(r * o.adaptive_scalar if o.use_grad_clip_per_layer else (r.norm(2) * o.adaptive_scalar).reshape(1))
                 self.last["adaptive_stats"] = r
@@ -512,7 +524,7 @@ class Trainer:
         if use_imm_sens:
             img.requires_grad = True
         fused = self._can_fuse(use_dp)
-        self._pending_penalty = None
+        self._pending_penalty, self._gp_joined = None, False
         if fused:
             pe.zero_grad()
             on_fake = (lambda f: self._launch_penalty(img, labels, f, y)) if self._penalty_overlap_ok(use_dp) else None
@@ -546,7 +558,8 @@ class Trainer:
             # launched on the second stream right after the generator forward (_launch_penalty): join, then train.py:429-431
             penalty, penalty_grad = self._pending_penalty
             self._pending_penalty = None
-            torch.cuda.current_stream().wait_stream(self._gp_stream)
+            if not self._gp_joined:
+                torch.cuda.current_stream().wait_stream(self._gp_stream)
             if use_grad_clip:
                 pe.accumulate_batch()
             with torch.no_grad():
@@ -890,6 +903,7 @@ class GraphedDStep:
             raise NotImplementedError("GraphedDStep covers the DP D-steps whose host never reads the device inside the step: dp_mode=gc "
                                       "and dp_mode=is (not the moving-average scaling mode, which reads gradient norms on the host)")
         self.graph, self.bufs, self.capture_error = None, None, None
+        self.graphs, self.between, self.segmented = [], [], False      # segmented recording (N > 1): graphs and the collectives between them
         self._pinned = []                  # generator filter workspaces pinned in ops.repack_cache for the recorded graph
         self._prev = (trainer.d_optimizer.capturable, trainer.explicit)
         trainer.d_optimizer.capturable = True
@@ -897,7 +911,7 @@ class GraphedDStep:
     def release(self):
         """Give the trainer back to plain eager stepping (bench.py times other variants on the same trainer afterwards)."""
         self.tr.d_optimizer.capturable, self.tr.explicit = self._prev
-        self.graph = None
+        self.graph, self.graphs, self.between = None, [], []
         if self._pinned:
             from . import ops
             ops.repack_cache.unpin(self._pinned)
@@ -951,6 +965,60 @@ class GraphedDStep:
         b = self.bufs
         self.tr.train_D(b["img"], b["labels"], b["z"], b["labels"], use_dp=True)
 
+    def _replay(self):
+        if not self.segmented:
+            return self.graph.replay()
+        for i, g in enumerate(self.graphs):      # graph, collective, graph, ... : the collectives are ordinary stream-ordered calls
+            g.replay()
+            if i < len(self.between):
+                self.between[i]()
+
+    def _capture_segments(self):
+        """Record the step as several graphs that END at each collective (distributed._boundary): nothing of RCCL / gloo is inside a
+        graph.  All graphs share the first one's memory pool (a tensor made in one segment is read in the next); the closures kept
+        in self.between hold the tensors their collectives run on, so those addresses stay reserved."""
+        from . import distributed as Dist
+        graphs, between, cur = [], [], [None]
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            if graphs:
+                g.capture_begin(pool=graphs[0].pool())
+            else:
+                g.capture_begin()
+            cur[0] = g
+
+        def boundary(fn):
+            g, cur[0] = cur[0], None
+            g.capture_end()
+            graphs.append(g)
+            out = fn()                           # issued for real (on whatever the unexecuted graph left in memory): keeps the ranks in step
+            between.append(fn)
+            begin()
+            return out
+
+        with torch.cuda.stream(cap):
+            begin()
+            Dist._boundary = boundary
+            try:
+                self._eager()
+                g, cur[0] = cur[0], None
+                g.capture_end()
+                graphs.append(g)
+            except BaseException:
+                if cur[0] is not None:           # leave capture mode before the error travels on
+                    try:
+                        cur[0].capture_end()
+                    except Exception:
+                        pass
+                raise
+            finally:
+                Dist._boundary = None
+        torch.cuda.current_stream().wait_stream(cap)
+        self.graphs, self.between = graphs, between
+
     def __call__(self, img, labels=None):
         tr = self.tr
         if self.bufs is None:
@@ -997,9 +1065,15 @@ class GraphedDStep:
             gc_was_on = gc.isenabled()
             gc.disable()
             err = None
+            from . import distributed as Dist
+            self.segmented = tr.world_size > 1 and not Dist.collectives_capturable()
             try:
-                with torch.cuda.graph(graph):
-                    self._eager()                # RECORDED, not executed; its host-side bookkeeping ran once
+                if self.segmented:
+                    self._capture_segments()
+                    graph = self.graphs[0]
+                else:
+                    with torch.cuda.graph(graph):
+                        self._eager()            # RECORDED, not executed; its host-side bookkeeping ran once
             except Exception as e:               # e.g. a collective this backend cannot record: the run goes on eagerly
                 err = e
             finally:
@@ -1024,13 +1098,13 @@ class GraphedDStep:
                 return self._eager()
             self.graph = graph
             ops.repack_cache.clear()             # entries made during capture point into the graph's private pool (pinned ones stay)
-            self.graph.replay()                  # the step itself
+            self._replay()                       # the step itself
             tr.d_optimizer.bump_versions()
             return
         if self._pinned:
             from . import ops
             ops.repack_cache.refresh_pinned()    # a train_G step since the last replay: the generator's filter workspaces, in place
-        self.graph.replay()
+        self._replay()
         pe = tr.privacy_engine                   # what the recorded python would have done on the host
         pe.steps += 1
         pe._noise_calls += 1

@@ -180,14 +180,68 @@ def test_graph_replay_records_the_rccl_all_reduce(tmp_path):
         assert (a - b).abs().max().item() <= 2.5 * 1e-4 * 4 * 0.5 + 1e-7, (a - b).abs().max().item()   # d_lr 2e-4 (MNIST): a fraction of the 4 Adam steps
 
 
-def test_bench_two_ranks_reports_the_eager_step_by_default(tmp_path):
+def _segments_worker(rank, world, port, out):
+    """One of two gloo ranks on the box's GPU: the D-step as GraphedDStep runs it for N > 1 by default — recorded as graphs that END at
+    each collective — and an eager twin on the same inputs."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    from csl_gan_amd import distributed as Dist, init_util, options
+    from csl_gan_amd.mean_sampler import MeanSampler
+    from csl_gan_amd.trainer import GraphedDStep, Trainer
+    Dist.init("gloo")
+    assert not Dist.collectives_capturable() and Dist.segments_enabled()
+    res = {}
+    for use_graph in (False, True):
+        torch.manual_seed(11 + rank); torch.cuda.manual_seed(11 + rank)
+        red = Dist.FlatGradReducer()
+        o = os.path.join(out, "r%d_g%d" % (rank, use_graph))
+        opt = options.parse(["MNIST", "--model", "DeepConvResNet", "-dpm", "gc", "-gcm", "adaptive-pl", "-nms", "4", "-bs", "8", "-gd", "cuda:0",
+                             "-dd", "cuda:0", "-o", o, "--manual_seed", "1", "--g_latent_dim", str(LATENT), "--sigma", "0.8", "--penalty", "WGAN-GP",
+                             "--hip_graph", "True"])
+        G, D = init_util.init_models(opt)
+        ms = MeanSampler(num_samples=4, mean_size=10, device="cuda:0", res=28, ch=1)
+        ms.mean_samples = (torch.randn((1, 4, 1, 28, 28), generator=torch.Generator().manual_seed(9)) * 0.2).cuda()
+        tr = Trainer(opt, G, D, mean_sampler=ms, log_to=os.path.join(o, "log.csv"), world_size=world, rank=rank, grad_reducer=red)
+        pe = tr.setup_privacy_engine()
+        assert tr.graphed is not None                  # N > 1 gets the replayed step by default now
+        step = GraphedDStep(tr, use_graph=use_graph, warmup=1)
+        g = torch.Generator().manual_seed(5 + rank)
+        for i in range(5):
+            step(torch.rand(8, 1, 28, 28, generator=g).cuda(), None)
+        torch.cuda.synchronize()
+        if use_graph:
+            assert step.graph is not None and step.segmented, step.capture_error
+            # adaptive statistic, gradient bucket: two collectives -> three graphs
+            assert len(step.graphs) == 3 and len(step.between) == 2, (len(step.graphs), len(step.between))
+        res[use_graph] = torch.cat([p.detach().reshape(-1).cpu() for p in D.parameters()]).numpy()
+        assert pe.steps == 5 and red.bytes_reduced > 0
+    np.savez(os.path.join(out, "seg_rank%d.npz" % rank), eager=res[False], graph=res[True])
+    Dist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_step_replays_as_graph_segments_around_its_collectives(tmp_path):
+    """N > 1 without recording a collective: the step's two collectives (adaptive statistic, flat gradient bucket) end the capture;
+    replays run graph - collective - graph - collective - graph.  Two gloo ranks (gloo cannot be captured at all) on the box's GPU:
+    five replayed steps leave the critic where five eager steps leave it, and both ranks hold the same weights."""
+    world = 2
+    mp.spawn(_segments_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "seg_rank0.npz"), np.load(tmp_path / "seg_rank1.npz")
+    assert np.array_equal(r0["graph"], r1["graph"]) and np.array_equal(r0["eager"], r1["eager"]), "ranks diverged"
+    assert np.abs(r0["graph"] - r0["eager"]).max() <= 2.5 * 1e-4 * 5 * 0.5 + 1e-7, np.abs(r0["graph"] - r0["eager"]).max()
+
+
+@pytest.mark.parametrize("segments", [True, False], ids=["segments", "eager"])
+def test_bench_two_ranks_reports_the_eager_step_by_default(tmp_path, segments):
     """`python bench.py --gpus 2` (two gloo ranks rehearsed on the box's one GPU): the line is printed once by rank 0, says n_gpus = 2,
-    aggregates both ranks' images, and — multi-rank graph capture being opt-in — is labelled `launch: "eager"` with no graph error."""
+    aggregates both ranks' images, and is labelled `launch: "hip_graph_segments"` (the default: no collective inside a graph) or, with
+    CSLGAN_GRAPH_SEGMENTS=0, `launch: "eager"` — with no graph error either way."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CSLGAN_DIST_BACKEND="gloo", CSLGAN_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, CSLGAN_DIST_BACKEND="gloo", CSLGAN_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               CSLGAN_GRAPH_SEGMENTS="1" if segments else "0")
     env.pop("CSLGAN_GRAPH_DIST", None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                         "--loop-steps", "0", "--no-variants"], env=env, capture_output=True, text=True, timeout=900)
@@ -195,6 +249,6 @@ def test_bench_two_ranks_reports_the_eager_step_by_default(tmp_path):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["config"]["launch"] == "eager" and line["graph_error"] is None
+    assert line["n_gpus"] == 2 and line["config"]["launch"] == ("hip_graph_segments" if segments else "eager") and line["graph_error"] is None, line
     assert line["config"]["global_batch"] == 256 and abs(line["value"] - 2 * line["per_gpu"]) <= 0.02
     assert "cpu_baseline" not in line                       # rank 0 at N = 1 only

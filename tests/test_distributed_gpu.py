@@ -180,7 +180,7 @@ def test_graph_replay_records_the_rccl_all_reduce(tmp_path):
         assert (a - b).abs().max().item() <= 2.5 * 1e-4 * 4 * 0.5 + 1e-7, (a - b).abs().max().item()   # d_lr 2e-4 (MNIST): a fraction of the 4 Adam steps
 
 
-def _segments_worker(rank, world, port, out):
+def _segments_worker(rank, world, port, out, mode):
     """One of two gloo ranks on the box's GPU: the D-step as GraphedDStep runs it for N > 1 by default — recorded as graphs that END at
     each collective — and an eager twin on the same inputs."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
@@ -195,9 +195,10 @@ def _segments_worker(rank, world, port, out):
         torch.manual_seed(11 + rank); torch.cuda.manual_seed(11 + rank)
         red = Dist.FlatGradReducer()
         o = os.path.join(out, "r%d_g%d" % (rank, use_graph))
-        opt = options.parse(["MNIST", "--model", "DeepConvResNet", "-dpm", "gc", "-gcm", "adaptive-pl", "-nms", "4", "-bs", "8", "-gd", "cuda:0",
+        extra = ["-dpm", "gc", "-gcm", "adaptive-pl"] if mode == "gc" else ["-dpm", "is", "-ispp", "True"]
+        opt = options.parse(["MNIST", "--model", "DeepConvResNet", "-nms", "4", "-bs", "8", "-gd", "cuda:0",
                              "-dd", "cuda:0", "-o", o, "--manual_seed", "1", "--g_latent_dim", str(LATENT), "--sigma", "0.8", "--penalty", "WGAN-GP",
-                             "--hip_graph", "True"])
+                             "--hip_graph", "True"] + extra)
         G, D = init_util.init_models(opt)
         ms = MeanSampler(num_samples=4, mean_size=10, device="cuda:0", res=28, ch=1)
         ms.mean_samples = (torch.randn((1, 4, 1, 28, 28), generator=torch.Generator().manual_seed(9)) * 0.2).cuda()
@@ -211,7 +212,7 @@ def _segments_worker(rank, world, port, out):
         torch.cuda.synchronize()
         if use_graph:
             assert step.graph is not None and step.segmented, step.capture_error
-            # adaptive statistic, gradient bucket: two collectives -> three graphs
+            # gc: adaptive statistic, gradient bucket; is: batch-maximum sensitivities, gradient bucket -> two collectives, three graphs
             assert len(step.graphs) == 3 and len(step.between) == 2, (len(step.graphs), len(step.between))
         res[use_graph] = torch.cat([p.detach().reshape(-1).cpu() for p in D.parameters()]).numpy()
         assert pe.steps == 5 and red.bytes_reduced > 0
@@ -220,12 +221,13 @@ def _segments_worker(rank, world, port, out):
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_step_replays_as_graph_segments_around_its_collectives(tmp_path):
+@pytest.mark.parametrize("mode", ["gc", "is"])
+def test_two_rank_step_replays_as_graph_segments_around_its_collectives(tmp_path, mode):
     """N > 1 without recording a collective: the step's two collectives (adaptive statistic, flat gradient bucket) end the capture;
     replays run graph - collective - graph - collective - graph.  Two gloo ranks (gloo cannot be captured at all) on the box's GPU:
     five replayed steps leave the critic where five eager steps leave it, and both ranks hold the same weights."""
     world = 2
-    mp.spawn(_segments_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_segments_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "seg_rank0.npz"), np.load(tmp_path / "seg_rank1.npz")
     assert np.array_equal(r0["graph"], r1["graph"]) and np.array_equal(r0["eager"], r1["eager"]), "ranks diverged"
     assert np.abs(r0["graph"] - r0["eager"]).max() <= 2.5 * 1e-4 * 5 * 0.5 + 1e-7, np.abs(r0["graph"] - r0["eager"]).max()
